@@ -1,0 +1,116 @@
+/* exmc_detmath.h — bit-reproducible f64 exp / log / log1p.
+ *
+ * Why this exists: the reference sampler (lib/exmc/nuts/tree.ex:1045,1398,1490,1603
+ * and the model log-densities, lib/exmc/dist/<name>.ex, lib/exmc/transform.ex:17-29)
+ * calls the platform libm through Erlang's :math / Nx.BinaryBackend. libm results
+ * differ by an ulp between platforms (glibc vs the ROCm device library), and NUTS
+ * is chaotic: one ulp in a log-weight eventually flips a tree decision. To make
+ * "GPU == CPU checker, bit for bit, over whole chains" a testable statement, both
+ * the HIP kernels and the oracle's deterministic mode evaluate exp/log through the
+ * functions below, which use only IEEE-754 correctly-rounded operations
+ * (+, -, *, /, fma, rint) in a fixed order. Compile every translation unit that
+ * includes this header with -ffp-contract=off (fma appears only where written).
+ *
+ * Accuracy (tests/test_detmath.py): <= 1 ulp vs glibc over the sampled ranges.
+ * Algorithms: exp = Cody-Waite reduction by ln2 (two fma) + degree-13 Taylor
+ * polynomial (Horner, fma) + two-step power-of-two scaling; log = the classic
+ * s = f/(2+f) atanh-series form with the 7 published fdlibm/musl coefficients;
+ * log1p = log(1+x) with the (x-(u-1))/u correction term.
+ */
+#ifndef EXMC_DETMATH_H
+#define EXMC_DETMATH_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define EXMC_HD __host__ __device__ __forceinline__
+#else
+#define EXMC_HD static inline
+#endif
+
+EXMC_HD double exmc_from_bits(uint64_t u) {
+  double d;
+  __builtin_memcpy(&d, &u, 8);
+  return d;
+}
+EXMC_HD uint64_t exmc_to_bits(double d) {
+  uint64_t u;
+  __builtin_memcpy(&u, &d, 8);
+  return u;
+}
+
+#define EXMC_INF_BITS 0x7FF0000000000000ULL
+#define EXMC_NAN_BITS 0x7FF8000000000000ULL
+
+EXMC_HD int exmc_isfinite(double x) {
+  return (exmc_to_bits(x) & EXMC_INF_BITS) != EXMC_INF_BITS;
+}
+
+EXMC_HD double exmc_exp(double x) {
+  if (!(x == x)) return x;                       /* NaN */
+  if (x > 709.782712893384) return exmc_from_bits(EXMC_INF_BITS);
+  if (x < -745.1332191019412) return 0.0;
+  double kf = __builtin_rint(x * 0x1.71547652b82fep+0);      /* x * log2(e) */
+  double r = __builtin_fma(kf, -0x1.62e42fefa39efp-1, x);    /* - k*ln2_hi */
+  r = __builtin_fma(kf, -0x1.abc9e3b39803fp-56, r);          /* - k*ln2_lo */
+  double p = 0x1.6124613a86d09p-33;                          /* 1/13! */
+  p = __builtin_fma(p, r, 0x1.1eed8eff8d898p-29);            /* 1/12! */
+  p = __builtin_fma(p, r, 0x1.ae64567f544e4p-26);            /* 1/11! */
+  p = __builtin_fma(p, r, 0x1.27e4fb7789f5cp-22);            /* 1/10! */
+  p = __builtin_fma(p, r, 0x1.71de3a556c734p-19);            /* 1/9!  */
+  p = __builtin_fma(p, r, 0x1.a01a01a01a01ap-16);            /* 1/8!  */
+  p = __builtin_fma(p, r, 0x1.a01a01a01a01ap-13);            /* 1/7!  */
+  p = __builtin_fma(p, r, 0x1.6c16c16c16c17p-10);            /* 1/6!  */
+  p = __builtin_fma(p, r, 0x1.1111111111111p-7);             /* 1/5!  */
+  p = __builtin_fma(p, r, 0x1.5555555555555p-5);             /* 1/4!  */
+  p = __builtin_fma(p, r, 0x1.5555555555555p-3);             /* 1/3!  */
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  int k = (int)kf;
+  int k1 = k >> 1;
+  int k2 = k - k1;
+  p *= exmc_from_bits((uint64_t)(k1 + 1023) << 52);
+  p *= exmc_from_bits((uint64_t)(k2 + 1023) << 52);
+  return p;
+}
+
+EXMC_HD double exmc_log(double x) {
+  uint64_t ix = exmc_to_bits(x);
+  int e = 0;
+  if (ix < 0x0010000000000000ULL || (ix >> 63)) {
+    if ((ix << 1) == 0) return -exmc_from_bits(EXMC_INF_BITS); /* +-0 */
+    if (ix >> 63) return exmc_from_bits(EXMC_NAN_BITS);        /* negative */
+    x *= 0x1p54;                                               /* subnormal */
+    ix = exmc_to_bits(x);
+    e = -54;
+  } else if (ix >= EXMC_INF_BITS) {
+    return x;                                                  /* +inf, NaN */
+  }
+  /* normalise mantissa into [sqrt(2)/2, sqrt(2)) */
+  uint64_t t = ix + (0x3FF0000000000000ULL - 0x3FE6A09E667F3BCDULL);
+  e += (int)(t >> 52) - 1023;
+  ix = (t & 0x000FFFFFFFFFFFFFULL) + 0x3FE6A09E667F3BCDULL;
+  double f = exmc_from_bits(ix) - 1.0;
+  double hfsq = 0.5 * f * f;
+  double s = f / (2.0 + f);
+  double z = s * s;
+  double w = z * z;
+  double t1 = w * (3.999999999940941908e-01 +
+                   w * (2.222219843214978396e-01 + w * 1.531383769920937332e-01));
+  double t2 = z * (6.666666666666735130e-01 +
+                   w * (2.857142874366239149e-01 +
+                        w * (1.818357216161805012e-01 + w * 1.479819860511658591e-01)));
+  double R = t2 + t1;
+  double dk = (double)e;
+  return s * (hfsq + R) + dk * 1.90821492927058770002e-10 - hfsq + f +
+         dk * 6.93147180369123816490e-01;
+}
+
+EXMC_HD double exmc_log1p(double x) {
+  double u = 1.0 + x;
+  if (u == 1.0) return x;
+  return exmc_log(u) + (x - (u - 1.0)) / u;
+}
+
+#endif /* EXMC_DETMATH_H */
