@@ -1,0 +1,90 @@
+"""ctypes binding of libexmc_hip.so (include/exmc_hip.h). No CPU fallback: if the library or a
+HIP device is missing, calls raise ExmcHipError."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libexmc_hip.so")
+
+MAX_D = 256
+OK, ERR_BADARG, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED = range(5)
+
+EXPORTS = [
+    "exmc_hip_last_error", "exmc_hip_device_count", "exmc_hip_model_create",
+    "exmc_hip_model_destroy", "exmc_hip_model_dim", "exmc_hip_model_default_lanes",
+    "exmc_hip_model_stream", "exmc_hip_logp_grad_host", "exmc_hip_multi_step",
+    "exmc_hip_multi_step_host", "exmc_hip_transitions_host", "exmc_hip_warmup",
+    "exmc_hip_sample_chains", "exmc_hip_sample_chains_host", "exmc_hip_sample_host",
+    "exmc_hip_ess", "exmc_hip_last_kernel_ms",
+]
+
+
+class ExmcHipError(RuntimeError):
+    pass
+
+
+class Opts(C.Structure):
+    _fields_ = [("num_warmup", C.c_int), ("num_samples", C.c_int), ("max_tree_depth", C.c_int),
+                ("target_accept", C.c_double), ("seed", C.c_uint64), ("lanes_per_chain", C.c_int)]
+
+
+class Tuning(C.Structure):
+    _fields_ = [("epsilon", C.c_double), ("inv_mass", C.c_double * MAX_D),
+                ("warmup_divergences", C.c_int)]
+
+
+class Trace(C.Structure):
+    _fields_ = [("draws", C.c_void_p), ("logp", C.c_void_p), ("tree_depth", C.c_void_p),
+                ("n_steps", C.c_void_p), ("divergent", C.c_void_p), ("accept_prob", C.c_void_p),
+                ("energy", C.c_void_p)]
+
+
+_lib = None
+
+
+def load():
+    """Load libexmc_hip.so. torch (if used in the same process) must be imported first so both
+    share one HIP runtime; exmc_amd/__init__ takes care of the order."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ExmcHipError(
+            "libexmc_hip.so is not built (%s): run `python -m exmc_amd.build`; there is no "
+            "CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    dp = C.POINTER(C.c_double)
+    vp = C.c_void_p
+    L.exmc_hip_last_error.restype = C.c_char_p
+    L.exmc_hip_device_count.restype = C.c_int
+    L.exmc_hip_model_create.argtypes = [C.c_int, C.c_int, dp, C.c_int, C.c_int, C.POINTER(vp)]
+    L.exmc_hip_model_destroy.argtypes = [vp]
+    L.exmc_hip_model_destroy.restype = None
+    L.exmc_hip_model_dim.argtypes = [vp]
+    L.exmc_hip_model_default_lanes.argtypes = [vp]
+    L.exmc_hip_model_stream.argtypes = [vp]
+    L.exmc_hip_model_stream.restype = vp
+    L.exmc_hip_logp_grad_host.argtypes = [vp, dp, C.c_int, C.c_int, dp, dp]
+    L.exmc_hip_multi_step.argtypes = [vp, vp, vp, vp, C.c_double, dp, C.c_int, C.c_int, C.c_int,
+                                      vp, vp, vp, vp]
+    L.exmc_hip_multi_step_host.argtypes = [vp, dp, dp, dp, C.c_double, dp, C.c_int, C.c_int,
+                                           C.c_int, dp, dp, dp, dp]
+    L.exmc_hip_transitions_host.argtypes = [vp, dp, dp, dp, C.POINTER(C.c_uint64), C.c_int,
+                                            C.c_int, C.c_double, dp, C.c_int, C.c_int, Trace]
+    L.exmc_hip_warmup.argtypes = [vp, dp, Opts, C.POINTER(Tuning)]
+    L.exmc_hip_sample_chains.argtypes = [vp, C.POINTER(Tuning), dp, C.c_int, C.c_int, C.c_int,
+                                         Opts, Trace, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
+    L.exmc_hip_sample_chains_host.argtypes = L.exmc_hip_sample_chains.argtypes
+    L.exmc_hip_sample_host.argtypes = [vp, dp, Opts, Trace, C.POINTER(Tuning),
+                                       C.POINTER(C.c_int32)]
+    L.exmc_hip_ess.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
+    L.exmc_hip_last_kernel_ms.argtypes = [vp]
+    L.exmc_hip_last_kernel_ms.restype = C.c_double
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != OK:
+        msg = load().exmc_hip_last_error()
+        raise ExmcHipError("libexmc_hip error %d: %s" % (rc, msg.decode() if msg else ""))

@@ -1,0 +1,53 @@
+"""Build libexmc_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SRC = os.path.join(HERE, "csrc", "exmc_hip.hip")
+OUT_DIR = os.path.join(HERE, "lib")
+OUT = os.path.join(OUT_DIR, "libexmc_hip.so")
+
+DEPS = [
+    SRC,
+    os.path.join(HERE, "csrc", "exmc_kernels.hpp"),
+    os.path.join(HERE, "csrc", "exmc_models.hpp"),
+    os.path.join(HERE, "csrc", "exmc_device.hpp"),
+    os.path.join(ROOT, "include", "exmc_hip.h"),
+    os.path.join(ROOT, "include", "exmc_detmath.h"),
+    os.path.join(ROOT, "include", "exmc_zig_tables.h"),
+]
+
+# -ffp-contract=off is part of the numeric contract (include/exmc_detmath.h): fma only where written.
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared",
+         "-Wall", "-Wno-unused-function"]
+
+
+def hipcc():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: libexmc_hip.so cannot be built (no CPU fallback exists)")
+
+
+def up_to_date():
+    if not os.path.exists(OUT):
+        return False
+    t = os.path.getmtime(OUT)
+    return all(os.path.getmtime(d) <= t for d in DEPS)
+
+
+def build(force=False, verbose=False):
+    if not force and up_to_date():
+        return OUT
+    os.makedirs(OUT_DIR, exist_ok=True)
+    cmd = [hipcc()] + FLAGS + ["-o", OUT, SRC]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=os.path.join(HERE, "csrc"))
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

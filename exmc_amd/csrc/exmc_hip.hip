@@ -1,0 +1,863 @@
+// exmc_hip.hip — C ABI of libexmc_hip.so (include/exmc_hip.h) over the gfx950 kernels.
+// Host control flow mirrors lib/exmc/nuts/sampler.ex (warmup schedule, dual averaging, Welford
+// mass matrix are plain Erlang-float code in the reference and plain C++ here); every leapfrog,
+// log-density, gradient, tree merge and U-turn test runs in the HIP kernels. There is no CPU
+// fallback: without a HIP device every compute entry point returns EXMC_ERR_NO_DEVICE.
+#include "../../include/exmc_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/exmc_zig_tables.h"
+#include "exmc_kernels.hpp"
+
+using namespace exmc;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                   \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess)                                                               \
+      return fail(EXMC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+  } while (0)
+
+const uint64_t kZigKi[256] = EXMC_ZIG_KI_INIT;
+const double kZigWi[256] = EXMC_ZIG_WI_INIT;
+const double kZigFi[256] = EXMC_ZIG_FI_INIT;
+
+double f32r(double x) { return (double)(float)x; }
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return EXMC_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    HIP_TRY(hipMalloc(&p, bytes));
+    cap = bytes;
+    return EXMC_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <class T>
+  T* as() const { return (T*)p; }
+};
+
+}  // namespace
+
+struct exmc_hip_model {
+  int kind = 0, d = 0, device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double last_ms = 0.0;
+  EightSchoolsConsts es{};
+  SimpleConsts sp{};
+  SVConsts sv{};
+  DevBuf zig;       // ki[256] u64, wi[256], fi[256]
+  DevBuf tuning;    // inv_mass[D], sqrt_inv_mass[D]
+  DevBuf state;     // q[D][C], g[D][C], logp[C], rng[2][C]
+  DevBuf stack;
+  DevBuf misc;      // eps_out (1), counters (2 u64), init_q[D]
+  DevBuf trace;     // staging for host-trace entry points
+  DevBuf io;        // staging for host vectors
+  int state_chains = 0;
+};
+
+namespace {
+
+ChainState state_view(exmc_hip_model* m, int C) {
+  ChainState s;
+  double* b = m->state.as<double>();
+  s.q = b;
+  s.g = b + (size_t)m->d * C;
+  s.logp = b + (size_t)2 * m->d * C;
+  s.rng = (uint64_t*)(b + (size_t)2 * m->d * C + C);
+  return s;
+}
+size_t state_bytes(int d, int C) { return ((size_t)2 * d * C + (size_t)3 * C) * 8; }
+
+int ensure_state(exmc_hip_model* m, int C) {
+  int rc = m->state.ensure(state_bytes(m->d, C));
+  if (rc) return rc;
+  m->state_chains = C;
+  return EXMC_OK;
+}
+
+int upload_tuning(exmc_hip_model* m, const double* inv_mass) {
+  std::vector<double> h(2 * (size_t)m->d);
+  for (int i = 0; i < m->d; i++) {
+    h[i] = inv_mass[i];
+    h[m->d + i] = std::sqrt(inv_mass[i]);  // :math.sqrt(inv_m), sampler.ex:397
+  }
+  int rc = m->tuning.ensure(h.size() * 8);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(m->tuning.p, h.data(), h.size() * 8, hipMemcpyHostToDevice, m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  return EXMC_OK;
+}
+
+// ---- model/lanes dispatch ---------------------------------------------------------------
+template <class M_, int G_>
+struct Tag {
+  using M = M_;
+  static constexpr int G = G_;
+};
+
+template <class F>
+int dispatch(exmc_hip_model* m, int lanes, F&& f) {
+  switch (m->kind) {
+    case EXMC_MODEL_EIGHT_SCHOOLS:
+      switch (lanes) {
+        case 1: return f(Tag<EightSchools<1>, 1>{}, m->es);
+        case 2: return f(Tag<EightSchools<2>, 2>{}, m->es);
+        case 4: return f(Tag<EightSchools<4>, 4>{}, m->es);
+        case 8: return f(Tag<EightSchools<8>, 8>{}, m->es);
+        case 16: return f(Tag<EightSchools<16>, 16>{}, m->es);
+        default: break;
+      }
+      break;
+    case EXMC_MODEL_SIMPLE:
+      if (lanes == 1) return f(Tag<Simple<1>, 1>{}, m->sp);
+      break;
+    case EXMC_MODEL_SV:
+      switch (lanes) {
+        case 32: return f(Tag<SV<32>, 32>{}, m->sv);
+        case 64: return f(Tag<SV<64>, 64>{}, m->sv);
+        default: break;
+      }
+      break;
+    default: break;
+  }
+  return fail(EXMC_ERR_UNSUPPORTED, "model kind / lanes_per_chain combination not compiled in");
+}
+
+int default_lanes(int kind) {
+  switch (kind) {
+    case EXMC_MODEL_EIGHT_SCHOOLS: return 16;
+    case EXMC_MODEL_SIMPLE: return 1;
+    case EXMC_MODEL_SV: return 64;
+    default: return 1;
+  }
+}
+
+int resolve_lanes(const exmc_hip_model* m, int lanes) { return lanes > 0 ? lanes : default_lanes(m->kind); }
+
+dim3 grid_for(int n_chains, int lanes, int block) {
+  size_t threads = (size_t)n_chains * lanes;
+  return dim3((unsigned)((threads + block - 1) / block));
+}
+
+constexpr int kBlock = 64;
+
+const uint64_t* zig_ki(exmc_hip_model* m) { return m->zig.as<uint64_t>(); }
+const double* zig_wi(exmc_hip_model* m) { return m->zig.as<double>() + 256; }
+const double* zig_fi(exmc_hip_model* m) { return m->zig.as<double>() + 512; }
+
+int launch_init(exmc_hip_model* m, int lanes, int C, int chain_lo, uint64_t seed,
+                const double* init_q_host) {
+  const double* init_dev = nullptr;
+  if (init_q_host) {
+    double* dst = m->misc.as<double>() + 8;
+    HIP_TRY(hipMemcpyAsync(dst, init_q_host, (size_t)m->d * 8, hipMemcpyHostToDevice, m->stream));
+    init_dev = dst;
+  }
+  InitParams P;
+  P.st = state_view(m, C);
+  P.n_chains = C;
+  P.chain_lo = chain_lo;
+  P.base_seed = seed;
+  P.init_q = init_dev;
+  P.zig_ki = zig_ki(m); P.zig_wi = zig_wi(m); P.zig_fi = zig_fi(m);
+  P.nor_r = EXMC_NOR_R;
+  return dispatch(m, lanes, [&](auto tag, const auto& mc) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL((init_chains_kernel<typename T::M, T::G>), grid_for(C, T::G, kBlock),
+                       dim3(kBlock), 0, m->stream, P, mc);
+    HIP_TRY(hipGetLastError());
+    return (int)EXMC_OK;
+  });
+}
+
+int launch_nuts(exmc_hip_model* m, int lanes, int C, int n_draws, int draw_offset, double eps,
+                int max_depth, TraceDev tr, bool timed) {
+  if (max_depth < 1 || max_depth > kMaxLevels) return fail(EXMC_ERR_BADARG, "max_tree_depth out of range");
+  return dispatch(m, lanes, [&](auto tag, const auto& mc) {
+    using T = decltype(tag);
+    using M = typename T::M;
+    dim3 grid = grid_for(C, T::G, kBlock);
+    size_t nthreads = (size_t)grid.x * kBlock;
+    int rc = m->stack.ensure((size_t)kMaxLevels * nuts_nslot<M>() * nthreads * 8);
+    if (rc) return rc;
+    NutsParams P;
+    P.st = state_view(m, C);
+    P.n_chains = C;
+    P.n_draws = n_draws;
+    P.draw_offset = draw_offset;
+    P.eps = eps;
+    P.max_depth = max_depth;
+    P.inv_mass = m->tuning.as<double>();
+    P.sqrt_inv_mass = m->tuning.as<double>() + m->d;
+    P.tr = tr;
+    P.stack = m->stack.as<double>();
+    P.counters = (unsigned long long*)(m->misc.as<double>() + 1);
+    P.zig_ki = zig_ki(m); P.zig_wi = zig_wi(m); P.zig_fi = zig_fi(m);
+    P.nor_r = EXMC_NOR_R;
+    if (timed) HIP_TRY(hipEventRecord(m->ev0, m->stream));
+    hipLaunchKernelGGL((nuts_kernel<M, T::G>), grid, dim3(kBlock), 0, m->stream, P, mc);
+    HIP_TRY(hipGetLastError());
+    if (timed) HIP_TRY(hipEventRecord(m->ev1, m->stream));
+    return (int)EXMC_OK;
+  });
+}
+
+int reset_counters(exmc_hip_model* m) {
+  HIP_TRY(hipMemsetAsync(m->misc.as<double>() + 1, 0, 16, m->stream));
+  return EXMC_OK;
+}
+int read_counters(exmc_hip_model* m, int64_t* lf, int32_t* div) {
+  unsigned long long h[2];
+  HIP_TRY(hipMemcpyAsync(h, m->misc.as<double>() + 1, 16, hipMemcpyDeviceToHost, m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  if (lf) *lf = (int64_t)h[0];
+  if (div) *div = (int32_t)h[1];
+  return EXMC_OK;
+}
+
+int finish_timing(exmc_hip_model* m) {
+  HIP_TRY(hipEventSynchronize(m->ev1));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, m->ev0, m->ev1));
+  m->last_ms = ms;
+  return EXMC_OK;
+}
+
+// [C][n][d] host <- [n][d][C] device-layout host copy
+void transpose_trace_vec(const double* src, double* dst, int n, int d, int C) {
+  for (int s = 0; s < n; s++)
+    for (int i = 0; i < d; i++)
+      for (int c = 0; c < C; c++) dst[((size_t)c * n + s) * d + i] = src[((size_t)s * d + i) * C + c];
+}
+template <class T>
+void transpose_trace_scalar(const T* src, T* dst, int n, int C) {
+  for (int s = 0; s < n; s++)
+    for (int c = 0; c < C; c++) dst[(size_t)c * n + s] = src[(size_t)s * C + c];
+}
+
+struct TraceLayout {
+  size_t off_draws, off_logp, off_depth, off_nsteps, off_div, off_acc, off_energy, total;
+};
+TraceLayout trace_layout(int S, int d, int C) {
+  TraceLayout L;
+  size_t o = 0;
+  L.off_draws = o; o += (size_t)S * d * C * 8;
+  L.off_logp = o; o += (size_t)S * C * 8;
+  L.off_acc = o; o += (size_t)S * C * 8;
+  L.off_energy = o; o += (size_t)S * C * 8;
+  L.off_depth = o; o += (size_t)S * C * 4;
+  L.off_nsteps = o; o += (size_t)S * C * 4;
+  L.off_div = o; o += (size_t)S * C * 4;
+  L.total = (o + 7) & ~(size_t)7;
+  return L;
+}
+TraceDev trace_view(void* base, const TraceLayout& L) {
+  char* b = (char*)base;
+  TraceDev t;
+  t.draws = (double*)(b + L.off_draws);
+  t.logp = (double*)(b + L.off_logp);
+  t.accept_prob = (double*)(b + L.off_acc);
+  t.energy = (double*)(b + L.off_energy);
+  t.tree_depth = (int32_t*)(b + L.off_depth);
+  t.n_steps = (int32_t*)(b + L.off_nsteps);
+  t.divergent = (int32_t*)(b + L.off_div);
+  return t;
+}
+
+// copy a device-layout staging trace to the caller's host trace ([chain][draw][dim])
+int download_trace(exmc_hip_model* m, const TraceLayout& L, int S, int C, exmc_hip_trace out) {
+  std::vector<char> h(L.total);
+  HIP_TRY(hipMemcpyAsync(h.data(), m->trace.p, L.total, hipMemcpyDeviceToHost, m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  TraceDev t = trace_view(h.data(), L);
+  if (out.draws) transpose_trace_vec(t.draws, out.draws, S, m->d, C);
+  if (out.logp) transpose_trace_scalar(t.logp, out.logp, S, C);
+  if (out.accept_prob) transpose_trace_scalar(t.accept_prob, out.accept_prob, S, C);
+  if (out.energy) transpose_trace_scalar(t.energy, out.energy, S, C);
+  if (out.tree_depth) transpose_trace_scalar(t.tree_depth, out.tree_depth, S, C);
+  if (out.n_steps) transpose_trace_scalar(t.n_steps, out.n_steps, S, C);
+  if (out.divergent) transpose_trace_scalar(t.divergent, out.divergent, S, C);
+  return EXMC_OK;
+}
+
+// ---- host-side adaptation: step_size.ex:13-50, mass_matrix.ex:40-97, sampler.ex:764-785 ----
+struct DualAvg {
+  double log_epsilon, log_epsilon_bar, h_bar, mu;
+  int m;
+  double gamma, t0, kappa, target;
+  void init(double epsilon, double target_accept) {
+    log_epsilon = std::log(epsilon);
+    log_epsilon_bar = std::log(epsilon);
+    h_bar = 0.0;
+    mu = std::log(10.0 * epsilon);
+    m = 0;
+    gamma = 0.05; t0 = 10.0; kappa = 0.75;
+    target = target_accept;
+  }
+  void update(double accept_stat) {
+    const int mm = m + 1;
+    const double eta = 1.0 / (mm + t0);
+    const double hb = (1.0 - eta) * h_bar + eta * (target - accept_stat);
+    const double le = mu - std::sqrt((double)mm) / gamma * hb;
+    const double mk = std::pow((double)mm, -kappa);
+    const double leb = mk * le + (1.0 - mk) * log_epsilon_bar;
+    m = mm; h_bar = hb; log_epsilon = le; log_epsilon_bar = leb;
+  }
+  double current() const { return std::exp(log_epsilon); }
+  double finalize() const { return std::exp(log_epsilon_bar); }
+};
+
+struct WelfordDiag {
+  int n = 0, d = 0;
+  std::vector<double> mean, m2;
+  void init(int dim) { n = 0; d = dim; mean.assign(dim, 0.0); m2.assign(dim, 0.0); }
+  void update(const double* q) {
+    const int nn = n + 1;
+    for (int i = 0; i < d; i++) {
+      const double delta = q[i] - mean[i];
+      const double nm = mean[i] + delta / ((double)nn * 1.0);
+      const double d2 = q[i] - nm;
+      m2[i] = m2[i] + delta * d2;
+      mean[i] = nm;
+    }
+    n = nn;
+  }
+  void finalize(double* inv_mass) const {
+    if (n < 3) {
+      for (int i = 0; i < d; i++) inv_mass[i] = 1.0;
+      return;
+    }
+    const double alpha = 5.0 / (n + 5.0);
+    for (int i = 0; i < d; i++) {
+      double var = m2[i] / ((double)(n - 1) * 1.0);
+      var = std::fmax(var, 1.0e-6);
+      inv_mass[i] = (1.0 - alpha) * var + alpha * 1.0e-3;
+    }
+  }
+};
+
+std::vector<std::pair<int, int>> build_windows(int from, int to, int base) {
+  std::vector<std::pair<int, int>> w;
+  if (to - from <= 0) return w;
+  int cur = from;
+  double size = base;
+  while (cur < to) {
+    const int remaining = to - cur;
+    const int actual = ((double)remaining <= size * 1.5) ? remaining : (int)size;
+    w.push_back({cur, cur + actual});
+    cur += actual;
+    size *= 2;
+  }
+  return w;
+}
+
+// One warmup transition of chain 0 on the GPU; returns accept stat, divergence flag, new q.
+struct WarmupStep {
+  double accept;
+  int divergent;
+};
+
+int warmup_transition(exmc_hip_model* m, int lanes, double eps, int max_depth, std::vector<double>& qhost,
+                      WarmupStep* out) {
+  // mini trace: draws [d], accept [1], divergent (int32) in the next 8 bytes
+  const int d = m->d;
+  int rc = m->trace.ensure((size_t)(d + 2) * 8);
+  if (rc) return rc;
+  TraceDev tr{};
+  tr.draws = m->trace.as<double>();
+  tr.accept_prob = m->trace.as<double>() + d;
+  tr.divergent = (int32_t*)(m->trace.as<double>() + d + 1);
+  rc = launch_nuts(m, lanes, 1, 1, 0, eps, max_depth, tr, false);
+  if (rc) return rc;
+  std::vector<double> h(d + 2);
+  HIP_TRY(hipMemcpyAsync(h.data(), m->trace.p, (size_t)(d + 2) * 8, hipMemcpyDeviceToHost, m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  qhost.assign(h.begin(), h.begin() + d);
+  out->accept = h[d];
+  int32_t dv;
+  std::memcpy(&dv, &h[d + 1], 4);
+  out->divergent = dv;
+  return EXMC_OK;
+}
+
+int find_eps(exmc_hip_model* m, int lanes, double* eps) {
+  FindEpsParams P;
+  P.st = state_view(m, 1);
+  P.n_chains = 1;
+  P.inv_mass = m->tuning.as<double>();
+  P.sqrt_inv_mass = m->tuning.as<double>() + m->d;
+  P.log_half = std::log(0.5);
+  P.eps_out = m->misc.as<double>();
+  P.zig_ki = zig_ki(m); P.zig_wi = zig_wi(m); P.zig_fi = zig_fi(m);
+  P.nor_r = EXMC_NOR_R;
+  int rc = dispatch(m, lanes, [&](auto tag, const auto& mc) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL((find_eps_kernel<typename T::M, T::G>), dim3(1), dim3(64), 0, m->stream, P, mc);
+    HIP_TRY(hipGetLastError());
+    return (int)EXMC_OK;
+  });
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(eps, m->misc.p, 8, hipMemcpyDeviceToHost, m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  return EXMC_OK;
+}
+
+// run_warmup (sampler.ex:537-762) on the single-chain state already initialised in m->state
+int run_warmup(exmc_hip_model* m, int lanes, exmc_hip_opts o, exmc_hip_tuning* tun) {
+  const int d = m->d, W = o.num_warmup;
+  std::vector<double> im(d, 1.0), qh(d);
+  int rc = upload_tuning(m, im.data());
+  if (rc) return rc;
+  double eps = 1.0;
+  rc = find_eps(m, lanes, &eps);
+  if (rc) return rc;
+  int divergences = 0;
+  auto finish = [&](double e) {
+    tun->epsilon = e;
+    for (int i = 0; i < d; i++) tun->inv_mass[i] = im[i];
+    tun->warmup_divergences = divergences;
+    return (int)EXMC_OK;
+  };
+  if (W == 0) return finish(eps);
+  const int init_buffer = (75 < W / 3) ? 75 : W / 3;
+  const int adapt_end = W - 50;
+  DualAvg da;
+  da.init(eps, o.target_accept);
+  WarmupStep ws;
+  for (int i = 0; i < init_buffer; i++) {
+    rc = warmup_transition(m, lanes, da.current(), o.max_tree_depth, qh, &ws);
+    if (rc) return rc;
+    divergences += ws.divergent;
+    da.update(ws.accept);
+  }
+  eps = da.current();
+  if (adapt_end <= init_buffer) return finish(da.finalize());
+  for (auto win : build_windows(init_buffer, adapt_end, 25)) {
+    WelfordDiag wf;
+    wf.init(d);
+    da.init(eps, o.target_accept);
+    for (int i = win.first; i < win.second; i++) {
+      const int cap = (i < 200) ? (o.max_tree_depth < 8 ? o.max_tree_depth : 8) : o.max_tree_depth;
+      rc = warmup_transition(m, lanes, da.current(), cap, qh, &ws);
+      if (rc) return rc;
+      divergences += ws.divergent;
+      da.update(ws.accept);
+      if (!ws.divergent) wf.update(qh.data());
+    }
+    wf.finalize(im.data());
+    rc = upload_tuning(m, im.data());
+    if (rc) return rc;
+    rc = find_eps(m, lanes, &eps);
+    if (rc) return rc;
+  }
+  da.init(eps, o.target_accept);
+  for (int i = adapt_end; i < W; i++) {
+    rc = warmup_transition(m, lanes, da.current(), o.max_tree_depth, qh, &ws);
+    if (rc) return rc;
+    divergences += ws.divergent;
+    da.update(ws.accept);
+  }
+  return finish(da.finalize());
+}
+
+int check_model(const exmc_hip_model* m) {
+  if (!m) return fail(EXMC_ERR_BADARG, "null model handle");
+  return EXMC_OK;
+}
+
+}  // namespace
+
+// =========================================== C ABI ==========================================
+extern "C" {
+
+const char* exmc_hip_last_error(void) { return g_last_error.c_str(); }
+
+int exmc_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int exmc_hip_model_create(int kind, int d, const double* data, int n_data, int device,
+                          exmc_hip_model** out) {
+  if (!out) return fail(EXMC_ERR_BADARG, "out is null");
+  *out = nullptr;
+  int ndev = exmc_hip_device_count();
+  if (ndev <= 0)
+    return fail(EXMC_ERR_NO_DEVICE, "no HIP device visible: libexmc_hip has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail(EXMC_ERR_BADARG, "device index out of range");
+  exmc_hip_model* m = new exmc_hip_model();
+  m->kind = kind;
+  m->device = device;
+  const double log2pi32 = f32r(std::log(f32r(2.0 * M_PI)));
+  switch (kind) {
+    case EXMC_MODEL_EIGHT_SCHOOLS: {
+      if (n_data != 16 || !data) { delete m; return fail(EXMC_ERR_BADARG, "eight_schools needs y[8],sigma[8]"); }
+      m->d = 10;
+      for (int j = 0; j < 8; j++) {
+        m->es.y[j] = data[j];
+        m->es.sg[j] = data[8 + j];
+        m->es.lsg[j] = std::log(data[8 + j]);
+      }
+      m->es.c_mu = log2pi32 + 2.0 * std::log(5.0);
+      m->es.c_hc = f32r(std::log(2.0 / M_PI)) - std::log(5.0);
+      m->es.c1 = log2pi32 + 2.0 * 0.0;
+      break;
+    }
+    case EXMC_MODEL_SIMPLE: {
+      if (n_data < 1 || n_data > 64 || !data) { delete m; return fail(EXMC_ERR_BADARG, "simple needs 1..64 observations"); }
+      m->d = 2;
+      m->sp.n = n_data;
+      for (int i = 0; i < n_data; i++) m->sp.y[i] = data[i];
+      m->sp.c_mu = log2pi32 + 2.0 * std::log(5.0);
+      m->sp.log2pi32 = log2pi32;
+      m->sp.tiny32 = f32r(1.0e-30);
+      break;
+    }
+    case EXMC_MODEL_SV: {
+      if (n_data != 100 || !data) { delete m; return fail(EXMC_ERR_BADARG, "sv is compiled for T = 100 returns"); }
+      m->d = 102;
+      static const double lanczos[9] = {0.99999999999980993,  676.5203681218851,     -1259.1392167224028,
+                                        771.32342877765313,   -176.61502916214059,   12.507343278686905,
+                                        -0.13857109526572012, 9.9843695780195716e-6, 1.5056327351493116e-7};
+      for (int i = 0; i < 100; i++) m->sv.r[i] = data[i];
+      for (int i = 0; i < 9; i++) m->sv.lanczos[i] = f32r(lanczos[i]);
+      m->sv.half_log_2pi32 = f32r(0.5 * std::log(2.0 * M_PI));
+      m->sv.log2pi32 = log2pi32;
+      m->sv.pi32 = f32r(M_PI);
+      m->sv.tiny32 = f32r(1.0e-30);
+      m->sv.lam_s = 50.0;
+      m->sv.lam_n = f32r(0.1);
+      m->sv.log_lam_s32 = f32r(std::log(50.0));
+      m->sv.log_lam_n32 = f32r(std::log(f32r(0.1)));
+      break;
+    }
+    default:
+      delete m;
+      return fail(EXMC_ERR_UNSUPPORTED, "model kind not compiled into libexmc_hip");
+  }
+  if (d != 0 && d != m->d) { delete m; return fail(EXMC_ERR_BADARG, "d does not match the model kind"); }
+  auto bail = [&](int rc) { exmc_hip_model_destroy(m); return rc; };
+  if (hipSetDevice(device) != hipSuccess) return bail(fail(EXMC_ERR_HIP, "hipSetDevice failed"));
+  if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess)
+    return bail(fail(EXMC_ERR_HIP, "hipStreamCreate failed"));
+  if (hipEventCreate(&m->ev0) != hipSuccess || hipEventCreate(&m->ev1) != hipSuccess)
+    return bail(fail(EXMC_ERR_HIP, "hipEventCreate failed"));
+  int rc = m->zig.ensure(768 * 8);
+  if (rc) return bail(rc);
+  rc = m->misc.ensure((8 + EXMC_HIP_MAX_D) * 8);
+  if (rc) return bail(rc);
+  if (hipMemcpy(m->zig.p, kZigKi, 256 * 8, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(m->zig.as<double>() + 256, kZigWi, 256 * 8, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(m->zig.as<double>() + 512, kZigFi, 256 * 8, hipMemcpyHostToDevice) != hipSuccess)
+    return bail(fail(EXMC_ERR_HIP, "table upload failed"));
+  *out = m;
+  return EXMC_OK;
+}
+
+void exmc_hip_model_destroy(exmc_hip_model* m) {
+  if (!m) return;
+  (void)hipSetDevice(m->device);
+  m->zig.release(); m->tuning.release(); m->state.release(); m->stack.release();
+  m->misc.release(); m->trace.release(); m->io.release();
+  if (m->ev0) (void)hipEventDestroy(m->ev0);
+  if (m->ev1) (void)hipEventDestroy(m->ev1);
+  if (m->stream) (void)hipStreamDestroy(m->stream);
+  delete m;
+}
+
+int exmc_hip_model_dim(const exmc_hip_model* m) { return m ? m->d : -1; }
+int exmc_hip_model_default_lanes(const exmc_hip_model* m) { return m ? default_lanes(m->kind) : -1; }
+void* exmc_hip_model_stream(const exmc_hip_model* m) { return m ? (void*)m->stream : nullptr; }
+double exmc_hip_last_kernel_ms(const exmc_hip_model* m) { return m ? m->last_ms : 0.0; }
+
+int exmc_hip_logp_grad_host(exmc_hip_model* m, const double* q, int C, int lanes, double* logp,
+                            double* grad) {
+  if (check_model(m)) return EXMC_ERR_BADARG;
+  if (!q || C < 1) return fail(EXMC_ERR_BADARG, "bad arguments");
+  HIP_TRY(hipSetDevice(m->device));
+  lanes = resolve_lanes(m, lanes);
+  const int d = m->d;
+  // io: q [d][C], grad [d][C], logp [C]
+  int rc = m->io.ensure(((size_t)2 * d * C + C) * 8);
+  if (rc) return rc;
+  std::vector<double> h((size_t)d * C);
+  for (int c = 0; c < C; c++)
+    for (int i = 0; i < d; i++) h[(size_t)i * C + c] = q[(size_t)c * d + i];
+  double* dq = m->io.as<double>();
+  double* dg = dq + (size_t)d * C;
+  double* dl = dg + (size_t)d * C;
+  HIP_TRY(hipMemcpyAsync(dq, h.data(), h.size() * 8, hipMemcpyHostToDevice, m->stream));
+  rc = dispatch(m, lanes, [&](auto tag, const auto& mc) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL((logp_grad_kernel<typename T::M, T::G>), grid_for(C, T::G, kBlock),
+                       dim3(kBlock), 0, m->stream, (const double*)dq, C, dl, dg, mc);
+    HIP_TRY(hipGetLastError());
+    return (int)EXMC_OK;
+  });
+  if (rc) return rc;
+  std::vector<double> hg((size_t)d * C), hl(C);
+  HIP_TRY(hipMemcpyAsync(hg.data(), dg, hg.size() * 8, hipMemcpyDeviceToHost, m->stream));
+  HIP_TRY(hipMemcpyAsync(hl.data(), dl, (size_t)C * 8, hipMemcpyDeviceToHost, m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  for (int c = 0; c < C; c++) {
+    if (logp) logp[c] = hl[c];
+    if (grad)
+      for (int i = 0; i < d; i++) grad[(size_t)c * d + i] = hg[(size_t)i * C + c];
+  }
+  return EXMC_OK;
+}
+
+int exmc_hip_multi_step(exmc_hip_model* m, const double* q, const double* p, const double* g,
+                        double eps, const double* inv_mass_host, int n_steps, int n_chains,
+                        int lanes, double* all_q, double* all_p, double* all_logp, double* all_g) {
+  if (check_model(m)) return EXMC_ERR_BADARG;
+  if (!q || !p || !g || !inv_mass_host || n_steps < 0 || n_chains < 1 || !all_q || !all_p ||
+      !all_logp || !all_g)
+    return fail(EXMC_ERR_BADARG, "bad arguments");
+  HIP_TRY(hipSetDevice(m->device));
+  lanes = resolve_lanes(m, lanes);
+  int rc = upload_tuning(m, inv_mass_host);
+  if (rc) return rc;
+  MultiStepParams P;
+  P.q = q; P.p = p; P.g = g;
+  P.eps = eps;
+  P.inv_mass = m->tuning.as<double>();
+  P.n_steps = n_steps;
+  P.n_chains = n_chains;
+  P.all_q = all_q; P.all_p = all_p; P.all_g = all_g; P.all_logp = all_logp;
+  return dispatch(m, lanes, [&](auto tag, const auto& mc) {
+    using T = decltype(tag);
+    HIP_TRY(hipEventRecord(m->ev0, m->stream));
+    hipLaunchKernelGGL((multi_step_kernel<typename T::M, T::G>), grid_for(n_chains, T::G, kBlock),
+                       dim3(kBlock), 0, m->stream, P, mc);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(m->ev1, m->stream));
+    return finish_timing(m);
+  });
+}
+
+int exmc_hip_multi_step_host(exmc_hip_model* m, const double* q, const double* p, const double* g,
+                             double eps, const double* inv_mass, int n_steps, int C, int lanes,
+                             double* all_q, double* all_p, double* all_logp, double* all_g) {
+  if (check_model(m)) return EXMC_ERR_BADARG;
+  if (!q || !p || !g || !inv_mass || n_steps < 0 || C < 1)
+    return fail(EXMC_ERR_BADARG, "bad arguments");
+  HIP_TRY(hipSetDevice(m->device));
+  const int d = m->d;
+  const size_t vec = (size_t)d * C, rows = (size_t)n_steps * d * C;
+  int rc = m->io.ensure((3 * vec + 3 * rows + (size_t)n_steps * C) * 8);
+  if (rc) return rc;
+  double* dq = m->io.as<double>();
+  double* dp = dq + vec;
+  double* dg = dp + vec;
+  double* aq = dg + vec;
+  double* ap = aq + rows;
+  double* ag = ap + rows;
+  double* al = ag + rows;
+  std::vector<double> h(3 * vec);
+  for (int c = 0; c < C; c++)
+    for (int i = 0; i < d; i++) {
+      h[(size_t)i * C + c] = q[(size_t)c * d + i];
+      h[vec + (size_t)i * C + c] = p[(size_t)c * d + i];
+      h[2 * vec + (size_t)i * C + c] = g[(size_t)c * d + i];
+    }
+  HIP_TRY(hipMemcpyAsync(dq, h.data(), h.size() * 8, hipMemcpyHostToDevice, m->stream));
+  rc = exmc_hip_multi_step(m, dq, dp, dg, eps, inv_mass, n_steps, C, lanes, aq, ap, al, ag);
+  if (rc) return rc;
+  std::vector<double> out(3 * rows + (size_t)n_steps * C);
+  HIP_TRY(hipMemcpyAsync(out.data(), aq, out.size() * 8, hipMemcpyDeviceToHost, m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  if (all_q) transpose_trace_vec(out.data(), all_q, n_steps, d, C);
+  if (all_p) transpose_trace_vec(out.data() + rows, all_p, n_steps, d, C);
+  if (all_g) transpose_trace_vec(out.data() + 2 * rows, all_g, n_steps, d, C);
+  if (all_logp) transpose_trace_scalar(out.data() + 3 * rows, all_logp, n_steps, C);
+  return EXMC_OK;
+}
+
+int exmc_hip_transitions_host(exmc_hip_model* m, double* q, double* logp, double* grad,
+                              uint64_t* rng, int C, int n_draws, double eps,
+                              const double* inv_mass, int max_depth, int lanes,
+                              exmc_hip_trace trace) {
+  if (check_model(m)) return EXMC_ERR_BADARG;
+  if (!q || !logp || !grad || !rng || !inv_mass || C < 1 || n_draws < 0)
+    return fail(EXMC_ERR_BADARG, "bad arguments");
+  HIP_TRY(hipSetDevice(m->device));
+  lanes = resolve_lanes(m, lanes);
+  const int d = m->d;
+  int rc = ensure_state(m, C);
+  if (rc) return rc;
+  rc = upload_tuning(m, inv_mass);
+  if (rc) return rc;
+  std::vector<double> hs(state_bytes(d, C) / 8);
+  double* hq = hs.data();
+  double* hg = hq + (size_t)d * C;
+  double* hl = hg + (size_t)d * C;
+  uint64_t* hr = (uint64_t*)(hl + C);
+  for (int c = 0; c < C; c++) {
+    for (int i = 0; i < d; i++) {
+      hq[(size_t)i * C + c] = q[(size_t)c * d + i];
+      hg[(size_t)i * C + c] = grad[(size_t)c * d + i];
+    }
+    hl[c] = logp[c];
+    hr[c] = rng[2 * (size_t)c];
+    hr[(size_t)C + c] = rng[2 * (size_t)c + 1];
+  }
+  HIP_TRY(hipMemcpyAsync(m->state.p, hs.data(), hs.size() * 8, hipMemcpyHostToDevice, m->stream));
+  TraceLayout L = trace_layout(n_draws > 0 ? n_draws : 1, d, C);
+  rc = m->trace.ensure(L.total);
+  if (rc) return rc;
+  rc = reset_counters(m);
+  if (rc) return rc;
+  rc = launch_nuts(m, lanes, C, n_draws, 0, eps, max_depth, trace_view(m->trace.p, L), true);
+  if (rc) return rc;
+  rc = finish_timing(m);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(hs.data(), m->state.p, hs.size() * 8, hipMemcpyDeviceToHost, m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  for (int c = 0; c < C; c++) {
+    for (int i = 0; i < d; i++) {
+      q[(size_t)c * d + i] = hq[(size_t)i * C + c];
+      grad[(size_t)c * d + i] = hg[(size_t)i * C + c];
+    }
+    logp[c] = hl[c];
+    rng[2 * (size_t)c] = hr[c];
+    rng[2 * (size_t)c + 1] = hr[(size_t)C + c];
+  }
+  if (n_draws > 0) return download_trace(m, L, n_draws, C, trace);
+  return EXMC_OK;
+}
+
+int exmc_hip_warmup(exmc_hip_model* m, const double* init_q, exmc_hip_opts o,
+                    exmc_hip_tuning* tuning) {
+  if (check_model(m)) return EXMC_ERR_BADARG;
+  if (!tuning || o.num_warmup < 0) return fail(EXMC_ERR_BADARG, "bad arguments");
+  HIP_TRY(hipSetDevice(m->device));
+  const int lanes = resolve_lanes(m, o.lanes_per_chain);
+  int rc = ensure_state(m, 1);
+  if (rc) return rc;
+  rc = launch_init(m, lanes, 1, 0, o.seed, init_q);
+  if (rc) return rc;
+  return run_warmup(m, lanes, o, tuning);
+}
+
+int exmc_hip_sample_chains(exmc_hip_model* m, const exmc_hip_tuning* tuning, const double* init_q,
+                           int n_chains, int chain_lo, int chain_hi, exmc_hip_opts o,
+                           exmc_hip_trace tr, int64_t* total_leapfrogs,
+                           int32_t* total_divergences) {
+  if (check_model(m)) return EXMC_ERR_BADARG;
+  if (!tuning || n_chains < 1 || chain_lo < 0 || chain_hi > n_chains || chain_hi <= chain_lo ||
+      o.num_samples < 0)
+    return fail(EXMC_ERR_BADARG, "bad arguments");
+  HIP_TRY(hipSetDevice(m->device));
+  const int lanes = resolve_lanes(m, o.lanes_per_chain);
+  const int C = chain_hi - chain_lo;
+  int rc = ensure_state(m, C);
+  if (rc) return rc;
+  rc = upload_tuning(m, tuning->inv_mass);
+  if (rc) return rc;
+  rc = launch_init(m, lanes, C, chain_lo, o.seed, init_q);
+  if (rc) return rc;
+  rc = reset_counters(m);
+  if (rc) return rc;
+  TraceDev t;
+  t.draws = tr.draws; t.logp = tr.logp; t.tree_depth = tr.tree_depth; t.n_steps = tr.n_steps;
+  t.divergent = tr.divergent; t.accept_prob = tr.accept_prob; t.energy = tr.energy;
+  rc = launch_nuts(m, lanes, C, o.num_samples, 0, tuning->epsilon, o.max_tree_depth, t, true);
+  if (rc) return rc;
+  rc = finish_timing(m);
+  if (rc) return rc;
+  return read_counters(m, total_leapfrogs, total_divergences);
+}
+
+int exmc_hip_sample_chains_host(exmc_hip_model* m, const exmc_hip_tuning* tuning,
+                                const double* init_q, int n_chains, int chain_lo, int chain_hi,
+                                exmc_hip_opts o, exmc_hip_trace tr, int64_t* total_leapfrogs,
+                                int32_t* total_divergences) {
+  if (check_model(m)) return EXMC_ERR_BADARG;
+  if (chain_hi <= chain_lo || o.num_samples < 1) return fail(EXMC_ERR_BADARG, "bad arguments");
+  HIP_TRY(hipSetDevice(m->device));
+  const int C = chain_hi - chain_lo;
+  TraceLayout L = trace_layout(o.num_samples, m->d, C);
+  int rc = m->trace.ensure(L.total);
+  if (rc) return rc;
+  TraceDev t = trace_view(m->trace.p, L);
+  exmc_hip_trace dv;
+  dv.draws = t.draws; dv.logp = t.logp; dv.tree_depth = t.tree_depth; dv.n_steps = t.n_steps;
+  dv.divergent = t.divergent; dv.accept_prob = t.accept_prob; dv.energy = t.energy;
+  rc = exmc_hip_sample_chains(m, tuning, init_q, n_chains, chain_lo, chain_hi, o, dv,
+                              total_leapfrogs, total_divergences);
+  if (rc) return rc;
+  return download_trace(m, L, o.num_samples, C, tr);
+}
+
+int exmc_hip_sample_host(exmc_hip_model* m, const double* init_q, exmc_hip_opts o,
+                         exmc_hip_trace tr, exmc_hip_tuning* tuning_out, int32_t* divergences) {
+  if (check_model(m)) return EXMC_ERR_BADARG;
+  if (o.num_samples < 1) return fail(EXMC_ERR_BADARG, "num_samples must be >= 1");
+  exmc_hip_tuning tun;
+  int rc = exmc_hip_warmup(m, init_q, o, &tun);  // leaves chain 0's state in m->state
+  if (rc) return rc;
+  const int lanes = resolve_lanes(m, o.lanes_per_chain);
+  rc = upload_tuning(m, tun.inv_mass);
+  if (rc) return rc;
+  TraceLayout L = trace_layout(o.num_samples, m->d, 1);
+  rc = m->trace.ensure(L.total);
+  if (rc) return rc;
+  rc = reset_counters(m);
+  if (rc) return rc;
+  rc = launch_nuts(m, lanes, 1, o.num_samples, 0, tun.epsilon, o.max_tree_depth,
+                   trace_view(m->trace.p, L), true);
+  if (rc) return rc;
+  rc = finish_timing(m);
+  if (rc) return rc;
+  int32_t div = 0;
+  rc = read_counters(m, nullptr, &div);
+  if (rc) return rc;
+  if (divergences) *divergences = div + tun.warmup_divergences;  // stats.divergences, sampler.ex:245
+  if (tuning_out) *tuning_out = tun;
+  return download_trace(m, L, o.num_samples, 1, tr);
+}
+
+int exmc_hip_ess(exmc_hip_model* m, const double* draws_dev, int n_draws, int d, int n_chains,
+                 double* ess_dev) {
+  if (check_model(m)) return EXMC_ERR_BADARG;
+  if (!draws_dev || !ess_dev || n_draws < 1 || d < 1 || n_chains < 1)
+    return fail(EXMC_ERR_BADARG, "bad arguments");
+  if ((size_t)n_draws * 16 > 64 * 1024) return fail(EXMC_ERR_UNSUPPORTED, "n_draws too large for the LDS ess kernel");
+  HIP_TRY(hipSetDevice(m->device));
+  HIP_TRY(hipEventRecord(m->ev0, m->stream));
+  hipLaunchKernelGGL(ess_kernel, dim3((unsigned)(d * n_chains)), dim3(256), (size_t)n_draws * 16,
+                     m->stream, draws_dev, n_draws, d, n_chains, ess_dev);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(m->ev1, m->stream));
+  return finish_timing(m);
+}
+
+}  // extern "C"

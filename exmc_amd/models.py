@@ -1,0 +1,75 @@
+"""Model descriptions for the BASELINE configs.
+
+The reference describes models as Builder/DSL IR (lib/exmc/builder.ex); the HIP library takes a
+model *kind* plus its data. A ModelSpec carries what Exmc.PointMap carries for the kind: the free
+variables in kernel order, their transforms (lib/exmc/transform.ex) and the reference's flat
+(alphabetical, point_map.ex:37) order.
+"""
+import numpy as np
+
+STD_NORMAL, SIMPLE, EIGHT_SCHOOLS, SV, LOGISTIC, RADON = range(6)
+
+EIGHT_SCHOOLS_Y = [28.0, 8.0, -3.0, 7.0, -1.0, 1.0, 18.0, 12.0]
+EIGHT_SCHOOLS_SIGMA = [15.0, 10.0, 16.0, 11.0, 9.0, 11.0, 10.0, 18.0]
+# README.md:72-74 (Nx.tensor([...]) defaults to f32)
+SIMPLE_Y = [float(np.float32(v)) for v in (2.1, 1.8, 2.5, 2.0, 1.9, 2.3, 2.2, 1.7, 2.4, 2.6)]
+
+
+class ModelSpec:
+    def __init__(self, kind, name, data, var_names, transforms, default_init=None):
+        self.kind = kind
+        self.name = name
+        self.data = np.ascontiguousarray(np.asarray(data, dtype=np.float64))
+        self.var_names = list(var_names)          # kernel order
+        self.transforms = dict(transforms)        # var name -> "log" | None
+        self.d = len(self.var_names)
+        self.default_init = default_init
+
+    # reference flat layout = ids sorted as strings (point_map.ex:37)
+    def flat_order(self):
+        return sorted(range(self.d), key=lambda i: self.var_names[i])
+
+    def to_unconstrained(self, init_values):
+        """PointMap.to_unconstrained + pack (sampler.ex:351-356); missing names are an error, as
+        Map.fetch! is in the reference."""
+        q = np.zeros(self.d)
+        for i, name in enumerate(self.var_names):
+            x = float(init_values[name])
+            q[i] = np.log(x) if self.transforms.get(name) == "log" else x
+        return q
+
+    def constrain(self, q):
+        """Transform.apply per entry (transform.ex:15-29): q [..., d] -> constrained."""
+        x = np.array(q, dtype=np.float64, copy=True)
+        for i, name in enumerate(self.var_names):
+            if self.transforms.get(name) == "log":
+                x[..., i] = np.exp(np.clip(x[..., i], -200.0, 200.0))
+        return x
+
+
+def eight_schools(y=EIGHT_SCHOOLS_Y, sigma=EIGHT_SCHOOLS_SIGMA):
+    """Non-centered eight schools (benchmark/posteriordb/validate_posteriordb.exs:246-324)."""
+    names = ["mu", "tau"] + ["theta_trans_%d" % j for j in range(8)]
+    init = {n: 0.0 for n in names}
+    init["tau"] = 1.0   # validate_posteriordb.exs:310-313
+    return ModelSpec(EIGHT_SCHOOLS, "eight_schools", list(y) + list(sigma), names, {"tau": "log"},
+                     init)
+
+
+def simple(y=SIMPLE_Y):
+    """d=2 plumbing model: mu ~ N(0,5), sigma ~ Exponential(1), y ~ N(mu, sigma)."""
+    return ModelSpec(SIMPLE, "simple", list(y), ["mu", "sigma"], {"sigma": "log"},
+                     {"mu": 2.0, "sigma": 1.0})
+
+
+def sv(returns):
+    """Stochastic volatility, T = 100 (STANDARD_BENCHMARKS.md:51-61). Kernel order s_1..s_T,
+    sigma, nu; the reference's flat order is the string sort (nu, s_1, s_10, s_100, ...)."""
+    r = list(returns)
+    if len(r) != 100:
+        raise ValueError("libexmc_hip compiles sv for T = 100")
+    names = ["s_%d" % t for t in range(1, 101)] + ["sigma", "nu"]
+    init = {n: 0.0 for n in names}
+    init["sigma"] = 0.1
+    init["nu"] = 10.0
+    return ModelSpec(SV, "sv", r, names, {"sigma": "log", "nu": "log"}, init)

@@ -1,0 +1,239 @@
+"""Host-side mirror of Exmc.NUTS.Sampler (lib/exmc/nuts/sampler.ex) over libexmc_hip.so.
+
+Same entry points, option names, return shapes and error behaviour as the reference module:
+    sample(ir, init_values, opts)            -> {trace, stats}          sampler.ex:33-37
+    sample_chains(ir, num_chains, opts)      -> {[trace], [stats]}      sampler.ex:992-1000
+    sample_stream(ir, receiver, init, opts)  -> :ok + messages          sampler.ex:1186-1277
+    compile / sample_compiled / sample_compiled_tuned / sample_chains_compiled
+The "ir" here is an exmc_amd.models.ModelSpec. All arithmetic of the hot path runs in the HIP
+kernels; this file only marshals buffers. There is no CPU fallback.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .models import ModelSpec
+
+DEFAULT_OPTS = dict(num_warmup=1000, num_samples=1000, max_tree_depth=10, target_accept=0.8,
+                    seed=0, supervised=False)  # sampler.ex:16-23
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class Compiled:
+    """Compiler.compile_for_sampling/2 result (compiler.ex:46-58): owns the device handle."""
+
+    def __init__(self, spec, device=0):
+        if not isinstance(spec, ModelSpec):
+            raise TypeError("expected a ModelSpec")
+        self.spec = spec
+        L = _lib.load()
+        h = C.c_void_p()
+        _lib.check(L.exmc_hip_model_create(spec.kind, spec.d, _dp(spec.data), int(spec.data.size),
+                                           int(device), C.byref(h)))
+        self.h = h
+        self.d = spec.d
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            _lib.load().exmc_hip_model_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def default_lanes(self):
+        return _lib.load().exmc_hip_model_default_lanes(self.h)
+
+    @property
+    def last_kernel_ms(self):
+        return _lib.load().exmc_hip_last_kernel_ms(self.h)
+
+
+def compile(ir, opts=None):  # noqa: A001  (name mirrors Sampler.compile/2)
+    opts = opts or {}
+    return Compiled(ir, device=opts.get("device", 0))
+
+
+def _merge_opts(opts):
+    o = dict(DEFAULT_OPTS)
+    o.update(opts or {})
+    return o
+
+
+def _c_opts(o, lanes=None):
+    return _lib.Opts(int(o["num_warmup"]), int(o["num_samples"]), int(o["max_tree_depth"]),
+                     float(o["target_accept"]), int(o["seed"]),
+                     int(lanes if lanes is not None else o.get("lanes_per_chain", 0)))
+
+
+def _init_q(spec, init_values):
+    if not init_values:
+        return None  # sampler.ex:339-349: 0.1 * normal_s per dimension
+    return np.ascontiguousarray(spec.to_unconstrained(init_values))
+
+
+def _host_trace(n_chains, num_samples, d):
+    n = n_chains * num_samples
+    t = dict(draws=np.zeros((n_chains, num_samples, d)), logp=np.zeros((n_chains, num_samples)),
+             tree_depth=np.zeros((n_chains, num_samples), np.int32),
+             n_steps=np.zeros((n_chains, num_samples), np.int32),
+             divergent=np.zeros((n_chains, num_samples), np.int32),
+             accept_prob=np.zeros((n_chains, num_samples)),
+             energy=np.zeros((n_chains, num_samples)))
+    assert n >= 0
+    tr = _lib.Trace(*[t[k].ctypes.data for k in
+                      ("draws", "logp", "tree_depth", "n_steps", "divergent", "accept_prob",
+                       "energy")])
+    return t, tr
+
+
+class SampleStats:
+    """stats.sample_stats (sampler.ex:960-967): a sequence of per-draw maps, backed by arrays."""
+
+    def __init__(self, raw, chain):
+        self._raw = raw
+        self._c = chain
+
+    def __len__(self):
+        return self._raw["tree_depth"].shape[1]
+
+    def __getitem__(self, i):
+        r, c = self._raw, self._c
+        return dict(tree_depth=int(r["tree_depth"][c, i]), n_steps=int(r["n_steps"][c, i]),
+                    divergent=bool(r["divergent"][c, i]), accept_prob=float(r["accept_prob"][c, i]),
+                    energy=float(r["energy"][c, i]), recovered=False)
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+    def column(self, key):
+        return self._raw[key][self._c]
+
+
+def _build_trace(spec, draws):
+    """build_trace (sampler.ex:1281-1298): slice per entry + forward transform."""
+    x = spec.constrain(draws)
+    return {name: x[:, i] for i, name in enumerate(spec.var_names)}
+
+
+def _tuning_struct(tuning, d):
+    t = _lib.Tuning()
+    t.epsilon = float(tuning["epsilon"])
+    im = np.asarray(tuning["inv_mass"], dtype=np.float64)
+    if im.ndim != 1 or im.shape[0] != d:
+        raise ValueError("inv_mass must be a rank-1 tensor of length d (dense mass is not built)")
+    for i in range(d):
+        t.inv_mass[i] = im[i]
+    return t
+
+
+def sample_compiled(compiled, init_values=None, opts=None):
+    """sample_from_compiled (sampler.ex:126-257), cold start, diagonal mass."""
+    o = _merge_opts(opts)
+    spec = compiled.spec
+    L = _lib.load()
+    t, tr = _host_trace(1, o["num_samples"], spec.d)
+    tun = _lib.Tuning()
+    div = C.c_int32()
+    iq = _init_q(spec, init_values)
+    _lib.check(L.exmc_hip_sample_host(compiled.h, None if iq is None else _dp(iq), _c_opts(o), tr,
+                                      C.byref(tun), C.byref(div)))
+    trace = _build_trace(spec, t["draws"][0])
+    stats = dict(step_size=tun.epsilon, inv_mass_diag=np.array(tun.inv_mass[:spec.d]),
+                 divergences=int(div.value), recoveries=0, num_warmup=o["num_warmup"],
+                 num_samples=o["num_samples"], sample_stats=SampleStats(t, 0), raw=t)
+    return trace, stats
+
+
+def sample(ir, init_values=None, opts=None):
+    """Exmc.NUTS.Sampler.sample/3."""
+    opts = opts or {}
+    compiled = ir if isinstance(ir, Compiled) else Compiled(ir, device=opts.get("device", 0))
+    return sample_compiled(compiled, init_values, opts)
+
+
+def warmup(compiled, init_values=None, opts=None):
+    """Shared warmup on chain 0 (sampler.ex:1053-1080); returns the tuning map."""
+    o = _merge_opts(opts)
+    L = _lib.load()
+    tun = _lib.Tuning()
+    iq = _init_q(compiled.spec, init_values)
+    _lib.check(L.exmc_hip_warmup(compiled.h, None if iq is None else _dp(iq), _c_opts(o),
+                                 C.byref(tun)))
+    return dict(epsilon=tun.epsilon, inv_mass=np.array(tun.inv_mass[:compiled.d]), chol_cov=None,
+                warmup_divergences=tun.warmup_divergences)
+
+
+def sample_compiled_tuned(compiled, tuning, init_values=None, opts=None, num_chains=1,
+                          chain_lo=0, chain_hi=None):
+    """sample_compiled_tuned/4 (sampler.ex:69-71, 260-335), generalised to a chain range: chain i
+    uses seed + 7919*i (sampler.ex:1083)."""
+    o = _merge_opts(opts)
+    spec = compiled.spec
+    L = _lib.load()
+    chain_hi = num_chains if chain_hi is None else chain_hi
+    nc = chain_hi - chain_lo
+    t, tr = _host_trace(nc, o["num_samples"], spec.d)
+    tun = _tuning_struct(tuning, spec.d)
+    lf = C.c_int64()
+    dv = C.c_int32()
+    iq = _init_q(spec, init_values)
+    _lib.check(L.exmc_hip_sample_chains_host(compiled.h, C.byref(tun),
+                                             None if iq is None else _dp(iq), num_chains,
+                                             chain_lo, chain_hi, _c_opts(o), tr, C.byref(lf),
+                                             C.byref(dv)))
+    traces, stats = [], []
+    for c in range(nc):
+        traces.append(_build_trace(spec, t["draws"][c]))
+        stats.append(dict(step_size=tun.epsilon, inv_mass_diag=np.array(tun.inv_mass[:spec.d]),
+                          divergences=int(t["divergent"][c].sum()), num_warmup=o["num_warmup"],
+                          num_samples=o["num_samples"], sample_stats=SampleStats(t, c)))
+    extra = dict(total_leapfrogs=int(lf.value), total_divergences=int(dv.value), raw=t,
+                 kernel_ms=compiled.last_kernel_ms)
+    return traces, stats, extra
+
+
+def sample_chains_compiled(compiled, num_chains, opts=None):
+    """sample_chains_vectorized_compiled (sampler.ex:1020-1136): warmup once on chain 0, then all
+    chains share epsilon and the mass matrix. On the GPU the chains run as one batch."""
+    if num_chains < 1:
+        raise ValueError("num_chains must be >= 1")
+    o = _merge_opts(opts)
+    init_values = o.get("init_values") or {}
+    tuning = warmup(compiled, init_values, o)
+    traces, stats, extra = sample_compiled_tuned(compiled, tuning, init_values, o,
+                                                 num_chains=num_chains)
+    for s in stats:
+        s["extra"] = extra
+    return traces, stats
+
+
+def sample_chains(ir, num_chains, opts=None):
+    """Exmc.NUTS.Sampler.sample_chains/3."""
+    opts = opts or {}
+    compiled = ir if isinstance(ir, Compiled) else Compiled(ir, device=opts.get("device", 0))
+    return sample_chains_compiled(compiled, num_chains, opts)
+
+
+def sample_stream(ir, receiver, init_values=None, opts=None):
+    """Exmc.NUTS.Sampler.sample_stream/4: `receiver` is called with the reference's messages,
+    ("exmc_sample", i, point_map, step_stat) for i = 1..n then ("exmc_done", n). Draws are produced
+    by one GPU launch and delivered in order (per-draw host notification is a later row)."""
+    o = _merge_opts(opts)
+    trace, stats = sample(ir, init_values, o)
+    n = o["num_samples"]
+    names = list(trace.keys())
+    for i in range(n):
+        point_map = {k: float(trace[k][i]) for k in names}
+        receiver(("exmc_sample", i + 1, point_map, stats["sample_stats"][i]))
+    receiver(("exmc_done", n))
+    return "ok"

@@ -1,0 +1,158 @@
+/* exmc_hip.h — C ABI of libexmc_hip.so: the MI355X (gfx950) NUTS inner loop for eXMC.
+ *
+ * Drop-in boundary. Each entry point names the reference interface it replaces
+ * (paths under the reference repository). Plain pointers and sizes only; integer error codes;
+ * the library never calls back into the host VM; one HIP stream per model handle.
+ *
+ * Memory conventions
+ *   "dev"  pointers are device (HBM) pointers on the handle's GPU.
+ *   "host" pointers are ordinary host memory; the call copies in/out (PCIe inclusive).
+ *   Chain-batched device layout: vectors are [dim][chain] (chain index fastest, so a 64-lane
+ *   wavefront reads 64 consecutive chains), scalars are [chain], traces are
+ *   [draw][dim][chain] and [draw][chain].
+ *   Host layout follows the reference NIF: native-endian f64, row-major [chain][step][dim]
+ *   (native/exmc_tree/src/lib.rs:19-24, types.rs:36-43).
+ *
+ * Numeric contract: IEEE f64 throughout (lib/exmc/jit.ex:90-98 => :f64); exp/log through
+ * include/exmc_detmath.h; reductions over a chain's dimensions in the G-lane order documented
+ * in DESIGN.md (G = lanes_per_chain; G = 1 is the reference's left-to-right order).
+ */
+#ifndef EXMC_HIP_H
+#define EXMC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EXMC_HIP_MAX_D 256
+
+/* error codes */
+enum {
+  EXMC_OK = 0,
+  EXMC_ERR_BADARG = 1,      /* NIF badarg equivalent (lib.rs NifResult) */
+  EXMC_ERR_NO_DEVICE = 2,   /* no HIP device / extension cannot run: callers must fail loudly */
+  EXMC_ERR_HIP = 3,         /* a HIP runtime call failed; see exmc_hip_last_error() */
+  EXMC_ERR_UNSUPPORTED = 4  /* model kind / lanes_per_chain combination not compiled in */
+};
+
+/* model kinds: the BASELINE.json configs */
+enum {
+  EXMC_MODEL_STD_NORMAL = 0,
+  EXMC_MODEL_SIMPLE = 1,
+  EXMC_MODEL_EIGHT_SCHOOLS = 2,
+  EXMC_MODEL_SV = 3,
+  EXMC_MODEL_LOGISTIC = 4,
+  EXMC_MODEL_RADON = 5
+};
+
+typedef struct exmc_hip_model exmc_hip_model;
+
+/* Sampler options: Exmc.NUTS.Sampler @default_opts (lib/exmc/nuts/sampler.ex:16-23). */
+typedef struct {
+  int num_warmup;       /* 1000 */
+  int num_samples;      /* 1000 */
+  int max_tree_depth;   /* 10   */
+  double target_accept; /* 0.8  */
+  uint64_t seed;        /* 0    */
+  int lanes_per_chain;  /* G: 0 = library default for the model */
+} exmc_hip_opts;
+
+/* Tuning hand-off: the `tuning` map of sample_compiled_tuned (sampler.ex:62-71) and
+ * Distributed's %{epsilon, inv_mass, chol_cov: nil} (lib/exmc/nuts/distributed.ex:141-146). */
+typedef struct {
+  double epsilon;
+  double inv_mass[EXMC_HIP_MAX_D];
+  int warmup_divergences;
+} exmc_hip_tuning;
+
+/* Per-draw outputs = stats.sample_stats + draws (sampler.ex:242-250, 960-967).
+ * Any pointer may be NULL. */
+typedef struct {
+  double* draws;       /* unconstrained position q */
+  double* logp;
+  int32_t* tree_depth;
+  int32_t* n_steps;
+  int32_t* divergent;
+  double* accept_prob;
+  double* energy;
+} exmc_hip_trace;
+
+const char* exmc_hip_last_error(void);
+int exmc_hip_device_count(void);
+
+/* Replaces Compiler.compile_for_sampling/2 for the built-in model kinds
+ * (lib/exmc/compiler.ex:46-58): uploads model data, prepares per-model constants.
+ * `data`/`n_data` per kind: EIGHT_SCHOOLS y[8],sigma[8]; SIMPLE y[n]; SV r[T]; STD_NORMAL none. */
+int exmc_hip_model_create(int kind, int d, const double* data, int n_data, int device,
+                          exmc_hip_model** out);
+void exmc_hip_model_destroy(exmc_hip_model* m);
+int exmc_hip_model_dim(const exmc_hip_model* m);
+int exmc_hip_model_default_lanes(const exmc_hip_model* m);
+/* the model handle's HIP stream (hipStream_t as void*) */
+void* exmc_hip_model_stream(const exmc_hip_model* m);
+
+/* vag_fn batched (compiler.ex:131-141): q host [C][d] -> logp host [C], grad host [C][d]. */
+int exmc_hip_logp_grad_host(exmc_hip_model* m, const double* q, int n_chains, int lanes,
+                            double* logp, double* grad);
+
+/* multi_step_fn, chain-batched (lib/exmc/nuts/batched_leapfrog.ex:21-48, :50-101).
+ * Device form: q,p,g dev [d][C]; outputs dev all_q/all_p/all_g [n][d][C], all_logp [n][C]
+ * (raw logp, not joint; batched_leapfrog.ex:87). eps may be negative (tree.ex:516-519).
+ * Only n_steps rows are written. */
+int exmc_hip_multi_step(exmc_hip_model* m, const double* q, const double* p, const double* g,
+                        double eps, const double* inv_mass_host, int n_steps, int n_chains,
+                        int lanes, double* all_q, double* all_p, double* all_logp, double* all_g);
+/* Host form, reference layout: q,p,g [C][d]; outputs [C][n][d], [C][n]. */
+int exmc_hip_multi_step_host(exmc_hip_model* m, const double* q, const double* p, const double* g,
+                             double eps, const double* inv_mass, int n_steps, int n_chains,
+                             int lanes, double* all_q, double* all_p, double* all_logp,
+                             double* all_g);
+
+/* One NUTS transition per chain from explicit state, for parity tests of Tree.build/12
+ * (lib/exmc/nuts/tree.ex:65-151) + nuts_step_with_stats (sampler.ex:854-925).
+ * Host in/out: q [C][d], logp [C], grad [C][d], rng [C][2] (exsss words a,b). */
+int exmc_hip_transitions_host(exmc_hip_model* m, double* q, double* logp, double* grad,
+                              uint64_t* rng, int n_chains, int n_draws, double eps,
+                              const double* inv_mass, int max_depth, int lanes,
+                              exmc_hip_trace trace /* host, [C][n_draws][..] */);
+
+/* Shared warmup on chain 0 (sampler.ex:1053-1080 -> run_warmup :537-621): transitions run on
+ * the GPU, dual averaging / Welford / window schedule on the host as the reference does
+ * (step_size.ex, mass_matrix.ex are plain Erlang floats there too).
+ * init_q NULL => 0.1*normal_s per dim (sampler.ex:339-349). */
+int exmc_hip_warmup(exmc_hip_model* m, const double* init_q, exmc_hip_opts opts,
+                    exmc_hip_tuning* tuning);
+
+/* Exmc.NUTS.Sampler.sample_chains vectorized, sampling phase (sampler.ex:1082-1130) for chains
+ * [chain_lo, chain_hi) of n_chains: chain i is seeded seed + 7919*i whatever the shard.
+ * Device trace layout [draw][dim][chain_local] / [draw][chain_local]; the trace buffers are
+ * caller-owned device memory. total_leapfrogs (may be NULL) receives sum of n_steps. */
+int exmc_hip_sample_chains(exmc_hip_model* m, const exmc_hip_tuning* tuning, const double* init_q,
+                           int n_chains, int chain_lo, int chain_hi, exmc_hip_opts opts,
+                           exmc_hip_trace trace_dev, int64_t* total_leapfrogs,
+                           int32_t* total_divergences);
+/* Same with host trace buffers in the reference's per-chain layout [chain][draw][dim]. */
+int exmc_hip_sample_chains_host(exmc_hip_model* m, const exmc_hip_tuning* tuning,
+                                const double* init_q, int n_chains, int chain_lo, int chain_hi,
+                                exmc_hip_opts opts, exmc_hip_trace trace_host,
+                                int64_t* total_leapfrogs, int32_t* total_divergences);
+
+/* Exmc.NUTS.Sampler.sample/3 for one chain (sampler.ex:126-257): warmup + sampling. */
+int exmc_hip_sample_host(exmc_hip_model* m, const double* init_q, exmc_hip_opts opts,
+                         exmc_hip_trace trace_host, exmc_hip_tuning* tuning_out,
+                         int32_t* divergences);
+
+/* Exmc.Diagnostics.ess / rhat (lib/exmc/diagnostics.ex:42-52, 80-115) over a device trace
+ * [draw][dim][chain]: ess_out dev [dim][chain]; rhat computed across all chains per dim. */
+int exmc_hip_ess(exmc_hip_model* m, const double* draws_dev, int n_draws, int d, int n_chains,
+                 double* ess_dev);
+
+/* wall-clock of the last timed kernel region on the handle's stream, HIP events (ms) */
+double exmc_hip_last_kernel_ms(const exmc_hip_model* m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,191 @@
+"""GPU parity: the HIP path (through the C ABI) vs the CPU checker, bit for bit.
+
+The checker runs in deterministic-math mode with the same lane layout G as the kernel
+(oracle/exmc_oracle.h). Integer outputs (tree depth, n_steps, divergence flags) AND floating
+outputs (positions, log-prob, accept stat, energy) are required to be identical bits; the
+tolerance against libm mode (the reference's own arithmetic) is asserted separately in
+tests/test_oracle_modes.py.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle as O
+from exmc_amd import _lib, models, sampler
+
+pytestmark = pytest.mark.gpu
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+@pytest.fixture(scope="module")
+def es(hip):
+    spec = models.eight_schools()
+    return spec, sampler.compile(spec), O.eight_schools()
+
+
+def _rand_q(rng, n, d, scale=1.0):
+    return np.ascontiguousarray(rng.normal(size=(n, d)) * scale)
+
+
+@pytest.mark.parametrize("lanes", [1, 2, 4, 8, 16])
+def test_logp_grad_bit_exact(es, hip, lanes):
+    spec, comp, om = es
+    rng = np.random.default_rng(7)
+    C_ = 257
+    q = _rand_q(rng, C_, spec.d, 1.5)
+    q[0] = 0.0
+    q[1, 1] = 250.0   # outside the :log clamp (transform.ex:17-29)
+    q[2, 1] = -250.0
+    lp = np.zeros(C_)
+    g = np.zeros((C_, spec.d))
+    _lib.check(hip.exmc_hip_logp_grad_host(comp.h, _dp(q), C_, lanes, _dp(lp), _dp(g)))
+    cfg = O.Cfg(1, lanes)
+    for c in range(C_):
+        olp, og = om.logp_grad(q[c], cfg)
+        assert olp == lp[c] or (np.isnan(olp) and np.isnan(lp[c])), (c, olp, lp[c])
+        assert np.array_equal(og, g[c]), (c, og, g[c])
+
+
+@pytest.mark.parametrize("lanes", [1, 8, 16])
+@pytest.mark.parametrize("eps", [0.3, -0.3])
+def test_multi_step_bit_exact(es, hip, lanes, eps):
+    spec, comp, om = es
+    rng = np.random.default_rng(11)
+    C_, n = 70, 37
+    d = spec.d
+    q = _rand_q(rng, C_, d, 0.5)
+    p = _rand_q(rng, C_, d)
+    im = np.ascontiguousarray(rng.uniform(0.5, 2.0, size=d))
+    cfg = O.Cfg(1, lanes)
+    g = np.array([om.logp_grad(q[c], cfg)[1] for c in range(C_)])
+    aq = np.zeros((C_, n, d)); ap = np.zeros((C_, n, d)); ag = np.zeros((C_, n, d))
+    alp = np.zeros((C_, n))
+    _lib.check(hip.exmc_hip_multi_step_host(comp.h, _dp(q), _dp(p), _dp(g), eps, _dp(im), n, C_,
+                                            lanes, _dp(aq), _dp(ap), _dp(alp), _dp(ag)))
+    for c in range(0, C_, 7):
+        oq, op, olp, og = om.multi_step(q[c], p[c], g[c], eps, im, n, cfg)
+        assert np.array_equal(oq, aq[c]) and np.array_equal(op, ap[c])
+        assert np.array_equal(olp, alp[c]) and np.array_equal(og, ag[c])
+
+
+def _oracle_transitions(om, q, logp, g, rngs, n_draws, eps, im, max_depth, cfg):
+    """Apply n_draws NUTS transitions per chain with the checker (sampler.ex:854-925)."""
+    L = O.lib()
+    C_, d = q.shape
+    out = dict(draws=np.zeros((C_, n_draws, d)), logp=np.zeros((C_, n_draws)),
+               tree_depth=np.zeros((C_, n_draws), np.int32), n_steps=np.zeros((C_, n_draws), np.int32),
+               divergent=np.zeros((C_, n_draws), np.int32), accept_prob=np.zeros((C_, n_draws)),
+               energy=np.zeros((C_, n_draws)))
+    for c in range(C_):
+        r = O.Rng(int(rngs[c, 0]), int(rngs[c, 1]))
+        qc, gc, lpc = q[c].copy(), g[c].copy(), float(logp[c])
+        for s in range(n_draws):
+            p = np.array([L.exo_rng_normal(C.byref(r), cfg.math_mode) / np.sqrt(im[i])
+                          for i in range(d)])
+            ke = L.exo_kinetic_energy(_dp(p), _dp(im), d, cfg)
+            jlp0 = lpc - ke
+            qo, go, res = om.tree_build(qc, p, lpc, gc, eps, im, max_depth, r, jlp0, cfg)
+            L.exo_rng_uniform(C.byref(r))
+            qc, gc, lpc = qo, go, res.logp
+            out["draws"][c, s] = qc
+            out["logp"][c, s] = lpc
+            out["tree_depth"][c, s] = res.depth
+            out["n_steps"][c, s] = res.n_steps
+            out["divergent"][c, s] = res.divergent
+            out["accept_prob"][c, s] = res.accept_sum / res.n_steps if res.n_steps else 0.0
+            out["energy"][c, s] = -jlp0
+        rngs[c, 0], rngs[c, 1] = r.a, r.b
+        q[c], g[c], logp[c] = qc, gc, lpc
+    return out
+
+
+@pytest.mark.parametrize("lanes,eps,max_depth", [(1, 0.45, 10), (16, 0.45, 10), (8, 0.2, 6),
+                                                 (16, 1.6, 10), (4, 0.02, 5), (2, 0.45, 3)])
+def test_transitions_bit_exact(es, hip, lanes, eps, max_depth):
+    """Whole transitions from explicit state: every per-draw output identical to the checker,
+    including divergent trees (eps 1.6) and depth-capped trees (eps 0.02, depth 5)."""
+    spec, comp, om = es
+    rng = np.random.default_rng(5 + lanes)
+    C_, n_draws, d = 33, 12, spec.d
+    cfg = O.Cfg(1, lanes)
+    q = _rand_q(rng, C_, d, 0.7)
+    im = np.ascontiguousarray(rng.uniform(0.3, 3.0, size=d))
+    g = np.zeros((C_, d)); logp = np.zeros(C_)
+    for c in range(C_):
+        logp[c], g[c] = om.logp_grad(q[c], cfg)
+    rngs = np.zeros((C_, 2), dtype=np.uint64)
+    for c in range(C_):
+        r = O.Rng()
+        O.lib().exo_rng_seed(C.byref(r), 1000 + c)
+        rngs[c] = (r.a, r.b)
+    hq, hg, hl, hr = q.copy(), g.copy(), logp.copy(), rngs.copy()
+    t, tr = sampler._host_trace(C_, n_draws, d)
+    _lib.check(hip.exmc_hip_transitions_host(comp.h, _dp(hq), _dp(hl), _dp(hg),
+                                             hr.ctypes.data_as(C.POINTER(C.c_uint64)), C_, n_draws,
+                                             eps, _dp(im), max_depth, lanes, tr))
+    o = _oracle_transitions(om, q, logp, g, rngs, n_draws, eps, im, max_depth, cfg)
+    for k in ("tree_depth", "n_steps", "divergent"):
+        assert np.array_equal(o[k], t[k]), k
+    for k in ("draws", "logp", "accept_prob", "energy"):
+        assert np.array_equal(o[k], t[k]), k
+    assert np.array_equal(hq, q) and np.array_equal(hg, g) and np.array_equal(hl, logp)
+    assert np.array_equal(hr, rngs)
+    if eps > 1.0:
+        assert t["divergent"].sum() > 0
+
+
+@pytest.mark.parametrize("lanes", [1, 16])
+def test_warmup_and_chains_bit_exact(es, hip, lanes):
+    """sample_chains vectorized semantics (sampler.ex:1020-1136): shared warmup on chain 0, then
+    chains seeded seed + 7919*i. Tuning and every draw identical to the checker."""
+    spec, comp, om = es
+    opts = dict(num_warmup=150, num_samples=60, seed=42, lanes_per_chain=lanes)
+    tuning = sampler.warmup(comp, spec.default_init, opts)
+    q0 = spec.to_unconstrained(spec.default_init)
+    cfg = O.Cfg(1, lanes)
+    n_chains = 24
+    t, st = O.sample_chains(om, n_chains, init_q=q0, num_warmup=150, num_samples=60, seed=42, cfg=cfg)
+    assert st.step_size == tuning["epsilon"]
+    assert np.array_equal(np.array(st.inv_mass[:spec.d]), tuning["inv_mass"])
+    traces, stats, extra = sampler.sample_compiled_tuned(comp, tuning, spec.default_init, opts,
+                                                         num_chains=n_chains)
+    raw = extra["raw"]
+    for k in ("tree_depth", "n_steps", "divergent", "draws", "logp", "accept_prob", "energy"):
+        assert np.array_equal(t[k], raw[k]), k
+    assert extra["total_leapfrogs"] == int(t["n_steps"].sum()) == st.total_leapfrogs
+    # a shard [8, 16) reproduces the same chains (seed + 7919*i is shard independent)
+    _, _, ex2 = sampler.sample_compiled_tuned(comp, tuning, spec.default_init, opts,
+                                              num_chains=n_chains, chain_lo=8, chain_hi=16)
+    assert np.array_equal(ex2["raw"]["draws"], raw["draws"][8:16])
+
+
+def test_random_init_bit_exact(es, hip):
+    """init_values = %{} => 0.1 * normal_s per dimension (sampler.ex:339-349)."""
+    spec, comp, om = es
+    opts = dict(num_warmup=40, num_samples=20, seed=3, lanes_per_chain=16)
+    tuning = sampler.warmup(comp, None, opts)
+    t, st = O.sample_chains(om, 5, init_q=None, num_warmup=40, num_samples=20, seed=3,
+                            cfg=O.Cfg(1, 16))
+    assert st.step_size == tuning["epsilon"]
+    _, _, extra = sampler.sample_compiled_tuned(comp, tuning, None, opts, num_chains=5)
+    assert np.array_equal(t["draws"], extra["raw"]["draws"])
+    assert np.array_equal(t["tree_depth"], extra["raw"]["tree_depth"])
+
+
+def test_single_chain_sample_bit_exact(hip):
+    """Sampler.sample/3 on the d=2 plumbing config (BASELINE configs[0])."""
+    spec = models.simple()
+    trace, stats = sampler.sample(spec, spec.default_init,
+                                  dict(num_warmup=200, num_samples=100, seed=0))
+    om = O.simple()
+    t, st = O.sample(om, spec.to_unconstrained(spec.default_init), num_warmup=200, num_samples=100,
+                     seed=0, cfg=O.Cfg(1, 1))
+    assert st.step_size == stats["step_size"]
+    assert np.array_equal(t["draws"], stats["raw"]["draws"][0])
+    assert np.array_equal(t["tree_depth"], stats["raw"]["tree_depth"][0])
+    assert st.divergences == stats["divergences"]
+    assert abs(trace["mu"].mean() - 2.15) < 0.3
