@@ -1,0 +1,263 @@
+#!/usr/bin/env python3
+"""bench.py — leapfrog steps/s and ESS/s of the NUTS hot path on MI355X.
+
+A "step" is one NUTS transition (draw) for every resident chain. After the shared adaptation
+warmup (sampler.ex:1053-1080, run once, untimed for `value`, wall time reported) the chains are
+initialised in HBM, W untimed draws are taken, then exactly K draws are timed between
+barrier + synchronize pairs. value = useful leapfrogs (sum of n_steps, tree.ex:1612) per second
+over all GPUs; ESS/s, the roofline of the NUTS kernel and the CPU checker's numbers ride along.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from exmc_amd import _lib, models, sampler  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def synthetic_sv_returns(seed=42, T=100, sigma=0.15, nu=10.0):
+    """returns simulated with sigma*=0.15, nu*=10 (STANDARD_BENCHMARKS.md:79)."""
+    rng = np.random.default_rng(seed)
+    s = np.cumsum(rng.normal(0, sigma, T))
+    return (np.exp(s) * rng.standard_t(nu, T)).tolist()
+
+
+def make_spec(name):
+    if name == "eight_schools":
+        return models.eight_schools(), 488  # (6d+1)*8 bytes per leapfrog per chain, SURVEY 8d
+    if name == "sv":
+        return models.sv(synthetic_sv_returns()), 4904
+    raise SystemExit("unknown model %s" % name)
+
+
+def split_rhat(draws):
+    """diagnostics.ex:80-115 on a [S][D][C] tensor -> [D]."""
+    S = draws.shape[0]
+    mid = S // 2
+    n = min(mid, S - mid)
+    halves = torch.cat([draws[:n], draws[mid:mid + n]], dim=2)  # [n][D][2C]
+    m = halves.shape[2]
+    means = halves.mean(dim=0)                       # [D][m]
+    var = halves.var(dim=0, unbiased=True)           # [D][m]
+    gm = means.mean(dim=1, keepdim=True)
+    b = n / (m - 1) * ((means - gm) ** 2).sum(dim=1)
+    w = var.mean(dim=1)
+    return torch.sqrt(((n - 1) / n * w + b / n) / w)
+
+
+def cpu_baseline(spec, init, K, n_chains_total, budget_s=15.0):
+    """The CPU checker (oracle/, libm mode = the reference's own arithmetic, one chain per host
+    thread) on a bounded sample of the same workload. A reported baseline, not the target."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle as O
+    om = O.Model(spec.kind, spec.d, spec.data)
+    q0 = spec.to_unconstrained(init)
+    cfg = O.Cfg(0, 1)
+    cores = min(os.cpu_count() or 1, 64)
+    t0 = time.perf_counter()
+    O.sample_chains(om, 1, init_q=q0, num_warmup=1000, num_samples=K, seed=42, cfg=cfg)
+    one = time.perf_counter() - t0            # warmup + one chain
+    t0 = time.perf_counter()
+    O.sample_chains(om, 2, init_q=q0, num_warmup=1000, num_samples=K, seed=42, cfg=cfg)
+    per_chain = max(time.perf_counter() - t0 - one, 1e-6)
+    n = int(max(cores, min(n_chains_total, budget_s * cores / per_chain)))
+    n -= n % cores
+    n = max(n, cores)
+    t0 = time.perf_counter()
+    t, st = O.sample_chains(om, n, init_q=q0, num_warmup=1000, num_samples=K, seed=42,
+                            n_threads=cores, cfg=cfg)
+    wall = time.perf_counter() - t0
+    L = O.lib()
+    ess = np.zeros(spec.d)
+    sub = min(n, 4 * cores)
+    for c in range(sub):
+        for i in range(spec.d):
+            x = np.ascontiguousarray(t["draws"][c, :, i])
+            ess[i] += L.exo_ess(O.dptr(x), K)
+    ess_min = float(ess.min()) * n / sub
+    return {
+        "value": st.total_leapfrogs / wall,
+        "unit": "leapfrog_steps/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "%d chains x %d draws after the shared 1000-iteration warmup, oracle libm mode, "
+                  "%d host threads, wall %.2f s (includes the serial warmup)" % (n, K, cores, wall),
+        "ess_per_s": ess_min / wall,
+        "chains": n,
+        "wall_s": wall,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--model", default="eight_schools")
+    ap.add_argument("--chains-per-gpu", type=int, default=0)
+    ap.add_argument("--lanes", type=int, default=0)
+    ap.add_argument("--adapt", type=int, default=1000, help="NUTS adaptation iterations")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device is visible (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    spec, bytes_per_leapfrog = make_spec(args.model)
+    K, W, d = args.steps, args.warmup, spec.d
+    Cper = args.chains_per_gpu or (4096 if args.model == "eight_schools" else 2048)
+    Ctot = Cper * world
+    comp = sampler.compile(spec, {"device": local_rank})
+    lanes = args.lanes or comp.default_lanes
+    opts = sampler._merge_opts(dict(num_warmup=args.adapt, num_samples=K, seed=42,
+                                    lanes_per_chain=lanes))
+    init = spec.default_init
+    L = _lib.load()
+
+    # --- shared adaptation warmup: every rank runs it with the same seed (deterministic, so no
+    # broadcast is needed) ---
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tuning = sampler.warmup(comp, init, opts)
+    adapt_s = time.perf_counter() - t0
+    tun = sampler._tuning_struct(tuning, d)
+    if rank == 0:
+        log("adaptation: eps=%.5f, %d iterations in %.3f s" % (tuning["epsilon"], args.adapt, adapt_s))
+
+    # --- resident chains + trace buffers in HBM ---
+    draws = torch.empty((K, d, Cper), dtype=torch.float64, device=dev)
+    n_steps = torch.empty((K, Cper), dtype=torch.int32, device=dev)
+    depth = torch.empty((K, Cper), dtype=torch.int32, device=dev)
+    diverg = torch.empty((K, Cper), dtype=torch.int32, device=dev)
+    accept = torch.empty((K, Cper), dtype=torch.float64, device=dev)
+    tr = _lib.Trace(draws.data_ptr(), None, depth.data_ptr(), n_steps.data_ptr(), diverg.data_ptr(),
+                    accept.data_ptr(), None)
+    iq = np.ascontiguousarray(spec.to_unconstrained(init))
+    iqp = iq.ctypes.data_as(C.POINTER(C.c_double))
+    lo, hi = rank * Cper, (rank + 1) * Cper
+    _lib.check(L.exmc_hip_chains_init(comp.h, C.byref(tun), iqp, Ctot, lo, hi, sampler._c_opts(opts)))
+    lf, dv = C.c_int64(), C.c_int32()
+    if W > 0:
+        _lib.check(L.exmc_hip_chains_advance(comp.h, min(W, K), 0, tr, C.byref(lf), C.byref(dv)))
+
+    # --- timed region: exactly K draws for every chain ---
+    barrier()
+    t0 = time.perf_counter()
+    _lib.check(L.exmc_hip_chains_advance(comp.h, K, 0, tr, C.byref(lf), C.byref(dv)))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = comp.last_kernel_ms
+    stats = torch.tensor([elapsed, float(lf.value), float(dv.value)], dtype=torch.float64, device=dev)
+    if dist is not None:
+        mx = stats.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = stats.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        elapsed, leapfrogs, divs = float(mx[0]), float(sm[1]), float(sm[2])
+    else:
+        leapfrogs, divs = float(lf.value), float(dv.value)
+
+    # --- diagnostics: per-chain Geyer ESS on device, summed over chains; RCCL all-gather of the
+    # finished traces for split R-hat (the only collective on the path) ---
+    ess = torch.empty((d, Cper), dtype=torch.float64, device=dev)
+    _lib.check(L.exmc_hip_ess(comp.h, draws.data_ptr(), K, d, Cper, ess.data_ptr()))
+    ess_ms = comp.last_kernel_ms
+    ess_sum = ess.sum(dim=1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    if dist is not None:
+        dist.all_reduce(ess_sum, op=dist.ReduceOp.SUM)
+        gathered = torch.empty((world, K, d, Cper), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(gathered, draws)
+        all_draws = gathered.permute(1, 2, 0, 3).reshape(K, d, Ctot)
+    else:
+        all_draws = draws
+    torch.cuda.synchronize()
+    gather_s = time.perf_counter() - t0
+    rhat = split_rhat(all_draws)
+    ess_min = float(ess_sum.min())
+    total_s = adapt_s + elapsed + gather_s
+    value = leapfrogs / elapsed
+
+    if rank == 0:
+        local_lf = float(lf.value)
+        achieved = bytes_per_leapfrog * local_lf / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "leapfrog_steps_per_s",
+            "value": value,
+            "unit": "leapfrog_steps/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": elapsed * 1e3 / K,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "%s d=%d, %d chains/GPU (%d total), %d draws/chain after one shared "
+                                   "%d-iteration warmup, max_tree_depth 10, target_accept 0.8"
+                                   % (args.model, d, Cper, Ctot, K, args.adapt),
+                       "lanes_per_chain": lanes, "seed": 42},
+            "ess_per_s": ess_min / total_s,
+            "ess_min_total": ess_min,
+            "ess_wall_s": {"adaptation": adapt_s, "sampling": elapsed, "gather": gather_s},
+            "rhat_max": float(rhat.max()),
+            "divergent_transitions": divs,
+            "mean_leapfrogs_per_draw": leapfrogs / (K * Ctot),
+            "step_size": tuning["epsilon"],
+            "ess_kernel_ms": ess_ms,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "nuts_kernel", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_leapfrog": bytes_per_leapfrog,
+                         "leapfrogs_per_launch": local_lf},
+        }
+        if world == 1 and not args.no_cpu:
+            cb = cpu_baseline(spec, init, K, Ctot)
+            out["cpu_baseline"] = cb
+            out["gpu_over_cpu"] = {"leapfrog_steps_per_s": value / cb["value"],
+                                   "ess_per_s": out["ess_per_s"] / cb["ess_per_s"]}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

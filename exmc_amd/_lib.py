@@ -15,6 +15,7 @@ EXPORTS = [
     "exmc_hip_model_stream", "exmc_hip_logp_grad_host", "exmc_hip_multi_step",
     "exmc_hip_multi_step_host", "exmc_hip_transitions_host", "exmc_hip_warmup",
     "exmc_hip_sample_chains", "exmc_hip_sample_chains_host", "exmc_hip_sample_host",
+    "exmc_hip_chains_init", "exmc_hip_chains_advance",
     "exmc_hip_ess", "exmc_hip_last_kernel_ms",
 ]
 
@@ -75,6 +76,9 @@ def load():
     L.exmc_hip_sample_chains.argtypes = [vp, C.POINTER(Tuning), dp, C.c_int, C.c_int, C.c_int,
                                          Opts, Trace, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
     L.exmc_hip_sample_chains_host.argtypes = L.exmc_hip_sample_chains.argtypes
+    L.exmc_hip_chains_init.argtypes = [vp, C.POINTER(Tuning), dp, C.c_int, C.c_int, C.c_int, Opts]
+    L.exmc_hip_chains_advance.argtypes = [vp, C.c_int, C.c_int, Trace, C.POINTER(C.c_int64),
+                                          C.POINTER(C.c_int32)]
     L.exmc_hip_sample_host.argtypes = [vp, dp, Opts, Trace, C.POINTER(Tuning),
                                        C.POINTER(C.c_int32)]
     L.exmc_hip_ess.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]

@@ -79,6 +79,9 @@ struct exmc_hip_model {
   DevBuf trace;     // staging for host-trace entry points
   DevBuf io;        // staging for host vectors
   int state_chains = 0;
+  // resident chains (exmc_hip_chains_init / _advance)
+  int res_C = 0, res_lanes = 0, res_max_depth = 10;
+  double res_eps = 0.0;
 };
 
 namespace {
@@ -95,6 +98,7 @@ ChainState state_view(exmc_hip_model* m, int C) {
 size_t state_bytes(int d, int C) { return ((size_t)2 * d * C + (size_t)3 * C) * 8; }
 
 int ensure_state(exmc_hip_model* m, int C) {
+  m->res_C = 0;  // whoever re-lays-out the state buffer evicts the resident chains
   int rc = m->state.ensure(state_bytes(m->d, C));
   if (rc) return rc;
   m->state_chains = C;
@@ -767,33 +771,56 @@ int exmc_hip_warmup(exmc_hip_model* m, const double* init_q, exmc_hip_opts o,
   return run_warmup(m, lanes, o, tuning);
 }
 
-int exmc_hip_sample_chains(exmc_hip_model* m, const exmc_hip_tuning* tuning, const double* init_q,
-                           int n_chains, int chain_lo, int chain_hi, exmc_hip_opts o,
-                           exmc_hip_trace tr, int64_t* total_leapfrogs,
-                           int32_t* total_divergences) {
+int exmc_hip_chains_init(exmc_hip_model* m, const exmc_hip_tuning* tuning, const double* init_q,
+                         int n_chains, int chain_lo, int chain_hi, exmc_hip_opts o) {
   if (check_model(m)) return EXMC_ERR_BADARG;
-  if (!tuning || n_chains < 1 || chain_lo < 0 || chain_hi > n_chains || chain_hi <= chain_lo ||
-      o.num_samples < 0)
+  if (!tuning || n_chains < 1 || chain_lo < 0 || chain_hi > n_chains || chain_hi <= chain_lo)
     return fail(EXMC_ERR_BADARG, "bad arguments");
   HIP_TRY(hipSetDevice(m->device));
   const int lanes = resolve_lanes(m, o.lanes_per_chain);
   const int C = chain_hi - chain_lo;
+  m->res_C = 0;
   int rc = ensure_state(m, C);
   if (rc) return rc;
   rc = upload_tuning(m, tuning->inv_mass);
   if (rc) return rc;
   rc = launch_init(m, lanes, C, chain_lo, o.seed, init_q);
   if (rc) return rc;
-  rc = reset_counters(m);
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  m->res_C = C;
+  m->res_lanes = lanes;
+  m->res_eps = tuning->epsilon;
+  m->res_max_depth = o.max_tree_depth;
+  return EXMC_OK;
+}
+
+int exmc_hip_chains_advance(exmc_hip_model* m, int n_draws, int row_offset, exmc_hip_trace tr,
+                            int64_t* leapfrogs, int32_t* divergences) {
+  if (check_model(m)) return EXMC_ERR_BADARG;
+  if (m->res_C < 1) return fail(EXMC_ERR_BADARG, "no resident chains: call exmc_hip_chains_init");
+  if (n_draws < 0 || row_offset < 0) return fail(EXMC_ERR_BADARG, "bad arguments");
+  HIP_TRY(hipSetDevice(m->device));
+  int rc = reset_counters(m);
   if (rc) return rc;
   TraceDev t;
   t.draws = tr.draws; t.logp = tr.logp; t.tree_depth = tr.tree_depth; t.n_steps = tr.n_steps;
   t.divergent = tr.divergent; t.accept_prob = tr.accept_prob; t.energy = tr.energy;
-  rc = launch_nuts(m, lanes, C, o.num_samples, 0, tuning->epsilon, o.max_tree_depth, t, true);
+  rc = launch_nuts(m, m->res_lanes, m->res_C, n_draws, row_offset, m->res_eps, m->res_max_depth, t,
+                   true);
   if (rc) return rc;
   rc = finish_timing(m);
   if (rc) return rc;
-  return read_counters(m, total_leapfrogs, total_divergences);
+  return read_counters(m, leapfrogs, divergences);
+}
+
+int exmc_hip_sample_chains(exmc_hip_model* m, const exmc_hip_tuning* tuning, const double* init_q,
+                           int n_chains, int chain_lo, int chain_hi, exmc_hip_opts o,
+                           exmc_hip_trace tr, int64_t* total_leapfrogs,
+                           int32_t* total_divergences) {
+  if (o.num_samples < 0) return fail(EXMC_ERR_BADARG, "bad arguments");
+  int rc = exmc_hip_chains_init(m, tuning, init_q, n_chains, chain_lo, chain_hi, o);
+  if (rc) return rc;
+  return exmc_hip_chains_advance(m, o.num_samples, 0, tr, total_leapfrogs, total_divergences);
 }
 
 int exmc_hip_sample_chains_host(exmc_hip_model* m, const exmc_hip_tuning* tuning,

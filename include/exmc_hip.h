@@ -133,6 +133,15 @@ int exmc_hip_sample_chains(exmc_hip_model* m, const exmc_hip_tuning* tuning, con
                            int n_chains, int chain_lo, int chain_hi, exmc_hip_opts opts,
                            exmc_hip_trace trace_dev, int64_t* total_leapfrogs,
                            int32_t* total_divergences);
+/* The two halves of exmc_hip_sample_chains, for callers that keep chains resident in HBM and
+ * draw in several launches (run_sampling's Enum.reduce, sampler.ex:946-970, split anywhere):
+ * _init seeds / positions chains [chain_lo, chain_hi) and evaluates logp+grad;
+ * _advance runs n_draws more transitions of every resident chain, writing trace rows
+ * [row_offset, row_offset + n_draws) of buffers that hold `trace_rows` rows in total. */
+int exmc_hip_chains_init(exmc_hip_model* m, const exmc_hip_tuning* tuning, const double* init_q,
+                         int n_chains, int chain_lo, int chain_hi, exmc_hip_opts opts);
+int exmc_hip_chains_advance(exmc_hip_model* m, int n_draws, int row_offset,
+                            exmc_hip_trace trace_dev, int64_t* leapfrogs, int32_t* divergences);
 /* Same with host trace buffers in the reference's per-chain layout [chain][draw][dim]. */
 int exmc_hip_sample_chains_host(exmc_hip_model* m, const exmc_hip_tuning* tuning,
                                 const double* init_q, int n_chains, int chain_lo, int chain_hi,
