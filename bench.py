@@ -24,6 +24,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from exmc_amd import _lib, models, sampler  # noqa: E402
+from exmc_amd import distributed as xd  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -45,21 +46,6 @@ def make_spec(name):
     if name == "sv":
         return models.sv(synthetic_sv_returns()), 4904
     raise SystemExit("unknown model %s" % name)
-
-
-def split_rhat(draws):
-    """diagnostics.ex:80-115 on a [S][D][C] tensor -> [D]."""
-    S = draws.shape[0]
-    mid = S // 2
-    n = min(mid, S - mid)
-    halves = torch.cat([draws[:n], draws[mid:mid + n]], dim=2)  # [n][D][2C]
-    m = halves.shape[2]
-    means = halves.mean(dim=0)                       # [D][m]
-    var = halves.var(dim=0, unbiased=True)           # [D][m]
-    gm = means.mean(dim=1, keepdim=True)
-    b = n / (m - 1) * ((means - gm) ** 2).sum(dim=1)
-    w = var.mean(dim=1)
-    return torch.sqrt(((n - 1) / n * w + b / n) / w)
 
 
 def cpu_baseline(spec, init, K, n_chains_total, budget_s=15.0):
@@ -200,16 +186,11 @@ def main():
     ess_sum = ess.sum(dim=1)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    if dist is not None:
-        dist.all_reduce(ess_sum, op=dist.ReduceOp.SUM)
-        gathered = torch.empty((world, K, d, Cper), dtype=torch.float64, device=dev)
-        dist.all_gather_into_tensor(gathered, draws)
-        all_draws = gathered.permute(1, 2, 0, 3).reshape(K, d, Ctot)
-    else:
-        all_draws = draws
+    xd.reduce_sum(ess_sum, dist)
+    all_draws = xd.gather_traces(draws, dist)
     torch.cuda.synchronize()
     gather_s = time.perf_counter() - t0
-    rhat = split_rhat(all_draws)
+    rhat = xd.split_rhat(all_draws)
     ess_min = float(ess_sum.min())
     total_s = adapt_s + elapsed + gather_s
     value = leapfrogs / elapsed

@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/oracle_traces.npz: seeded per-draw outputs of the CPU checker in
+deterministic-math mode with fixed tuning (no libm on the path => the bits are platform
+independent). Used (a) on CPU to catch any change of the checker / numeric contract and (b) on
+the GPU as a committed golden fixture for the HIP path.  Run:  python tests/golden/make_oracle_traces.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import oracle as O  # noqa: E402
+
+CASES = {
+    # name: (model factory, lanes, eps, n_chains, n_draws, max_depth, base_seed)
+    "es_g1": ("eight_schools", 1, 0.40, 3, 50, 10, 42),
+    "es_g16": ("eight_schools", 16, 0.40, 3, 50, 10, 42),
+    "es_g8_deep": ("eight_schools", 8, 0.05, 2, 12, 7, 7),
+    "es_g16_div": ("eight_schools", 16, 1.70, 3, 40, 10, 11),
+    "simple_g1": ("simple", 1, 0.30, 2, 40, 10, 0),
+    "sv_g64": ("sv", 64, 0.05, 2, 10, 6, 42),
+}
+
+
+def sv_returns(seed=42, T=100):
+    rng = np.random.default_rng(seed)
+    s = np.cumsum(rng.normal(0, 0.15, T))
+    return np.exp(s) * rng.standard_t(10.0, T)
+
+
+def inv_mass_for(d):
+    return 0.5 + 1.5 * (np.arange(d) % 7) / 6.0
+
+
+def init_for(name, d):
+    if name == "simple":
+        return np.array([2.0, 0.0])
+    if name == "sv":
+        q = np.zeros(d)
+        q[100], q[101] = np.log(0.1), np.log(10.0)
+        return q
+    return np.zeros(d)
+
+
+def model_for(name):
+    if name == "eight_schools":
+        return O.eight_schools()
+    if name == "simple":
+        return O.simple()
+    return O.Model(O.SV, 102, sv_returns())
+
+
+def run_case(name):
+    mname, lanes, eps, nc, nd, md, seed = CASES[name]
+    m = model_for(mname)
+    im = inv_mass_for(m.d)
+    out = {}
+    for c in range(nc):
+        t, _ = O.sample_tuned(m, eps, im, init_for(mname, m.d), num_samples=nd, max_tree_depth=md,
+                              seed=seed + 7919 * c, cfg=O.Cfg(1, lanes))
+        for k, v in t.items():
+            out.setdefault(k, []).append(v)
+    return {k: np.stack(v) for k, v in out.items()}
+
+
+def main():
+    blob = {}
+    for name in CASES:
+        for k, v in run_case(name).items():
+            blob["%s/%s" % (name, k)] = v
+    blob["sv_returns"] = sv_returns()
+    np.savez_compressed(os.path.join(HERE, "oracle_traces.npz"), **blob)
+    print("wrote oracle_traces.npz with", len(blob), "arrays")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,128 @@
+"""CPU tests: the C-ABI library loads and exports every symbol include/exmc_hip.h declares, the
+product path fails loudly without a GPU (no CPU fallback), and the host-side mirror of
+Exmc.NUTS.Sampler marshals what the reference API promises. No compute calls here."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "exmc_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(exmc_hip_\w+)\s*\(", txt)))
+
+
+def test_build_entry_compiles_for_gfx950():
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    g.build()
+    from exmc_amd import build as b
+    assert os.path.exists(b.OUT)
+    assert "--offload-arch=gfx950" in b.FLAGS and "-ffp-contract=off" in b.FLAGS
+    # the code object inside the .so targets gfx950
+    out = subprocess.run(["strings", "-n", "6", b.OUT], capture_output=True, text=True).stdout
+    assert "gfx950" in out
+
+
+def test_library_exports_every_declared_symbol():
+    from exmc_amd import _lib
+    L = _lib.load()
+    syms = declared_symbols()
+    assert len(syms) >= 15
+    for s in syms:
+        assert hasattr(L, s), s
+    assert sorted(_lib.EXPORTS) == syms
+
+
+def test_header_is_plain_c():
+    """The boundary is a C ABI: the header must compile as C with no torch/HIP types."""
+    src = '#include "exmc_hip.h"\nint main(void){return (int)sizeof(exmc_hip_opts) == 0;}\n'
+    p = subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                        "-x", "c", "-", "-o", "/dev/null"], input=src, text=True, capture_output=True)
+    assert p.returncode == 0, p.stderr
+
+
+def test_struct_layouts_match_header():
+    from exmc_amd import _lib
+    src = ('#include <stdio.h>\n#include <stddef.h>\n#include "exmc_hip.h"\n'
+           'int main(void){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(exmc_hip_opts),'
+           'offsetof(exmc_hip_opts, seed), sizeof(exmc_hip_tuning),'
+           'offsetof(exmc_hip_tuning, warmup_divergences), sizeof(exmc_hip_trace),'
+           'offsetof(exmc_hip_trace, energy));return 0;}\n')
+    exe = "/tmp/exmc_layout_check"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-x", "c", "-", "-o", exe],
+                   input=src.encode(), check=True)
+    got = [int(x) for x in subprocess.check_output([exe]).split()]
+    assert got == [C.sizeof(_lib.Opts), _lib.Opts.seed.offset, C.sizeof(_lib.Tuning),
+                   _lib.Tuning.warmup_divergences.offset, C.sizeof(_lib.Trace),
+                   _lib.Trace.energy.offset]
+
+
+def test_fails_loudly_without_a_gpu():
+    """No HIP device => model creation returns EXMC_ERR_NO_DEVICE and the Python mirror raises;
+    nothing silently falls back to the CPU."""
+    from exmc_amd import _lib, models, sampler
+    L = _lib.load()
+    if L.exmc_hip_device_count() > 0:
+        pytest.skip("a GPU is present; covered by the -m gpu tests")
+    h = C.c_void_p()
+    spec = models.eight_schools()
+    rc = L.exmc_hip_model_create(spec.kind, spec.d, spec.data.ctypes.data_as(C.POINTER(C.c_double)),
+                                 16, 0, C.byref(h))
+    assert rc == _lib.ERR_NO_DEVICE and not h.value
+    assert b"no CPU fallback" in L.exmc_hip_last_error()
+    with pytest.raises(_lib.ExmcHipError):
+        sampler.sample(spec, spec.default_init, dict(num_warmup=10, num_samples=10))
+    with pytest.raises(_lib.ExmcHipError):
+        sampler.sample_chains(spec, 4, dict(num_warmup=10, num_samples=10))
+    assert L.exmc_hip_model_dim(None) == -1
+
+
+def test_product_never_touches_the_oracle():
+    """oracle/ is test infrastructure: nothing under exmc_amd/ or include/ may reference it."""
+    bad = []
+    for base in ("exmc_amd", "include"):
+        for dp, _, fs in os.walk(os.path.join(ROOT, base)):
+            for f in fs:
+                if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                    txt = open(os.path.join(dp, f), errors="ignore").read()
+                    if re.search(r"exmc_oracle|libexmc_oracle|import oracle|from oracle|exo_", txt):
+                        bad.append(os.path.join(dp, f))
+    assert not bad, bad
+
+
+def test_model_specs_and_point_map():
+    from exmc_amd import models
+    es = models.eight_schools()
+    assert es.d == 10 and es.var_names[:2] == ["mu", "tau"]
+    # point_map.ex:37: flat order = ids sorted as strings; eight_schools is already sorted
+    assert es.flat_order() == list(range(10))
+    q = es.to_unconstrained(es.default_init)
+    assert np.array_equal(q, np.zeros(10))          # log(tau = 1) = 0
+    x = es.constrain(np.array([[0.5, np.log(3.0)] + [0.0] * 8]))
+    assert abs(x[0, 1] - 3.0) < 1e-12 and x[0, 0] == 0.5
+    sv = models.sv(np.linspace(-1, 1, 100))
+    names = [sv.var_names[i] for i in sv.flat_order()]
+    assert names[:5] == ["nu", "s_1", "s_10", "s_100", "s_11"] and names[-1] == "sigma"
+    with pytest.raises(KeyError):
+        es.to_unconstrained({"mu": 0.0})            # Map.fetch! semantics
+    with pytest.raises(ValueError):
+        models.sv([0.0] * 99)
+
+
+def test_sampler_option_defaults_match_reference():
+    from exmc_amd import sampler
+    o = sampler._merge_opts({"seed": 7})
+    assert (o["num_warmup"], o["num_samples"], o["max_tree_depth"], o["target_accept"], o["seed"]) \
+        == (1000, 1000, 10, 0.8, 7)       # sampler.ex:16-23
+    c = sampler._c_opts(o)
+    assert (c.num_warmup, c.num_samples, c.max_tree_depth, c.seed, c.lanes_per_chain) == (1000, 1000, 10, 7, 0)
+    with pytest.raises(ValueError):
+        sampler._tuning_struct({"epsilon": 0.1, "inv_mass": np.ones((3, 3))}, 3)

@@ -1,0 +1,47 @@
+"""Committed per-draw golden traces (tests/golden/oracle_traces.npz).
+
+CPU: the checker still reproduces them bit for bit (catches drift of the checker or of the numeric
+contract). GPU (-m gpu): the HIP path reproduces the same committed bits through the C ABI."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import make_oracle_traces as G  # noqa: E402
+
+GOLD = np.load(os.path.join(HERE, "golden", "oracle_traces.npz"))
+KEYS = ("draws", "logp", "tree_depth", "n_steps", "divergent", "accept_prob", "energy")
+
+
+@pytest.mark.parametrize("name", sorted(G.CASES))
+def test_oracle_reproduces_committed_traces(name):
+    got = G.run_case(name)
+    for k in KEYS:
+        assert np.array_equal(got[k], GOLD["%s/%s" % (name, k)]), (name, k)
+
+
+def test_golden_traces_cover_edge_cases():
+    assert GOLD["es_g16_div/divergent"].sum() > 0            # divergent transitions
+    assert GOLD["es_g8_deep/tree_depth"].max() == 7          # depth cap reached
+    assert GOLD["es_g8_deep/n_steps"].max() == 127
+    assert GOLD["sv_g64/draws"].shape == (2, 10, 102)
+    assert np.array_equal(GOLD["sv_returns"], G.sv_returns())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(G.CASES))
+def test_hip_reproduces_committed_traces(name, hip):
+    from exmc_amd import models, sampler
+    mname, lanes, eps, nc, nd, md, seed = G.CASES[name]
+    spec = {"eight_schools": models.eight_schools, "simple": models.simple,
+            "sv": lambda: models.sv(GOLD["sv_returns"])}[mname]()
+    comp = sampler.compile(spec)
+    tuning = dict(epsilon=eps, inv_mass=G.inv_mass_for(spec.d))
+    opts = dict(num_samples=nd, max_tree_depth=md, seed=seed, lanes_per_chain=lanes)
+    _, _, extra = sampler.sample_compiled_tuned(comp, tuning, spec.default_init, opts, num_chains=nc)
+    assert np.array_equal(spec.to_unconstrained(spec.default_init), G.init_for(mname, spec.d))
+    for k in KEYS:
+        assert np.array_equal(extra["raw"][k], GOLD["%s/%s" % (name, k)]), (name, k)

@@ -1,0 +1,217 @@
+"""CPU tests: models (gradients vs central differences, as test/compiler_test.exs and the dist
+tests do), the two numeric modes / lane layouts of the oracle, tree invariants
+(test/nuts/statham_tree_test.exs) and statistical acceptance bands."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden",
+                                   "reference_known_answers.json")))
+
+
+def sv_returns(seed=42, T=100):
+    rng = np.random.default_rng(seed)
+    s = np.cumsum(rng.normal(0, 0.15, T))
+    return np.exp(s) * rng.standard_t(10.0, T)
+
+
+def all_models():
+    return [("std_normal", O.std_normal(7)), ("simple", O.simple()),
+            ("eight_schools", O.eight_schools()), ("sv", O.Model(O.SV, 102, sv_returns()))]
+
+
+def fd_grad(m, q, cfg, h=1e-6):
+    g = np.zeros_like(q)
+    for i in range(len(q)):
+        a, b = q.copy(), q.copy()
+        a[i] += h
+        b[i] -= h
+        g[i] = (m.logp_grad(a, cfg)[0] - m.logp_grad(b, cfg)[0]) / (2 * h)
+    return g
+
+
+@pytest.mark.parametrize("name,m", all_models(), ids=lambda x: x if isinstance(x, str) else "")
+@pytest.mark.parametrize("mode", [0, 1])
+def test_gradient_matches_central_differences(name, m, mode):
+    rng = np.random.default_rng(5)
+    cfg = O.Cfg(mode, 1)
+    for _ in range(4):
+        q = rng.normal(size=m.d) * 0.5
+        if name == "sv":
+            q[100] = np.log(0.15) + 0.2 * rng.normal()
+            q[101] = np.log(10.0) + 0.2 * rng.normal()
+        _, g = m.logp_grad(q, cfg)
+        fd = fd_grad(m, q, cfg)
+        assert np.allclose(g, fd, rtol=2e-5, atol=2e-5), np.abs(g - fd).max()
+
+
+def test_log_clamp_has_zero_gradient_outside():
+    """transform.ex:17-29: x = exp(max(-200, min(z, 200))); outside the clamp d/dz vanishes."""
+    m = O.eight_schools()
+    q = np.zeros(10)
+    q[1] = 250.0
+    assert m.logp_grad(q)[1][1] == 0.0
+    q[1] = -250.0
+    assert m.logp_grad(q)[1][1] == 0.0
+    assert m.constrain(q)[1] == np.exp(-200.0)
+
+
+@pytest.mark.parametrize("name,m", all_models(), ids=lambda x: x if isinstance(x, str) else "")
+def test_modes_and_lane_layouts_agree_to_rounding(name, m):
+    """det-math vs libm and G-lane vs left-to-right sums differ only by rounding: the stated
+    floating tolerance between the GPU contract and the reference's own arithmetic."""
+    rng = np.random.default_rng(9)
+    lanes = {"sv": [32, 64], "simple": [1], "std_normal": [2, 4], "eight_schools": [2, 4, 8, 16]}[name]
+    for _ in range(5):
+        q = rng.normal(size=m.d) * 0.7
+        lp0, g0 = m.logp_grad(q, O.Cfg(0, 1))
+        for cfg in [O.Cfg(1, 1)] + [O.Cfg(1, G) for G in lanes]:
+            lp, g = m.logp_grad(q, cfg)
+            assert abs(lp - lp0) <= 1e-12 * max(1.0, abs(lp0))
+            assert np.allclose(g, g0, rtol=1e-11, atol=1e-12)
+
+
+def test_single_transition_tolerance_between_modes():
+    """One NUTS transition from the same state and rng: integer outputs identical, floats within
+    1e-9 relative, for libm vs deterministic math and G = 1 vs 16."""
+    L = O.lib()
+    m = O.eight_schools()
+    rng = np.random.default_rng(11)
+    im = np.ones(10)
+    agree = 0
+    n = 300
+    for k in range(n):
+        q = rng.normal(size=10) * 0.6
+        outs = []
+        for cfg in (O.Cfg(0, 1), O.Cfg(1, 1), O.Cfg(1, 16)):
+            lp, g = m.logp_grad(q, cfg)
+            r = O.Rng()
+            L.exo_rng_seed(C.byref(r), 500 + k)
+            p = np.array([L.exo_rng_normal(C.byref(r), cfg.math_mode) for _ in range(10)])
+            jlp0 = lp - L.exo_kinetic_energy(O.dptr(p), O.dptr(im), 10, cfg)
+            qo, go, res = m.tree_build(q, p, lp, g, 0.4, im, 10, r, jlp0, cfg)
+            outs.append((qo, res.depth, res.n_steps, res.divergent, res.logp, res.accept_sum))
+        a = outs[0]
+        same = all((o[1], o[2], o[3]) == (a[1], a[2], a[3]) and
+                   np.allclose(o[0], a[0], rtol=1e-9, atol=1e-9) for o in outs[1:])
+        agree += same
+    # a rounding-level change can flip a multinomial/U-turn decision only on a knife edge
+    assert agree >= n - 2
+
+
+@pytest.mark.parametrize("cfg", [O.Cfg(0, 1), O.Cfg(1, 16)], ids=["libm", "det-G16"])
+def test_tree_invariants(cfg):
+    """statham_tree_test.exs:141-170,350-412: 0 <= depth <= max, n_steps <= 2^depth - 1,
+    accept-rate in [0,1], duplicates well below 50 %."""
+    m = O.eight_schools()
+    t, st = O.sample(m, np.zeros(10), num_warmup=300, num_samples=400, seed=1, cfg=cfg)
+    assert np.all((t["tree_depth"] >= 1) & (t["tree_depth"] <= 10))
+    assert np.all(t["n_steps"] <= 2 ** t["tree_depth"].astype(np.int64) - 1)
+    assert np.all(t["n_steps"] >= 1)
+    assert np.all((t["accept_prob"] >= 0) & (t["accept_prob"] <= 1.0 + 1e-12))
+    dup = np.mean(np.all(t["draws"][1:] == t["draws"][:-1], axis=1))
+    assert dup < 0.5
+    # a non-divergent tree that stopped before max depth stopped because it turned: depth d means
+    # 2^(d-1) <= n_steps unless a subtree was cut short
+    assert np.all(np.isfinite(t["energy"])) and np.all(np.isfinite(t["logp"]))
+    assert st.total_leapfrogs == int(t["n_steps"].sum())
+
+
+def test_max_depth_cap_and_divergence():
+    m = O.eight_schools()
+    t, _ = O.sample_tuned(m, 1e-4, np.ones(10), np.zeros(10), num_samples=5, max_tree_depth=4, seed=2)
+    assert np.all(t["tree_depth"] == 4) and np.all(t["n_steps"] == 15)
+    t, _ = O.sample_tuned(m, 50.0, np.ones(10), np.zeros(10), num_samples=20, seed=2)
+    assert t["divergent"].sum() > 0
+    d = t["divergent"] == 1
+    assert np.all(t["n_steps"][d] >= 1)
+
+
+def test_seed_reproducibility_and_seed_dependence():
+    """test/nuts_test.exs:384-393."""
+    m = O.eight_schools()
+    a, sa = O.sample(m, np.zeros(10), num_warmup=100, num_samples=50, seed=3)
+    b, sb = O.sample(m, np.zeros(10), num_warmup=100, num_samples=50, seed=3)
+    c, _ = O.sample(m, np.zeros(10), num_warmup=100, num_samples=50, seed=4)
+    assert np.array_equal(a["draws"], b["draws"]) and sa.step_size == sb.step_size
+    assert not np.array_equal(a["draws"], c["draws"])
+
+
+def test_sample_chains_semantics():
+    """sampler.ex:1020-1136: one warmup (chain 0's seed), chains seeded seed + 7919*i, shared
+    step size (test/integration_test.exs:799-801); shards and threads do not change results."""
+    m = O.eight_schools()
+    q0 = np.zeros(10)
+    t, st = O.sample_chains(m, 6, init_q=q0, num_warmup=120, num_samples=30, seed=42)
+    w = O.warmup(m, q0, num_warmup=120, seed=42)
+    assert w.step_size == st.step_size
+    for i in (0, 3, 5):
+        ti, _ = O.sample_tuned(m, st.step_size, np.array(st.inv_mass[:10]), q0, num_samples=30,
+                               seed=42 + 7919 * i)
+        assert np.array_equal(ti["draws"], t["draws"][i])
+    t2, _ = O.sample_chains(m, 6, init_q=q0, num_warmup=120, num_samples=30, seed=42, chain_lo=2,
+                            chain_hi=5, n_threads=3)
+    assert np.array_equal(t2["draws"], t["draws"][2:5])
+    assert np.array_equal(t2["tree_depth"], t["tree_depth"][2:5])
+
+
+def test_eight_schools_statistical_band():
+    """benchmark/posteriordb/validation_results.md:18 and validate_posteriordb.exs:361-364."""
+    band = GOLD["statistical"]["eight_schools_posteriordb"]
+    m = O.eight_schools()
+    t, st = O.sample(m, np.zeros(10), seed=42)
+    assert band["step_size_band"][0] < st.step_size < band["step_size_band"][1]
+    assert st.divergences <= band["divergences_max"]
+    x = t["draws"]
+    mu, tau = x[:, 0], np.exp(x[:, 1])
+    # posteriordb reference posterior: mu ~ 4.4 (sd 3.3), tau ~ 3.6 (sd 3.2); 0.5 SD criterion
+    assert abs(mu.mean() - 4.4) < 0.5 * 3.3
+    assert abs(tau.mean() - 3.6) < 0.5 * 3.2
+    assert 0.5 < mu.std() / 3.3 < 2.0 and 0.5 < tau.std() / 3.2 < 2.0
+
+
+def test_simple_model_posterior():
+    s = GOLD["statistical"]["simple_posterior_mean"]
+    m = O.simple()
+    t, st = O.sample(m, np.array([2.0, 0.0]), num_warmup=500, num_samples=1000, seed=0)
+    assert abs(t["draws"][:, 0].mean() - s["expect"]) < s["tol"]
+    assert st.divergences < 20
+
+
+def test_sv_oracle_runs_and_is_sane():
+    m = O.Model(O.SV, 102, sv_returns())
+    q0 = np.zeros(102)
+    q0[100], q0[101] = np.log(0.1), np.log(10.0)
+    t, st = O.sample(m, q0, num_warmup=150, num_samples=100, seed=42)
+    assert 0.005 < st.step_size < 1.0
+    assert np.all(np.isfinite(t["draws"]))
+    sigma = np.exp(t["draws"][:, 100])
+    assert 0.01 < sigma.mean() < 1.0
+
+
+def test_diagnostics_ess_and_rhat():
+    """diagnostics.ex: iid draws => ESS ~ n; AR(1) => n(1-rho)/(1+rho); split R-hat ~ 1."""
+    L = O.lib()
+    rng = np.random.default_rng(0)
+    n = 1000
+    x = np.ascontiguousarray(rng.normal(size=n))
+    assert 700 < L.exo_ess(O.dptr(x), n) <= 1000.0 + 1e-9
+    assert 700 < L.exo_ess_bulk(O.dptr(x), n) <= 1000.0 + 1e-9
+    rho = 0.7
+    y = np.zeros(n)
+    for i in range(1, n):
+        y[i] = rho * y[i - 1] + rng.normal()
+    ess = L.exo_ess(O.dptr(np.ascontiguousarray(y)), n)
+    assert 0.4 * n * (1 - rho) / (1 + rho) < ess < 2.5 * n * (1 - rho) / (1 + rho)
+    assert L.exo_ess(O.dptr(x), 3) == 3.0
+    ch = np.ascontiguousarray(rng.normal(size=(4, n)))
+    assert abs(L.exo_rhat(O.dptr(ch), 4, n) - 1.0) < 0.02
+    ch[0] += 3.0
+    assert L.exo_rhat(O.dptr(ch), 4, n) > 1.3
+    const = np.ones(50)
+    assert L.exo_ess(O.dptr(const), 50) == 50.0     # var == 0 => acf 0 => tau -1 => n/max(tau,1)
