@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libexmc_hip.so")
+LIB_PATH = os.environ.get("EXMC_HIP_LIB") or os.path.join(HERE, "lib", "libexmc_hip.so")
 
 MAX_D = 256
 OK, ERR_BADARG, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED = range(5)

@@ -42,7 +42,8 @@ def build(force=False, verbose=False):
     if not force and up_to_date():
         return OUT
     os.makedirs(OUT_DIR, exist_ok=True)
-    cmd = [hipcc()] + FLAGS + ["-o", OUT, SRC]
+    extra = os.environ.get("EXMC_EXTRA_FLAGS", "").split()
+    cmd = [hipcc()] + FLAGS + extra + ["-o", OUT, SRC]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=os.path.join(HERE, "csrc"))

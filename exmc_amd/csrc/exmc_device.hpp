@@ -6,6 +6,11 @@
 // products of tree.ex:1578-1588, model sums) are lane-partial sums followed by an
 // xor-butterfly over the group, so every lane of the group ends with the same bits.
 // Control flow is uniform inside a group and may diverge between groups.
+//
+// The butterfly runs on DPP (quad_perm, row_half_mirror, row_mirror: VALU-speed cross-lane
+// moves inside a 16-lane row) and, above 16 lanes, on v_readlane: after the row stages every
+// lane of a row holds the row sum, so mirror moves deliver exactly the operands the xor pattern
+// would, and the result is bit-identical to `v[l] + v[l ^ m]` for m = 1, 2, 4, ...
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -17,11 +22,65 @@ namespace exmc {
 
 constexpr uint64_t kMask58 = (1ULL << 58) - 1;
 
+// DPP controls (gfx9 encoding)
+constexpr int kDppXor1 = 0xB1;        // quad_perm [1,0,3,2]
+constexpr int kDppXor2 = 0x4E;        // quad_perm [2,3,0,1]
+constexpr int kDppHalfMirror = 0x141; // lane i <- lane 7-i within 8
+constexpr int kDppRowMirror = 0x140;  // lane i <- lane 15-i within 16
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
+// N independent all-reduce sums over the G-lane group, stage by stage (the N moves of a stage
+// are independent, so their latencies overlap).
+template <int G, int N>
+__device__ __forceinline__ void group_allsum_n(double (&v)[N]) {
+  static_assert(G == 1 || G == 2 || G == 4 || G == 8 || G == 16 || G == 32 || G == 64, "G");
+  if (G >= 2) {
+#pragma unroll
+    for (int j = 0; j < N; j++) v[j] = v[j] + dpp_move<kDppXor1>(v[j]);
+  }
+  if (G >= 4) {
+#pragma unroll
+    for (int j = 0; j < N; j++) v[j] = v[j] + dpp_move<kDppXor2>(v[j]);
+  }
+  if (G >= 8) {
+#pragma unroll
+    for (int j = 0; j < N; j++) v[j] = v[j] + dpp_move<kDppHalfMirror>(v[j]);
+  }
+  if (G >= 16) {
+#pragma unroll
+    for (int j = 0; j < N; j++) v[j] = v[j] + dpp_move<kDppRowMirror>(v[j]);
+  }
+  if (G >= 32) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      const double r0 = readlane_f64(v[j], 0), r1 = readlane_f64(v[j], 16);
+      const double r2 = readlane_f64(v[j], 32), r3 = readlane_f64(v[j], 48);
+      const double h0 = r0 + r1, h1 = r2 + r3;   // == row + (row ^ 1) for every row
+      if (G == 32) v[j] = (lane < 32) ? h0 : h1;
+      else v[j] = h0 + h1;                        // == half + (half ^ 1)
+    }
+  }
+}
+
 template <int G>
 __device__ __forceinline__ double group_allsum(double v) {
-#pragma unroll
-  for (int m = 1; m < G; m <<= 1) v = v + __shfl_xor(v, m, 64);
-  return v;
+  double a[1] = {v};
+  group_allsum_n<G, 1>(a);
+  return a[0];
 }
 
 // value held by lane `src` (0..G-1) of this lane's group
@@ -30,6 +89,17 @@ __device__ __forceinline__ double group_bcast(double v, int src) {
   if (G == 1) return v;
   const int lane = threadIdx.x & 63;
   return __shfl(v, (lane & ~(G - 1)) | src, 64);
+}
+
+// true iff `ok` holds on every lane of this lane's group (the group's lanes are all active)
+template <int G>
+__device__ __forceinline__ bool group_all(bool ok) {
+  if (G == 1) return ok;
+  const unsigned long long b = __ballot(ok);
+  const int lane = threadIdx.x & 63;
+  const int base = lane & ~(G - 1);
+  const unsigned long long m = (G == 64) ? ~0ULL : (((1ULL << G) - 1) << base);
+  return (b & m) == m;
 }
 
 // ---- OTP :rand exsss (Xorshift116**, 58-bit words); call sites sampler.ex:154,343,396,836,897,
@@ -42,14 +112,23 @@ __device__ __forceinline__ uint64_t rotl58(uint64_t x, int n) {
   return ((x << n) & kMask58) | (x >> (58 - n));
 }
 
-__device__ __forceinline__ uint64_t rng_next(Rng& r) {
-  const uint64_t s1 = r.a, s0 = r.b;
+// output word of a step = ** scrambler of the state's tail word; the state update is separate
+__device__ __forceinline__ uint64_t rng_scramble(uint64_t s0) {
   const uint64_t v1 = (s0 + ((s0 << 2) & kMask58)) & kMask58;
   const uint64_t v2 = rotl58(v1, 7);
-  const uint64_t out = (v2 + ((v2 << 3) & kMask58)) & kMask58;
+  return (v2 + ((v2 << 3) & kMask58)) & kMask58;
+}
+
+__device__ __forceinline__ void rng_advance(Rng& r) {
+  const uint64_t s1 = r.a, s0 = r.b;
   const uint64_t s1b = s1 ^ ((s1 << 24) & kMask58);
   r.a = s0;
   r.b = s1b ^ s0 ^ (s1b >> 11) ^ (s0 >> 41);
+}
+
+__device__ __forceinline__ uint64_t rng_next(Rng& r) {
+  const uint64_t out = rng_scramble(r.b);
+  rng_advance(r);
   return out;
 }
 
@@ -109,11 +188,23 @@ __device__ inline double rng_normal(Rng& r, const ZigTables& zt, double nor_r) {
   }
 }
 
-// tree.ex:1597-1605
+// The fast-accept branch of normal_s on a word already drawn: returns true and the variate when
+// the word is accepted without a second draw (~98.5 % of words).
+__device__ __forceinline__ bool normal_fast(uint64_t w, const ZigTables& zt, double& z) {
+  const int sign = (int)((w >> 6) & 1);
+  const uint64_t R = w >> 7;
+  const int idx = (int)(R & 255);
+  const double x = (double)R * zt.wi[idx];
+  z = sign ? -x : x;
+  return R < zt.ki[idx];
+}
+
+// tree.ex:1597-1605. exp(0) = 1 exactly under exmc_exp, so the larger term is not evaluated.
 __device__ __forceinline__ double log_sum_exp(double a, double b) {
   const double mx = (a > b) ? a : b;
   if (mx == -exmc_from_bits(EXMC_INF_BITS) || mx == -1.0e300) return -1.0e300;
-  return mx + exmc_log(exmc_exp(a - mx) + exmc_exp(b - mx));
+  const double mn = (a > b) ? b : a;
+  return mx + exmc_log(1.0 + exmc_exp(mn - mx));
 }
 
 // lane-partial sum over this lane's valid slots, lane 0 seeded with init0, then butterfly
@@ -136,21 +227,52 @@ __device__ __forceinline__ double kinetic_energy(const double (&p)[DPL], const d
   return 0.5 * group_allsum<G>(acc);
 }
 
-// tree.ex:1578-1588: rho-based U-turn test against two endpoint momenta
-template <int G, int DPL>
-__device__ __forceinline__ bool uturn(const double (&rho)[DPL], const double (&pa)[DPL],
-                                      const double (&pb)[DPL], const double (&im)[DPL],
-                                      const bool (&valid)[DPL]) {
-  double sa = 0.0, sb = 0.0;
+// lane partials of the two dot products of tree.ex:1578-1588 for one (rho, pa, pb) triple
+template <int DPL>
+__device__ __forceinline__ void uturn_partials(const double (&rho)[DPL], const double (&pa)[DPL],
+                                               const double (&pb)[DPL], const double (&im)[DPL],
+                                               const bool (&valid)[DPL], double& sa, double& sb) {
+  sa = 0.0;
+  sb = 0.0;
 #pragma unroll
   for (int k = 0; k < DPL; k++) {
     const double v = rho[k] * im[k];
     sa = valid[k] ? (sa + v * pa[k]) : sa;
     sb = valid[k] ? (sb + v * pb[k]) : sb;
   }
-  sa = group_allsum<G>(sa);
-  sb = group_allsum<G>(sb);
-  return (sa < 0.0) || (sb < 0.0);
+}
+
+// tree.ex:1578-1588: rho-based U-turn test against two endpoint momenta
+template <int G, int DPL>
+__device__ __forceinline__ bool uturn(const double (&rho)[DPL], const double (&pa)[DPL],
+                                      const double (&pb)[DPL], const double (&im)[DPL],
+                                      const bool (&valid)[DPL]) {
+  double s[2];
+  uturn_partials<DPL>(rho, pa, pb, im, valid, s[0], s[1]);
+  group_allsum_n<G, 2>(s);
+  return (s[0] < 0.0) || (s[1] < 0.0);
+}
+
+// The three U-turn tests of one merge (tree.ex:1428-1446) in one pass of six reductions.
+//   check 1: rho_all      against (pa1, pb1)
+//   check 2: rho2         against (pa2, pb2)
+//   check 3: rho3         against (pa3, pb3)
+// The tests have no side effects, so evaluating all three (instead of short-circuiting) leaves
+// every output unchanged. Returns {c1, c2 || c3}.
+template <int G, int DPL>
+__device__ __forceinline__ void uturn3(const double (&r1)[DPL], const double (&a1)[DPL],
+                                       const double (&b1)[DPL], const double (&r2)[DPL],
+                                       const double (&a2)[DPL], const double (&b2)[DPL],
+                                       const double (&r3)[DPL], const double (&a3)[DPL],
+                                       const double (&b3)[DPL], const double (&im)[DPL],
+                                       const bool (&valid)[DPL], bool& c1, bool& c23) {
+  double s[6];
+  uturn_partials<DPL>(r1, a1, b1, im, valid, s[0], s[1]);
+  uturn_partials<DPL>(r2, a2, b2, im, valid, s[2], s[3]);
+  uturn_partials<DPL>(r3, a3, b3, im, valid, s[4], s[5]);
+  group_allsum_n<G, 6>(s);
+  c1 = (s[0] < 0.0) || (s[1] < 0.0);
+  c23 = (s[2] < 0.0) || (s[3] < 0.0) || (s[4] < 0.0) || (s[5] < 0.0);
 }
 
 }  // namespace exmc

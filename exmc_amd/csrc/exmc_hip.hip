@@ -119,32 +119,35 @@ int upload_tuning(exmc_hip_model* m, const double* inv_mass) {
 }
 
 // ---- model/lanes dispatch ---------------------------------------------------------------
-template <class M_, int G_>
+template <class M_, int G_, int LDSL_>
 struct Tag {
   using M = M_;
   static constexpr int G = G_;
+  static constexpr int LDSL = LDSL_;  // tree-stack levels kept in LDS by nuts_kernel
 };
 
+// LDS budget per one-wave workgroup: 4096 chains x G=16 lanes = 1024 workgroups = 4 per CU of
+// 160 KB; sv at 2048 chains x 64 lanes = 8 per CU.
 template <class F>
 int dispatch(exmc_hip_model* m, int lanes, F&& f) {
   switch (m->kind) {
     case EXMC_MODEL_EIGHT_SCHOOLS:
       switch (lanes) {
-        case 1: return f(Tag<EightSchools<1>, 1>{}, m->es);
-        case 2: return f(Tag<EightSchools<2>, 2>{}, m->es);
-        case 4: return f(Tag<EightSchools<4>, 4>{}, m->es);
-        case 8: return f(Tag<EightSchools<8>, 8>{}, m->es);
-        case 16: return f(Tag<EightSchools<16>, 16>{}, m->es);
+        case 1: return f(Tag<EightSchools<1>, 1, 2>{}, m->es);
+        case 2: return f(Tag<EightSchools<2>, 2, 3>{}, m->es);
+        case 4: return f(Tag<EightSchools<4>, 4, 4>{}, m->es);
+        case 8: return f(Tag<EightSchools<8>, 8, 5>{}, m->es);
+        case 16: return f(Tag<EightSchools<16>, 16, 6>{}, m->es);
         default: break;
       }
       break;
     case EXMC_MODEL_SIMPLE:
-      if (lanes == 1) return f(Tag<Simple<1>, 1>{}, m->sp);
+      if (lanes == 1) return f(Tag<Simple<1>, 1, 6>{}, m->sp);
       break;
     case EXMC_MODEL_SV:
       switch (lanes) {
-        case 32: return f(Tag<SV<32>, 32>{}, m->sv);
-        case 64: return f(Tag<SV<64>, 64>{}, m->sv);
+        case 32: return f(Tag<SV<32>, 32, 2>{}, m->sv);
+        case 64: return f(Tag<SV<64>, 64, 2>{}, m->sv);
         default: break;
       }
       break;
@@ -206,9 +209,10 @@ int launch_nuts(exmc_hip_model* m, int lanes, int C, int n_draws, int draw_offse
   return dispatch(m, lanes, [&](auto tag, const auto& mc) {
     using T = decltype(tag);
     using M = typename T::M;
-    dim3 grid = grid_for(C, T::G, kBlock);
-    size_t nthreads = (size_t)grid.x * kBlock;
-    int rc = m->stack.ensure((size_t)kMaxLevels * nuts_nslot<M>() * nthreads * 8);
+    dim3 grid = grid_for(C, T::G, kNutsBlock);
+    size_t nthreads = (size_t)grid.x * kNutsBlock;
+    constexpr int kSpill = (kMaxLevels > T::LDSL) ? (kMaxLevels - T::LDSL) : 1;
+    int rc = m->stack.ensure((size_t)kSpill * nuts_nslot<M>() * nthreads * 8);
     if (rc) return rc;
     NutsParams P;
     P.st = state_view(m, C);
@@ -225,7 +229,9 @@ int launch_nuts(exmc_hip_model* m, int lanes, int C, int n_draws, int draw_offse
     P.zig_ki = zig_ki(m); P.zig_wi = zig_wi(m); P.zig_fi = zig_fi(m);
     P.nor_r = EXMC_NOR_R;
     if (timed) HIP_TRY(hipEventRecord(m->ev0, m->stream));
-    hipLaunchKernelGGL((nuts_kernel<M, T::G>), grid, dim3(kBlock), 0, m->stream, P, mc);
+    const size_t lds_bytes = nuts_lds_bytes<M, T::LDSL>();
+    hipLaunchKernelGGL((nuts_kernel<M, T::G, T::LDSL>), grid, dim3(kNutsBlock), lds_bytes,
+                       m->stream, P, mc);
     HIP_TRY(hipGetLastError());
     if (timed) HIP_TRY(hipEventRecord(m->ev1, m->stream));
     return (int)EXMC_OK;

@@ -70,9 +70,16 @@ struct EightSchools {
       T[k] = -0.5 * (th * th + c.c1);
       g[k] = (-th) + a * tau;
     }
-    const double lik = group_sum_slots<G, DPL>(L, valid, l, 0.0);
-    const double sa = group_sum_slots<G, DPL>(A, valid, l, 0.0);
-    const double sb = group_sum_slots<G, DPL>(B, valid, l, 0.0);
+    // three independent group sums in one butterfly pass
+    double s3[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < DPL; k++) {
+      s3[0] = valid[k] ? (s3[0] + L[k]) : s3[0];
+      s3[1] = valid[k] ? (s3[1] + A[k]) : s3[1];
+      s3[2] = valid[k] ? (s3[2] + B[k]) : s3[2];
+    }
+    group_allsum_n<G, 3>(s3);
+    const double lik = s3[0], sa = s3[1], sb = s3[2];
     const double zmu = (mu - 0.0) / 5.0;
     const double t_mu = -0.5 * (zmu * zmu + c.c_mu);
     const double zt = tau / 5.0;
