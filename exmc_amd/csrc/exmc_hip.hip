@@ -9,6 +9,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -321,11 +322,13 @@ struct DualAvg {
   double log_epsilon, log_epsilon_bar, h_bar, mu;
   int m;
   double gamma, t0, kappa, target;
+  // exp/log through the numeric contract (exmc_detmath.h), m^-kappa as exp(-kappa*log(m)):
+  // the same arithmetic warmup_kernel performs on the device.
   void init(double epsilon, double target_accept) {
-    log_epsilon = std::log(epsilon);
-    log_epsilon_bar = std::log(epsilon);
+    log_epsilon = exmc_log(epsilon);
+    log_epsilon_bar = exmc_log(epsilon);
     h_bar = 0.0;
-    mu = std::log(10.0 * epsilon);
+    mu = exmc_log(10.0 * epsilon);
     m = 0;
     gamma = 0.05; t0 = 10.0; kappa = 0.75;
     target = target_accept;
@@ -335,12 +338,12 @@ struct DualAvg {
     const double eta = 1.0 / (mm + t0);
     const double hb = (1.0 - eta) * h_bar + eta * (target - accept_stat);
     const double le = mu - std::sqrt((double)mm) / gamma * hb;
-    const double mk = std::pow((double)mm, -kappa);
+    const double mk = exmc_exp(-kappa * exmc_log((double)mm));
     const double leb = mk * le + (1.0 - mk) * log_epsilon_bar;
     m = mm; h_bar = hb; log_epsilon = le; log_epsilon_bar = leb;
   }
-  double current() const { return std::exp(log_epsilon); }
-  double finalize() const { return std::exp(log_epsilon_bar); }
+  double current() const { return exmc_exp(log_epsilon); }
+  double finalize() const { return exmc_exp(log_epsilon_bar); }
 };
 
 struct WelfordDiag {
@@ -494,6 +497,59 @@ int run_warmup(exmc_hip_model* m, int lanes, exmc_hip_opts o, exmc_hip_tuning* t
     da.update(ws.accept);
   }
   return finish(da.finalize());
+}
+
+// run_warmup (sampler.ex:537-762) in one launch: warmup_kernel keeps dual averaging, Welford and
+// the step-size searches on the device; the host only lays out the window schedule.
+int run_warmup_device(exmc_hip_model* m, int lanes, exmc_hip_opts o, exmc_hip_tuning* tun) {
+  if (o.max_tree_depth < 1 || o.max_tree_depth > kMaxLevels)
+    return fail(EXMC_ERR_BADARG, "max_tree_depth out of range");
+  const int d = m->d, W = o.num_warmup;
+  WarmupParams P;
+  P.st = state_view(m, 1);
+  P.num_warmup = W;
+  P.max_depth = o.max_tree_depth;
+  P.target_accept = o.target_accept;
+  P.log_half = std::log(0.5);
+  P.init_buffer = (75 < W / 3) ? 75 : W / 3;
+  P.adapt_end = W - 50;
+  auto wins = build_windows(P.init_buffer, P.adapt_end, 25);
+  if (wins.size() > 32) return fail(EXMC_ERR_BADARG, "num_warmup needs more than 32 windows");
+  P.n_windows = (int)wins.size();
+  for (int k = 0; k < 32; k++) {
+    P.win_start[k] = k < P.n_windows ? wins[k].first : -1;
+    P.win_end[k] = k < P.n_windows ? wins[k].second : -1;
+  }
+  P.zig_ki = zig_ki(m); P.zig_wi = zig_wi(m); P.zig_fi = zig_fi(m);
+  P.nor_r = EXMC_NOR_R;
+  int rc = m->io.ensure((size_t)(3 + d) * 8);
+  if (rc) return rc;
+  P.out = m->io.as<double>();
+  rc = dispatch(m, lanes, [&](auto tag, const auto& mc) {
+    using T = decltype(tag);
+    using M = typename T::M;
+    constexpr int kSpill = (kMaxLevels > T::LDSL) ? (kMaxLevels - T::LDSL) : 1;
+    int r2 = m->stack.ensure((size_t)kSpill * nuts_nslot<M>() * kNutsBlock * 8);
+    if (r2) return r2;
+    P.stack = m->stack.as<double>();
+    const size_t lds_bytes = nuts_lds_bytes<M, T::LDSL>();
+    HIP_TRY(hipEventRecord(m->ev0, m->stream));
+    hipLaunchKernelGGL((warmup_kernel<M, T::G, T::LDSL>), dim3(1), dim3(kNutsBlock), lds_bytes,
+                       m->stream, P, mc);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(m->ev1, m->stream));
+    return (int)EXMC_OK;
+  });
+  if (rc) return rc;
+  std::vector<double> h(3 + d);
+  HIP_TRY(hipMemcpyAsync(h.data(), m->io.p, h.size() * 8, hipMemcpyDeviceToHost, m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  rc = finish_timing(m);
+  if (rc) return rc;
+  tun->epsilon = h[0];
+  tun->warmup_divergences = (int)h[1];
+  for (int i = 0; i < d; i++) tun->inv_mass[i] = h[3 + i];
+  return EXMC_OK;
 }
 
 int check_model(const exmc_hip_model* m) {
@@ -774,7 +830,11 @@ int exmc_hip_warmup(exmc_hip_model* m, const double* init_q, exmc_hip_opts o,
   if (rc) return rc;
   rc = launch_init(m, lanes, 1, 0, o.seed, init_q);
   if (rc) return rc;
-  return run_warmup(m, lanes, o, tuning);
+  // EXMC_HIP_HOST_WARMUP=1 keeps the adaptation scalars on the host (one launch per
+  // transition); the default runs the whole schedule in one kernel. Both give the same bits.
+  const char* hw = std::getenv("EXMC_HIP_HOST_WARMUP");
+  if (hw && hw[0] == '1') return run_warmup(m, lanes, o, tuning);
+  return run_warmup_device(m, lanes, o, tuning);
 }
 
 int exmc_hip_chains_init(exmc_hip_model* m, const exmc_hip_tuning* tuning, const double* init_q,

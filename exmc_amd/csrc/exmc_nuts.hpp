@@ -1,9 +1,14 @@
-// exmc_nuts.hpp — the NUTS transition kernel for gfx950.
+// exmc_nuts.hpp — the NUTS transition kernel and the on-device adaptation warmup for gfx950
+// (SURVEY.md 8a a4-a19).
 //
-//   nuts_kernel  whole NUTS transitions (momentum draw, iterative tree with multinomial
-//                proposals, rho-based U-turn checks, divergence guard) for every chain;
-//                replaces Tree.build/12 + nuts_step_with_stats (tree.ex:65-151,
+//   nuts_run     device function: n NUTS transitions of this lane group's chain (momentum draw,
+//                iterative tree with multinomial proposals, rho-based U-turn checks, divergence
+//                guard); replaces Tree.build/12 + nuts_step_with_stats (tree.ex:65-151,
 //                sampler.ex:854-925) and the Rust crate native/exmc_tree.
+//   nuts_kernel  nuts_run for every resident chain (sampling phase, sampler.ex:929-973).
+//   warmup_kernel  run_warmup (sampler.ex:537-762) for chain 0 in ONE launch: dual averaging
+//                (step_size.ex:13-50), Welford windows (mass_matrix.ex:40-97),
+//                find_reasonable_epsilon (sampler.ex:451-530) all on the device.
 //
 // The tree is built iteratively. The reference recursion (tree.ex:1144-1203) is unrolled into a
 // per-level stack of pending "first halves": after leaf k completes, one inner merge fires for
@@ -93,57 +98,100 @@ __device__ __forceinline__ void node_store(double* base, size_t stride, const do
   for (int s = 0; s < N; s++) base[(size_t)s * stride] = nd[s];
 }
 
-// stack slots of one pending node: rho, p_in, p_out, q_prop, g_prop (DPL each), lsw, logp_prop, acc
-template <class M, int G, int LDSL>
-__global__ void __launch_bounds__(kNutsBlock) nuts_kernel(NutsParams P, typename M::Consts mc) {
-  constexpr int D = M::D, DPL = M::DPL;
-  constexpr int NSLOT = 5 * DPL + 3;
-  extern __shared__ double lds[];
-  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t nthreads = (size_t)gridDim.x * blockDim.x;
-  const int l = threadIdx.x & (G - 1);
-  const int chain = tid / G;
-  const int C = P.n_chains;
-
-  // ziggurat tables -> LDS (all lanes help, before any lane leaves)
-  double* lz = lds + (size_t)LDSL * NSLOT * kNutsBlock;
-  for (int i = threadIdx.x; i < 256; i += kNutsBlock) {
-    lz[i] = __longlong_as_double((long long)P.zig_ki[i]);
-    lz[256 + i] = P.zig_wi[i];
-    lz[512 + i] = P.zig_fi[i];
-  }
-  __syncthreads();
-  if (chain >= C) return;
-  const ZigTables zt{(const uint64_t*)lz, lz + 256, lz + 512};
-
+// per-lane constants of a chain group
+template <class M, int G>
+struct NutsLane {
+  static constexpr int DPL = M::DPL;
   typename M::Lane ln;
-  M::load(mc, l, ln);
-
   double im[DPL], sim[DPL];
   bool valid[DPL];
-#pragma unroll
-  for (int k = 0; k < DPL; k++) {
-    const int i = l + k * G;
-    valid[k] = i < D;
-    im[k] = valid[k] ? P.inv_mass[i] : 1.0;
-    sim[k] = valid[k] ? P.sqrt_inv_mass[i] : 1.0;
-  }
+  int l;
+  double* lstk;      // this lane's column of the LDS stack
+  double* gstk;      // this lane's column of the global spill stack
+  size_t nthreads;
+  ZigTables zt;
+  double nor_r;
+};
 
-  // chain state between transitions
-  double sq[DPL], sg[DPL];
-  double slogp = P.st.logp[chain];
+// a chain's state between transitions
+template <int DPL>
+struct ChainRegs {
+  double q[DPL], g[DPL];
+  double logp;
   Rng rng;
-  rng.a = P.st.rng[chain];
-  rng.b = P.st.rng[(size_t)C + chain];
+};
+
+// cooperative: every lane of the workgroup must call this before any lane leaves
+template <int LDSL, int NSLOT>
+__device__ __forceinline__ ZigTables stage_zig_tables(double* lds, const uint64_t* ki,
+                                                      const double* wi, const double* fi) {
+  double* lz = lds + (size_t)LDSL * NSLOT * kNutsBlock;
+  for (int i = threadIdx.x; i < 256; i += kNutsBlock) {
+    lz[i] = __longlong_as_double((long long)ki[i]);
+    lz[256 + i] = wi[i];
+    lz[512 + i] = fi[i];
+  }
+  __syncthreads();
+  return ZigTables{(const uint64_t*)lz, lz + 256, lz + 512};
+}
+
+// sampler.ex:393-403: d sequential normal_s draws -> p = z / sqrt(M^-1). Fast path: the group
+// advances the stream d words, each lane scrambles and tests the word of its own dimension; if
+// every word is accepted at once (~86 % of transitions at d = 10) the stream position is exactly
+// d words further. Otherwise the draws are redone one by one, as normal_s consumes a
+// data-dependent number of words.
+template <class M, int G>
+__device__ __forceinline__ void draw_momentum(const NutsLane<M, G>& L, Rng& rng,
+                                              double (&p)[M::DPL]) {
+  constexpr int D = M::D, DPL = M::DPL;
+  Rng r2 = rng;
+  bool ok = true;
+  double z[DPL];
+  uint64_t s0[DPL];
+#pragma unroll
+  for (int k = 0; k < DPL; k++) { z[k] = 0.0; s0[k] = 0; }
+#pragma unroll
+  for (int i = 0; i < D; i++) {
+#pragma unroll
+    for (int k = 0; k < DPL; k++) s0[k] = (L.l + k * G == i) ? r2.b : s0[k];
+    rng_advance(r2);
+  }
 #pragma unroll
   for (int k = 0; k < DPL; k++) {
-    const int i = l + k * G;
-    sq[k] = valid[k] ? P.st.q[(size_t)i * C + chain] : 0.0;
-    sg[k] = valid[k] ? P.st.g[(size_t)i * C + chain] : 0.0;
+    double zz;
+    const bool acc = normal_fast(rng_scramble(s0[k]), L.zt, zz);
+    ok = (acc || !L.valid[k]) && ok;
+    z[k] = zz;
   }
+  if (group_all<G>(ok)) {
+    rng = r2;
+#pragma unroll
+    for (int k = 0; k < DPL; k++) p[k] = z[k] / L.sim[k];
+  } else {
+    for (int i = 0; i < D; i++) {
+      const double zz = rng_normal(rng, L.zt, L.nor_r);
+#pragma unroll
+      for (int k = 0; k < DPL; k++)
+        if (L.l + k * G == i) p[k] = zz / L.sim[k];
+    }
+  }
+}
 
-  double* lstk = lds + threadIdx.x;
-  double* gstk = P.stack + tid;
+// n_draws NUTS transitions of this group's chain. sink(draw, q, logp, depth, n_steps, divergent,
+// accept_sum, jlp0) is called once per finished transition.
+// stack slots of one pending node: rho, p_in, p_out, q_prop, g_prop (DPL each), lsw, logp_prop, acc
+template <class M, int G, int LDSL, class Sink>
+__device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const NutsLane<M, G>& L,
+                                         ChainRegs<M::DPL>& st, int n_draws, double eps,
+                                         int max_depth, Sink&& sink) {
+  constexpr int DPL = M::DPL;
+  constexpr int NSLOT = 5 * DPL + 3;
+  const int l = L.l;
+  const auto& im = L.im;
+  const auto& valid = L.valid;
+  double* lstk = L.lstk;
+  double* gstk = L.gstk;
+  const size_t nthreads = L.nthreads;
 
   // integrator state and tree registers
   double q[DPL], p[DPL], g[DPL], qold[DPL], gold[DPL];
@@ -159,64 +207,25 @@ __global__ void __launch_bounds__(kNutsBlock) nuts_kernel(NutsParams P, typename
   double t_logpP = 0.0, t_lsw = 0.0, t_acc = 0.0, jlp0 = 0.0;
   int t_n = 0, depth = 0;
   bool t_div = false, t_turn = false, go_right = true;
-  double eps_dir = P.eps;
+  double eps_dir = eps;
   unsigned pending = 0;
-  Rng trng = rng;
+  Rng trng = st.rng;
 
-  unsigned long long lf_total = 0, div_total = 0;
   int draw = 0;
   bool start_transition = true, start_doubling = false;
 
-  while (draw < P.n_draws) {
+  while (draw < n_draws) {
     if (start_transition) {
-      // sampler.ex:393-403: d sequential normal_s draws. Fast path: the group draws d words, each
-      // lane tests the word of its own dimension; if every word is accepted at once (~86 % of
-      // transitions at d = 10) the stream position is exactly d words further. Otherwise the
-      // draws are redone one by one, as normal_s consumes a data-dependent number of words.
-      {
-        Rng r2 = rng;
-        bool ok = true;
-        double z[DPL];
-        uint64_t s0[DPL];
-#pragma unroll
-        for (int k = 0; k < DPL; k++) { z[k] = 0.0; s0[k] = 0; }
-        // advance the state d times (cheap recurrence); each lane keeps the tail word its own
-        // dimension's output is scrambled from, and scrambles only that one
-#pragma unroll
-        for (int i = 0; i < D; i++) {
-#pragma unroll
-          for (int k = 0; k < DPL; k++) s0[k] = (l + k * G == i) ? r2.b : s0[k];
-          rng_advance(r2);
-        }
-#pragma unroll
-        for (int k = 0; k < DPL; k++) {
-          double zz;
-          const bool acc = normal_fast(rng_scramble(s0[k]), zt, zz);
-          ok = (acc || !valid[k]) && ok;
-          z[k] = zz;
-        }
-        if (group_all<G>(ok)) {
-          rng = r2;
-#pragma unroll
-          for (int k = 0; k < DPL; k++) pL[k] = z[k] / sim[k];
-        } else {
-          for (int i = 0; i < D; i++) {
-            const double zz = rng_normal(rng, zt, P.nor_r);
-#pragma unroll
-            for (int k = 0; k < DPL; k++)
-              if (l + k * G == i) pL[k] = zz / sim[k];
-          }
-        }
-      }
-      jlp0 = slogp - kinetic_energy<G, DPL>(pL, im, valid);
-      trng = rng;  // the tree consumes a copy (sampler.ex:897 discards its draws)
+      draw_momentum<M, G>(L, st.rng, pL);
+      jlp0 = st.logp - kinetic_energy<G, DPL>(pL, im, valid);
+      trng = st.rng;  // the tree consumes a copy (sampler.ex:897 discards its draws)
 #pragma unroll
       for (int k = 0; k < DPL; k++) {
-        qL[k] = qR[k] = t_qp[k] = sq[k];
-        gL[k] = gR[k] = t_gp[k] = sg[k];
+        qL[k] = qR[k] = t_qp[k] = st.q[k];
+        gL[k] = gR[k] = t_gp[k] = st.g[k];
         pR[k] = t_rho[k] = pL[k];
       }
-      t_logpP = slogp;
+      t_logpP = st.logp;
       t_lsw = 0.0;
       t_acc = 0.0;
       t_n = 0;
@@ -229,7 +238,7 @@ __global__ void __launch_bounds__(kNutsBlock) nuts_kernel(NutsParams P, typename
       // tree.ex:403-413 direction + outward endpoint
       const double u = rng_uniform(trng);
       go_right = u > 0.5;
-      eps_dir = go_right ? P.eps : -P.eps;
+      eps_dir = go_right ? eps : -eps;
 #pragma unroll
       for (int k = 0; k < DPL; k++) {
         q[k] = go_right ? qR[k] : qL[k];
@@ -256,7 +265,7 @@ __global__ void __launch_bounds__(kNutsBlock) nuts_kernel(NutsParams P, typename
     for (int k = 0; k < DPL; k++) { g[k] = -q[k]; logp_new = logp_new - 0.5 * q[k] * q[k]; }
     logp_new = group_allsum<G>(logp_new);
 #else
-    const double logp_new = M::logp_grad(mc, ln, l, q, g);
+    const double logp_new = M::logp_grad(mc, L.ln, l, q, g);
 #endif
 #pragma unroll
     for (int k = 0; k < DPL; k++) p[k] = p[k] + h * g[k];
@@ -418,53 +427,328 @@ __global__ void __launch_bounds__(kNutsBlock) nuts_kernel(NutsParams P, typename
       depth++;
     }
 
-    if (depth >= P.max_depth || t_div || t_turn) {
+    if (depth >= max_depth || t_div || t_turn) {
       // ---- transition done (tree.ex:1607-1618, sampler.ex:890-925) ----
-      (void)rng_uniform(rng);
-      slogp = t_logpP;
+      (void)rng_uniform(st.rng);
+      st.logp = t_logpP;
 #pragma unroll
-      for (int k = 0; k < DPL; k++) { sq[k] = t_qp[k]; sg[k] = t_gp[k]; }
-      const size_t row = (size_t)(P.draw_offset + draw);
-      if (P.tr.draws) {
-#pragma unroll
-        for (int k = 0; k < DPL; k++)
-          if (valid[k]) P.tr.draws[(row * D + (l + k * G)) * C + chain] = sq[k];
-      }
-      if (l == 0) {
-        const size_t o = row * C + chain;
-        if (P.tr.logp) P.tr.logp[o] = slogp;
-        if (P.tr.tree_depth) P.tr.tree_depth[o] = depth;
-        if (P.tr.n_steps) P.tr.n_steps[o] = t_n;
-        if (P.tr.divergent) P.tr.divergent[o] = t_div ? 1 : 0;
-        if (P.tr.accept_prob) P.tr.accept_prob[o] = (t_n > 0) ? (t_acc / (double)t_n) : 0.0;
-        if (P.tr.energy) P.tr.energy[o] = -jlp0;
-      }
-      lf_total += (unsigned long long)t_n;
-      div_total += t_div ? 1u : 0u;
+      for (int k = 0; k < DPL; k++) { st.q[k] = t_qp[k]; st.g[k] = t_gp[k]; }
+      sink(draw, st.q, st.logp, depth, t_n, t_div, t_acc, jlp0);
       draw++;
       start_transition = true;
     } else {
       start_doubling = true;
     }
   }
+}
 
-  // write back chain state
-  P.st.logp[chain] = slogp;
+// fill the per-lane constants; inv_mass / sqrt_inv_mass may be null (identity mass)
+template <class M, int G, int LDSL>
+__device__ __forceinline__ void lane_setup(NutsLane<M, G>& L, const typename M::Consts& mc,
+                                           double* lds, double* stack, const double* inv_mass,
+                                           const double* sqrt_inv_mass, const ZigTables& zt,
+                                           double nor_r) {
+  constexpr int D = M::D, DPL = M::DPL;
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  L.l = threadIdx.x & (G - 1);
+  L.nthreads = (size_t)gridDim.x * blockDim.x;
+  L.lstk = lds + threadIdx.x;
+  L.gstk = stack + tid;
+  L.zt = zt;
+  L.nor_r = nor_r;
+  M::load(mc, L.l, L.ln);
+#pragma unroll
+  for (int k = 0; k < DPL; k++) {
+    const int i = L.l + k * G;
+    L.valid[k] = i < D;
+    L.im[k] = (L.valid[k] && inv_mass) ? inv_mass[i] : 1.0;
+    L.sim[k] = (L.valid[k] && sqrt_inv_mass) ? sqrt_inv_mass[i] : 1.0;
+  }
+}
+
+template <class M, int G>
+__device__ __forceinline__ void chain_load(const ChainState& s, int C, int chain, int l,
+                                           ChainRegs<M::DPL>& st) {
+  constexpr int D = M::D, DPL = M::DPL;
+  st.logp = s.logp[chain];
+  st.rng.a = s.rng[chain];
+  st.rng.b = s.rng[(size_t)C + chain];
+#pragma unroll
+  for (int k = 0; k < DPL; k++) {
+    const int i = l + k * G;
+    st.q[k] = (i < D) ? s.q[(size_t)i * C + chain] : 0.0;
+    st.g[k] = (i < D) ? s.g[(size_t)i * C + chain] : 0.0;
+  }
+}
+
+template <class M, int G>
+__device__ __forceinline__ void chain_store(const ChainState& s, int C, int chain, int l,
+                                            const ChainRegs<M::DPL>& st) {
+  constexpr int D = M::D, DPL = M::DPL;
   if (l == 0) {
-    P.st.rng[chain] = rng.a;
-    P.st.rng[(size_t)C + chain] = rng.b;
-    if (P.counters) {
-      atomicAdd(&P.counters[0], lf_total);
-      atomicAdd(&P.counters[1], div_total);
-    }
+    s.logp[chain] = st.logp;
+    s.rng[chain] = st.rng.a;
+    s.rng[(size_t)C + chain] = st.rng.b;
   }
 #pragma unroll
   for (int k = 0; k < DPL; k++) {
-    if (valid[k]) {
-      const int i = l + k * G;
-      P.st.q[(size_t)i * C + chain] = sq[k];
-      P.st.g[(size_t)i * C + chain] = sg[k];
+    const int i = l + k * G;
+    if (i < D) {
+      s.q[(size_t)i * C + chain] = st.q[k];
+      s.g[(size_t)i * C + chain] = st.g[k];
     }
+  }
+}
+
+template <class M, int G, int LDSL>
+__global__ void __launch_bounds__(kNutsBlock) nuts_kernel(NutsParams P, typename M::Consts mc) {
+  constexpr int D = M::D, DPL = M::DPL;
+  constexpr int NSLOT = 5 * DPL + 3;
+  extern __shared__ double lds[];
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int chain = tid / G;
+  const int C = P.n_chains;
+  const ZigTables zt = stage_zig_tables<LDSL, NSLOT>(lds, P.zig_ki, P.zig_wi, P.zig_fi);
+  if (chain >= C) return;
+
+  NutsLane<M, G> L;
+  lane_setup<M, G, LDSL>(L, mc, lds, P.stack, P.inv_mass, P.sqrt_inv_mass, zt, P.nor_r);
+  ChainRegs<DPL> st;
+  chain_load<M, G>(P.st, C, chain, L.l, st);
+
+  unsigned long long lf_total = 0, div_total = 0;
+  const int l = L.l;
+  auto sink = [&](int draw, const double (&sq)[DPL], double slogp, int depth, int t_n, bool t_div,
+                  double t_acc, double jlp0) {
+    const size_t row = (size_t)(P.draw_offset + draw);
+    if (P.tr.draws) {
+#pragma unroll
+      for (int k = 0; k < DPL; k++)
+        if (L.valid[k]) P.tr.draws[(row * D + (l + k * G)) * C + chain] = sq[k];
+    }
+    if (l == 0) {
+      const size_t o = row * C + chain;
+      if (P.tr.logp) P.tr.logp[o] = slogp;
+      if (P.tr.tree_depth) P.tr.tree_depth[o] = depth;
+      if (P.tr.n_steps) P.tr.n_steps[o] = t_n;
+      if (P.tr.divergent) P.tr.divergent[o] = t_div ? 1 : 0;
+      if (P.tr.accept_prob) P.tr.accept_prob[o] = (t_n > 0) ? (t_acc / (double)t_n) : 0.0;
+      if (P.tr.energy) P.tr.energy[o] = -jlp0;
+    }
+    lf_total += (unsigned long long)t_n;
+    div_total += t_div ? 1u : 0u;
+  };
+  nuts_run<M, G, LDSL>(mc, L, st, P.n_draws, P.eps, P.max_depth, sink);
+
+  chain_store<M, G>(P.st, C, chain, l, st);
+  if (l == 0 && P.counters) {
+    atomicAdd(&P.counters[0], lf_total);
+    atomicAdd(&P.counters[1], div_total);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// find_reasonable_epsilon_with_rng (sampler.ex:451-530) for this group's chain
+// ------------------------------------------------------------------------------------------
+template <class M, int G>
+__device__ __forceinline__ double find_eps_dev(const typename M::Consts& mc,
+                                               const NutsLane<M, G>& L, ChainRegs<M::DPL>& st,
+                                               double log_half) {
+  constexpr int DPL = M::DPL;
+  double p0[DPL];
+#pragma unroll
+  for (int k = 0; k < DPL; k++) p0[k] = 0.0;
+  // plain sequential normal_s draws (as sample_momentum_fast does); identical to draw_momentum
+  draw_momentum<M, G>(L, st.rng, p0);
+  const double jlp0 = st.logp - kinetic_energy<G, DPL>(p0, L.im, L.valid);
+  auto try_eps = [&](double eps) -> double {
+    double q[DPL], p[DPL], g[DPL];
+    const double h = eps / 2.0;
+#pragma unroll
+    for (int k = 0; k < DPL; k++) {
+      const double ph = p0[k] + h * st.g[k];
+      p[k] = ph;
+      q[k] = st.q[k] + eps * (L.im[k] * ph);
+      g[k] = 0.0;
+    }
+    const double lp = M::logp_grad(mc, L.ln, L.l, q, g);
+#pragma unroll
+    for (int k = 0; k < DPL; k++) p[k] = p[k] + h * g[k];
+    const double jlp = lp - kinetic_energy<G, DPL>(p, L.im, L.valid);
+    return (exmc_isfinite(jlp0) && exmc_isfinite(jlp)) ? (jlp - jlp0) : -1000.0;
+  };
+  double eps = 1.0;
+  double la = try_eps(eps);
+  const double dir = (la > log_half) ? 1.0 : -1.0;
+  const double factor = (dir > 0) ? 2.0 : 0.5;
+  double result = 0.0;
+  bool done = false;
+  for (int count = 0; count < 100 && !done; count++) {
+    const double ne = eps * factor;
+    la = try_eps(ne);
+    const bool crossed = (dir > 0) ? (la < log_half) : (la > log_half);
+    if (crossed || !exmc_isfinite(la)) {
+      result = fmax(ne, 1.0e-10);
+      done = true;
+    } else {
+      eps = ne;
+    }
+  }
+  if (!done) result = fmax(eps, 1.0e-10);
+  return result;
+}
+
+// ------------------------------------------------------------------------------------------
+// On-device adaptation warmup for chain 0 (run_warmup, sampler.ex:537-762).
+// Scalar adaptation math follows step_size.ex / mass_matrix.ex with exp/log from the numeric
+// contract (exmc_detmath.h), sqrt IEEE, m^-kappa as exp(-kappa*log(m)).
+// ------------------------------------------------------------------------------------------
+struct WarmupParams {
+  ChainState st;            // single-chain state (C = 1), initialised by init_chains_kernel
+  int num_warmup;
+  int max_depth;
+  double target_accept;
+  double log_half;          // log(0.5) as the host computes it (sampler.ex:469)
+  int init_buffer, adapt_end;
+  int n_windows;
+  int win_start[32], win_end[32];   // build_windows (sampler.ex:764-785), computed on the host
+  double* stack;
+  double* out;              // [0] eps_final, [1] divergences, [2] leapfrogs, [3..3+D) inv_mass
+  const uint64_t* zig_ki;
+  const double* zig_wi;
+  const double* zig_fi;
+  double nor_r;
+};
+
+struct DualAvgDev {
+  double log_epsilon, log_epsilon_bar, h_bar, mu, target;
+  int m;
+  __device__ __forceinline__ void init(double epsilon, double target_accept) {
+    log_epsilon = exmc_log(epsilon);
+    log_epsilon_bar = log_epsilon;
+    h_bar = 0.0;
+    mu = exmc_log(10.0 * epsilon);
+    m = 0;
+    target = target_accept;
+  }
+  __device__ __forceinline__ void update(double accept_stat) {
+    const int mm = m + 1;
+    const double eta = 1.0 / (mm + 10.0);
+    const double hb = (1.0 - eta) * h_bar + eta * (target - accept_stat);
+    const double le = mu - __dsqrt_rn((double)mm) / 0.05 * hb;
+    const double mk = exmc_exp(-0.75 * exmc_log((double)mm));
+    const double leb = mk * le + (1.0 - mk) * log_epsilon_bar;
+    m = mm;
+    h_bar = hb;
+    log_epsilon = le;
+    log_epsilon_bar = leb;
+  }
+};
+
+template <class M, int G, int LDSL>
+__global__ void __launch_bounds__(kNutsBlock) warmup_kernel(WarmupParams P, typename M::Consts mc) {
+  constexpr int D = M::D, DPL = M::DPL;
+  constexpr int NSLOT = 5 * DPL + 3;
+  extern __shared__ double lds[];
+  const ZigTables zt = stage_zig_tables<LDSL, NSLOT>(lds, P.zig_ki, P.zig_wi, P.zig_fi);
+  if (blockIdx.x != 0 || threadIdx.x >= G) return;
+
+  NutsLane<M, G> L;
+  lane_setup<M, G, LDSL>(L, mc, lds, P.stack, nullptr, nullptr, zt, P.nor_r);
+  ChainRegs<DPL> st;
+  chain_load<M, G>(P.st, 1, 0, L.l, st);
+
+  double accept = 0.0;
+  bool diverged = false;
+  unsigned long long leapfrogs = 0;
+  int divergences = 0;
+  auto sink = [&](int, const double (&)[DPL], double, int, int t_n, bool t_div, double t_acc,
+                  double) {
+    accept = (t_n > 0) ? (t_acc / (double)t_n) : 0.0;
+    diverged = t_div;
+    leapfrogs += (unsigned long long)t_n;
+  };
+
+  const int W = P.num_warmup;
+  double eps = find_eps_dev<M, G>(mc, L, st, P.log_half);
+  double eps_final = eps;
+  if (W > 0) {
+    const bool has_windows = P.adapt_end > P.init_buffer;
+    const int n_iter = has_windows ? W : P.init_buffer;
+    DualAvgDev da;
+    da.init(eps, P.target_accept);
+    int win = 0;
+    bool in_window = false;
+    int wn = 0;
+    double wmean[DPL], wm2[DPL];
+#pragma unroll
+    for (int k = 0; k < DPL; k++) wmean[k] = wm2[k] = 0.0;
+    for (int i = 0; i < n_iter; i++) {
+      if (has_windows) {
+        if (win < P.n_windows && i == P.win_start[win]) {
+          if (win == 0) eps = exmc_exp(da.log_epsilon);   // sampler.ex:578
+          wn = 0;
+#pragma unroll
+          for (int k = 0; k < DPL; k++) wmean[k] = wm2[k] = 0.0;
+          da.init(eps, P.target_accept);
+          in_window = true;
+        }
+        if (i == P.adapt_end) da.init(eps, P.target_accept);   // Phase III (sampler.ex:601)
+      }
+      // sampler.ex:709: depth cap 8 for absolute warmup index < 200, Phase II only
+      const int cap = (in_window && i < 200) ? (P.max_depth < 8 ? P.max_depth : 8) : P.max_depth;
+      nuts_run<M, G, LDSL>(mc, L, st, 1, exmc_exp(da.log_epsilon), cap, sink);
+      divergences += diverged ? 1 : 0;
+      da.update(accept);
+      if (in_window) {
+        if (!diverged) {
+          // mass_matrix.ex:40-54
+          const int nn = wn + 1;
+#pragma unroll
+          for (int k = 0; k < DPL; k++) {
+            const double delta = st.q[k] - wmean[k];
+            const double nm = wmean[k] + delta / ((double)nn * 1.0);
+            const double d2 = st.q[k] - nm;
+            wm2[k] = wm2[k] + delta * d2;
+            wmean[k] = nm;
+          }
+          wn = nn;
+        }
+        if (i + 1 == P.win_end[win]) {
+          // mass_matrix.ex:77-97, then re-search the step size (sampler.ex:747-756)
+          if (wn < 3) {
+#pragma unroll
+            for (int k = 0; k < DPL; k++) L.im[k] = 1.0;
+          } else {
+            const double alpha = 5.0 / (wn + 5.0);
+#pragma unroll
+            for (int k = 0; k < DPL; k++) {
+              double var = wm2[k] / ((double)(wn - 1) * 1.0);
+              var = fmax(var, 1.0e-6);
+              L.im[k] = L.valid[k] ? ((1.0 - alpha) * var + alpha * 1.0e-3) : 1.0;
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < DPL; k++) L.sim[k] = __dsqrt_rn(L.im[k]);
+          eps = find_eps_dev<M, G>(mc, L, st, P.log_half);
+          win++;
+          in_window = false;
+        }
+      }
+    }
+    eps_final = exmc_exp(da.log_epsilon_bar);
+  }
+
+  chain_store<M, G>(P.st, 1, 0, L.l, st);
+  if (L.l == 0) {
+    P.out[0] = eps_final;
+    P.out[1] = (double)divergences;
+    P.out[2] = (double)leapfrogs;
+  }
+#pragma unroll
+  for (int k = 0; k < DPL; k++) {
+    const int i = L.l + k * G;
+    if (i < D) P.out[3 + i] = L.im[k];
   }
 }
 

@@ -692,15 +692,20 @@ void exo_tree_build(const exo_model* m, const double* q, const double* p, double
 /* ======================================================================================
  * Adaptation
  * ==================================================================================== */
-void exo_da_init(exo_da* s, double epsilon, double target_accept) {
-  /* step_size.ex:13-30 */
-  s->log_epsilon = log(epsilon);
-  s->log_epsilon_bar = log(epsilon);
+void exo_da_init_mode(exo_da* s, double epsilon, double target_accept, int math_mode) {
+  /* step_size.ex:13-30. math_mode 1: exp/log through exmc_detmath.h and m^-kappa as
+   * exp(-kappa*log(m)) — the arithmetic the device-side warmup performs. */
+  s->math_mode = math_mode;
+  s->log_epsilon = exo_log(epsilon, math_mode);
+  s->log_epsilon_bar = exo_log(epsilon, math_mode);
   s->h_bar = 0.0;
-  s->mu = log(10.0 * epsilon);
+  s->mu = exo_log(10.0 * epsilon, math_mode);
   s->m = 0;
   s->gamma = 0.05; s->t0 = 10.0; s->kappa = 0.75;
   s->target_accept = target_accept;
+}
+void exo_da_init(exo_da* s, double epsilon, double target_accept) {
+  exo_da_init_mode(s, epsilon, target_accept, 0);
 }
 void exo_da_update(exo_da* s, double accept_stat) {
   /* step_size.ex:35-44 */
@@ -708,11 +713,12 @@ void exo_da_update(exo_da* s, double accept_stat) {
   double eta = 1.0 / (m + s->t0);
   double h_bar = (1.0 - eta) * s->h_bar + eta * (s->target_accept - accept_stat);
   double le = s->mu - sqrt((double)m) / s->gamma * h_bar;
-  double mk = pow((double)m, -s->kappa);
+  double mk = s->math_mode ? exmc_exp(-s->kappa * exmc_log((double)m)) : pow((double)m, -s->kappa);
   double leb = mk * le + (1.0 - mk) * s->log_epsilon_bar;
   s->m = m; s->h_bar = h_bar; s->log_epsilon = le; s->log_epsilon_bar = leb;
 }
-double exo_da_finalize(const exo_da* s) { return exp(s->log_epsilon_bar); }
+double exo_da_finalize(const exo_da* s) { return exo_exp(s->log_epsilon_bar, s->math_mode); }
+static double da_current(const exo_da* s) { return exo_exp(s->log_epsilon, s->math_mode); }
 
 void exo_welford_init(exo_welford* w, int d) {
   w->n = 0; w->d = d;
@@ -844,7 +850,7 @@ static void run_phase(const exo_model* m, cstate* s, const double* im, int max_d
   /* sampler.ex:623-666 */
   for (int i = from; i < to; i++) {
     step_info info;
-    nuts_step(m, s, exp(da->log_epsilon), im, max_depth, &info, c);
+    nuts_step(m, s, da_current(da), im, max_depth, &info, c);
     exo_da_update(da, info.accept);
   }
 }
@@ -857,28 +863,28 @@ static double run_warmup(const exo_model* m, cstate* s, double eps, double* im, 
   int init_buffer = (75 < W / 3) ? 75 : W / 3;
   int adapt_end = W - 50;
   exo_da da;
-  exo_da_init(&da, eps, o.target_accept);
+  exo_da_init_mode(&da, eps, o.target_accept, c.math_mode);
   run_phase(m, s, im, o.max_tree_depth, &da, 0, init_buffer, c);
-  eps = exp(da.log_epsilon);
+  eps = da_current(&da);
   if (adapt_end <= init_buffer) return exo_da_finalize(&da);
   int ws[32], we[32];
   int nw = exo_build_windows(init_buffer, adapt_end, 25, ws, we, 32);
   for (int k = 0; k < nw; k++) {
     exo_welford wf;
     exo_welford_init(&wf, d);
-    exo_da_init(&da, eps, o.target_accept);
+    exo_da_init_mode(&da, eps, o.target_accept, c.math_mode);
     for (int i = ws[k]; i < we[k]; i++) {
       int cap = (i < 200) ? (o.max_tree_depth < 8 ? o.max_tree_depth : 8) : o.max_tree_depth;
       int div_before = s->divergences;
       step_info info;
-      nuts_step(m, s, exp(da.log_epsilon), im, cap, &info, c);
+      nuts_step(m, s, da_current(&da), im, cap, &info, c);
       exo_da_update(&da, info.accept);
       if (s->divergences == div_before) exo_welford_update(&wf, s->q);
     }
     exo_welford_finalize(&wf, im);
     eps = find_reasonable_epsilon(m, s, im, c);
   }
-  exo_da_init(&da, eps, o.target_accept);
+  exo_da_init_mode(&da, eps, o.target_accept, c.math_mode);
   run_phase(m, s, im, o.max_tree_depth, &da, adapt_end, W, c);
   return exo_da_finalize(&da);
 }

@@ -116,8 +116,10 @@ typedef struct {
   double log_epsilon, log_epsilon_bar, h_bar, mu;
   int m;
   double gamma, t0, kappa, target_accept;
+  int math_mode;
 } exo_da;
-void exo_da_init(exo_da* s, double epsilon, double target_accept);
+void exo_da_init(exo_da* s, double epsilon, double target_accept);          /* libm */
+void exo_da_init_mode(exo_da* s, double epsilon, double target_accept, int math_mode);
 void exo_da_update(exo_da* s, double accept_stat);
 double exo_da_finalize(const exo_da* s);
 typedef struct {

@@ -32,7 +32,7 @@ class DA(C.Structure):
     _fields_ = [("log_epsilon", C.c_double), ("log_epsilon_bar", C.c_double),
                 ("h_bar", C.c_double), ("mu", C.c_double), ("m", C.c_int),
                 ("gamma", C.c_double), ("t0", C.c_double), ("kappa", C.c_double),
-                ("target_accept", C.c_double)]
+                ("target_accept", C.c_double), ("math_mode", C.c_int)]
 
 
 class Welford(C.Structure):
@@ -125,6 +125,7 @@ def lib():
     L.exo_check_uturn.argtypes = [dp, dp, dp, dp, C.c_int, Cfg]
     L.exo_check_uturn.restype = C.c_int
     L.exo_da_init.argtypes = [C.POINTER(DA), C.c_double, C.c_double]
+    L.exo_da_init_mode.argtypes = [C.POINTER(DA), C.c_double, C.c_double, C.c_int]
     L.exo_da_update.argtypes = [C.POINTER(DA), C.c_double]
     L.exo_da_finalize.argtypes = [C.POINTER(DA)]
     L.exo_da_finalize.restype = C.c_double

@@ -163,6 +163,25 @@ def test_warmup_and_chains_bit_exact(es, hip, lanes):
     assert np.array_equal(ex2["raw"]["draws"], raw["draws"][8:16])
 
 
+@pytest.mark.parametrize("num_warmup", [0, 2, 60, 150, 320])
+def test_device_warmup_equals_host_driven_and_oracle(es, hip, num_warmup, monkeypatch):
+    """run_warmup (sampler.ex:537-762) in one kernel == one launch per transition with the
+    adaptation scalars on the host == the checker; covers the short schedules (no Phase II when
+    adapt_end <= init_buffer, sampler.ex:580-582)."""
+    spec, comp, om = es
+    opts = dict(num_warmup=num_warmup, num_samples=1, seed=9, lanes_per_chain=16)
+    dev = sampler.warmup(comp, spec.default_init, opts)
+    monkeypatch.setenv("EXMC_HIP_HOST_WARMUP", "1")
+    host = sampler.warmup(comp, spec.default_init, opts)
+    monkeypatch.delenv("EXMC_HIP_HOST_WARMUP")
+    st = O.warmup(om, spec.to_unconstrained(spec.default_init), num_warmup=num_warmup, seed=9,
+                  cfg=O.Cfg(1, 16))
+    assert dev["epsilon"] == host["epsilon"] == st.step_size
+    assert np.array_equal(dev["inv_mass"], host["inv_mass"])
+    assert np.array_equal(dev["inv_mass"], np.array(st.inv_mass[:spec.d]))
+    assert dev["warmup_divergences"] == host["warmup_divergences"] == st.divergences
+
+
 def test_random_init_bit_exact(es, hip):
     """init_values = %{} => 0.1 * normal_s per dimension (sampler.ex:339-349)."""
     spec, comp, om = es
