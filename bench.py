@@ -45,7 +45,14 @@ def make_spec(name):
         return models.eight_schools(), 488  # (6d+1)*8 bytes per leapfrog per chain, SURVEY 8d
     if name == "sv":
         return models.sv(synthetic_sv_returns()), 4904
+    if name == "logistic":
+        return models.logistic(), 1016
+    if name == "radon":
+        return models.radon(), 4328
     raise SystemExit("unknown model %s" % name)
+
+
+DEFAULT_CHAINS_PER_GPU = {"eight_schools": 4096, "logistic": 8192, "sv": 2048, "radon": 1024}
 
 
 def cpu_baseline(spec, init, K, n_chains_total, budget_s=15.0):
@@ -126,7 +133,7 @@ def main():
 
     spec, bytes_per_leapfrog = make_spec(args.model)
     K, W, d = args.steps, args.warmup, spec.d
-    Cper = args.chains_per_gpu or (4096 if args.model == "eight_schools" else 2048)
+    Cper = args.chains_per_gpu or DEFAULT_CHAINS_PER_GPU[args.model]
     Ctot = Cper * world
     comp = sampler.compile(spec, {"device": local_rank})
     lanes = args.lanes or comp.default_lanes

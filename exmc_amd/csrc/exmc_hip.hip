@@ -72,6 +72,9 @@ struct exmc_hip_model {
   EightSchoolsConsts es{};
   SimpleConsts sp{};
   SVConsts sv{};
+  LogisticConsts lg{};
+  RadonConsts rd{};
+  DevBuf data;      // model data kept in HBM (logistic X,y; radon u,starts,floor,y)
   DevBuf zig;       // ki[256] u64, wi[256], fi[256]
   DevBuf tuning;    // inv_mass[D], sqrt_inv_mass[D]
   DevBuf state;     // q[D][C], g[D][C], logp[C], rng[2][C]
@@ -152,6 +155,20 @@ int dispatch(exmc_hip_model* m, int lanes, F&& f) {
         default: break;
       }
       break;
+    case EXMC_MODEL_LOGISTIC:
+      switch (lanes) {
+        case 8: return f(Tag<Logistic<8>, 8, 2>{}, m->lg);
+        case 16: return f(Tag<Logistic<16>, 16, 2>{}, m->lg);
+        default: break;
+      }
+      break;
+    case EXMC_MODEL_RADON:
+      switch (lanes) {
+        case 32: return f(Tag<Radon<32>, 32, 2>{}, m->rd);
+        case 64: return f(Tag<Radon<64>, 64, 2>{}, m->rd);
+        default: break;
+      }
+      break;
     default: break;
   }
   return fail(EXMC_ERR_UNSUPPORTED, "model kind / lanes_per_chain combination not compiled in");
@@ -162,6 +179,8 @@ int default_lanes(int kind) {
     case EXMC_MODEL_EIGHT_SCHOOLS: return 16;
     case EXMC_MODEL_SIMPLE: return 1;
     case EXMC_MODEL_SV: return 64;
+    case EXMC_MODEL_LOGISTIC: return 16;
+    case EXMC_MODEL_RADON: return 64;
     default: return 1;
   }
 }
@@ -624,6 +643,33 @@ int exmc_hip_model_create(int kind, int d, const double* data, int n_data, int d
       m->sv.log_lam_n32 = f32r(std::log(f32r(0.1)));
       break;
     }
+    case EXMC_MODEL_LOGISTIC: {
+      // data = X[N][20] row-major, y[N]
+      if (!data || n_data < 21 || n_data % 21 != 0) { delete m; return fail(EXMC_ERR_BADARG, "logistic needs X[N][20], y[N]"); }
+      m->d = 21;
+      m->lg.N = n_data / 21;
+      m->lg.c10 = log2pi32 + 2.0 * std::log(10.0);
+      m->lg.lo = f32r(1.0e-7);
+      m->lg.hi = 1.0 - f32r(1.0e-7);
+      break;
+    }
+    case EXMC_MODEL_RADON: {
+      // data = u[85], county_start[86], floor[N], y[N] (observations sorted by county)
+      const int J = 85;
+      if (!data || n_data < 2 * J + 1 || (n_data - (2 * J + 1)) % 2 != 0) { delete m; return fail(EXMC_ERR_BADARG, "radon needs u[85], start[86], floor[N], y[N]"); }
+      const int N = (n_data - (2 * J + 1)) / 2;
+      if ((int)data[J] != 0 || (int)data[2 * J] != N) { delete m; return fail(EXMC_ERR_BADARG, "radon county offsets do not cover the observations"); }
+      for (int j = 0; j < J; j++)
+        if (data[J + j + 1] < data[J + j]) { delete m; return fail(EXMC_ERR_BADARG, "radon county offsets must be non-decreasing"); }
+      m->d = J + 5;
+      m->rd.log2pi32 = log2pi32;
+      m->rd.tiny32 = f32r(1.0e-30);
+      m->rd.c_mu10 = log2pi32 + 2.0 * std::log(10.0);
+      m->rd.c_n5 = log2pi32 + 2.0 * std::log(5.0);
+      m->rd.c1 = log2pi32 + 2.0 * 0.0;
+      m->rd.c_hc = f32r(std::log(2.0 / M_PI)) - std::log(2.5);
+      break;
+    }
     default:
       delete m;
       return fail(EXMC_ERR_UNSUPPORTED, "model kind not compiled into libexmc_hip");
@@ -643,6 +689,23 @@ int exmc_hip_model_create(int kind, int d, const double* data, int n_data, int d
       hipMemcpy(m->zig.as<double>() + 256, kZigWi, 256 * 8, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(m->zig.as<double>() + 512, kZigFi, 256 * 8, hipMemcpyHostToDevice) != hipSuccess)
     return bail(fail(EXMC_ERR_HIP, "table upload failed"));
+  if (kind == EXMC_MODEL_LOGISTIC || kind == EXMC_MODEL_RADON) {
+    rc = m->data.ensure((size_t)n_data * 8);
+    if (rc) return bail(rc);
+    if (hipMemcpy(m->data.p, data, (size_t)n_data * 8, hipMemcpyHostToDevice) != hipSuccess)
+      return bail(fail(EXMC_ERR_HIP, "model data upload failed"));
+    const double* base = m->data.as<double>();
+    if (kind == EXMC_MODEL_LOGISTIC) {
+      m->lg.X = base;
+      m->lg.y = base + (size_t)m->lg.N * 20;
+    } else {
+      const int J = 85, N = (n_data - (2 * J + 1)) / 2;
+      m->rd.u = base;
+      m->rd.cs = base + J;
+      m->rd.fl = base + 2 * J + 1;
+      m->rd.y = base + 2 * J + 1 + N;
+    }
+  }
   *out = m;
   return EXMC_OK;
 }
@@ -651,7 +714,7 @@ void exmc_hip_model_destroy(exmc_hip_model* m) {
   if (!m) return;
   (void)hipSetDevice(m->device);
   m->zig.release(); m->tuning.release(); m->state.release(); m->stack.release();
-  m->misc.release(); m->trace.release(); m->io.release();
+  m->misc.release(); m->trace.release(); m->io.release(); m->data.release();
   if (m->ev0) (void)hipEventDestroy(m->ev0);
   if (m->ev1) (void)hipEventDestroy(m->ev1);
   if (m->stream) (void)hipStreamDestroy(m->stream);

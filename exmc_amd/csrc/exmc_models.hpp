@@ -266,4 +266,177 @@ struct SV {
   }
 };
 
+// ------------------------------------------------------------------------------------------
+// logistic regression, K = 20 covariates, N observations (STANDARD_BENCHMARKS.md:41-49;
+// Bernoulli clip dist/bernoulli.ex:17-27). dims: 0 alpha, 1..20 beta_j. Observation n is
+// handled by lane n mod G of the chain's group (row n of X stays in registers for both the
+// linear predictor and the gradient accumulation); contractions are fma chains.
+// ------------------------------------------------------------------------------------------
+struct LogisticConsts {
+  const double* X;   // dev [N][K] row-major
+  const double* y;   // dev [N]
+  int N;
+  double c10;        // f32(log(f32(2pi))) + 2*log(10)
+  double lo, hi;     // f32(1e-7), 1 - f32(1e-7)
+};
+
+template <int G>
+struct Logistic {
+  static constexpr int K = 20;
+  static constexpr int D = K + 1;
+  static constexpr int DPL = (D + G - 1) / G;
+  using Consts = LogisticConsts;
+  struct Lane {};
+  __device__ static __forceinline__ void load(const Consts&, int, Lane&) {}
+
+  __device__ static __forceinline__ double logp_grad(const Consts& c, const Lane&, int l,
+                                                     const double (&q)[DPL], double (&g)[DPL]) {
+    double qf[D];
+#pragma unroll
+    for (int i = 0; i < D; i++) qf[i] = group_bcast<G>(q[i / G], i % G);
+    double s[D + 1];   // s[0..D-1] gradient partials, s[D] likelihood partial
+#pragma unroll
+    for (int j = 0; j <= D; j++) s[j] = 0.0;
+    for (int n = l; n < c.N; n += G) {
+      const double* x = c.X + (size_t)n * K;
+      double xr[K];
+#pragma unroll
+      for (int j = 0; j < K; j++) xr[j] = x[j];
+      const double yn = c.y[n];
+      double eta = __builtin_fma(1.0, qf[0], 0.0);
+#pragma unroll
+      for (int j = 0; j < K; j++) eta = __builtin_fma(xr[j], qf[1 + j], eta);
+      const double p = 1.0 / (1.0 + exmc_exp(-eta));
+      const double pc = fmin(fmax(p, c.lo), c.hi);
+      const double ll = exmc_log((yn == 1.0) ? pc : (1.0 - pc));
+      const double r = (p > c.lo && p < c.hi) ? (yn - p) : 0.0;
+      s[D] = s[D] + ll;
+      s[0] = __builtin_fma(1.0, r, s[0]);
+#pragma unroll
+      for (int j = 0; j < K; j++) s[1 + j] = __builtin_fma(xr[j], r, s[1 + j]);
+    }
+    group_allsum_n<G, D + 1>(s);
+    double T[DPL];
+    bool valid[DPL];
+#pragma unroll
+    for (int k = 0; k < DPL; k++) {
+      const int i = l + k * G;
+      valid[k] = i < D;
+      double gi = 0.0;
+#pragma unroll
+      for (int j = 0; j < D; j++) gi = (i == j) ? s[j] : gi;
+      const double z = (q[k] - 0.0) / 10.0;
+      T[k] = -0.5 * (z * z + c.c10);
+      g[k] = valid[k] ? ((-(z / 10.0)) + gi) : 0.0;
+    }
+    return group_sum_slots<G, DPL>(T, valid, l, s[D]);
+  }
+};
+
+// ------------------------------------------------------------------------------------------
+// hierarchical radon, J = 85 counties (notebooks/09_radon_bhm.livemd "The Radon Model").
+// dims: 0..J-1 alpha_raw_j, J mu_alpha, J+1 gamma_u, J+2 log sigma_alpha, J+3 log sigma_y,
+// J+4 beta. The lane that owns alpha_raw_j walks county j's observations (sorted by county).
+// ------------------------------------------------------------------------------------------
+struct RadonConsts {
+  const double* u;      // dev [J]
+  const double* cs;     // dev [J+1] county start offsets (as doubles)
+  const double* fl;     // dev [N]
+  const double* y;      // dev [N]
+  double log2pi32, tiny32;
+  double c_mu10;        // log2pi32 + 2*log(10)
+  double c_n5;          // log2pi32 + 2*log(5)
+  double c1;            // log2pi32 + 2*log(1)
+  double c_hc;          // f32(log(2/pi)) - log(2.5)
+};
+
+template <int G>
+struct Radon {
+  static constexpr int J = 85;
+  static constexpr int D = J + 5;
+  static constexpr int DPL = (D + G - 1) / G;
+  using Consts = RadonConsts;
+  struct Lane {
+    double u[DPL];
+    int i0[DPL], i1[DPL];
+  };
+  __device__ static __forceinline__ void load(const Consts& c, int l, Lane& ln) {
+#pragma unroll
+    for (int k = 0; k < DPL; k++) {
+      const int j = l + k * G;
+      const bool cty = j < J;
+      ln.u[k] = cty ? c.u[j] : 0.0;
+      ln.i0[k] = cty ? (int)c.cs[j] : 0;
+      ln.i1[k] = cty ? (int)c.cs[j + 1] : 0;
+    }
+  }
+  __device__ static __forceinline__ double half_cauchy_d(const Consts& c, double x, double& dx) {
+    const double z = x / 2.5;
+    const double z2 = z * z;
+    dx = -(((2.0 * z) / 2.5) / (1.0 + z2));
+    return c.c_hc - exmc_log(1.0 + z2);
+  }
+  __device__ static __forceinline__ double logp_grad(const Consts& c, const Lane& ln, int l,
+                                                     const double (&q)[DPL], double (&g)[DPL]) {
+    const double mu = group_bcast<G>(q[J / G], J % G);
+    const double gam = group_bcast<G>(q[(J + 1) / G], (J + 1) % G);
+    const double zsa_raw = group_bcast<G>(q[(J + 2) / G], (J + 2) % G);
+    const double zsy_raw = group_bcast<G>(q[(J + 3) / G], (J + 3) % G);
+    const double beta = group_bcast<G>(q[(J + 4) / G], (J + 4) % G);
+    const double zsa = clamp200(zsa_raw), zsy = clamp200(zsy_raw);
+    const double sa = exmc_exp(zsa), sy = exmc_exp(zsy);
+    const double ssy = fmax(sy, c.tiny32);
+    const double cn = c.log2pi32 + 2.0 * exmc_log(ssy);
+    double s[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // lik, S, S*u, S*alpha_raw, F, Z2 partials
+    double T[DPL];
+    bool valid[DPL];
+#pragma unroll
+    for (int k = 0; k < DPL; k++) {
+      const int j = l + k * G;
+      valid[k] = j < D;
+      const double ar = q[k];
+      const double alpha = (mu + gam * ln.u[k]) + sa * ar;
+      double lik = 0.0, sj = 0.0, f = 0.0, z2s = 0.0;
+      for (int i = ln.i0[k]; i < ln.i1[k]; i++) {
+        const double fi = c.fl[i];
+        const double mean = alpha + beta * fi;
+        const double z = (c.y[i] - mean) / ssy;
+        const double a = z / ssy;
+        lik = lik + (-0.5 * (z * z + cn));
+        sj = sj + a;
+        f = f + a * fi;
+        z2s = z2s + (z * z - 1.0);
+      }
+      if (valid[k]) {
+        s[0] = s[0] + lik;
+        s[1] = s[1] + sj;
+        s[2] = s[2] + sj * ln.u[k];
+        s[3] = s[3] + sj * ar;
+        s[4] = s[4] + f;
+        s[5] = s[5] + z2s;
+      }
+      T[k] = -0.5 * (ar * ar + c.c1);
+      g[k] = (-ar) + sj * sa;
+    }
+    group_allsum_n<G, 6>(s);
+    const double zmu = (mu - 0.0) / 10.0, zg = (gam - 0.0) / 5.0, zb = (beta - 0.0) / 5.0;
+    double dsa, dsy;
+    const double t_sa = half_cauchy_d(c, sa, dsa) + zsa;
+    const double t_sy = half_cauchy_d(c, sy, dsy) + zsy;
+    const bool in_a = (zsa_raw > -200.0) && (zsa_raw < 200.0);
+    const bool in_y = (zsy_raw > -200.0) && (zsy_raw < 200.0);
+#pragma unroll
+    for (int k = 0; k < DPL; k++) {
+      const int j = l + k * G;
+      if (j == J) { T[k] = -0.5 * (zmu * zmu + c.c_mu10); g[k] = (-(zmu / 10.0)) + s[1]; }
+      if (j == J + 1) { T[k] = -0.5 * (zg * zg + c.c_n5); g[k] = (-(zg / 5.0)) + s[2]; }
+      if (j == J + 2) { T[k] = t_sa; g[k] = in_a ? ((dsa + s[3]) * sa + 1.0) : 0.0; }
+      if (j == J + 3) { T[k] = t_sy; g[k] = in_y ? ((dsy * sy + s[5]) + 1.0) : 0.0; }
+      if (j == J + 4) { T[k] = -0.5 * (zb * zb + c.c_n5); g[k] = (-(zb / 5.0)) + s[4]; }
+      if (j >= D) g[k] = 0.0;
+    }
+    return group_sum_slots<G, DPL>(T, valid, l, s[0]);
+  }
+};
+
 }  // namespace exmc

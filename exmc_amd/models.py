@@ -62,6 +62,67 @@ def simple(y=SIMPLE_Y):
                      {"mu": 2.0, "sigma": 1.0})
 
 
+def logistic_data(seed=42, n=500, k=20):
+    """X iid N(0,1), beta* = 0.5*N(0,1), alpha* = 0.5 (STANDARD_BENCHMARKS.md:77),
+    y ~ Bernoulli(sigmoid(alpha* + X beta*)). The reference's generator is not in its
+    repository; this one (numpy default_rng(seed)) is build-defined."""
+    rng = np.random.default_rng(seed)
+    X = rng.normal(size=(n, k))
+    beta = 0.5 * rng.normal(size=k)
+    p = 1.0 / (1.0 + np.exp(-(0.5 + X @ beta)))
+    y = (rng.uniform(size=n) < p).astype(np.float64)
+    return X, y
+
+
+def logistic(X=None, y=None):
+    """Logistic regression, d = K+1 (STANDARD_BENCHMARKS.md:41-49). Kernel order alpha,
+    beta_1..beta_K; the reference's flat order is the string sort (alpha, beta_1, beta_10, ...)."""
+    if X is None:
+        X, y = logistic_data()
+    X = np.ascontiguousarray(np.asarray(X, dtype=np.float64))
+    y = np.asarray(y, dtype=np.float64)
+    n, k = X.shape
+    names = ["alpha"] + ["beta_%d" % j for j in range(1, k + 1)]
+    spec = ModelSpec(LOGISTIC, "logistic", np.concatenate([X.ravel(), y]), names, {},
+                     {nm: 0.0 for nm in names})
+    spec.n_obs = n
+    return spec
+
+
+def radon_data(seed=42, n_counties=85, n_obs=919):
+    """notebooks/09_radon_bhm.livemd: 85 counties, ~919 observations, truth mu_alpha 1.4,
+    gamma_u 0.7, sigma_alpha 0.4, sigma_y 0.7, beta -0.7. benchmark/radon_data.exs is absent from
+    the reference repository, so this generator (numpy default_rng(seed)) is build-defined."""
+    rng = np.random.default_rng(seed)
+    w = rng.gamma(1.5, 1.0, size=n_counties) + 0.15
+    counts = np.maximum(2, np.floor(w / w.sum() * n_obs)).astype(int)
+    while counts.sum() > n_obs:
+        counts[np.argmax(counts)] -= 1
+    while counts.sum() < n_obs:
+        counts[np.argmin(counts)] += 1
+    u = rng.normal(0.0, 0.5, size=n_counties)
+    alpha = 1.4 + 0.7 * u + 0.4 * rng.normal(size=n_counties)
+    start = np.concatenate([[0], np.cumsum(counts)])
+    county = np.repeat(np.arange(n_counties), counts)
+    floor = (rng.uniform(size=n_obs) < 0.2).astype(np.float64)
+    y = alpha[county] - 0.7 * floor + 0.7 * rng.normal(size=n_obs)
+    return u, start, floor, y
+
+
+def radon(data=None):
+    """Hierarchical radon, d = J+5 = 90. Kernel order alpha_raw_0..J-1, mu_alpha, gamma_u,
+    sigma_alpha, sigma_y, beta (the reference's flat order is the string sort)."""
+    u, start, floor, y = data if data is not None else radon_data()
+    J = len(u)
+    names = ["alpha_raw_%d" % j for j in range(J)] + ["mu_alpha", "gamma_u", "sigma_alpha",
+                                                        "sigma_y", "beta"]
+    init = {nm: 0.0 for nm in names}
+    init.update(sigma_alpha=1.0, sigma_y=1.0)
+    blob = np.concatenate([np.asarray(u, float), np.asarray(start, float), np.asarray(floor, float),
+                           np.asarray(y, float)])
+    return ModelSpec(RADON, "radon", blob, names, {"sigma_alpha": "log", "sigma_y": "log"}, init)
+
+
 def sv(returns):
     """Stochastic volatility, T = 100 (STANDARD_BENCHMARKS.md:51-61). Kernel order s_1..s_T,
     sigma, nu; the reference's flat order is the string sort (nu, s_1, s_10, s_100, ...)."""

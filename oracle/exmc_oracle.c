@@ -263,6 +263,16 @@ exo_model* exo_model_create(int kind, int d, const double* data, int n_data) {
     case EXO_MODEL_SV:
       m->d = n_data + 2; /* data = r[T] */
       break;
+    case EXO_MODEL_LOGISTIC:
+      /* data = X[N][K] row-major, y[N]; d = K + 1 */
+      if (d < 2 || n_data % d != 0) { exo_model_free(m); return 0; }
+      m->d = d;
+      break;
+    case EXO_MODEL_RADON:
+      /* data = u[J], county_start[J+1], floor[N], y[N] (observations sorted by county); d = J+5 */
+      if (d < 6 || (n_data - (2 * (d - 5) + 1)) % 2 != 0) { exo_model_free(m); return 0; }
+      m->d = d;
+      break;
     default:
       break;
   }
@@ -412,8 +422,127 @@ static double logp_sv(const exo_model* m, const double* q, double* g, exo_cfg c)
   return ((t_sigma + t_nu) + sp) + sl;
 }
 
+/* multiply-accumulate of the dense contractions: fused in the GPU contract, mul + add in the
+ * reference's arithmetic (Nx.dot on BinaryBackend) */
+static double mac(double a, double b, double acc, int mm) {
+  return mm ? __builtin_fma(a, b, acc) : (a * b + acc);
+}
+
+static double logp_logistic(const exo_model* m, const double* q, double* g, exo_cfg c) {
+  /* STANDARD_BENCHMARKS.md:41-49: alpha, beta_j ~ N(0,10); y_n ~ Bernoulli(sigmoid(alpha + X beta))
+   * with p clipped to [1e-7, 1-1e-7] (bernoulli.ex:17-27). Kernel order alpha, beta_1..beta_K.
+   * Observation n belongs to lane n mod G; each lane walks its observations in increasing n. */
+  int mm = c.math_mode, d = m->d, K = d - 1, N = m->n / d;
+  int G = c.lanes < 1 ? 1 : c.lanes;
+  const double* X = m->data;
+  const double* y = m->data + (size_t)N * K;
+  double lo = f32r(1.0e-7), hi = 1.0 - f32r(1.0e-7);
+  double lik_part[64], gp[64][EXO_MAX_D];
+  for (int l = 0; l < G; l++) {
+    double lik = 0.0;
+    double* acc = gp[l];
+    for (int j = 0; j < d; j++) acc[j] = 0.0;
+    for (int n = l; n < N; n += G) {
+      const double* x = X + (size_t)n * K;
+      double eta = mac(1.0, q[0], 0.0, mm);
+      for (int j = 0; j < K; j++) eta = mac(x[j], q[1 + j], eta, mm);
+      double p = 1.0 / (1.0 + exo_exp(-eta, mm));
+      double pc = fmin(fmax(p, lo), hi);
+      double ll = (y[n] == 1.0) ? exo_log(pc, mm) : exo_log(1.0 - pc, mm);
+      double r = (p > lo && p < hi) ? (y[n] - p) : 0.0;
+      lik = lik + ll;
+      acc[0] = mac(1.0, r, acc[0], mm);
+      for (int j = 0; j < K; j++) acc[1 + j] = mac(x[j], r, acc[1 + j], mm);
+    }
+    lik_part[l] = lik;
+  }
+  /* butterflies over the lane partials (lane_sum with one slot per lane) */
+  double lik = lane_sum(lik_part, G, G, 0.0);
+  double T[EXO_MAX_D];
+  double c10 = LOG_2PI_F32() + 2.0 * log(10.0);
+  for (int j = 0; j < d; j++) {
+    double col[64];
+    for (int l = 0; l < G; l++) col[l] = gp[l][j];
+    double gj = lane_sum(col, G, G, 0.0);
+    double z = (q[j] - 0.0) / 10.0;
+    T[j] = -0.5 * (z * z + c10);
+    g[j] = (-(z / 10.0)) + gj;
+  }
+  return lane_sum(T, d, G, lik);
+}
+
+static double half_cauchy_d(double x, double s, double* dx, int mm) {
+  /* half_cauchy.ex:17-25 value and d/dx */
+  double z = x / s;
+  double z2 = z * z;
+  *dx = -(((2.0 * z) / s) / (1.0 + z2));
+  return (LOG_2_OVER_PI_F32() - log(s)) - exo_log(1.0 + z2, mm);
+}
+
+static double logp_radon(const exo_model* m, const double* q, double* g, exo_cfg c) {
+  /* notebooks/09_radon_bhm.livemd "The Radon Model": alpha_raw_j ~ N(0,1), mu_alpha ~ N(0,10),
+   * gamma_u ~ N(0,5), sigma_alpha, sigma_y ~ HalfCauchy(2.5) [:log], beta ~ N(0,5),
+   * alpha_j = mu_alpha + gamma_u*u_j + sigma_alpha*alpha_raw_j, y ~ N(alpha_j + beta*floor, sigma_y).
+   * Kernel order: alpha_raw_0..J-1, mu_alpha, gamma_u, log sigma_alpha, log sigma_y, beta. */
+  int mm = c.math_mode, d = m->d, J = d - 5;
+  int G = c.lanes < 1 ? 1 : c.lanes;
+  const double* u = m->data;
+  const double* cs = m->data + J;           /* county_start[J+1] */
+  int N = (int)cs[J];
+  const double* fl = m->data + J + (J + 1);
+  const double* y = fl + N;
+  double mu = q[J], gam = q[J + 1], zsa = clamp200(q[J + 2]), zsy = clamp200(q[J + 3]), beta = q[J + 4];
+  double sa = exo_exp(zsa, mm), sy = exo_exp(zsy, mm);
+  double ssy = fmax(sy, TINY_F32());
+  double cn = LOG_2PI_F32() + 2.0 * exo_log(ssy, mm);
+  double c1 = LOG_2PI_F32() + 2.0 * 0.0;
+  double LIK[EXO_MAX_D], S[EXO_MAX_D], SU[EXO_MAX_D], SA[EXO_MAX_D], F[EXO_MAX_D], Z2[EXO_MAX_D];
+  double T[EXO_MAX_D];
+  for (int j = 0; j < d; j++) LIK[j] = S[j] = SU[j] = SA[j] = F[j] = Z2[j] = T[j] = 0.0;
+  for (int j = 0; j < J; j++) {
+    double ar = q[j];
+    double alpha = (mu + gam * u[j]) + sa * ar;
+    double lik = 0.0, s = 0.0, f = 0.0, z2s = 0.0;
+    for (int i = (int)cs[j]; i < (int)cs[j + 1]; i++) {
+      double mean = alpha + beta * fl[i];
+      double z = (y[i] - mean) / ssy;
+      double a = z / ssy;
+      lik = lik + (-0.5 * (z * z + cn));
+      s = s + a;
+      f = f + a * fl[i];
+      z2s = z2s + (z * z - 1.0);
+    }
+    LIK[j] = lik; S[j] = s; SU[j] = s * u[j]; SA[j] = s * ar; F[j] = f; Z2[j] = z2s;
+    T[j] = -0.5 * (ar * ar + c1);
+    g[j] = (-ar) + s * sa;
+  }
+  double lik = lane_sum(LIK, d, G, 0.0);
+  double ss = lane_sum(S, d, G, 0.0);
+  double su = lane_sum(SU, d, G, 0.0);
+  double sar = lane_sum(SA, d, G, 0.0);
+  double sf = lane_sum(F, d, G, 0.0);
+  double sz2 = lane_sum(Z2, d, G, 0.0);
+  double zmu = (mu - 0.0) / 10.0, zg = (gam - 0.0) / 5.0, zb = (beta - 0.0) / 5.0;
+  T[J] = -0.5 * (zmu * zmu + (LOG_2PI_F32() + 2.0 * log(10.0)));
+  T[J + 1] = -0.5 * (zg * zg + (LOG_2PI_F32() + 2.0 * log(5.0)));
+  double dsa, dsy;
+  T[J + 2] = half_cauchy_d(sa, 2.5, &dsa, mm) + zsa;
+  T[J + 3] = half_cauchy_d(sy, 2.5, &dsy, mm) + zsy;
+  T[J + 4] = -0.5 * (zb * zb + (LOG_2PI_F32() + 2.0 * log(5.0)));
+  int in_a = (q[J + 2] > -200.0) && (q[J + 2] < 200.0);
+  int in_y = (q[J + 3] > -200.0) && (q[J + 3] < 200.0);
+  g[J] = (-(zmu / 10.0)) + ss;
+  g[J + 1] = (-(zg / 5.0)) + su;
+  g[J + 2] = in_a ? ((dsa + sar) * sa + 1.0) : 0.0;
+  g[J + 3] = in_y ? ((dsy * sy + sz2) + 1.0) : 0.0;
+  g[J + 4] = (-(zb / 5.0)) + sf;
+  return lane_sum(T, d, G, lik);
+}
+
 double exo_logp_grad(const exo_model* m, const double* q, double* grad, exo_cfg cfg) {
   switch (m->kind) {
+    case EXO_MODEL_LOGISTIC: return logp_logistic(m, q, grad, cfg);
+    case EXO_MODEL_RADON: return logp_radon(m, q, grad, cfg);
     case EXO_MODEL_STD_NORMAL: return logp_std_normal(m, q, grad, cfg);
     case EXO_MODEL_SIMPLE: return logp_simple(m, q, grad, cfg);
     case EXO_MODEL_EIGHT_SCHOOLS: return logp_eight_schools(m, q, grad, cfg);
@@ -431,6 +560,10 @@ void exo_constrain(const exo_model* m, const double* q, double* x) {
     case EXO_MODEL_SV:
       x[m->n] = exp(clamp200(q[m->n]));
       x[m->n + 1] = exp(clamp200(q[m->n + 1]));
+      break;
+    case EXO_MODEL_RADON:
+      x[m->d - 3] = exp(clamp200(q[m->d - 3]));
+      x[m->d - 2] = exp(clamp200(q[m->d - 2]));
       break;
     default: break;
   }

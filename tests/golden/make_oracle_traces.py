@@ -21,6 +21,8 @@ CASES = {
     "es_g16_div": ("eight_schools", 16, 1.70, 3, 40, 10, 11),
     "simple_g1": ("simple", 1, 0.30, 2, 40, 10, 0),
     "sv_g64": ("sv", 64, 0.05, 2, 10, 6, 42),
+    "logistic_g16": ("logistic", 16, 0.30, 2, 12, 6, 5),
+    "radon_g64": ("radon", 64, 0.20, 2, 12, 6, 6),
 }
 
 
@@ -41,7 +43,14 @@ def init_for(name, d):
         q = np.zeros(d)
         q[100], q[101] = np.log(0.1), np.log(10.0)
         return q
-    return np.zeros(d)
+    return np.zeros(d)   # eight_schools, logistic, radon: zeros (log of unit scales = 0)
+
+
+def spec_for(name):
+    """The product's model descriptions double as the source of the synthetic data sets."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from exmc_amd import models
+    return {"logistic": models.logistic, "radon": models.radon}[name]()
 
 
 def model_for(name):
@@ -49,6 +58,9 @@ def model_for(name):
         return O.eight_schools()
     if name == "simple":
         return O.simple()
+    if name in ("logistic", "radon"):
+        spec = spec_for(name)
+        return O.Model(spec.kind, spec.d, spec.data)
     return O.Model(O.SV, 102, sv_returns())
 
 

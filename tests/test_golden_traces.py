@@ -28,6 +28,8 @@ def test_golden_traces_cover_edge_cases():
     assert GOLD["es_g8_deep/tree_depth"].max() == 7          # depth cap reached
     assert GOLD["es_g8_deep/n_steps"].max() == 127
     assert GOLD["sv_g64/draws"].shape == (2, 10, 102)
+    assert GOLD["logistic_g16/draws"].shape == (2, 12, 21)
+    assert GOLD["radon_g64/draws"].shape == (2, 12, 90)
     assert np.array_equal(GOLD["sv_returns"], G.sv_returns())
 
 
@@ -37,7 +39,8 @@ def test_hip_reproduces_committed_traces(name, hip):
     from exmc_amd import models, sampler
     mname, lanes, eps, nc, nd, md, seed = G.CASES[name]
     spec = {"eight_schools": models.eight_schools, "simple": models.simple,
-            "sv": lambda: models.sv(GOLD["sv_returns"])}[mname]()
+            "sv": lambda: models.sv(GOLD["sv_returns"]), "logistic": models.logistic,
+            "radon": models.radon}[mname]()
     comp = sampler.compile(spec)
     tuning = dict(epsilon=eps, inv_mass=G.inv_mass_for(spec.d))
     opts = dict(num_samples=nd, max_tree_depth=md, seed=seed, lanes_per_chain=lanes)

@@ -50,6 +50,35 @@ def test_logp_grad_bit_exact(es, hip, lanes):
         assert np.array_equal(og, g[c]), (c, og, g[c])
 
 
+def _other_models():
+    import test_golden_traces as TG
+    return [("sv", lambda: models.sv(TG.GOLD["sv_returns"]), [32, 64]),
+            ("logistic", models.logistic, [8, 16]),
+            ("radon", models.radon, [32, 64])]
+
+
+@pytest.mark.parametrize("name,factory,lane_list", _other_models(), ids=lambda x: x if isinstance(x, str) else "")
+def test_model_logp_grad_bit_exact(hip, name, factory, lane_list):
+    """vag_fn (compiler.ex:131-141) for the other BASELINE configs: sv (d=102), logistic (d=21,
+    N=500 dense X@beta), radon (d=90, 919 observations in 85 counties)."""
+    spec = factory()
+    comp = sampler.compile(spec)
+    om = O.Model(spec.kind, spec.d, spec.data)
+    rng = np.random.default_rng(3)
+    C_ = 37
+    q = _rand_q(rng, C_, spec.d, 0.4)
+    q[0] = spec.to_unconstrained(spec.default_init)
+    for lanes in lane_list:
+        lp = np.zeros(C_)
+        g = np.zeros((C_, spec.d))
+        _lib.check(hip.exmc_hip_logp_grad_host(comp.h, _dp(q), C_, lanes, _dp(lp), _dp(g)))
+        cfg = O.Cfg(1, lanes)
+        for c in range(C_):
+            olp, og = om.logp_grad(q[c], cfg)
+            assert olp == lp[c], (name, lanes, c, olp, lp[c])
+            assert np.array_equal(og, g[c]), (name, lanes, c)
+
+
 @pytest.mark.parametrize("lanes", [1, 8, 16])
 @pytest.mark.parametrize("eps", [0.3, -0.3])
 def test_multi_step_bit_exact(es, hip, lanes, eps):

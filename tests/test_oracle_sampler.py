@@ -21,8 +21,11 @@ def sv_returns(seed=42, T=100):
 
 
 def all_models():
+    from exmc_amd import models
+    lg, rd = models.logistic(), models.radon()
     return [("std_normal", O.std_normal(7)), ("simple", O.simple()),
-            ("eight_schools", O.eight_schools()), ("sv", O.Model(O.SV, 102, sv_returns()))]
+            ("eight_schools", O.eight_schools()), ("sv", O.Model(O.SV, 102, sv_returns())),
+            ("logistic", O.Model(lg.kind, lg.d, lg.data)), ("radon", O.Model(rd.kind, rd.d, rd.data))]
 
 
 def fd_grad(m, q, cfg, h=1e-6):
@@ -66,7 +69,8 @@ def test_modes_and_lane_layouts_agree_to_rounding(name, m):
     """det-math vs libm and G-lane vs left-to-right sums differ only by rounding: the stated
     floating tolerance between the GPU contract and the reference's own arithmetic."""
     rng = np.random.default_rng(9)
-    lanes = {"sv": [32, 64], "simple": [1], "std_normal": [2, 4], "eight_schools": [2, 4, 8, 16]}[name]
+    lanes = {"sv": [32, 64], "simple": [1], "std_normal": [2, 4], "eight_schools": [2, 4, 8, 16],
+             "logistic": [8, 16], "radon": [32, 64]}[name]
     for _ in range(5):
         q = rng.normal(size=m.d) * 0.7
         lp0, g0 = m.logp_grad(q, O.Cfg(0, 1))
