@@ -15,7 +15,7 @@ EXPORTS = [
     "exmc_hip_model_stream", "exmc_hip_logp_grad_host", "exmc_hip_multi_step",
     "exmc_hip_multi_step_host", "exmc_hip_transitions_host", "exmc_hip_warmup",
     "exmc_hip_sample_chains", "exmc_hip_sample_chains_host", "exmc_hip_sample_host",
-    "exmc_hip_chains_init", "exmc_hip_chains_advance",
+    "exmc_hip_chains_init", "exmc_hip_chains_advance", "exmc_hip_build_full_tree_host",
     "exmc_hip_ess", "exmc_hip_last_kernel_ms",
 ]
 
@@ -81,6 +81,10 @@ def load():
                                           C.POINTER(C.c_int32)]
     L.exmc_hip_sample_host.argtypes = [vp, dp, Opts, Trace, C.POINTER(Tuning),
                                        C.POINTER(C.c_int32)]
+    ip = C.POINTER(C.c_int32)
+    L.exmc_hip_build_full_tree_host.argtypes = [
+        C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, dp, dp, C.c_int, dp, dp, dp, dp,
+        C.c_int, dp, dp, C.c_int, C.POINTER(C.c_uint64), dp, dp, dp, ip, ip, dp, ip]
     L.exmc_hip_ess.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
     L.exmc_hip_last_kernel_ms.argtypes = [vp]
     L.exmc_hip_last_kernel_ms.restype = C.c_double

@@ -12,6 +12,8 @@ OUT = os.path.join(OUT_DIR, "libexmc_hip.so")
 DEPS = [
     SRC,
     os.path.join(HERE, "csrc", "exmc_kernels.hpp"),
+    os.path.join(HERE, "csrc", "exmc_nuts.hpp"),
+    os.path.join(HERE, "csrc", "exmc_native_tree.hpp"),
     os.path.join(HERE, "csrc", "exmc_models.hpp"),
     os.path.join(HERE, "csrc", "exmc_device.hpp"),
     os.path.join(ROOT, "include", "exmc_hip.h"),

@@ -16,6 +16,7 @@
 
 #include "../../include/exmc_zig_tables.h"
 #include "exmc_kernels.hpp"
+#include "exmc_native_tree.hpp"
 
 using namespace exmc;
 
@@ -999,6 +1000,84 @@ int exmc_hip_sample_host(exmc_hip_model* m, const double* init_q, exmc_hip_opts 
   if (divergences) *divergences = div + tun.warmup_divergences;  // stats.divergences, sampler.ex:245
   if (tuning_out) *tuning_out = tun;
   return download_trace(m, L, o.num_samples, 1, tr);
+}
+
+int exmc_hip_build_full_tree_host(int device, int C, int d, const double* q0, const double* p0,
+                                  const double* g0, const double* logp0, const double* fwd_q,
+                                  const double* fwd_p, const double* fwd_logp, const double* fwd_g,
+                                  int n_fwd, const double* bwd_q, const double* bwd_p,
+                                  const double* bwd_logp, const double* bwd_g, int n_bwd,
+                                  const double* inv_mass, const double* jlp0, int max_depth,
+                                  const uint64_t* seeds, double* q_out, double* logp_out,
+                                  double* g_out, int32_t* n_steps, int32_t* divergent,
+                                  double* accept_sum, int32_t* depth) {
+  if (C < 1 || d < 1 || n_fwd < 0 || n_bwd < 0 || max_depth < 0 || max_depth > kFtLevels ||
+      !q0 || !p0 || !g0 || !logp0 || !inv_mass || !jlp0 || !seeds || !q_out || !logp_out ||
+      !g_out || !n_steps || !divergent || !accept_sum || !depth ||
+      (n_fwd > 0 && (!fwd_q || !fwd_p || !fwd_logp || !fwd_g)) ||
+      (n_bwd > 0 && (!bwd_q || !bwd_p || !bwd_logp || !bwd_g)))
+    return fail(EXMC_ERR_BADARG, "bad arguments");   // NifResult badarg (lib.rs)
+  int ndev = exmc_hip_device_count();
+  if (ndev <= 0)
+    return fail(EXMC_ERR_NO_DEVICE, "no HIP device visible: libexmc_hip has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail(EXMC_ERR_BADARG, "device index out of range");
+  HIP_TRY(hipSetDevice(device));
+  const size_t vec = (size_t)C * d, fw = (size_t)C * n_fwd * d, bw = (size_t)C * n_bwd * d;
+  // one device arena: inputs, scratch, outputs (doubles), then int32 outputs
+  const size_t n_in = 3 * vec + C + 3 * fw + (size_t)C * n_fwd + 3 * bw + (size_t)C * n_bwd + d + C + C;
+  const size_t n_scr = (size_t)C * (kFtLevels + 3) * d;
+  const size_t n_out = 2 * vec + 2 * (size_t)C;
+  const size_t total = (n_in + n_scr + n_out) * 8 + 3 * (size_t)C * 4;
+  DevBuf arena;
+  int rc = arena.ensure(total);
+  if (rc) return rc;
+  double* b = arena.as<double>();
+  FullTreeParams P;
+  P.n_chains = C; P.d = d; P.n_fwd = n_fwd; P.n_bwd = n_bwd; P.max_depth = max_depth;
+  std::vector<std::pair<const void*, size_t>> ups;
+  auto put = [&](const double* src, size_t n) {
+    double* dst = b;
+    if (n) ups.push_back({src, n});
+    b += n;
+    return (const double*)dst;
+  };
+  P.q0 = put(q0, vec); P.p0 = put(p0, vec); P.g0 = put(g0, vec); P.logp0 = put(logp0, C);
+  P.fwd_q = put(fwd_q, fw); P.fwd_p = put(fwd_p, fw); P.fwd_g = put(fwd_g, fw);
+  P.fwd_logp = put(fwd_logp, (size_t)C * n_fwd);
+  P.bwd_q = put(bwd_q, bw); P.bwd_p = put(bwd_p, bw); P.bwd_g = put(bwd_g, bw);
+  P.bwd_logp = put(bwd_logp, (size_t)C * n_bwd);
+  P.inv_mass = put(inv_mass, d); P.jlp0 = put(jlp0, C);
+  P.seeds = (const uint64_t*)put((const double*)seeds, C);
+  {
+    double* dst = arena.as<double>();
+    for (auto& u : ups) {
+      if (hipMemcpy(dst, u.first, u.second * 8, hipMemcpyHostToDevice) != hipSuccess) {
+        arena.release();
+        return fail(EXMC_ERR_HIP, "upload failed");
+      }
+      dst += u.second;
+    }
+  }
+  P.scratch = b; b += n_scr;
+  P.out_q = b; b += vec;
+  P.out_g = b; b += vec;
+  P.out_logp = b; b += C;
+  P.out_accept_sum = b; b += C;
+  int32_t* ib = (int32_t*)b;
+  P.out_n_steps = ib; P.out_divergent = ib + C; P.out_depth = ib + 2 * (size_t)C;
+  hipLaunchKernelGGL(full_tree_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, 0, P);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(q_out, P.out_q, vec * 8, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(g_out, P.out_g, vec * 8, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(logp_out, P.out_logp, (size_t)C * 8, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(accept_sum, P.out_accept_sum, (size_t)C * 8, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(n_steps, P.out_n_steps, (size_t)C * 4, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(divergent, P.out_divergent, (size_t)C * 4, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(depth, P.out_depth, (size_t)C * 4, hipMemcpyDeviceToHost);
+  arena.release();
+  if (e != hipSuccess) return fail(EXMC_ERR_HIP, std::string("build_full_tree: ") + hipGetErrorString(e));
+  return EXMC_OK;
 }
 
 int exmc_hip_ess(exmc_hip_model* m, const double* draws_dev, int n_draws, int d, int n_chains,

@@ -160,6 +160,26 @@ int exmc_hip_sample_host(exmc_hip_model* m, const double* init_q, exmc_hip_opts 
 int exmc_hip_ess(exmc_hip_model* m, const double* draws_dev, int n_draws, int d, int n_chains,
                  double* ess_dev);
 
+/* Exmc.NUTS.NativeTree.build_full_tree_bin/17 (lib/exmc/nuts/native_tree.ex:55-75,
+ * native/exmc_tree/src/lib.rs:219-302, tree.rs:276-326), batched over n_chains independent
+ * trees: pre-computed forward / backward leapfrog chains in, proposal + tree statistics out.
+ * Host buffers in the NIF's layout (native-endian f64, row-major [chain][step][dim]):
+ *   q0,p0,grad0 [C][d]; logp0 [C]; fwd_* / bwd_* [C][n][d] with logp [C][n]; inv_mass [d];
+ *   joint_logp_0 [C]; rng_seed [C] (Xoshiro256** seed_from_u64, lib.rs:262).
+ * Outputs q,grad [C][d]; logp, accept_sum [C]; n_steps, divergent, depth int32 [C].
+ * Keeps the Rust crate's semantics where they differ from the Elixir path (a divergent leaf
+ * keeps the new state; the tree stops when a direction's budget is exhausted). */
+int exmc_hip_build_full_tree_host(int device, int n_chains, int d, const double* q0,
+                                  const double* p0, const double* grad0, const double* logp0,
+                                  const double* fwd_q, const double* fwd_p, const double* fwd_logp,
+                                  const double* fwd_grad, int n_fwd, const double* bwd_q,
+                                  const double* bwd_p, const double* bwd_logp,
+                                  const double* bwd_grad, int n_bwd, const double* inv_mass,
+                                  const double* joint_logp_0, int max_depth,
+                                  const uint64_t* rng_seed, double* q_out, double* logp_out,
+                                  double* grad_out, int32_t* n_steps, int32_t* divergent,
+                                  double* accept_sum, int32_t* depth);
+
 /* wall-clock of the last timed kernel region on the handle's stream, HIP events (ms) */
 double exmc_hip_last_kernel_ms(const exmc_hip_model* m);
 

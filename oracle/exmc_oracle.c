@@ -1275,11 +1275,16 @@ static int nt_uturn(const double* rho, const double* pl, const double* pr, const
   }
   return dr < 0.0 || dl < 0.0;
 }
+/* 0 = libm (what the Rust crate calls); 1 = exmc_detmath.h (the GPU-batched entry point's contract) */
+static int g_nt_math_mode = 0;
+void exo_nt_set_math_mode(int mode) { g_nt_math_mode = mode; }
+static double nt_exp(double x) { return exo_exp(x, g_nt_math_mode); }
+static double nt_log(double x) { return exo_log(x, g_nt_math_mode); }
 static double nt_lse(double a, double b) {
   /* math.rs:3-10 */
   double m = fmax(a, b);
   if (m == -INFINITY) return -INFINITY;
-  return m + log(exp(a - m) + exp(b - m));
+  return m + nt_log(nt_exp(a - m) + nt_exp(b - m));
 }
 static void nt_node_alloc(ntctx* t, node* n) {
   int d = t->d;
@@ -1313,7 +1318,7 @@ static void nt_build_subtree(ntctx* t, int depth, int going_right, int* counter,
       double dl = jlp - t->jlp0;
       div = dl < -1000.0;
       lw = dl;
-      acc = fmin(exp(fmin(dl, 0.0)), 1.0);
+      acc = fmin(nt_exp(fmin(dl, 0.0)), 1.0);
     } else {
       div = 1; lw = -1001.0; acc = 0.0;
     }
@@ -1339,7 +1344,7 @@ static void nt_build_subtree(ntctx* t, int depth, int going_right, int* counter,
   double lsw = nt_lse(a.lsw, b.lsw);
   int divg = a.div || b.div;
   double u = exo_xoshiro_f64(t->rng);
-  int use_b = u < exp(b.lsw - lsw);
+  int use_b = u < nt_exp(b.lsw - lsw);
   double rho[EXO_MAX_D];
   for (int i = 0; i < d; i++) rho[i] = a.rho[i] + b.rho[i];
   const node* L = going_right ? &a : &b;
@@ -1371,7 +1376,7 @@ static void nt_merge_into(exo_nt_traj* tr, const node* sub, int go_right, const 
     sub_turning = nt_sub_uturn(L, R, im, d);
   }
   double u = exo_xoshiro_f64(rng);
-  if (log(u) < (sub->lsw - tr->lsw)) {
+  if (nt_log(u) < (sub->lsw - tr->lsw)) {
     vcp(tr->qP, sub->qP, d); vcp(tr->gP, sub->gP, d);
     tr->logpP = sub->logpP;
   }

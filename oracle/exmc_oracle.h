@@ -178,6 +178,8 @@ double exo_rhat(const double* chains, int n_chains, int n);  /* chains [n_chains
 
 /* ---- NativeTree NIF semantics (native/exmc_tree/src/{tree,lib}.rs) */
 typedef struct exo_nt_traj exo_nt_traj;
+/* 0 (default) = libm as the Rust crate; 1 = exmc_detmath.h, the GPU entry point's contract */
+void exo_nt_set_math_mode(int mode);
 exo_nt_traj* exo_nt_init_trajectory(const double* q, const double* p, const double* g, double logp,
                                     int d);
 void exo_nt_free(exo_nt_traj* t);
