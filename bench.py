@@ -55,6 +55,17 @@ def make_spec(name):
 DEFAULT_CHAINS_PER_GPU = {"eight_schools": 4096, "logistic": 8192, "sv": 2048, "radon": 1024}
 
 
+def measured_traffic(model, chains, steps, lanes):
+    """HBM bytes of one timed launch from the PMC passes committed under profiles/ (rocprofv3
+    --pmc FETCH_SIZE / WRITE_SIZE on this same command, see profiles/README.md); None when no
+    measurement of this exact workload is on file. bench.py cannot collect PMC counters itself."""
+    try:
+        table = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    except (OSError, ValueError):
+        return None
+    return table.get("%s:%d:%d:%d" % (model, chains, steps, lanes), {}).get("hbm_bytes")
+
+
 def cpu_baseline(spec, init, K, n_chains_total, budget_s=15.0):
     """The CPU checker (oracle/, libm mode = the reference's own arithmetic, one chain per host
     thread) on a bounded sample of the same workload. A reported baseline, not the target."""
@@ -231,7 +242,8 @@ def main():
             "step_size": tuning["epsilon"],
             "ess_kernel_ms": ess_ms,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": measured_traffic(args.model, Cper, K, lanes),
                          "kernel": "nuts_kernel", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_leapfrog": bytes_per_leapfrog,
                          "leapfrogs_per_launch": local_lf},
