@@ -158,6 +158,7 @@ int dispatch(exmc_hip_model* m, int lanes, F&& f) {
       break;
     case EXMC_MODEL_LOGISTIC:
       switch (lanes) {
+        case 4: return f(Tag<Logistic<4>, 4, 2>{}, m->lg);   // matrix-core path
         case 8: return f(Tag<Logistic<8>, 8, 2>{}, m->lg);
         case 16: return f(Tag<Logistic<16>, 16, 2>{}, m->lg);
         default: break;
@@ -217,8 +218,9 @@ int launch_init(exmc_hip_model* m, int lanes, int C, int chain_lo, uint64_t seed
   P.nor_r = EXMC_NOR_R;
   return dispatch(m, lanes, [&](auto tag, const auto& mc) {
     using T = decltype(tag);
+    const size_t xlds = aux_lds_bytes<typename T::M>();
     hipLaunchKernelGGL((init_chains_kernel<typename T::M, T::G>), grid_for(C, T::G, kBlock),
-                       dim3(kBlock), 0, m->stream, P, mc);
+                       dim3(kBlock), xlds, m->stream, P, mc);
     HIP_TRY(hipGetLastError());
     return (int)EXMC_OK;
   });
@@ -451,7 +453,9 @@ int find_eps(exmc_hip_model* m, int lanes, double* eps) {
   P.nor_r = EXMC_NOR_R;
   int rc = dispatch(m, lanes, [&](auto tag, const auto& mc) {
     using T = decltype(tag);
-    hipLaunchKernelGGL((find_eps_kernel<typename T::M, T::G>), dim3(1), dim3(64), 0, m->stream, P, mc);
+    const size_t lds_bytes = nuts_lds_bytes<typename T::M, 0>();
+    hipLaunchKernelGGL((find_eps_kernel<typename T::M, T::G>), dim3(1), dim3(kNutsBlock), lds_bytes,
+                       m->stream, P, mc);
     HIP_TRY(hipGetLastError());
     return (int)EXMC_OK;
   });
@@ -691,14 +695,40 @@ int exmc_hip_model_create(int kind, int d, const double* data, int n_data, int d
       hipMemcpy(m->zig.as<double>() + 512, kZigFi, 256 * 8, hipMemcpyHostToDevice) != hipSuccess)
     return bail(fail(EXMC_ERR_HIP, "table upload failed"));
   if (kind == EXMC_MODEL_LOGISTIC || kind == EXMC_MODEL_RADON) {
-    rc = m->data.ensure((size_t)n_data * 8);
+    std::vector<double> blob(data, data + n_data);
+    size_t off_xat = 0, off_xa32 = 0, off_yp = 0;
+    if (kind == EXMC_MODEL_LOGISTIC) {
+      // MFMA operands: Xa = [1 | X] zero-padded to 24 / 32 features and Npad observations
+      const int N = m->lg.N, K = 20, Npad = (N + 15) / 16 * 16;
+      m->lg.Npad = Npad;
+      off_xat = blob.size();
+      blob.resize(blob.size() + (size_t)24 * Npad, 0.0);
+      off_xa32 = blob.size();
+      blob.resize(blob.size() + (size_t)Npad * 32, 0.0);
+      off_yp = blob.size();
+      blob.resize(blob.size() + (size_t)Npad, 0.0);
+      for (int n = 0; n < N; n++) {
+        blob[off_xat + n] = 1.0;
+        blob[off_xa32 + (size_t)n * 32] = 1.0;
+        for (int j = 0; j < K; j++) {
+          const double x = data[(size_t)n * K + j];
+          blob[off_xat + (size_t)(1 + j) * Npad + n] = x;
+          blob[off_xa32 + (size_t)n * 32 + 1 + j] = x;
+        }
+        blob[off_yp + n] = data[(size_t)N * K + n];
+      }
+    }
+    rc = m->data.ensure(blob.size() * 8);
     if (rc) return bail(rc);
-    if (hipMemcpy(m->data.p, data, (size_t)n_data * 8, hipMemcpyHostToDevice) != hipSuccess)
+    if (hipMemcpy(m->data.p, blob.data(), blob.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
       return bail(fail(EXMC_ERR_HIP, "model data upload failed"));
     const double* base = m->data.as<double>();
     if (kind == EXMC_MODEL_LOGISTIC) {
       m->lg.X = base;
       m->lg.y = base + (size_t)m->lg.N * 20;
+      m->lg.XaT = base + off_xat;
+      m->lg.Xa32 = base + off_xa32;
+      m->lg.ypad = base + off_yp;
     } else {
       const int J = 85, N = (n_data - (2 * J + 1)) / 2;
       m->rd.u = base;
@@ -746,8 +776,9 @@ int exmc_hip_logp_grad_host(exmc_hip_model* m, const double* q, int C, int lanes
   HIP_TRY(hipMemcpyAsync(dq, h.data(), h.size() * 8, hipMemcpyHostToDevice, m->stream));
   rc = dispatch(m, lanes, [&](auto tag, const auto& mc) {
     using T = decltype(tag);
+    const size_t xlds = aux_lds_bytes<typename T::M>();
     hipLaunchKernelGGL((logp_grad_kernel<typename T::M, T::G>), grid_for(C, T::G, kBlock),
-                       dim3(kBlock), 0, m->stream, (const double*)dq, C, dl, dg, mc);
+                       dim3(kBlock), xlds, m->stream, (const double*)dq, C, dl, dg, mc);
     HIP_TRY(hipGetLastError());
     return (int)EXMC_OK;
   });
@@ -785,8 +816,9 @@ int exmc_hip_multi_step(exmc_hip_model* m, const double* q, const double* p, con
   return dispatch(m, lanes, [&](auto tag, const auto& mc) {
     using T = decltype(tag);
     HIP_TRY(hipEventRecord(m->ev0, m->stream));
+    const size_t xlds = aux_lds_bytes<typename T::M>();
     hipLaunchKernelGGL((multi_step_kernel<typename T::M, T::G>), grid_for(n_chains, T::G, kBlock),
-                       dim3(kBlock), 0, m->stream, P, mc);
+                       dim3(kBlock), xlds, m->stream, P, mc);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(m->ev1, m->stream));
     return finish_timing(m);

@@ -1,16 +1,30 @@
-// exmc_kernels.hpp — the other gfx950 kernels of the hot path (the NUTS transition kernel is in
-// exmc_nuts.hpp).
+// exmc_kernels.hpp — the other gfx950 kernels of the hot path (the NUTS transition kernel and
+// the adaptation warmup are in exmc_nuts.hpp).
 //
 //   multi_step_kernel  B2 `multi_step_fn` contract, chain-batched (batched_leapfrog.ex:50-101).
 //   init_chains_kernel seed :rand, init position, first logp/grad (sampler.ex:154-165,339-349).
 //   find_eps_kernel    find_reasonable_epsilon_with_rng (sampler.ex:451-530).
 //   logp_grad_kernel   vag_fn batched (compiler.ex:131-141).
 //   ess_kernel         Diagnostics.ess (diagnostics.ex:42-52,123-167).
+//
+// All are launched with one wavefront per workgroup (64 threads) and M::kExtraLdsDoubles * 8
+// bytes of dynamic LDS. For wave-cooperative models (M::kCoop, the MFMA logistic) lane groups
+// without a chain shadow the last chain instead of leaving, so that logp_grad sees a full wave.
 #pragma once
 
 #include "exmc_nuts.hpp"
 
 namespace exmc {
+
+constexpr int kAuxBlock = 64;
+
+template <class M>
+__host__ __device__ constexpr size_t aux_lds_bytes() { return (size_t)M::kExtraLdsDoubles * 8; }
+
+template <class M>
+__device__ __forceinline__ void attach_scratch(typename M::Lane& ln, double* sh) {
+  if constexpr (M::kExtraLdsDoubles > 0) ln.sh = sh;
+}
 
 // ------------------------------------------------------------------------------------------
 // B2: chain-batched multi_step (batched_leapfrog.ex:50-101). all_* rows are [step][dim][chain].
@@ -30,15 +44,19 @@ struct MultiStepParams {
 };
 
 template <class M, int G>
-__global__ void __launch_bounds__(256) multi_step_kernel(MultiStepParams P, typename M::Consts mc) {
+__global__ void __launch_bounds__(kAuxBlock) multi_step_kernel(MultiStepParams P,
+                                                               typename M::Consts mc) {
   constexpr int D = M::D, DPL = M::DPL;
+  extern __shared__ double xlds[];
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   const int l = threadIdx.x & (G - 1);
-  const int chain = tid / G;
   const int C = P.n_chains;
-  if (chain >= C) return;
+  const bool has_chain = (tid / G) < C;
+  const int chain = has_chain ? (tid / G) : (C - 1);
+  if (!M::kCoop && !has_chain) return;
   typename M::Lane ln;
   M::load(mc, l, ln);
+  attach_scratch<M>(ln, xlds);
   double q[DPL], p[DPL], g[DPL], im[DPL];
   bool valid[DPL];
 #pragma unroll
@@ -64,28 +82,31 @@ __global__ void __launch_bounds__(256) multi_step_kernel(MultiStepParams P, type
 #pragma unroll
     for (int k = 0; k < DPL; k++) {
       p[k] = p[k] + h * g[k];
-      if (valid[k]) {
+      if (valid[k] && has_chain) {
         const size_t o = ((size_t)s * D + (l + k * G)) * C + chain;
         P.all_q[o] = q[k];
         P.all_p[o] = p[k];
         P.all_g[o] = g[k];
       }
     }
-    if (l == 0) P.all_logp[(size_t)s * C + chain] = logp;
+    if (l == 0 && has_chain) P.all_logp[(size_t)s * C + chain] = logp;
   }
 }
 
 // vag_fn batched: q [D][C] -> logp [C], grad [D][C]
 template <class M, int G>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(kAuxBlock)
 logp_grad_kernel(const double* qin, int C, double* logp, double* grad, typename M::Consts mc) {
   constexpr int D = M::D, DPL = M::DPL;
+  extern __shared__ double xlds[];
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   const int l = threadIdx.x & (G - 1);
-  const int chain = tid / G;
-  if (chain >= C) return;
+  const bool has_chain = (tid / G) < C;
+  const int chain = has_chain ? (tid / G) : (C - 1);
+  if (!M::kCoop && !has_chain) return;
   typename M::Lane ln;
   M::load(mc, l, ln);
+  attach_scratch<M>(ln, xlds);
   double q[DPL], g[DPL];
 #pragma unroll
   for (int k = 0; k < DPL; k++) {
@@ -94,6 +115,7 @@ logp_grad_kernel(const double* qin, int C, double* logp, double* grad, typename 
     g[k] = 0.0;
   }
   const double lp = M::logp_grad(mc, ln, l, q, g);
+  if (!has_chain) return;
   if (l == 0) logp[chain] = lp;
 #pragma unroll
   for (int k = 0; k < DPL; k++) {
@@ -116,15 +138,19 @@ struct InitParams {
 };
 
 template <class M, int G>
-__global__ void __launch_bounds__(256) init_chains_kernel(InitParams P, typename M::Consts mc) {
+__global__ void __launch_bounds__(kAuxBlock) init_chains_kernel(InitParams P,
+                                                                typename M::Consts mc) {
   constexpr int D = M::D, DPL = M::DPL;
+  extern __shared__ double xlds[];
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   const int l = threadIdx.x & (G - 1);
-  const int chain = tid / G;
   const int C = P.n_chains;
-  if (chain >= C) return;
+  const bool has_chain = (tid / G) < C;
+  const int chain = has_chain ? (tid / G) : (C - 1);
+  if (!M::kCoop && !has_chain) return;
   typename M::Lane ln;
   M::load(mc, l, ln);
+  attach_scratch<M>(ln, xlds);
   const ZigTables zt{P.zig_ki, P.zig_wi, P.zig_fi};
   Rng rng;
   rng_seed(rng, P.base_seed + 7919ULL * (uint64_t)(P.chain_lo + chain));
@@ -146,6 +172,7 @@ __global__ void __launch_bounds__(256) init_chains_kernel(InitParams P, typename
     }
   }
   const double lp = M::logp_grad(mc, ln, l, q, g);
+  if (!has_chain) return;
   if (l == 0) {
     P.st.logp[chain] = lp;
     P.st.rng[chain] = rng.a;
@@ -161,7 +188,9 @@ __global__ void __launch_bounds__(256) init_chains_kernel(InitParams P, typename
   }
 }
 
-// find_reasonable_epsilon_with_rng (sampler.ex:451-530) for chain 0 of the state buffers
+// find_reasonable_epsilon_with_rng (sampler.ex:451-530) for chain 0 of the state buffers (the
+// host-driven warmup path; the device warmup calls find_eps_dev directly). Launched with
+// nuts_lds_bytes<M, 0>() of dynamic LDS.
 struct FindEpsParams {
   ChainState st;
   int n_chains;
@@ -176,76 +205,23 @@ struct FindEpsParams {
 };
 
 template <class M, int G>
-__global__ void __launch_bounds__(64) find_eps_kernel(FindEpsParams P, typename M::Consts mc) {
-  constexpr int D = M::D, DPL = M::DPL;
-  const int l = threadIdx.x & (G - 1);
-  if (threadIdx.x >= G || blockIdx.x != 0) return;
-  const int chain = 0;
-  const int C = P.n_chains;
-  typename M::Lane ln;
-  M::load(mc, l, ln);
-  const ZigTables zt{P.zig_ki, P.zig_wi, P.zig_fi};
-  double q0[DPL], g0[DPL], p0[DPL], im[DPL], sim[DPL];
-  bool valid[DPL];
-#pragma unroll
-  for (int k = 0; k < DPL; k++) {
-    const int i = l + k * G;
-    valid[k] = i < D;
-    q0[k] = valid[k] ? P.st.q[(size_t)i * C + chain] : 0.0;
-    g0[k] = valid[k] ? P.st.g[(size_t)i * C + chain] : 0.0;
-    im[k] = valid[k] ? P.inv_mass[i] : 1.0;
-    sim[k] = valid[k] ? P.sqrt_inv_mass[i] : 1.0;
-    p0[k] = 0.0;
-  }
-  const double logp0 = P.st.logp[chain];
-  Rng rng;
-  rng.a = P.st.rng[chain];
-  rng.b = P.st.rng[(size_t)C + chain];
-  for (int i = 0; i < D; i++) {
-    const double z = rng_normal(rng, zt, P.nor_r);
-#pragma unroll
-    for (int k = 0; k < DPL; k++)
-      if (l + k * G == i) p0[k] = z / sim[k];
-  }
-  const double jlp0 = logp0 - kinetic_energy<G, DPL>(p0, im, valid);
-  auto try_eps = [&](double eps) -> double {
-    double q[DPL], p[DPL], g[DPL];
-    const double h = eps / 2.0;
-#pragma unroll
-    for (int k = 0; k < DPL; k++) {
-      const double ph = p0[k] + h * g0[k];
-      p[k] = ph;
-      q[k] = q0[k] + eps * (im[k] * ph);
-      g[k] = 0.0;
-    }
-    const double lp = M::logp_grad(mc, ln, l, q, g);
-#pragma unroll
-    for (int k = 0; k < DPL; k++) p[k] = p[k] + h * g[k];
-    const double jlp = lp - kinetic_energy<G, DPL>(p, im, valid);
-    return (exmc_isfinite(jlp0) && exmc_isfinite(jlp)) ? (jlp - jlp0) : -1000.0;
-  };
-  double eps = 1.0;
-  double la = try_eps(eps);
-  const double dir = (la > P.log_half) ? 1.0 : -1.0;
-  const double factor = (dir > 0) ? 2.0 : 0.5;
-  double result = 0.0;
-  bool done = false;
-  for (int count = 0; count < 100 && !done; count++) {
-    const double ne = eps * factor;
-    la = try_eps(ne);
-    const bool crossed = (dir > 0) ? (la < P.log_half) : (la > P.log_half);
-    if (crossed || !exmc_isfinite(la)) {
-      result = fmax(ne, 1.0e-10);
-      done = true;
-    } else {
-      eps = ne;
-    }
-  }
-  if (!done) result = fmax(eps, 1.0e-10);
-  if (l == 0) {
-    *P.eps_out = result;
-    P.st.rng[chain] = rng.a;
-    P.st.rng[(size_t)C + chain] = rng.b;
+__global__ void __launch_bounds__(kNutsBlock) find_eps_kernel(FindEpsParams P,
+                                                              typename M::Consts mc) {
+  constexpr int DPL = M::DPL;
+  constexpr int NSLOT = 5 * DPL + 3;
+  extern __shared__ double lds[];
+  const ZigTables zt = stage_zig_tables<0, NSLOT>(lds, P.zig_ki, P.zig_wi, P.zig_fi);
+  const bool writer = threadIdx.x < G;
+  if (blockIdx.x != 0 || (!M::kCoop && !writer)) return;
+  NutsLane<M, G> L;
+  lane_setup<M, G, 0>(L, mc, lds, nullptr, P.inv_mass, P.sqrt_inv_mass, zt, P.nor_r);
+  ChainRegs<DPL> st;
+  chain_load<M, G>(P.st, P.n_chains, 0, L.l, st);
+  const double eps = find_eps_dev<M, G>(mc, L, st, P.log_half);
+  if (writer && L.l == 0) {
+    *P.eps_out = eps;
+    P.st.rng[0] = st.rng.a;
+    P.st.rng[(size_t)P.n_chains] = st.rng.b;
   }
 }
 

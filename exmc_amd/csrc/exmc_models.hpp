@@ -16,6 +16,13 @@ namespace exmc {
 
 __device__ __forceinline__ double clamp200(double z) { return fmax(-200.0, fmin(z, 200.0)); }
 
+// kCoop: logp_grad is wave-cooperative (MFMA) and needs every lane of the wavefront active;
+// kExtraLdsDoubles: LDS scratch the functor wants per wavefront (Lane::sh points at it).
+struct ModelDefaults {
+  static constexpr bool kCoop = false;
+  static constexpr int kExtraLdsDoubles = 0;
+};
+
 // ------------------------------------------------------------------------------------------
 // eight_schools, non-centered (benchmark/posteriordb/validate_posteriordb.exs:246-324).
 // dims: 0 mu, 1 log tau, 2..9 theta_trans_0..7 (point_map.ex:37 alphabetical order).
@@ -28,7 +35,7 @@ struct EightSchoolsConsts {
 };
 
 template <int G>
-struct EightSchools {
+struct EightSchools : ModelDefaults {
   static constexpr int D = 10;
   static constexpr int DPL = (D + G - 1) / G;
   using Consts = EightSchoolsConsts;
@@ -112,7 +119,7 @@ struct SimpleConsts {
 };
 
 template <int G>
-struct Simple {
+struct Simple : ModelDefaults {
   static_assert(G == 1, "simple model is one lane per chain");
   static constexpr int D = 2;
   static constexpr int DPL = 2;
@@ -172,7 +179,7 @@ __device__ __forceinline__ double lanczos_val_d(const SVConsts& c, double x, dou
 }
 
 template <int G>
-struct SV {
+struct SV : ModelDefaults {
   static constexpr int T = 100;
   static constexpr int D = T + 2;
   static constexpr int DPL = (D + G - 1) / G;
@@ -278,10 +285,15 @@ struct LogisticConsts {
   int N;
   double c10;        // f32(log(f32(2pi))) + 2*log(10)
   double lo, hi;     // f32(1e-7), 1 - f32(1e-7)
+  // MFMA path (G = 4): design matrix augmented with a ones column (feature 0), zero padded
+  const double* XaT;   // dev [24][Npad]  feature-major: A operand of eta = Xa @ beta
+  const double* Xa32;  // dev [Npad][32]  observation-major: A operand of grad = Xa^T @ r
+  const double* ypad;  // dev [Npad]
+  int Npad;            // N rounded up to a multiple of 16
 };
 
 template <int G>
-struct Logistic {
+struct Logistic : ModelDefaults {
   static constexpr int K = 20;
   static constexpr int D = K + 1;
   static constexpr int DPL = (D + G - 1) / G;
@@ -334,6 +346,108 @@ struct Logistic {
 };
 
 // ------------------------------------------------------------------------------------------
+// logistic regression on the matrix cores: G = 4 lanes per chain => 16 chains per wavefront, the
+// N dimension of v_mfma_f64_16x16x4_f64. Per 16-observation tile:
+//     eta[16 obs][16 chains]   = Xa[16 obs][24] @ beta[24][16 chains]      6 MFMAs (K = 4 each)
+//     p, log-lik, r = y - p    on the C/D fragment: 4 (obs, chain) pairs per lane, all 64 lanes
+//     grad[32 feats][16 chains] += Xa^T[32][16 obs] @ r[16 obs][16 chains]  8 MFMAs
+// The C/D register r of the eta tile (rows 4r..4r+3 across the four 16-lane rows) is exactly the
+// B fragment of the K-step that consumes observations 4r..4r+3, so r never leaves registers.
+// The f64 MFMA is an fma chain over k = 0..3 from C (tools/probe/mfma_f64_probe.hip: 256/256
+// bitwise), so the CPU checker reproduces it with fma loops: eta over features 0..23 in order,
+// grad over observations 0..Npad-1 in order, log-lik per row group then xor-butterfly.
+// Needs every lane of the wavefront active (kCoop) and 912 doubles of LDS to move beta and the
+// gradient between the chain-group layout and the MFMA fragment layout.
+// ------------------------------------------------------------------------------------------
+typedef double exmc_v4d __attribute__((ext_vector_type(4)));
+
+template <>
+struct Logistic<4> : ModelDefaults {
+  static constexpr int G = 4;
+  static constexpr int K = 20;
+  static constexpr int D = K + 1;
+  static constexpr int DPL = 6;
+  static constexpr bool kCoop = true;
+  static constexpr int kExtraLdsDoubles = 24 * 16 + 32 * 16 + 16;
+  using Consts = LogisticConsts;
+  struct Lane {
+    double* sh;   // wavefront-shared LDS scratch: beta [24][16], grad [32][16], lik [16]
+  };
+  __device__ static __forceinline__ void load(const Consts&, int, Lane&) {}
+
+  __device__ static __forceinline__ double logp_grad(const Consts& c, const Lane& ln, int l,
+                                                     const double (&q)[DPL], double (&g)[DPL]) {
+    const int lane = threadIdx.x & 63;
+    const int grp = lane >> 2;        // chain of this lane within the wavefront
+    const int col = lane & 15;        // MFMA column (= chain) this lane's fragment belongs to
+    const int rowg = lane >> 4;       // MFMA row group
+    double* bsh = ln.sh;
+    double* gsh = ln.sh + 24 * 16;
+    double* lsh = ln.sh + 24 * 16 + 32 * 16;
+#pragma unroll
+    for (int k = 0; k < DPL; k++) {
+      const int i = l + k * G;        // 0..23: rows 21..23 are the zero padding of K
+      bsh[i * 16 + grp] = (i < D) ? q[k] : 0.0;
+    }
+    double bfrag[6];
+#pragma unroll
+    for (int ks = 0; ks < 6; ks++) bfrag[ks] = bsh[(4 * ks + rowg) * 16 + col];
+    exmc_v4d g0 = {0.0, 0.0, 0.0, 0.0}, g1 = {0.0, 0.0, 0.0, 0.0};
+    double likp = 0.0;
+    const int Npad = c.Npad;
+    for (int n0 = 0; n0 < Npad; n0 += 16) {
+      exmc_v4d eta = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ks = 0; ks < 6; ks++) {
+        const double a = c.XaT[(size_t)(4 * ks + rowg) * Npad + n0 + col];
+        eta = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bfrag[ks], eta, 0, 0, 0);
+      }
+      exmc_v4d rr;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int n = n0 + rowg + 4 * r;
+        const double yn = c.ypad[n];
+        const double p = 1.0 / (1.0 + exmc_exp(-eta[r]));
+        const double pc = fmin(fmax(p, c.lo), c.hi);
+        const double ll = exmc_log((yn == 1.0) ? pc : (1.0 - pc));
+        const double rv = (p > c.lo && p < c.hi) ? (yn - p) : 0.0;
+        const bool live = n < c.N;
+        likp = live ? (likp + ll) : likp;
+        rr[r] = live ? rv : 0.0;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const double* row = c.Xa32 + (size_t)(n0 + 4 * r + rowg) * 32 + col;
+        g0 = __builtin_amdgcn_mfma_f64_16x16x4f64(row[0], rr[r], g0, 0, 0, 0);
+        g1 = __builtin_amdgcn_mfma_f64_16x16x4f64(row[16], rr[r], g1, 0, 0, 0);
+      }
+    }
+    // log-likelihood: the four row groups of a column hold partial sums of the same chain
+    likp = likp + __shfl_xor(likp, 16, 64);
+    likp = likp + __shfl_xor(likp, 32, 64);
+    if (rowg == 0) lsh[col] = likp;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      gsh[(rowg + 4 * r) * 16 + col] = g0[r];
+      gsh[(16 + rowg + 4 * r) * 16 + col] = g1[r];
+    }
+    const double lik = lsh[grp];
+    double T[DPL];
+    bool valid[DPL];
+#pragma unroll
+    for (int k = 0; k < DPL; k++) {
+      const int i = l + k * G;
+      valid[k] = i < D;
+      const double gi = gsh[i * 16 + grp];
+      const double z = (q[k] - 0.0) / 10.0;
+      T[k] = -0.5 * (z * z + c.c10);
+      g[k] = valid[k] ? ((-(z / 10.0)) + gi) : 0.0;
+    }
+    return group_sum_slots<G, DPL>(T, valid, l, lik);
+  }
+};
+
+// ------------------------------------------------------------------------------------------
 // hierarchical radon, J = 85 counties (notebooks/09_radon_bhm.livemd "The Radon Model").
 // dims: 0..J-1 alpha_raw_j, J mu_alpha, J+1 gamma_u, J+2 log sigma_alpha, J+3 log sigma_y,
 // J+4 beta. The lane that owns alpha_raw_j walks county j's observations (sorted by county).
@@ -351,7 +465,7 @@ struct RadonConsts {
 };
 
 template <int G>
-struct Radon {
+struct Radon : ModelDefaults {
   static constexpr int J = 85;
   static constexpr int D = J + 5;
   static constexpr int DPL = (D + G - 1) / G;

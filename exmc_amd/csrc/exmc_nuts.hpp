@@ -84,7 +84,8 @@ __host__ __device__ constexpr int nuts_nslot() { return 5 * M::DPL + 3; }
 
 template <class M, int LDSL>
 __host__ __device__ constexpr size_t nuts_lds_bytes() {
-  return (size_t)LDSL * nuts_nslot<M>() * kNutsBlock * 8 + kZigLdsBytes;
+  return (size_t)LDSL * nuts_nslot<M>() * kNutsBlock * 8 + kZigLdsBytes +
+         (size_t)M::kExtraLdsDoubles * 8;
 }
 
 template <int N>
@@ -111,6 +112,7 @@ struct NutsLane {
   size_t nthreads;
   ZigTables zt;
   double nor_r;
+  bool alive;        // false: a lane group kept only so that wave-cooperative models see all lanes
 };
 
 // a chain's state between transitions
@@ -214,8 +216,11 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
   int draw = 0;
   bool start_transition = true, start_doubling = false;
 
-  while (draw < n_draws) {
-    if (start_transition) {
+  // Wave-cooperative models (kCoop) need all 64 lanes in logp_grad: a group that has finished its
+  // draws (or has no chain) keeps taking the leapfrog with the wave and skips the tree logic.
+  bool alive = L.alive && (n_draws > 0);
+  while (M::kCoop ? (__any(alive ? 1 : 0) != 0) : alive) {
+    if (alive && start_transition) {
       draw_momentum<M, G>(L, st.rng, pL);
       jlp0 = st.logp - kinetic_energy<G, DPL>(pL, im, valid);
       trng = st.rng;  // the tree consumes a copy (sampler.ex:897 discards its draws)
@@ -234,7 +239,7 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
       start_transition = false;
       start_doubling = true;
     }
-    if (start_doubling) {
+    if (alive && start_doubling) {
       // tree.ex:403-413 direction + outward endpoint
       const double u = rng_uniform(trng);
       go_right = u > 0.5;
@@ -270,6 +275,7 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
 #pragma unroll
     for (int k = 0; k < DPL; k++) p[k] = p[k] + h * g[k];
     const double jlp = logp_new - kinetic_energy<G, DPL>(p, im, valid);
+    if (M::kCoop && !alive) continue;
 
     // ---- leaf (tree.ex:1042-1109) ----
     bool c_div, c_turn = false;
@@ -435,6 +441,7 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
       for (int k = 0; k < DPL; k++) { st.q[k] = t_qp[k]; st.g[k] = t_gp[k]; }
       sink(draw, st.q, st.logp, depth, t_n, t_div, t_acc, jlp0);
       draw++;
+      alive = draw < n_draws;
       start_transition = true;
     } else {
       start_doubling = true;
@@ -456,7 +463,10 @@ __device__ __forceinline__ void lane_setup(NutsLane<M, G>& L, const typename M::
   L.gstk = stack + tid;
   L.zt = zt;
   L.nor_r = nor_r;
+  L.alive = true;
   M::load(mc, L.l, L.ln);
+  if constexpr (M::kExtraLdsDoubles > 0)
+    L.ln.sh = lds + (size_t)LDSL * nuts_nslot<M>() * kNutsBlock + kZigLdsBytes / 8;
 #pragma unroll
   for (int k = 0; k < DPL; k++) {
     const int i = L.l + k * G;
@@ -506,13 +516,15 @@ __global__ void __launch_bounds__(kNutsBlock) nuts_kernel(NutsParams P, typename
   constexpr int NSLOT = 5 * DPL + 3;
   extern __shared__ double lds[];
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int chain = tid / G;
   const int C = P.n_chains;
+  const bool has_chain = (tid / G) < C;
+  const int chain = has_chain ? (tid / G) : (C - 1);   // surplus groups shadow the last chain
   const ZigTables zt = stage_zig_tables<LDSL, NSLOT>(lds, P.zig_ki, P.zig_wi, P.zig_fi);
-  if (chain >= C) return;
+  if (!M::kCoop && !has_chain) return;
 
   NutsLane<M, G> L;
   lane_setup<M, G, LDSL>(L, mc, lds, P.stack, P.inv_mass, P.sqrt_inv_mass, zt, P.nor_r);
+  L.alive = has_chain;
   ChainRegs<DPL> st;
   chain_load<M, G>(P.st, C, chain, L.l, st);
 
@@ -540,6 +552,7 @@ __global__ void __launch_bounds__(kNutsBlock) nuts_kernel(NutsParams P, typename
   };
   nuts_run<M, G, LDSL>(mc, L, st, P.n_draws, P.eps, P.max_depth, sink);
 
+  if (!has_chain) return;
   chain_store<M, G>(P.st, C, chain, l, st);
   if (l == 0 && P.counters) {
     atomicAdd(&P.counters[0], lf_total);
@@ -651,7 +664,10 @@ __global__ void __launch_bounds__(kNutsBlock) warmup_kernel(WarmupParams P, type
   constexpr int NSLOT = 5 * DPL + 3;
   extern __shared__ double lds[];
   const ZigTables zt = stage_zig_tables<LDSL, NSLOT>(lds, P.zig_ki, P.zig_wi, P.zig_fi);
-  if (blockIdx.x != 0 || threadIdx.x >= G) return;
+  // Wave-cooperative models: every lane group of the wave runs the same chain 0 redundantly (they
+  // stay in lockstep, so the wave is fully populated at every logp_grad); group 0 writes.
+  const bool writer = threadIdx.x < G;
+  if (blockIdx.x != 0 || (!M::kCoop && !writer)) return;
 
   NutsLane<M, G> L;
   lane_setup<M, G, LDSL>(L, mc, lds, P.stack, nullptr, nullptr, zt, P.nor_r);
@@ -739,6 +755,7 @@ __global__ void __launch_bounds__(kNutsBlock) warmup_kernel(WarmupParams P, type
     eps_final = exmc_exp(da.log_epsilon_bar);
   }
 
+  if (!writer) return;
   chain_store<M, G>(P.st, 1, 0, L.l, st);
   if (L.l == 0) {
     P.out[0] = eps_final;

@@ -438,6 +438,11 @@ static double logp_logistic(const exo_model* m, const double* q, double* g, exo_
   const double* y = m->data + (size_t)N * K;
   double lo = f32r(1.0e-7), hi = 1.0 - f32r(1.0e-7);
   double lik_part[64], gp[64][EXO_MAX_D];
+  /* G == 4 is the matrix-core layout (16 chains per wavefront, v_mfma_f64_16x16x4_f64 = fma chain
+   * over k): the gradient contraction X^T r runs over ALL observations in increasing n in one
+   * chain; the log-likelihood keeps four row-group partials (n mod 4) + butterfly. */
+  int mfma = (G == 4);
+  double* rbuf = (double*)malloc(sizeof(double) * (size_t)(N > 0 ? N : 1));
   for (int l = 0; l < G; l++) {
     double lik = 0.0;
     double* acc = gp[l];
@@ -451,11 +456,23 @@ static double logp_logistic(const exo_model* m, const double* q, double* g, exo_
       double ll = (y[n] == 1.0) ? exo_log(pc, mm) : exo_log(1.0 - pc, mm);
       double r = (p > lo && p < hi) ? (y[n] - p) : 0.0;
       lik = lik + ll;
-      acc[0] = mac(1.0, r, acc[0], mm);
-      for (int j = 0; j < K; j++) acc[1 + j] = mac(x[j], r, acc[1 + j], mm);
+      rbuf[n] = r;
+      if (!mfma) {
+        acc[0] = mac(1.0, r, acc[0], mm);
+        for (int j = 0; j < K; j++) acc[1 + j] = mac(x[j], r, acc[1 + j], mm);
+      }
     }
     lik_part[l] = lik;
   }
+  if (mfma) {
+    double* acc = gp[0];
+    for (int n = 0; n < N; n++) {
+      const double* x = X + (size_t)n * K;
+      acc[0] = mac(1.0, rbuf[n], acc[0], mm);
+      for (int j = 0; j < K; j++) acc[1 + j] = mac(x[j], rbuf[n], acc[1 + j], mm);
+    }
+  }
+  free(rbuf);
   /* butterflies over the lane partials (lane_sum with one slot per lane) */
   double lik = lane_sum(lik_part, G, G, 0.0);
   double T[EXO_MAX_D];
@@ -463,7 +480,7 @@ static double logp_logistic(const exo_model* m, const double* q, double* g, exo_
   for (int j = 0; j < d; j++) {
     double col[64];
     for (int l = 0; l < G; l++) col[l] = gp[l][j];
-    double gj = lane_sum(col, G, G, 0.0);
+    double gj = mfma ? gp[0][j] : lane_sum(col, G, G, 0.0);
     double z = (q[j] - 0.0) / 10.0;
     T[j] = -0.5 * (z * z + c10);
     g[j] = (-(z / 10.0)) + gj;

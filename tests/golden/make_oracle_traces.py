@@ -23,6 +23,7 @@ CASES = {
     "sv_g64": ("sv", 64, 0.05, 2, 10, 6, 42),
     "logistic_g16": ("logistic", 16, 0.30, 2, 12, 6, 5),
     "radon_g64": ("radon", 64, 0.20, 2, 12, 6, 6),
+    "logistic_g4_mfma": ("logistic", 4, 0.30, 3, 12, 6, 5),
 }
 
 

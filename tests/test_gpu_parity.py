@@ -53,7 +53,7 @@ def test_logp_grad_bit_exact(es, hip, lanes):
 def _other_models():
     import test_golden_traces as TG
     return [("sv", lambda: models.sv(TG.GOLD["sv_returns"]), [32, 64]),
-            ("logistic", models.logistic, [8, 16]),
+            ("logistic", models.logistic, [4, 8, 16]),
             ("radon", models.radon, [32, 64])]
 
 

@@ -70,7 +70,7 @@ def test_modes_and_lane_layouts_agree_to_rounding(name, m):
     floating tolerance between the GPU contract and the reference's own arithmetic."""
     rng = np.random.default_rng(9)
     lanes = {"sv": [32, 64], "simple": [1], "std_normal": [2, 4], "eight_schools": [2, 4, 8, 16],
-             "logistic": [8, 16], "radon": [32, 64]}[name]
+             "logistic": [4, 8, 16], "radon": [32, 64]}[name]
     for _ in range(5):
         q = rng.normal(size=m.d) * 0.7
         lp0, g0 = m.logp_grad(q, O.Cfg(0, 1))
