@@ -556,7 +556,16 @@ int run_warmup_device(exmc_hip_model* m, int lanes, exmc_hip_opts o, exmc_hip_tu
     int r2 = m->stack.ensure((size_t)kSpill * nuts_nslot<M>() * kNutsBlock * 8);
     if (r2) return r2;
     P.stack = m->stack.as<double>();
-    const size_t lds_bytes = nuts_lds_bytes<M, T::LDSL>();
+    size_t lds_bytes = nuts_lds_bytes<M, T::LDSL>();
+    P.stage_model = 0;
+    if (M::kStageDoubles > 0 && lds_bytes + (size_t)M::kStageDoubles * 8 <= 160 * 1024 &&
+        (m->kind != EXMC_MODEL_LOGISTIC || m->lg.Npad <= 512)) {
+      P.stage_model = 1;
+      lds_bytes += (size_t)M::kStageDoubles * 8;
+    }
+    if (lds_bytes > 64 * 1024)
+      HIP_TRY(hipFuncSetAttribute((const void*)warmup_kernel<M, T::G, T::LDSL>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     HIP_TRY(hipEventRecord(m->ev0, m->stream));
     hipLaunchKernelGGL((warmup_kernel<M, T::G, T::LDSL>), dim3(1), dim3(kNutsBlock), lds_bytes,
                        m->stream, P, mc);

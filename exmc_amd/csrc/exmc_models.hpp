@@ -18,9 +18,12 @@ __device__ __forceinline__ double clamp200(double z) { return fmax(-200.0, fmin(
 
 // kCoop: logp_grad is wave-cooperative (MFMA) and needs every lane of the wavefront active;
 // kExtraLdsDoubles: LDS scratch the functor wants per wavefront (Lane::sh points at it).
+// kStageDoubles: model data a single-workgroup kernel (the adaptation warmup) may copy into LDS
+// (Lane::xs); with one wavefront on the whole chip every global load is an exposed round trip.
 struct ModelDefaults {
   static constexpr bool kCoop = false;
   static constexpr int kExtraLdsDoubles = 0;
+  static constexpr int kStageDoubles = 0;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -369,11 +372,31 @@ struct Logistic<4> : ModelDefaults {
   static constexpr int DPL = 6;
   static constexpr bool kCoop = true;
   static constexpr int kExtraLdsDoubles = 24 * 16 + 32 * 16 + 16;
+  // LDS image of the design matrix for single-workgroup kernels: Xa feature-major with row
+  // stride 514 doubles (the gradient fragment walks 16 features at a fixed observation: stride
+  // 514 = 2 mod 32 keeps those ds_read_b64 conflict-free; the eta fragment sees 2-way), then y.
+  static constexpr int kStageStride = 514;
+  static constexpr int kStageDoubles = 24 * kStageStride + 512;
   using Consts = LogisticConsts;
   struct Lane {
-    double* sh;   // wavefront-shared LDS scratch: beta [24][16], grad [32][16], lik [16]
+    double* sh;         // wavefront-shared LDS scratch: beta [24][16], grad [32][16], lik [16]
+    const double* xs;   // LDS image of Xa / y, or null (operands then stream from L2)
   };
-  __device__ static __forceinline__ void load(const Consts&, int, Lane&) {}
+  __device__ static __forceinline__ void load(const Consts&, int, Lane& ln) { ln.xs = nullptr; }
+  // cooperative (whole workgroup): fill the LDS image; the caller synchronises afterwards
+  __device__ static __forceinline__ void stage(const Consts& c, double* dst) {
+    for (int i = threadIdx.x; i < kStageDoubles; i += blockDim.x) {
+      double v = 0.0;
+      if (i < 24 * kStageStride) {
+        const int f = i / kStageStride, n = i % kStageStride;
+        if (n < c.Npad) v = c.XaT[(size_t)f * c.Npad + n];
+      } else {
+        const int n = i - 24 * kStageStride;
+        if (n < c.Npad) v = c.ypad[n];
+      }
+      dst[i] = v;
+    }
+  }
 
   __device__ static __forceinline__ double logp_grad(const Consts& c, const Lane& ln, int l,
                                                      const double (&q)[DPL], double (&g)[DPL]) {
@@ -395,18 +418,46 @@ struct Logistic<4> : ModelDefaults {
     exmc_v4d g0 = {0.0, 0.0, 0.0, 0.0}, g1 = {0.0, 0.0, 0.0, 0.0};
     double likp = 0.0;
     const int Npad = c.Npad;
+    // software pipeline: the A fragments of the next tile's eta product and of this tile's
+    // gradient product are requested before the exp/log section, whose branches would otherwise
+    // pin the loads right in front of the MFMAs that consume them (one wave per SIMD: nothing
+    // else hides an L2 round trip)
+    const double* xs = ln.xs;   // wave-uniform: LDS image or null
+    auto ld_eta = [&](int ks, int n) -> double {
+      return xs ? xs[(4 * ks + rowg) * kStageStride + n + col]
+                : c.XaT[(size_t)(4 * ks + rowg) * Npad + n + col];
+    };
+    auto ld_g = [&](int ft, int n) -> double {
+      if (xs) {
+        const int f = 16 * ft + col;
+        return (f < 24) ? xs[f * kStageStride + n] : 0.0;
+      }
+      return c.Xa32[(size_t)n * 32 + 16 * ft + col];
+    };
+    auto ld_y = [&](int n) -> double { return xs ? xs[24 * kStageStride + n] : c.ypad[n]; };
+    double a_eta[6];
+#pragma unroll
+    for (int ks = 0; ks < 6; ks++) a_eta[ks] = ld_eta(ks, 0);
     for (int n0 = 0; n0 < Npad; n0 += 16) {
+      double a_g0[4], a_g1[4], yv[4], a_next[6];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        a_g0[r] = ld_g(0, n0 + 4 * r + rowg);
+        a_g1[r] = ld_g(1, n0 + 4 * r + rowg);
+        yv[r] = ld_y(n0 + rowg + 4 * r);
+      }
+      const int nn = (n0 + 16 < Npad) ? (n0 + 16) : n0;
+#pragma unroll
+      for (int ks = 0; ks < 6; ks++) a_next[ks] = ld_eta(ks, nn);
       exmc_v4d eta = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int ks = 0; ks < 6; ks++) {
-        const double a = c.XaT[(size_t)(4 * ks + rowg) * Npad + n0 + col];
-        eta = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bfrag[ks], eta, 0, 0, 0);
-      }
+      for (int ks = 0; ks < 6; ks++)
+        eta = __builtin_amdgcn_mfma_f64_16x16x4f64(a_eta[ks], bfrag[ks], eta, 0, 0, 0);
       exmc_v4d rr;
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int n = n0 + rowg + 4 * r;
-        const double yn = c.ypad[n];
+        const double yn = yv[r];
         const double p = 1.0 / (1.0 + exmc_exp(-eta[r]));
         const double pc = fmin(fmax(p, c.lo), c.hi);
         const double ll = exmc_log((yn == 1.0) ? pc : (1.0 - pc));
@@ -417,10 +468,11 @@ struct Logistic<4> : ModelDefaults {
       }
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        const double* row = c.Xa32 + (size_t)(n0 + 4 * r + rowg) * 32 + col;
-        g0 = __builtin_amdgcn_mfma_f64_16x16x4f64(row[0], rr[r], g0, 0, 0, 0);
-        g1 = __builtin_amdgcn_mfma_f64_16x16x4f64(row[16], rr[r], g1, 0, 0, 0);
+        g0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a_g0[r], rr[r], g0, 0, 0, 0);
+        g1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a_g1[r], rr[r], g1, 0, 0, 0);
       }
+#pragma unroll
+      for (int ks = 0; ks < 6; ks++) a_eta[ks] = a_next[ks];
     }
     // log-likelihood: the four row groups of a column hold partial sums of the same chain
     likp = likp + __shfl_xor(likp, 16, 64);

@@ -626,6 +626,7 @@ struct WarmupParams {
   int n_windows;
   int win_start[32], win_end[32];   // build_windows (sampler.ex:764-785), computed on the host
   double* stack;
+  int stage_model;          // 1: dynamic LDS includes M::kStageDoubles for the model's LDS image
   double* out;              // [0] eps_final, [1] divergences, [2] leapfrogs, [3..3+D) inv_mass
   const uint64_t* zig_ki;
   const double* zig_wi;
@@ -664,6 +665,15 @@ __global__ void __launch_bounds__(kNutsBlock) warmup_kernel(WarmupParams P, type
   constexpr int NSLOT = 5 * DPL + 3;
   extern __shared__ double lds[];
   const ZigTables zt = stage_zig_tables<LDSL, NSLOT>(lds, P.zig_ki, P.zig_wi, P.zig_fi);
+  // single workgroup on an otherwise idle chip: keep the model data in LDS when it offers an image
+  double* stage_ptr = nullptr;
+  if constexpr (M::kStageDoubles > 0) {
+    if (P.stage_model) {
+      stage_ptr = lds + nuts_lds_bytes<M, LDSL>() / 8;
+      M::stage(mc, stage_ptr);
+      __syncthreads();
+    }
+  }
   // Wave-cooperative models: every lane group of the wave runs the same chain 0 redundantly (they
   // stay in lockstep, so the wave is fully populated at every logp_grad); group 0 writes.
   const bool writer = threadIdx.x < G;
@@ -671,6 +681,7 @@ __global__ void __launch_bounds__(kNutsBlock) warmup_kernel(WarmupParams P, type
 
   NutsLane<M, G> L;
   lane_setup<M, G, LDSL>(L, mc, lds, P.stack, nullptr, nullptr, zt, P.nor_r);
+  if constexpr (M::kStageDoubles > 0) L.ln.xs = stage_ptr;
   ChainRegs<DPL> st;
   chain_load<M, G>(P.st, 1, 0, L.l, st);
 
