@@ -66,6 +66,46 @@ def measured_traffic(model, chains, steps, lanes):
     return table.get("%s:%d:%d:%d" % (model, chains, steps, lanes), {}).get("hbm_bytes")
 
 
+def multi_step_roofline(comp, spec, dev, n_chains=262144, n_steps=32, lanes=1, reps=3):
+    """The B2 `multi_step_fn` contract at scale (batched_leapfrog.ex:50-101): every chain takes
+    n_steps leapfrogs and every intermediate (q, p, grad, logp) is written to HBM, [step][dim][chain].
+    Bytes per launch are algorithmic: reads 3*d*8*C, writes (3*d+1)*8*n*C. Kernel time from the HIP
+    events the library records on its own stream."""
+    d = spec.d
+    L = _lib.load()
+    g = torch.Generator(device=dev).manual_seed(1)
+    q = 0.3 * torch.randn((d, n_chains), dtype=torch.float64, device=dev, generator=g)
+    p = torch.randn((d, n_chains), dtype=torch.float64, device=dev, generator=g)
+    gr = torch.zeros((d, n_chains), dtype=torch.float64, device=dev)
+    aq = torch.empty((n_steps, d, n_chains), dtype=torch.float64, device=dev)
+    ap = torch.empty_like(aq)
+    ag = torch.empty_like(aq)
+    al = torch.empty((n_steps, n_chains), dtype=torch.float64, device=dev)
+    im = np.ones(d)
+    imp = im.ctypes.data_as(C.POINTER(C.c_double))
+    torch.cuda.synchronize()
+    times = []
+    for i in range(reps + 1):                      # first launch is untimed warmup
+        _lib.check(L.exmc_hip_multi_step(comp.h, q.data_ptr(), p.data_ptr(), gr.data_ptr(), 0.05, imp,
+                                         n_steps, n_chains, lanes, aq.data_ptr(), ap.data_ptr(),
+                                         al.data_ptr(), ag.data_ptr()))
+        if i:
+            times.append(comp.last_kernel_ms)
+    best = sum(times) / len(times)                 # average launch duration
+    nbytes = 3 * d * 8 * n_chains + (3 * d + 1) * 8 * n_steps * n_chains
+    achieved = nbytes / (best * 1e-3) / 1e9
+    try:
+        table = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    except (OSError, ValueError):
+        table = {}
+    traffic = table.get("multi_step:%s:%d:%d:%d" % (spec.name, n_chains, n_steps, lanes), {}).get("hbm_bytes")
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "multi_step_kernel",
+            "kernel_ms": best, "chains": n_chains, "steps": n_steps, "lanes_per_chain": lanes,
+            "leapfrog_steps_per_s": n_chains * n_steps / (best * 1e-3),
+            "bytes_per_launch": nbytes}
+
+
 def cpu_baseline(spec, init, K, n_chains_total, budget_s=15.0):
     """The CPU checker (oracle/, libm mode = the reference's own arithmetic, one chain per host
     thread) on a bounded sample of the same workload. A reported baseline, not the target."""
@@ -248,6 +288,9 @@ def main():
                          "algorithmic_bytes_per_leapfrog": bytes_per_leapfrog,
                          "leapfrogs_per_launch": local_lf},
         }
+        if world == 1 and args.model == "eight_schools":
+            # the B2 batched-leapfrog contract at a batch that fills the chip (not the timed path)
+            out["roofline_multi_step"] = multi_step_roofline(comp, spec, dev)
         if world == 1 and not args.no_cpu:
             cb = cpu_baseline(spec, init, K, Ctot)
             out["cpu_baseline"] = cb
