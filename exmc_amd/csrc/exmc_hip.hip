@@ -279,6 +279,22 @@ int finish_timing(exmc_hip_model* m) {
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, m->ev0, m->ev1));
   m->last_ms = ms;
+#if EXMC_PROFILE_SECTIONS
+  {
+    unsigned long long h[16], z[16] = {0};
+    HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_prof), sizeof(h)));
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)));
+    static const char* nm[9] = {"transition_start", "doubling_start", "leapfrog+model", "leaf",
+                                "ascend", "outer_merge", "transition_done", "", "loop"};
+    unsigned long long tot = 0;
+    for (int i = 0; i < 9; i++) tot += h[i];
+    fprintf(stderr, "[exmc prof] %.3f ms, passes (sum over waves) %llu\n", ms, h[9]);
+    for (int i = 0; i < 9; i++)
+      if (i != 7 && h[9])
+        fprintf(stderr, "[exmc prof]   %-18s %6.1f%%  %8.1f cycles/pass\n", nm[i],
+                100.0 * (double)h[i] / (double)tot, (double)h[i] / (double)h[9]);
+  }
+#endif
   return EXMC_OK;
 }
 

@@ -38,7 +38,30 @@
 #define EXMC_ABLATE 0
 #endif
 
+// EXMC_PROFILE_SECTIONS = 1 builds a variant whose main loop accumulates s_memtime cycles per
+// section (wave time, so divergence shows up where it is paid); the library prints the totals
+// after each timed launch. Development only, never the shipped build.
+#ifndef EXMC_PROFILE_SECTIONS
+#define EXMC_PROFILE_SECTIONS 0
+#endif
+
 namespace exmc {
+
+#if EXMC_PROFILE_SECTIONS
+__device__ unsigned long long g_prof[16];
+#define EXMC_PROF_DECL long long prof_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long prof_t_ = clock64();
+#define EXMC_PROF(i) { const long long n_ = clock64(); prof_[i] += n_ - prof_t_; prof_t_ = n_; }
+#define EXMC_PROF_COUNT(i) { prof_[i] += 1; }
+#define EXMC_PROF_FLUSH                                                        \
+  if ((threadIdx.x & 63) == 0) {                                               \
+    for (int i_ = 0; i_ < 10; i_++) atomicAdd(&g_prof[i_], (unsigned long long)prof_[i_]); \
+  }
+#else
+#define EXMC_PROF_DECL
+#define EXMC_PROF(i)
+#define EXMC_PROF_COUNT(i)
+#define EXMC_PROF_FLUSH
+#endif
 
 struct ChainState {
   double* q;       // [D][C]
@@ -183,9 +206,9 @@ __device__ __forceinline__ void draw_momentum(const NutsLane<M, G>& L, Rng& rng,
 // accept_sum, jlp0) is called once per finished transition.
 // stack slots of one pending node: rho, p_in, p_out, q_prop, g_prop (DPL each), lsw, logp_prop, acc
 template <class M, int G, int LDSL, class Sink>
-__device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const NutsLane<M, G>& L,
-                                         ChainRegs<M::DPL>& st, int n_draws, double eps,
-                                         int max_depth, Sink&& sink) {
+__device__ __forceinline__ void nuts_run_async(const typename M::Consts& mc, const NutsLane<M, G>& L,
+                                               ChainRegs<M::DPL>& st, int n_draws, double eps,
+                                               int max_depth, Sink&& sink) {
   constexpr int DPL = M::DPL;
   constexpr int NSLOT = 5 * DPL + 3;
   const int l = L.l;
@@ -219,7 +242,10 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
   // Wave-cooperative models (kCoop) need all 64 lanes in logp_grad: a group that has finished its
   // draws (or has no chain) keeps taking the leapfrog with the wave and skips the tree logic.
   bool alive = L.alive && (n_draws > 0);
+  EXMC_PROF_DECL
   while (M::kCoop ? (__any(alive ? 1 : 0) != 0) : alive) {
+    EXMC_PROF(8)
+    EXMC_PROF_COUNT(9)
     if (alive && start_transition) {
       draw_momentum<M, G>(L, st.rng, pL);
       jlp0 = st.logp - kinetic_energy<G, DPL>(pL, im, valid);
@@ -239,6 +265,7 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
       start_transition = false;
       start_doubling = true;
     }
+    EXMC_PROF(0)
     if (alive && start_doubling) {
       // tree.ex:403-413 direction + outward endpoint
       const double u = rng_uniform(trng);
@@ -253,6 +280,7 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
       pending = 0;
       start_doubling = false;
     }
+    EXMC_PROF(1)
 
     // ---- one leapfrog (batched_leapfrog.ex:79-85) ----
     const double h = eps_dir / 2.0;
@@ -275,6 +303,7 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
 #pragma unroll
     for (int k = 0; k < DPL; k++) p[k] = p[k] + h * g[k];
     const double jlp = logp_new - kinetic_energy<G, DPL>(p, im, valid);
+    EXMC_PROF(2)
     if (M::kCoop && !alive) continue;
 
     // ---- leaf (tree.ex:1042-1109) ----
@@ -304,6 +333,7 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
       c_rho[k] = p[k];
       c_pin[k] = p[k];
     }
+    EXMC_PROF(3)
 
     // ---- ascend: inner merges for every pending level (tree.ex:1144-1203, 1390-1476) ----
     int lvl = 0;
@@ -379,6 +409,7 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
         break;
       }
     }
+    EXMC_PROF(4)
     if (parked) continue;
 
     // ---- subtree for this doubling is complete: merge_trajectories (tree.ex:1479-1568) ----
@@ -432,6 +463,7 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
       t_turn = turning;
       depth++;
     }
+    EXMC_PROF(5)
 
     if (depth >= max_depth || t_div || t_turn) {
       // ---- transition done (tree.ex:1607-1618, sampler.ex:890-925) ----
@@ -446,7 +478,292 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
     } else {
       start_doubling = true;
     }
+    EXMC_PROF(6)
   }
+  EXMC_PROF_FLUSH
+}
+
+// Lock-step schedule: the chain groups of a wavefront start every transition together and walk
+// the same tree skeleton (doubling j, leaf k) in the same pass, so which levels merge after a
+// leaf (the trailing ones of k), the doubling and transition boundaries and the trace writes are
+// wave-uniform scalar control flow; per group only the direction, the proposal choices and the
+// stop flags differ. A group whose tree has ended (or ended early inside a subtree, the rare
+// tree.ex:1175-1177 path, handled by the same level loop) idles until the deepest tree of the
+// wavefront is finished: for eight_schools E[max of 4 trees] / E[tree] = 1.18 extra passes buy a
+// pass that costs ~0.6x of the asynchronous one (no union of divergent paths, no exec juggling).
+template <class M, int G, int LDSL, class Sink>
+__device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const NutsLane<M, G>& L,
+                                         ChainRegs<M::DPL>& st, int n_draws, double eps,
+                                         int max_depth, Sink&& sink) {
+  constexpr int DPL = M::DPL;
+  constexpr int NSLOT = 5 * DPL + 3;
+  const int l = L.l;
+  const auto& im = L.im;
+  const auto& valid = L.valid;
+  double* lstk = L.lstk;
+  double* gstk = L.gstk;
+  const size_t nthreads = L.nthreads;
+
+  double q[DPL], p[DPL], g[DPL], qold[DPL], gold[DPL];
+  double qL[DPL], pL[DPL], gL[DPL], qR[DPL], pR[DPL], gR[DPL];
+  double t_rho[DPL], t_qp[DPL], t_gp[DPL];
+  double c_rho[DPL], c_pin[DPL], c_qp[DPL], c_gp[DPL];
+#pragma unroll
+  for (int k = 0; k < DPL; k++) {
+    q[k] = p[k] = g[k] = qold[k] = gold[k] = 0.0;
+    qL[k] = pL[k] = gL[k] = qR[k] = pR[k] = gR[k] = 0.0;
+    t_rho[k] = t_qp[k] = t_gp[k] = c_rho[k] = c_pin[k] = c_qp[k] = c_gp[k] = 0.0;
+  }
+  double t_logpP = 0.0, t_lsw = 0.0, t_acc = 0.0, jlp0 = 0.0;
+  int t_n = 0, t_depth = 0;
+  bool t_div = false, t_turn = false, go_right = true;
+  double eps_dir = eps;
+  Rng trng = st.rng;
+  const bool has = L.alive;   // false: a lane group kept only for wave-cooperative models
+
+  EXMC_PROF_DECL
+  for (int draw = 0; draw < n_draws; draw++) {
+    EXMC_PROF(8)
+    // ---- transition start (sampler.ex:393-403, 890-899) ----
+    bool alive = has;
+    if (has) {
+      draw_momentum<M, G>(L, st.rng, pL);
+      jlp0 = st.logp - kinetic_energy<G, DPL>(pL, im, valid);
+      trng = st.rng;  // the tree consumes a copy (sampler.ex:897 discards its draws)
+#pragma unroll
+      for (int k = 0; k < DPL; k++) {
+        qL[k] = qR[k] = t_qp[k] = st.q[k];
+        gL[k] = gR[k] = t_gp[k] = st.g[k];
+        pR[k] = t_rho[k] = pL[k];
+      }
+      t_logpP = st.logp;
+      t_lsw = 0.0;
+      t_acc = 0.0;
+      t_n = 0;
+      t_div = t_turn = false;
+      t_depth = 0;
+    }
+    EXMC_PROF(0)
+
+    for (int depth = 0; __any(alive ? 1 : 0) != 0; depth++) {   // depth is wave-uniform
+      if (alive) {
+        // tree.ex:403-413 direction + outward endpoint
+        const double u = rng_uniform(trng);
+        go_right = u > 0.5;
+        eps_dir = go_right ? eps : -eps;
+#pragma unroll
+        for (int k = 0; k < DPL; k++) {
+          q[k] = go_right ? qR[k] : qL[k];
+          p[k] = go_right ? pR[k] : pL[k];
+          g[k] = go_right ? gR[k] : gL[k];
+        }
+      }
+      EXMC_PROF(1)
+
+      const int nleaf = 1 << depth;
+      for (int leaf = 0; leaf < nleaf; leaf++) {
+        if (leaf > 0 && __any(alive ? 1 : 0) == 0) break;
+        EXMC_PROF_COUNT(9)
+        // ---- one leapfrog on every lane (batched_leapfrog.ex:79-85); idle groups integrate
+        // scratch registers so that wave-cooperative models see all 64 lanes ----
+        const double h = eps_dir / 2.0;
+#pragma unroll
+        for (int k = 0; k < DPL; k++) {
+          qold[k] = q[k];
+          gold[k] = g[k];
+          const double ph = p[k] + h * g[k];
+          p[k] = ph;
+          q[k] = q[k] + eps_dir * (im[k] * ph);
+        }
+#if EXMC_ABLATE == 3
+        double logp_new = 0.0;
+#pragma unroll
+        for (int k = 0; k < DPL; k++) { g[k] = -q[k]; logp_new = logp_new - 0.5 * q[k] * q[k]; }
+        logp_new = group_allsum<G>(logp_new);
+#else
+        const double logp_new = M::logp_grad(mc, L.ln, l, q, g);
+#endif
+#pragma unroll
+        for (int k = 0; k < DPL; k++) p[k] = p[k] + h * g[k];
+        const double jlp = logp_new - kinetic_energy<G, DPL>(p, im, valid);
+        EXMC_PROF(2)
+
+        if (alive) {
+          // ---- leaf (tree.ex:1042-1109) ----
+          bool c_div, c_turn = false;
+          double c_lsw, c_acc, c_logpP;
+          int c_n = 1;
+          if (exmc_isfinite(jlp)) {
+            const double dl = jlp - jlp0;
+            c_div = dl < -1000.0;
+            c_lsw = dl;
+#if EXMC_ABLATE == 4
+            c_acc = fmin(1.0, 1.0 + fmin(dl, 0.0));
+#else
+            c_acc = fmin(1.0, exmc_exp(fmin(dl, 0.0)));
+#endif
+          } else {
+            c_div = true;
+            c_lsw = -1001.0;
+            c_acc = 0.0;
+          }
+          c_acc = c_div ? 0.0 : c_acc;
+          c_logpP = c_div ? -1.0e30 : logp_new;
+#pragma unroll
+          for (int k = 0; k < DPL; k++) {
+            c_qp[k] = c_div ? qold[k] : q[k];
+            c_gp[k] = c_div ? gold[k] : g[k];
+            c_rho[k] = p[k];
+            c_pin[k] = p[k];
+          }
+          EXMC_PROF(3)
+
+          // ---- ascend (tree.ex:1144-1203, 1390-1476): level lvl holds a pending first half iff
+          // bit lvl of `leaf` is set; the first clear bit is where an unfinished node parks ----
+          bool parked = false;
+          for (int lvl = 0; lvl < depth; lvl++) {
+            if ((leaf >> lvl) & 1) {
+              if (!parked) {
+                double nd[NSLOT];
+                if (lvl < LDSL) node_load<NSLOT>(lstk + (size_t)lvl * NSLOT * kNutsBlock, kNutsBlock, nd);
+                else node_load<NSLOT>(gstk + (size_t)(lvl - LDSL) * NSLOT * nthreads, nthreads, nd);
+                const double a_lsw = nd[5 * DPL + 0];
+                const double a_logpP = nd[5 * DPL + 1];
+                const double a_acc = nd[5 * DPL + 2];
+#if EXMC_ABLATE == 2
+                const double lsw = a_lsw + c_lsw;
+                const double u = rng_uniform(trng);
+                const bool use_b = u < 0.5;
+#else
+                const double lsw = log_sum_exp(a_lsw, c_lsw);
+                const double u = rng_uniform(trng);
+                const bool use_b = u < exmc_exp(c_lsw - lsw);
+#endif
+                if (!use_b) {
+                  c_logpP = a_logpP;
+#pragma unroll
+                  for (int k = 0; k < DPL; k++) { c_qp[k] = nd[3 * DPL + k]; c_gp[k] = nd[4 * DPL + k]; }
+                }
+                bool turning = c_div || c_turn;
+                if (!turning) {
+                  double rho[DPL], r2[DPL], r3[DPL], a_pin[DPL], a_pout[DPL];
+#pragma unroll
+                  for (int k = 0; k < DPL; k++) {
+                    a_pin[k] = nd[1 * DPL + k];
+                    a_pout[k] = nd[2 * DPL + k];
+                    rho[k] = nd[0 * DPL + k] + c_rho[k];
+                    r2[k] = nd[0 * DPL + k] + c_pin[k];
+                    r3[k] = a_pout[k] + c_rho[k];
+                  }
+                  bool c1, c23;
+#if EXMC_ABLATE == 1
+                  c1 = c23 = false;
+#else
+                  uturn3<G, DPL>(rho, a_pin, p, r2, a_pin, c_pin, r3, a_pout, p, im, valid, c1, c23);
+#endif
+                  turning = c1 || ((lvl > 0) && c23);
+#pragma unroll
+                  for (int k = 0; k < DPL; k++) { c_rho[k] = rho[k]; c_pin[k] = a_pin[k]; }
+                }
+                c_lsw = lsw;
+                c_acc = a_acc + c_acc;
+                c_n = (1 << lvl) + c_n;
+                c_turn = turning;
+              }
+            } else {
+              // a node that is divergent or turning is returned upward unmerged (tree.ex:1175-1177)
+              if (!parked && !(c_div || c_turn)) {
+                double nd[NSLOT];
+#pragma unroll
+                for (int k = 0; k < DPL; k++) {
+                  nd[0 * DPL + k] = c_rho[k];
+                  nd[1 * DPL + k] = c_pin[k];
+                  nd[2 * DPL + k] = p[k];
+                  nd[3 * DPL + k] = c_qp[k];
+                  nd[4 * DPL + k] = c_gp[k];
+                }
+                nd[5 * DPL + 0] = c_lsw;
+                nd[5 * DPL + 1] = c_logpP;
+                nd[5 * DPL + 2] = c_acc;
+                if (lvl < LDSL) node_store<NSLOT>(lstk + (size_t)lvl * NSLOT * kNutsBlock, kNutsBlock, nd);
+                else node_store<NSLOT>(gstk + (size_t)(lvl - LDSL) * NSLOT * nthreads, nthreads, nd);
+                parked = true;
+              }
+              if (__any(parked ? 0 : 1) == 0) break;   // every live group has parked
+            }
+          }
+          EXMC_PROF(4)
+
+          // ---- this doubling's subtree is complete (last leaf, or ended early):
+          // merge_trajectories (tree.ex:1479-1568) ----
+          if (!parked) {
+#if EXMC_ABLATE == 2
+            const double lsw = t_lsw + c_lsw;
+            const double u = rng_uniform(trng);
+            const bool use_sub = u < 0.5;
+#else
+            const double lsw = log_sum_exp(t_lsw, c_lsw);
+            const double u = rng_uniform(trng);
+            const bool use_sub = exmc_log(u) < (c_lsw - t_lsw);
+#endif
+            if (use_sub) {
+              t_logpP = c_logpP;
+#pragma unroll
+              for (int k = 0; k < DPL; k++) { t_qp[k] = c_qp[k]; t_gp[k] = c_gp[k]; }
+            }
+            const bool divg = t_div || c_div;
+            bool turning = divg || c_turn;
+            double rho[DPL];
+#pragma unroll
+            for (int k = 0; k < DPL; k++) rho[k] = t_rho[k] + c_rho[k];
+            if (!turning) {
+              double nearp[DPL], farp[DPL], r2[DPL], r3[DPL];
+#pragma unroll
+              for (int k = 0; k < DPL; k++) {
+                nearp[k] = go_right ? pR[k] : pL[k];
+                farp[k] = go_right ? pL[k] : pR[k];
+                r2[k] = t_rho[k] + c_pin[k];
+                r3[k] = nearp[k] + c_rho[k];
+              }
+              bool c1, c23;
+#if EXMC_ABLATE == 1
+              c1 = c23 = false;
+#else
+              uturn3<G, DPL>(rho, farp, p, r2, farp, c_pin, r3, nearp, p, im, valid, c1, c23);
+#endif
+              turning = c1 || c23;
+            }
+#pragma unroll
+            for (int k = 0; k < DPL; k++) {
+              t_rho[k] = rho[k];
+              if (go_right) { qR[k] = q[k]; pR[k] = p[k]; gR[k] = g[k]; }
+              else { qL[k] = q[k]; pL[k] = p[k]; gL[k] = g[k]; }
+            }
+            t_lsw = lsw;
+            t_n += c_n;
+            t_acc = t_acc + c_acc;
+            t_div = divg;
+            t_turn = turning;
+            t_depth = depth + 1;
+            // tree.ex:1607-1618: the trajectory stops at max depth, on divergence or on a U-turn
+            alive = !(t_depth >= max_depth || t_div || t_turn);
+          }
+          EXMC_PROF(5)
+        }
+      }
+    }
+
+    // ---- transition done for every group of the wavefront (sampler.ex:890-925) ----
+    if (has) {
+      (void)rng_uniform(st.rng);
+      st.logp = t_logpP;
+#pragma unroll
+      for (int k = 0; k < DPL; k++) { st.q[k] = t_qp[k]; st.g[k] = t_gp[k]; }
+      sink(draw, st.q, st.logp, t_depth, t_n, t_div, t_acc, jlp0);
+    }
+    EXMC_PROF(6)
+  }
+  EXMC_PROF_FLUSH
 }
 
 // fill the per-lane constants; inv_mass / sqrt_inv_mass may be null (identity mass)
