@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <utility>
+
 #include "../../include/exmc_detmath.h"
 
 namespace exmc {
@@ -89,6 +91,30 @@ __device__ __forceinline__ double group_bcast(double v, int src) {
   if (G == 1) return v;
   const int lane = threadIdx.x & 63;
   return __shfl(v, (lane & ~(G - 1)) | src, 64);
+}
+
+// the same for a compile-time source lane, without the LDS round trip of ds_bpermute wherever
+// the lane group maps onto a DPP pattern: quad_perm for G <= 4, row_newbcast for G = 16 (a group
+// is one DPP row), v_readlane for G >= 32.
+template <int G, int SRC>
+__device__ __forceinline__ double group_bcast_c(double v) {
+  static_assert(SRC >= 0 && SRC < G, "source lane outside the group");
+  if constexpr (G == 1) {
+    return v;
+  } else if constexpr (G == 2) {
+    return dpp_move<SRC | (SRC << 2) | ((2 + SRC) << 4) | ((2 + SRC) << 6)>(v);
+  } else if constexpr (G == 4) {
+    return dpp_move<SRC | (SRC << 2) | (SRC << 4) | (SRC << 6)>(v);
+  } else if constexpr (G == 16) {
+    return dpp_move<0x150 + SRC>(v);   // row_newbcast:SRC
+  } else if constexpr (G == 32) {
+    const double lo = readlane_f64(v, SRC), hi = readlane_f64(v, 32 + SRC);
+    return ((threadIdx.x & 63) < 32) ? lo : hi;
+  } else if constexpr (G == 64) {
+    return readlane_f64(v, SRC);
+  } else {
+    return group_bcast<G>(v, SRC);
+  }
 }
 
 // true iff `ok` holds on every lane of this lane's group (the group's lanes are all active)

@@ -59,8 +59,8 @@ struct EightSchools : ModelDefaults {
 
   __device__ static __forceinline__ double logp_grad(const Consts& c, const Lane& ln, int l,
                                                      const double (&q)[DPL], double (&g)[DPL]) {
-    const double mu = group_bcast<G>(q[0 / G], 0 % G);
-    const double zraw = group_bcast<G>(q[1 / G], 1 % G);
+    const double mu = group_bcast_c<G, 0 % G>(q[0 / G]);
+    const double zraw = group_bcast_c<G, 1 % G>(q[1 / G]);
     const double zc = clamp200(zraw);
     const double tau = exmc_exp(zc);
     double L[DPL], A[DPL], B[DPL], T[DPL];
@@ -200,8 +200,8 @@ struct SV : ModelDefaults {
   }
   __device__ static __forceinline__ double logp_grad(const Consts& c, const Lane& ln, int l,
                                                      const double (&q)[DPL], double (&g)[DPL]) {
-    const double zs_raw = group_bcast<G>(q[T / G], T % G);
-    const double zn_raw = group_bcast<G>(q[(T + 1) / G], (T + 1) % G);
+    const double zs_raw = group_bcast_c<G, T % G>(q[T / G]);
+    const double zn_raw = group_bcast_c<G, (T + 1) % G>(q[(T + 1) / G]);
     const double zs = clamp200(zs_raw), zn = clamp200(zn_raw);
     const double sigma = exmc_exp(zs), nu = exmc_exp(zn);
     const double ss = fmax(sigma, c.tiny32);
@@ -304,11 +304,17 @@ struct Logistic : ModelDefaults {
   struct Lane {};
   __device__ static __forceinline__ void load(const Consts&, int, Lane&) {}
 
+  // every lane needs the whole coefficient vector: dim i lives in slot i / G of lane i % G
+  template <int... I>
+  __device__ static __forceinline__ void bcast_all(const double (&q)[DPL], double (&qf)[D],
+                                                   std::integer_sequence<int, I...>) {
+    ((qf[I] = group_bcast_c<G, I % G>(q[I / G])), ...);
+  }
+
   __device__ static __forceinline__ double logp_grad(const Consts& c, const Lane&, int l,
                                                      const double (&q)[DPL], double (&g)[DPL]) {
     double qf[D];
-#pragma unroll
-    for (int i = 0; i < D; i++) qf[i] = group_bcast<G>(q[i / G], i % G);
+    bcast_all(q, qf, std::make_integer_sequence<int, D>{});
     double s[D + 1];   // s[0..D-1] gradient partials, s[D] likelihood partial
 #pragma unroll
     for (int j = 0; j <= D; j++) s[j] = 0.0;
@@ -544,11 +550,11 @@ struct Radon : ModelDefaults {
   }
   __device__ static __forceinline__ double logp_grad(const Consts& c, const Lane& ln, int l,
                                                      const double (&q)[DPL], double (&g)[DPL]) {
-    const double mu = group_bcast<G>(q[J / G], J % G);
-    const double gam = group_bcast<G>(q[(J + 1) / G], (J + 1) % G);
-    const double zsa_raw = group_bcast<G>(q[(J + 2) / G], (J + 2) % G);
-    const double zsy_raw = group_bcast<G>(q[(J + 3) / G], (J + 3) % G);
-    const double beta = group_bcast<G>(q[(J + 4) / G], (J + 4) % G);
+    const double mu = group_bcast_c<G, J % G>(q[J / G]);
+    const double gam = group_bcast_c<G, (J + 1) % G>(q[(J + 1) / G]);
+    const double zsa_raw = group_bcast_c<G, (J + 2) % G>(q[(J + 2) / G]);
+    const double zsy_raw = group_bcast_c<G, (J + 3) % G>(q[(J + 3) / G]);
+    const double beta = group_bcast_c<G, (J + 4) % G>(q[(J + 4) / G]);
     const double zsa = clamp200(zsa_raw), zsy = clamp200(zsy_raw);
     const double sa = exmc_exp(zsa), sy = exmc_exp(zsy);
     const double ssy = fmax(sy, c.tiny32);

@@ -17,13 +17,15 @@
 // `if first.divergent or first.turning` does (tree.ex:1175-1177); when the doubling's subtree is
 // complete it is merged into the trajectory (tree.ex:1479-1568).
 //
-// Schedule: a wavefront holds 64/G chains. Every pass of the main loop gives each chain group
-// exactly ONE leapfrog followed by the merges that leaf triggers, so chains with short trees
-// never wait for chains with long ones; the bookkeeping between leapfrogs diverges per group.
-// Two alternatives were measured and rejected on MI355X (eight_schools, 4096 chains, G = 16):
-// capping merges at one per pass (+20 % time: the extra passes cost more than the "max over
-// groups" merge trips they remove) and running inner and outer merges through one unified code
-// path (+22 %: operand selects and both proposal rules evaluated).
+// Schedule: a wavefront holds 64/G chains, one per G-lane group, and the groups walk the tree
+// skeleton in lock step (see nuts_run). The first schedule built was asynchronous — every pass
+// gave each group one leapfrog and whatever bookkeeping that group's own tree phase needed, so
+// no chain ever waited — but with four groups per wave nearly every pass paid for the union of
+// all paths (momentum draw, direction, inner merges at several levels, outer merge, trace
+// write): 27.7 ms for eight_schools 4096 x 1000 against 17.7 ms for the lock-step walk, where
+// idle groups cost 18 % more passes and each pass costs ~0.55x. Also measured and rejected on
+// the asynchronous loop: capping merges at one per pass (+20 %), one unified inner/outer merge
+// body (+22 %), G = 32 with two waves per SIMD (+31 %).
 //
 // Memory plan per workgroup (one wavefront): the first LDSL stack levels and the ziggurat
 // tables live in LDS; deeper levels spill to a global scratch that stays L2-resident. Per-chain
@@ -205,284 +207,7 @@ __device__ __forceinline__ void draw_momentum(const NutsLane<M, G>& L, Rng& rng,
 // n_draws NUTS transitions of this group's chain. sink(draw, q, logp, depth, n_steps, divergent,
 // accept_sum, jlp0) is called once per finished transition.
 // stack slots of one pending node: rho, p_in, p_out, q_prop, g_prop (DPL each), lsw, logp_prop, acc
-template <class M, int G, int LDSL, class Sink>
-__device__ __forceinline__ void nuts_run_async(const typename M::Consts& mc, const NutsLane<M, G>& L,
-                                               ChainRegs<M::DPL>& st, int n_draws, double eps,
-                                               int max_depth, Sink&& sink) {
-  constexpr int DPL = M::DPL;
-  constexpr int NSLOT = 5 * DPL + 3;
-  const int l = L.l;
-  const auto& im = L.im;
-  const auto& valid = L.valid;
-  double* lstk = L.lstk;
-  double* gstk = L.gstk;
-  const size_t nthreads = L.nthreads;
-
-  // integrator state and tree registers
-  double q[DPL], p[DPL], g[DPL], qold[DPL], gold[DPL];
-  double qL[DPL], pL[DPL], gL[DPL], qR[DPL], pR[DPL], gR[DPL];
-  double t_rho[DPL], t_qp[DPL], t_gp[DPL];
-  double c_rho[DPL], c_pin[DPL], c_qp[DPL], c_gp[DPL];
-#pragma unroll
-  for (int k = 0; k < DPL; k++) {
-    q[k] = p[k] = g[k] = qold[k] = gold[k] = 0.0;
-    qL[k] = pL[k] = gL[k] = qR[k] = pR[k] = gR[k] = 0.0;
-    t_rho[k] = t_qp[k] = t_gp[k] = c_rho[k] = c_pin[k] = c_qp[k] = c_gp[k] = 0.0;
-  }
-  double t_logpP = 0.0, t_lsw = 0.0, t_acc = 0.0, jlp0 = 0.0;
-  int t_n = 0, depth = 0;
-  bool t_div = false, t_turn = false, go_right = true;
-  double eps_dir = eps;
-  unsigned pending = 0;
-  Rng trng = st.rng;
-
-  int draw = 0;
-  bool start_transition = true, start_doubling = false;
-
-  // Wave-cooperative models (kCoop) need all 64 lanes in logp_grad: a group that has finished its
-  // draws (or has no chain) keeps taking the leapfrog with the wave and skips the tree logic.
-  bool alive = L.alive && (n_draws > 0);
-  EXMC_PROF_DECL
-  while (M::kCoop ? (__any(alive ? 1 : 0) != 0) : alive) {
-    EXMC_PROF(8)
-    EXMC_PROF_COUNT(9)
-    if (alive && start_transition) {
-      draw_momentum<M, G>(L, st.rng, pL);
-      jlp0 = st.logp - kinetic_energy<G, DPL>(pL, im, valid);
-      trng = st.rng;  // the tree consumes a copy (sampler.ex:897 discards its draws)
-#pragma unroll
-      for (int k = 0; k < DPL; k++) {
-        qL[k] = qR[k] = t_qp[k] = st.q[k];
-        gL[k] = gR[k] = t_gp[k] = st.g[k];
-        pR[k] = t_rho[k] = pL[k];
-      }
-      t_logpP = st.logp;
-      t_lsw = 0.0;
-      t_acc = 0.0;
-      t_n = 0;
-      t_div = t_turn = false;
-      depth = 0;
-      start_transition = false;
-      start_doubling = true;
-    }
-    EXMC_PROF(0)
-    if (alive && start_doubling) {
-      // tree.ex:403-413 direction + outward endpoint
-      const double u = rng_uniform(trng);
-      go_right = u > 0.5;
-      eps_dir = go_right ? eps : -eps;
-#pragma unroll
-      for (int k = 0; k < DPL; k++) {
-        q[k] = go_right ? qR[k] : qL[k];
-        p[k] = go_right ? pR[k] : pL[k];
-        g[k] = go_right ? gR[k] : gL[k];
-      }
-      pending = 0;
-      start_doubling = false;
-    }
-    EXMC_PROF(1)
-
-    // ---- one leapfrog (batched_leapfrog.ex:79-85) ----
-    const double h = eps_dir / 2.0;
-#pragma unroll
-    for (int k = 0; k < DPL; k++) {
-      qold[k] = q[k];
-      gold[k] = g[k];
-      const double ph = p[k] + h * g[k];
-      p[k] = ph;
-      q[k] = q[k] + eps_dir * (im[k] * ph);
-    }
-#if EXMC_ABLATE == 3
-    double logp_new = 0.0;
-#pragma unroll
-    for (int k = 0; k < DPL; k++) { g[k] = -q[k]; logp_new = logp_new - 0.5 * q[k] * q[k]; }
-    logp_new = group_allsum<G>(logp_new);
-#else
-    const double logp_new = M::logp_grad(mc, L.ln, l, q, g);
-#endif
-#pragma unroll
-    for (int k = 0; k < DPL; k++) p[k] = p[k] + h * g[k];
-    const double jlp = logp_new - kinetic_energy<G, DPL>(p, im, valid);
-    EXMC_PROF(2)
-    if (M::kCoop && !alive) continue;
-
-    // ---- leaf (tree.ex:1042-1109) ----
-    bool c_div, c_turn = false;
-    double c_lsw, c_acc, c_logpP;
-    int c_n = 1;
-    if (exmc_isfinite(jlp)) {
-      const double dl = jlp - jlp0;
-      c_div = dl < -1000.0;
-      c_lsw = dl;
-#if EXMC_ABLATE == 4
-      c_acc = fmin(1.0, 1.0 + fmin(dl, 0.0));
-#else
-      c_acc = fmin(1.0, exmc_exp(fmin(dl, 0.0)));
-#endif
-    } else {
-      c_div = true;
-      c_lsw = -1001.0;
-      c_acc = 0.0;
-    }
-    c_acc = c_div ? 0.0 : c_acc;
-    c_logpP = c_div ? -1.0e30 : logp_new;
-#pragma unroll
-    for (int k = 0; k < DPL; k++) {
-      c_qp[k] = c_div ? qold[k] : q[k];
-      c_gp[k] = c_div ? gold[k] : g[k];
-      c_rho[k] = p[k];
-      c_pin[k] = p[k];
-    }
-    EXMC_PROF(3)
-
-    // ---- ascend: inner merges for every pending level (tree.ex:1144-1203, 1390-1476) ----
-    int lvl = 0;
-    bool parked = false;
-    while (lvl < depth) {
-      if (pending & (1u << lvl)) {
-        double nd[NSLOT];
-        if (lvl < LDSL) node_load<NSLOT>(lstk + (size_t)lvl * NSLOT * kNutsBlock, kNutsBlock, nd);
-        else node_load<NSLOT>(gstk + (size_t)(lvl - LDSL) * NSLOT * nthreads, nthreads, nd);
-        const double a_lsw = nd[5 * DPL + 0];
-        const double a_logpP = nd[5 * DPL + 1];
-        const double a_acc = nd[5 * DPL + 2];
-#if EXMC_ABLATE == 2
-        const double lsw = a_lsw + c_lsw;
-        const double u = rng_uniform(trng);
-        const bool use_b = u < 0.5;
-#else
-        const double lsw = log_sum_exp(a_lsw, c_lsw);
-        const double u = rng_uniform(trng);
-        const bool use_b = u < exmc_exp(c_lsw - lsw);
-#endif
-        if (!use_b) {
-          c_logpP = a_logpP;
-#pragma unroll
-          for (int k = 0; k < DPL; k++) { c_qp[k] = nd[3 * DPL + k]; c_gp[k] = nd[4 * DPL + k]; }
-        }
-        bool turning = c_div || c_turn;
-        if (!turning) {
-          double rho[DPL], r2[DPL], r3[DPL], a_pin[DPL], a_pout[DPL];
-#pragma unroll
-          for (int k = 0; k < DPL; k++) {
-            a_pin[k] = nd[1 * DPL + k];
-            a_pout[k] = nd[2 * DPL + k];
-            rho[k] = nd[0 * DPL + k] + c_rho[k];
-            r2[k] = nd[0 * DPL + k] + c_pin[k];
-            r3[k] = a_pout[k] + c_rho[k];
-          }
-          bool c1, c23;
-#if EXMC_ABLATE == 1
-          c1 = c23 = false;
-#else
-          uturn3<G, DPL>(rho, a_pin, p, r2, a_pin, c_pin, r3, a_pout, p, im, valid, c1, c23);
-#endif
-          turning = c1 || ((lvl > 0) && c23);
-#pragma unroll
-          for (int k = 0; k < DPL; k++) { c_rho[k] = rho[k]; c_pin[k] = a_pin[k]; }
-        }
-        c_lsw = lsw;
-        c_acc = a_acc + c_acc;
-        c_n = (1 << lvl) + c_n;
-        c_turn = turning;
-        pending &= ~(1u << lvl);
-        lvl++;
-      } else if (c_div || c_turn) {
-        lvl++;  // returned upward unmerged (tree.ex:1175-1177)
-      } else {
-        double nd[NSLOT];
-#pragma unroll
-        for (int k = 0; k < DPL; k++) {
-          nd[0 * DPL + k] = c_rho[k];
-          nd[1 * DPL + k] = c_pin[k];
-          nd[2 * DPL + k] = p[k];
-          nd[3 * DPL + k] = c_qp[k];
-          nd[4 * DPL + k] = c_gp[k];
-        }
-        nd[5 * DPL + 0] = c_lsw;
-        nd[5 * DPL + 1] = c_logpP;
-        nd[5 * DPL + 2] = c_acc;
-        if (lvl < LDSL) node_store<NSLOT>(lstk + (size_t)lvl * NSLOT * kNutsBlock, kNutsBlock, nd);
-        else node_store<NSLOT>(gstk + (size_t)(lvl - LDSL) * NSLOT * nthreads, nthreads, nd);
-        pending |= (1u << lvl);
-        parked = true;
-        break;
-      }
-    }
-    EXMC_PROF(4)
-    if (parked) continue;
-
-    // ---- subtree for this doubling is complete: merge_trajectories (tree.ex:1479-1568) ----
-    {
-#if EXMC_ABLATE == 2
-      const double lsw = t_lsw + c_lsw;
-      const double u = rng_uniform(trng);
-      const bool use_sub = u < 0.5;
-#else
-      const double lsw = log_sum_exp(t_lsw, c_lsw);
-      const double u = rng_uniform(trng);
-      const bool use_sub = exmc_log(u) < (c_lsw - t_lsw);
-#endif
-      if (use_sub) {
-        t_logpP = c_logpP;
-#pragma unroll
-        for (int k = 0; k < DPL; k++) { t_qp[k] = c_qp[k]; t_gp[k] = c_gp[k]; }
-      }
-      const bool divg = t_div || c_div;
-      bool turning = divg || c_turn;
-      double rho[DPL];
-#pragma unroll
-      for (int k = 0; k < DPL; k++) rho[k] = t_rho[k] + c_rho[k];
-      if (!turning) {
-        double nearp[DPL], farp[DPL], r2[DPL], r3[DPL];
-#pragma unroll
-        for (int k = 0; k < DPL; k++) {
-          nearp[k] = go_right ? pR[k] : pL[k];
-          farp[k] = go_right ? pL[k] : pR[k];
-          r2[k] = t_rho[k] + c_pin[k];
-          r3[k] = nearp[k] + c_rho[k];
-        }
-        bool c1, c23;
-#if EXMC_ABLATE == 1
-        c1 = c23 = false;
-#else
-        uturn3<G, DPL>(rho, farp, p, r2, farp, c_pin, r3, nearp, p, im, valid, c1, c23);
-#endif
-        turning = c1 || c23;
-      }
-#pragma unroll
-      for (int k = 0; k < DPL; k++) {
-        t_rho[k] = rho[k];
-        if (go_right) { qR[k] = q[k]; pR[k] = p[k]; gR[k] = g[k]; }
-        else { qL[k] = q[k]; pL[k] = p[k]; gL[k] = g[k]; }
-      }
-      t_lsw = lsw;
-      t_n += c_n;
-      t_acc = t_acc + c_acc;
-      t_div = divg;
-      t_turn = turning;
-      depth++;
-    }
-    EXMC_PROF(5)
-
-    if (depth >= max_depth || t_div || t_turn) {
-      // ---- transition done (tree.ex:1607-1618, sampler.ex:890-925) ----
-      (void)rng_uniform(st.rng);
-      st.logp = t_logpP;
-#pragma unroll
-      for (int k = 0; k < DPL; k++) { st.q[k] = t_qp[k]; st.g[k] = t_gp[k]; }
-      sink(draw, st.q, st.logp, depth, t_n, t_div, t_acc, jlp0);
-      draw++;
-      alive = draw < n_draws;
-      start_transition = true;
-    } else {
-      start_doubling = true;
-    }
-    EXMC_PROF(6)
-  }
-  EXMC_PROF_FLUSH
-}
-
+//
 // Lock-step schedule: the chain groups of a wavefront start every transition together and walk
 // the same tree skeleton (doubling j, leaf k) in the same pass, so which levels merge after a
 // leaf (the trailing ones of k), the doubling and transition boundaries and the trace writes are
@@ -655,13 +380,16 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
                     r2[k] = nd[0 * DPL + k] + c_pin[k];
                     r3[k] = a_pout[k] + c_rho[k];
                   }
-                  bool c1, c23;
+                  bool c1, c23 = false;
 #if EXMC_ABLATE == 1
-                  c1 = c23 = false;
+                  c1 = false;
 #else
-                  uturn3<G, DPL>(rho, a_pin, p, r2, a_pin, c_pin, r3, a_pout, p, im, valid, c1, c23);
+                  // tree.ex:1428-1446: the two sub-span checks apply from depth 2 on; lvl is
+                  // wave-uniform, so the level-0 merges (3 of 4 in a 7-leaf tree) reduce 2 sums, not 6
+                  if (lvl == 0) c1 = uturn<G, DPL>(rho, a_pin, p, im, valid);
+                  else uturn3<G, DPL>(rho, a_pin, p, r2, a_pin, c_pin, r3, a_pout, p, im, valid, c1, c23);
 #endif
-                  turning = c1 || ((lvl > 0) && c23);
+                  turning = c1 || c23;
 #pragma unroll
                   for (int k = 0; k < DPL; k++) { c_rho[k] = rho[k]; c_pin[k] = a_pin[k]; }
                 }

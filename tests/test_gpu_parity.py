@@ -237,3 +237,38 @@ def test_single_chain_sample_bit_exact(hip):
     assert np.array_equal(t["tree_depth"], stats["raw"]["tree_depth"][0])
     assert st.divergences == stats["divergences"]
     assert abs(trace["mu"].mean() - 2.15) < 0.3
+
+
+def _bench_models():
+    import bench
+    return [("sv", lambda: bench.make_spec("sv")[0], 64, 6, 12),
+            ("radon", lambda: bench.make_spec("radon")[0], 64, 6, 25),
+            ("logistic", lambda: bench.make_spec("logistic")[0], 16, 37, 25),
+            ("logistic_mfma", lambda: bench.make_spec("logistic")[0], 4, 37, 25)]
+
+
+@pytest.mark.parametrize("name,factory,lanes,n_chains,n_draws", _bench_models(),
+                         ids=lambda x: x if isinstance(x, str) else "")
+def test_bench_protocol_other_models_bit_exact(hip, name, factory, lanes, n_chains, n_draws):
+    """The bench protocol on the other BASELINE configs at full depth: the shared 1000-iteration
+    warmup (sampler.ex:126-257; sv reaches tree depth 8-9, beyond the LDS-resident stack levels)
+    and max_tree_depth 10 sampling of more chain groups than one wavefront holds. Tuning and every
+    per-draw output identical to the checker."""
+    spec = factory()
+    comp = sampler.compile(spec)
+    om = O.Model(spec.kind, spec.d, spec.data)
+    opts = dict(num_warmup=1000, num_samples=n_draws, seed=42, lanes_per_chain=lanes)
+    tuning = sampler.warmup(comp, spec.default_init, opts)
+    q0 = spec.to_unconstrained(spec.default_init)
+    t, st = O.sample_chains(om, n_chains, init_q=q0, num_warmup=1000, num_samples=n_draws, seed=42,
+                            n_threads=8, cfg=O.Cfg(1, lanes))
+    assert st.step_size == tuning["epsilon"]
+    assert np.array_equal(np.array(st.inv_mass[:spec.d]), tuning["inv_mass"])
+    _, _, extra = sampler.sample_compiled_tuned(comp, tuning, spec.default_init, opts,
+                                                num_chains=n_chains)
+    raw = extra["raw"]
+    for k in ("tree_depth", "n_steps", "divergent", "draws", "logp", "accept_prob", "energy"):
+        assert np.array_equal(t[k], raw[k]), k
+    assert extra["total_leapfrogs"] == st.total_leapfrogs
+    if name == "sv":
+        assert t["tree_depth"].max() >= 7   # the global spill levels were exercised
