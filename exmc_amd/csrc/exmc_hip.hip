@@ -80,7 +80,7 @@ struct exmc_hip_model {
   DevBuf tuning;    // inv_mass[D], sqrt_inv_mass[D]
   DevBuf state;     // q[D][C], g[D][C], logp[C], rng[2][C]
   DevBuf stack;
-  DevBuf misc;      // eps_out (1), counters (2 u64), init_q[D]
+  DevBuf misc;      // [0] eps_out, [1..2] counters (u64), [3] trace scratch word, [8..8+D) init_q
   DevBuf trace;     // staging for host-trace entry points
   DevBuf io;        // staging for host vectors
   int state_chains = 0;
@@ -249,6 +249,7 @@ int launch_nuts(exmc_hip_model* m, int lanes, int C, int n_draws, int draw_offse
     P.tr = tr;
     P.stack = m->stack.as<double>();
     P.counters = (unsigned long long*)(m->misc.as<double>() + 1);
+    P.scratch = m->misc.as<double>() + 3;
     P.zig_ki = zig_ki(m); P.zig_wi = zig_wi(m); P.zig_fi = zig_fi(m);
     P.nor_r = EXMC_NOR_R;
     if (timed) HIP_TRY(hipEventRecord(m->ev0, m->stream));

@@ -94,6 +94,7 @@ struct NutsParams {
   TraceDev tr;
   double* stack;                // dev scratch for levels >= LDSL
   unsigned long long* counters; // [0] leapfrogs, [1] divergent transitions
+  void* scratch;                // dev, 8 bytes: where trace outputs the caller left null are written
   const uint64_t* zig_ki;
   const double* zig_wi;
   const double* zig_fi;
@@ -177,7 +178,9 @@ __device__ __forceinline__ void draw_momentum(const NutsLane<M, G>& L, Rng& rng,
   uint64_t s0[DPL];
 #pragma unroll
   for (int k = 0; k < DPL; k++) { z[k] = 0.0; s0[k] = 0; }
-#pragma unroll
+  // kept rolled: unrolled, the D lane predicates (l == i) are hoisted into scalar register pairs
+  // for the whole kernel and the sampling loop pays for them in v_readlane spills
+#pragma nounroll
   for (int i = 0; i < D; i++) {
 #pragma unroll
     for (int k = 0; k < DPL; k++) s0[k] = (L.l + k * G == i) ? r2.b : s0[k];
@@ -575,23 +578,54 @@ __global__ void __launch_bounds__(kNutsBlock) nuts_kernel(NutsParams P, typename
 
   unsigned long long lf_total = 0, div_total = 0;
   const int l = L.l;
-  auto sink = [&](int draw, const double (&sq)[DPL], double slogp, int depth, int t_n, bool t_div,
-                  double t_acc, double jlp0) {
-    const size_t row = (size_t)(P.draw_offset + draw);
-    if (P.tr.draws) {
+  // Trace cursors: one per-lane pointer per output, stepped by one trace row per draw. An output
+  // the caller left null (or that this lane does not own) points at an 8-byte scratch word with
+  // step 0, so the per-draw code is straight stores and 64-bit adds in vector registers: no
+  // null tests, no row * D * C address products and no kernel-argument pointers kept live in
+  // scalar registers across the sampling loop.
+  struct Cursor {
+    char* p;
+    long long step;
+  };
+  auto cursor = [&](void* base, bool mine, size_t elem, size_t index, size_t row_elems) -> Cursor {
+    const bool on = (base != nullptr) && mine;
+    return Cursor{on ? (char*)base + index * elem : (char*)P.scratch,
+                  on ? (long long)(row_elems * elem) : 0LL};
+  };
+  const size_t row0 = (size_t)P.draw_offset;
+  const size_t stat0 = row0 * C + chain;
+  const bool own = (l == 0);
+  Cursor c_draw[DPL];
 #pragma unroll
-      for (int k = 0; k < DPL; k++)
-        if (L.valid[k]) P.tr.draws[(row * D + (l + k * G)) * C + chain] = sq[k];
+  for (int k = 0; k < DPL; k++)
+    c_draw[k] = cursor(P.tr.draws, L.valid[k], 8, (row0 * D + (l + k * G)) * C + chain, (size_t)D * C);
+  Cursor c_logp = cursor(P.tr.logp, own, 8, stat0, C);
+  Cursor c_depth = cursor(P.tr.tree_depth, own, 4, stat0, C);
+  Cursor c_steps = cursor(P.tr.n_steps, own, 4, stat0, C);
+  Cursor c_div = cursor(P.tr.divergent, own, 4, stat0, C);
+  Cursor c_acc = cursor(P.tr.accept_prob, own, 8, stat0, C);
+  Cursor c_energy = cursor(P.tr.energy, own, 8, stat0, C);
+  auto sink = [&](int, const double (&sq)[DPL], double slogp, int depth, int t_n, bool t_div,
+                  double t_acc, double jlp0) {
+#pragma unroll
+    for (int k = 0; k < DPL; k++) {
+      if (L.valid[k]) *(double*)c_draw[k].p = sq[k];
+      c_draw[k].p += c_draw[k].step;
     }
-    if (l == 0) {
-      const size_t o = row * C + chain;
-      if (P.tr.logp) P.tr.logp[o] = slogp;
-      if (P.tr.tree_depth) P.tr.tree_depth[o] = depth;
-      if (P.tr.n_steps) P.tr.n_steps[o] = t_n;
-      if (P.tr.divergent) P.tr.divergent[o] = t_div ? 1 : 0;
-      if (P.tr.accept_prob) P.tr.accept_prob[o] = (t_n > 0) ? (t_acc / (double)t_n) : 0.0;
-      if (P.tr.energy) P.tr.energy[o] = -jlp0;
+    if (own) {
+      *(double*)c_logp.p = slogp;
+      *(int32_t*)c_depth.p = depth;
+      *(int32_t*)c_steps.p = t_n;
+      *(int32_t*)c_div.p = t_div ? 1 : 0;
+      *(double*)c_acc.p = (t_n > 0) ? (t_acc / (double)t_n) : 0.0;
+      *(double*)c_energy.p = -jlp0;
     }
+    c_logp.p += c_logp.step;
+    c_depth.p += c_depth.step;
+    c_steps.p += c_steps.step;
+    c_div.p += c_div.step;
+    c_acc.p += c_acc.step;
+    c_energy.p += c_energy.step;
     lf_total += (unsigned long long)t_n;
     div_total += t_div ? 1u : 0u;
   };

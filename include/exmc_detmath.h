@@ -41,23 +41,79 @@ EXMC_HD uint64_t exmc_to_bits(double d) {
   return u;
 }
 
-/* EXMC_FMA(a, b, c) = fma(a, b, c). In gfx950 device code it is spelled as the three-address
- * v_fma_f64 with all operands in vector registers: for a Horner step acc*r + C the compiler's own
- * choice is v_mov_b64 tmp, C; v_fmac_f64 tmp, acc, r (two issue slots per step, and the hoisted C
- * occupies scarce scalar registers). Same IEEE operation, same bits.
- * Rule: only for intermediates consumed by ordinary arithmetic inside this header. The last
- * operation of every function is a plain builtin, because LLVM's hazard recogniser does not see
- * the asm's register write and would not pad a DPP / lane-read consumer (measured: a logistic
- * chain went wrong when log() ended in the asm form). */
+/* The two polynomial kernels of exp and log. In gfx950 device code each is ONE inline-asm block of
+ * three-address v_fma_f64 with every operand in a vector register. Left to the compiler a Horner
+ * step acc*r + C becomes v_mov_b64 tmp, C; v_fmac_f64 tmp, acc, r (two issue slots, and the hoisted
+ * coefficients fill the scarce scalar registers until loop state spills to v_writelane/v_readlane);
+ * single-instruction asm statements are padded with an s_nop each (the hazard recogniser treats an
+ * asm result as a possible transcendental). The host restatement is the same fma sequence, so the
+ * bits are identical. The result of a block is only consumed by ordinary arithmetic in this file
+ * (a function never returns an asm output: a DPP or lane-read consumer must see a plain VALU op). */
 #if defined(__HIP_DEVICE_COMPILE__)
-static __device__ __forceinline__ double exmc_fma_vvv(double a, double b, double c) {
-  double d;
-  __asm__("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-  return d;
+static __device__ __forceinline__ void exmc_exp_core(double kf, double x, double* r_out, double* p_out) {
+  double p, r;
+  __asm__("v_fma_f64 %1, %2, %4, %3\n\t"
+          "v_fma_f64 %1, %2, %5, %1\n\t"
+          "v_fma_f64 %0, %6, %1, %7\n\t"
+          "v_fma_f64 %0, %0, %1, %8\n\t"
+          "v_fma_f64 %0, %0, %1, %9\n\t"
+          "v_fma_f64 %0, %0, %1, %10\n\t"
+          "v_fma_f64 %0, %0, %1, %11\n\t"
+          "v_fma_f64 %0, %0, %1, %12\n\t"
+          "v_fma_f64 %0, %0, %1, %13\n\t"
+          "v_fma_f64 %0, %0, %1, %14\n\t"
+          "v_fma_f64 %0, %0, %1, %15\n\t"
+          "v_fma_f64 %0, %0, %1, %16"
+          : "=&v"(p), "=&v"(r)
+          : "v"(kf), "v"(x), "v"(-0x1.62e42fefa39efp-1), "v"(-0x1.abc9e3b39803fp-56),
+            "v"(0x1.6124613a86d09p-33), "v"(0x1.1eed8eff8d898p-29), "v"(0x1.ae64567f544e4p-26),
+            "v"(0x1.27e4fb7789f5cp-22), "v"(0x1.71de3a556c734p-19), "v"(0x1.a01a01a01a01ap-16),
+            "v"(0x1.a01a01a01a01ap-13), "v"(0x1.6c16c16c16c17p-10), "v"(0x1.1111111111111p-7),
+            "v"(0x1.5555555555555p-5), "v"(0x1.5555555555555p-3));
+  *r_out = r;
+  *p_out = p;
 }
-#define EXMC_FMA(a, b, c) exmc_fma_vvv((a), (b), (c))
+static __device__ __forceinline__ void exmc_log_core(double w, double* u1_out, double* u2_out) {
+  double u1, u2;
+  __asm__("v_fma_f64 %0, %2, %3, %4\n\t"
+          "v_fma_f64 %1, %2, %6, %7\n\t"
+          "v_fma_f64 %0, %2, %0, %5\n\t"
+          "v_fma_f64 %1, %2, %1, %8\n\t"
+          "v_fma_f64 %1, %2, %1, %9"
+          : "=&v"(u1), "=&v"(u2)
+          : "v"(w), "v"(1.531383769920937332e-01), "v"(2.222219843214978396e-01),
+            "v"(3.999999999940941908e-01), "v"(1.479819860511658591e-01),
+            "v"(1.818357216161805012e-01), "v"(2.857142874366239149e-01),
+            "v"(6.666666666666735130e-01));
+  *u1_out = u1;
+  *u2_out = u2;
+}
 #else
-#define EXMC_FMA(a, b, c) __builtin_fma((a), (b), (c))
+static inline void exmc_exp_core(double kf, double x, double* r_out, double* p_out) {
+  double r = __builtin_fma(kf, -0x1.62e42fefa39efp-1, x);      /* - k*ln2_hi */
+  r = __builtin_fma(kf, -0x1.abc9e3b39803fp-56, r);            /* - k*ln2_lo */
+  double p = __builtin_fma(0x1.6124613a86d09p-33, r, 0x1.1eed8eff8d898p-29); /* 1/13!, 1/12! */
+  p = __builtin_fma(p, r, 0x1.ae64567f544e4p-26);              /* 1/11! */
+  p = __builtin_fma(p, r, 0x1.27e4fb7789f5cp-22);              /* 1/10! */
+  p = __builtin_fma(p, r, 0x1.71de3a556c734p-19);              /* 1/9!  */
+  p = __builtin_fma(p, r, 0x1.a01a01a01a01ap-16);              /* 1/8!  */
+  p = __builtin_fma(p, r, 0x1.a01a01a01a01ap-13);              /* 1/7!  */
+  p = __builtin_fma(p, r, 0x1.6c16c16c16c17p-10);              /* 1/6!  */
+  p = __builtin_fma(p, r, 0x1.1111111111111p-7);               /* 1/5!  */
+  p = __builtin_fma(p, r, 0x1.5555555555555p-5);               /* 1/4!  */
+  p = __builtin_fma(p, r, 0x1.5555555555555p-3);               /* 1/3!  */
+  *r_out = r;
+  *p_out = p;
+}
+static inline void exmc_log_core(double w, double* u1_out, double* u2_out) {
+  double u1 = __builtin_fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01);
+  double u2 = __builtin_fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01);
+  u1 = __builtin_fma(w, u1, 3.999999999940941908e-01);
+  u2 = __builtin_fma(w, u2, 2.857142874366239149e-01);
+  u2 = __builtin_fma(w, u2, 6.666666666666735130e-01);
+  *u1_out = u1;
+  *u2_out = u2;
+}
 #endif
 
 #define EXMC_INF_BITS 0x7FF0000000000000ULL
@@ -72,19 +128,8 @@ EXMC_HD double exmc_exp(double x) {
   if (x > 709.782712893384) return exmc_from_bits(EXMC_INF_BITS);
   if (x < -745.1332191019412) return 0.0;
   double kf = __builtin_rint(x * 0x1.71547652b82fep+0);      /* x * log2(e) */
-  double r = EXMC_FMA(kf, -0x1.62e42fefa39efp-1, x);         /* - k*ln2_hi */
-  r = EXMC_FMA(kf, -0x1.abc9e3b39803fp-56, r);               /* - k*ln2_lo */
-  double p = 0x1.6124613a86d09p-33;                          /* 1/13! */
-  p = EXMC_FMA(p, r, 0x1.1eed8eff8d898p-29);                 /* 1/12! */
-  p = EXMC_FMA(p, r, 0x1.ae64567f544e4p-26);                 /* 1/11! */
-  p = EXMC_FMA(p, r, 0x1.27e4fb7789f5cp-22);                 /* 1/10! */
-  p = EXMC_FMA(p, r, 0x1.71de3a556c734p-19);                 /* 1/9!  */
-  p = EXMC_FMA(p, r, 0x1.a01a01a01a01ap-16);                 /* 1/8!  */
-  p = EXMC_FMA(p, r, 0x1.a01a01a01a01ap-13);                 /* 1/7!  */
-  p = EXMC_FMA(p, r, 0x1.6c16c16c16c17p-10);                 /* 1/6!  */
-  p = EXMC_FMA(p, r, 0x1.1111111111111p-7);                  /* 1/5!  */
-  p = EXMC_FMA(p, r, 0x1.5555555555555p-5);                  /* 1/4!  */
-  p = EXMC_FMA(p, r, 0x1.5555555555555p-3);                  /* 1/3!  */
+  double r, p;
+  exmc_exp_core(kf, x, &r, &p);                                /* reduction + 1/13! .. 1/3! */
   p = __builtin_fma(p, r, 0.5);
   p = __builtin_fma(p, r, 1.0);
   p = __builtin_fma(p, r, 1.0);
@@ -117,20 +162,15 @@ EXMC_HD double exmc_log(double x) {
   double s = f / (2.0 + f);
   double z = s * s;
   double w = z * z;
-  double u1 = EXMC_FMA(w, 1.531383769920937332e-01, 2.222219843214978396e-01);
-  u1 = EXMC_FMA(w, u1, 3.999999999940941908e-01);
+  double u1, u2;
+  exmc_log_core(w, &u1, &u2);
   double t1 = w * u1;
-  double u2 = EXMC_FMA(w, 1.479819860511658591e-01, 1.818357216161805012e-01);
-  u2 = EXMC_FMA(w, u2, 2.857142874366239149e-01);
-  u2 = EXMC_FMA(w, u2, 6.666666666666735130e-01);
   double t2 = z * u2;
   double R = t2 + t1;
   double dk = (double)e;
-  double acc = EXMC_FMA(dk, 1.90821492927058770002e-10, s * (hfsq + R));   /* + k*ln2_lo */
+  double acc = __builtin_fma(dk, 1.90821492927058770002e-10, s * (hfsq + R));   /* + k*ln2_lo */
   acc = (acc - hfsq) + f;
-  /* + k*ln2_hi. Deliberately the plain builtin: the value a function returns may feed a DPP
-   * move next, and the compiler's hazard recogniser does not count an inline-asm VALU write. */
-  return __builtin_fma(dk, 6.93147180369123816490e-01, acc);
+  return __builtin_fma(dk, 6.93147180369123816490e-01, acc);                  /* + k*ln2_hi */
 }
 
 EXMC_HD double exmc_log1p(double x) {
