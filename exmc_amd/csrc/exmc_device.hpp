@@ -24,6 +24,65 @@ namespace exmc {
 
 constexpr uint64_t kMask58 = (1ULL << 58) - 1;
 
+// ---- IEEE f64 division without the range instructions (exmc_detmath.h: exmc_div_core) ----
+// The short sequence is bit-identical to the compiler's full f64 division when both operands
+// have magnitudes in [2^-380, 2^380): neither operand nor quotient is then zero, denormal or
+// huge, and the exponent difference stays below v_div_scale's 768 threshold. A model evaluates
+// its quotients through a Div<kFast> policy: with kFast the quotients are exmc_div_core and the
+// policy records whether every operand the model declared with `watch` was in range; the caller
+// re-evaluates with Div<false> (the ordinary `/`) when any lane of the wavefront saw an operand
+// outside it (zeros, infinities, NaN, extreme magnitudes: the first leapfrog from an all-zero
+// init, a diverging trajectory). Operands that are not watched carry a range argument at the
+// call site. A Recip keeps the refined reciprocal of a reused divisor, so a quotient by a model
+// constant costs 3 VALU operations instead of ~25 issue slots.
+__device__ __forceinline__ bool div_in_range(double x) {
+  const uint32_t h = (uint32_t)__double2hiint(x) & 0x7fffffffu;
+  return (h - 0x28300000u) < (0x57C00000u - 0x28300000u);   // biased exponent in [643, 1404)
+}
+
+struct Recip {
+  double b, r;
+};
+
+__device__ __forceinline__ Recip make_recip(double b) { return Recip{b, exmc_rcp_refined(b)}; }
+
+// Recip of a literal: the value is hidden from the optimiser so that the reciprocal comes from
+// v_rcp_f64 and the Newton steps at run time, like every other divisor (LLVM would otherwise fold
+// rcp(constant) to a correctly rounded 1/b, a different starting point than the hardware's).
+__device__ __forceinline__ Recip make_recip_literal(double b) {
+  __asm__ volatile("" : "+v"(b));
+  return make_recip(b);
+}
+
+template <bool kFast>
+struct Div {
+  bool ok = true;
+  __device__ __forceinline__ void watch(double x) {
+    if (kFast) ok = ok && div_in_range(x);
+  }
+  __device__ __forceinline__ void watch_if(bool relevant, double x) {
+    if (kFast) ok = ok && (!relevant || div_in_range(x));
+  }
+  __device__ __forceinline__ double operator()(double a, const Recip& c) const {
+    return kFast ? exmc_div_core(a, c.b, c.r) : (a / c.b);
+  }
+  __device__ __forceinline__ double operator()(double a, double b) const {
+    return kFast ? exmc_div_core(a, b, exmc_rcp_refined(b)) : (a / b);
+  }
+};
+
+// evaluate f(Div<true>&); if any lane of the wavefront left the fast range, evaluate f(Div<false>&)
+template <class F>
+__device__ __forceinline__ double with_fast_div(F&& f) {
+  Div<true> fast;
+  double r = f(fast);
+  if (__builtin_expect(__any(fast.ok ? 0 : 1) != 0, 0)) {
+    Div<false> exact;
+    r = f(exact);
+  }
+  return r;
+}
+
 // DPP controls (gfx9 encoding)
 constexpr int kDppXor1 = 0xB1;        // quad_perm [1,0,3,2]
 constexpr int kDppXor2 = 0x4E;        // quad_perm [2,3,0,1]

@@ -43,7 +43,9 @@ struct EightSchools : ModelDefaults {
   static constexpr int DPL = (D + G - 1) / G;
   using Consts = EightSchoolsConsts;
   struct Lane {
-    double y[DPL], sg[DPL], lsg[DPL];
+    double y[DPL], lsg[DPL];
+    Recip sg[DPL];   // sigma_j as a reusable divisor
+    Recip five;      // the prior scales Normal(0, 5), HalfCauchy(5)
   };
 
   __device__ static __forceinline__ void load(const Consts& c, int l, Lane& ln) {
@@ -52,17 +54,29 @@ struct EightSchools : ModelDefaults {
       const int i = l + k * G;
       const int j = (i >= 2 && i < D) ? (i - 2) : 0;
       ln.y[k] = c.y[j];
-      ln.sg[k] = c.sg[j];
+      ln.sg[k] = make_recip(c.sg[j]);
       ln.lsg[k] = c.lsg[j];
     }
+    ln.five = make_recip_literal(5.0);
   }
 
   __device__ static __forceinline__ double logp_grad(const Consts& c, const Lane& ln, int l,
                                                      const double (&q)[DPL], double (&g)[DPL]) {
+    return with_fast_div([&](auto& dv) -> double { return eval(c, ln, l, q, g, dv); });
+  }
+
+  // Quotients: (y - theta) / sigma_j and mu / 5 have watched numerators (sigma_j is watched at
+  // load); their quotients by the same moderate constants stay in range; tau = exp(clamp200(.))
+  // lies in [e^-200, e^200], so tau / 5, 2 zt / 5 and the final quotient by 1 + zt^2 in
+  // [1, e^400] have operands within 2^+-580 of each other and quotients >= e^-200: in range.
+  template <class DV>
+  __device__ static __forceinline__ double eval(const Consts& c, const Lane& ln, int l,
+                                                const double (&q)[DPL], double (&g)[DPL], DV& dv) {
     const double mu = group_bcast_c<G, 0 % G>(q[0 / G]);
     const double zraw = group_bcast_c<G, 1 % G>(q[1 / G]);
     const double zc = clamp200(zraw);
     const double tau = exmc_exp(zc);
+    dv.watch(mu);
     double L[DPL], A[DPL], B[DPL], T[DPL];
     bool valid[DPL];
 #pragma unroll
@@ -72,8 +86,11 @@ struct EightSchools : ModelDefaults {
       const bool isth = (i >= 2) && (i < D);
       const double th = q[k];
       const double theta = mu + tau * th;
-      const double z = (ln.y[k] - theta) / ln.sg[k];
-      const double a = z / ln.sg[k];
+      const double resid = ln.y[k] - theta;
+      dv.watch_if(isth, resid);
+      dv.watch_if(isth, ln.sg[k].b);
+      const double z = dv(resid, ln.sg[k]);
+      const double a = dv(z, ln.sg[k]);
       L[k] = isth ? ((-0.5 * (z * z)) - ln.lsg[k]) : 0.0;
       A[k] = isth ? a : 0.0;
       B[k] = isth ? (a * th) : 0.0;
@@ -90,13 +107,13 @@ struct EightSchools : ModelDefaults {
     }
     group_allsum_n<G, 3>(s3);
     const double lik = s3[0], sa = s3[1], sb = s3[2];
-    const double zmu = (mu - 0.0) / 5.0;
+    const double zmu = dv(mu - 0.0, ln.five);
     const double t_mu = -0.5 * (zmu * zmu + c.c_mu);
-    const double zt = tau / 5.0;
+    const double zt = dv(tau, ln.five);
     const double zt2 = zt * zt;
     const double t_tau = (c.c_hc - exmc_log(1.0 + zt2)) + zc;
-    const double g_mu = (-(zmu / 5.0)) + sa;
-    const double dhc = -(((2.0 * zt) / 5.0) / (1.0 + zt2));
+    const double g_mu = (-dv(zmu, ln.five)) + sa;
+    const double dhc = -dv(dv(2.0 * zt, ln.five), 1.0 + zt2);
     const bool in = (zraw > -200.0) && (zraw < 200.0);
     const double g_tau = in ? ((dhc + sb) * tau + 1.0) : 0.0;
 #pragma unroll

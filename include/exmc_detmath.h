@@ -41,6 +41,30 @@ EXMC_HD uint64_t exmc_to_bits(double d) {
   return u;
 }
 
+#if defined(__HIPCC__)
+/* a / b, correctly rounded, for operands that need no range scaling (device only). The compiler
+ * expands an f64 division into v_div_scale x2, v_rcp_f64, two Newton steps, quotient, residual,
+ * v_div_fmas, v_div_fixup; scale / fmas / fixup only act when an operand or the quotient is zero,
+ * denormal, huge, infinite or NaN, and they issue at quarter rate (a division costs ~25 issue
+ * slots of a lone wave). These two functions are that sequence without the three range
+ * instructions, so for in-range operands the bits are the hardware division's, i.e. IEEE
+ * (tests/test_gpu_fastdiv.py checks them against `/` on the device). Callers own the range
+ * argument. */
+static __device__ __forceinline__ double exmc_rcp_refined(double b) {
+  double r = __builtin_amdgcn_rcp(b);
+  double e = __builtin_fma(-b, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-b, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  return r;
+}
+static __device__ __forceinline__ double exmc_div_core(double a, double b, double r) {
+  const double q = a * r;
+  const double e = __builtin_fma(-b, q, a);
+  return __builtin_fma(e, r, q);
+}
+#endif
+
 /* The two polynomial kernels of exp and log. In gfx950 device code each is ONE inline-asm block of
  * three-address v_fma_f64 with every operand in a vector register. Left to the compiler a Horner
  * step acc*r + C becomes v_mov_b64 tmp, C; v_fmac_f64 tmp, acc, r (two issue slots, and the hoisted
@@ -73,6 +97,8 @@ static __device__ __forceinline__ void exmc_exp_core(double kf, double x, double
   *r_out = r;
   *p_out = p;
 }
+/* log's s = f / (2 + f): f is 0 or 2^-53 <= |f| < 0.42, the denominator lies in [1.7, 2.42] */
+#define EXMC_DIV_LOG(f, d) exmc_div_core((f), (d), exmc_rcp_refined(d))
 static __device__ __forceinline__ void exmc_log_core(double w, double* u1_out, double* u2_out) {
   double u1, u2;
   __asm__("v_fma_f64 %0, %2, %3, %4\n\t"
@@ -89,6 +115,7 @@ static __device__ __forceinline__ void exmc_log_core(double w, double* u1_out, d
   *u2_out = u2;
 }
 #else
+#define EXMC_DIV_LOG(f, d) ((f) / (d))
 static inline void exmc_exp_core(double kf, double x, double* r_out, double* p_out) {
   double r = __builtin_fma(kf, -0x1.62e42fefa39efp-1, x);      /* - k*ln2_hi */
   r = __builtin_fma(kf, -0x1.abc9e3b39803fp-56, r);            /* - k*ln2_lo */
@@ -159,7 +186,8 @@ EXMC_HD double exmc_log(double x) {
   ix = (t & 0x000FFFFFFFFFFFFFULL) + 0x3FE6A09E667F3BCDULL;
   double f = exmc_from_bits(ix) - 1.0;
   double hfsq = 0.5 * f * f;
-  double s = f / (2.0 + f);
+  double dn = 2.0 + f;
+  double s = EXMC_DIV_LOG(f, dn);
   double z = s * s;
   double w = z * z;
   double u1, u2;
