@@ -63,6 +63,17 @@ struct Div {
   __device__ __forceinline__ void watch_if(bool relevant, double x) {
     if (kFast) ok = ok && (!relevant || div_in_range(x));
   }
+  // |x| in [2^ELO, 2^EHI): a tighter declaration, for operands whose products or quotients are
+  // used as operands again and must themselves stay inside the 2^+-380 window
+  template <int ELO, int EHI>
+  __device__ __forceinline__ void watch_exp_if(bool relevant, double x) {
+    static_assert(ELO >= -380 && EHI <= 380 && ELO < EHI, "inside the division window");
+    if (kFast) {
+      const uint32_t h = (uint32_t)__double2hiint(x) & 0x7fffffffu;
+      const bool in = (h - ((uint32_t)(1023 + ELO) << 20)) < ((uint32_t)(EHI - ELO) << 20);
+      ok = ok && (!relevant || in);
+    }
+  }
   __device__ __forceinline__ double operator()(double a, const Recip& c) const {
     return kFast ? exmc_div_core(a, c.b, c.r) : (a / c.b);
   }
@@ -284,13 +295,27 @@ __device__ __forceinline__ bool normal_fast(uint64_t w, const ZigTables& zt, dou
   return R < zt.ki[idx];
 }
 
-// tree.ex:1597-1605. exp(0) = 1 exactly under exmc_exp, so the larger term is not evaluated.
-__device__ __forceinline__ double log_sum_exp(double a, double b) {
-  const double mx = (a > b) ? a : b;
-  if (mx == -exmc_from_bits(EXMC_INF_BITS) || mx == -1.0e300) return -1.0e300;
-  const double mn = (a > b) ? b : a;
-  return mx + exmc_log(1.0 + exmc_exp(mn - mx));
-}
+// Which spelling of exp / log a kernel uses (exmc_detmath.h): kVreg = the asm-block cores with
+// coefficients pinned in ~40 vector registers. Same bits either way; models whose chain state
+// already fills the 256 architectural VGPRs (DPL >= 2 at G = 64) keep the compiler's spelling.
+template <bool kVreg>
+struct Math {
+  __device__ static __forceinline__ double exp(double x) {
+    if constexpr (kVreg) return exmc_exp_v(x);
+    else return exmc_exp(x);
+  }
+  __device__ static __forceinline__ double log(double x) {
+    if constexpr (kVreg) return exmc_log_v(x);
+    else return exmc_log(x);
+  }
+  // tree.ex:1597-1605. exp(0) = 1 exactly under exmc_exp, so the larger term is not evaluated.
+  __device__ static __forceinline__ double log_sum_exp(double a, double b) {
+    const double mx = (a > b) ? a : b;
+    if (mx == -exmc_from_bits(EXMC_INF_BITS) || mx == -1.0e300) return -1.0e300;
+    const double mn = (a > b) ? b : a;
+    return mx + log(1.0 + exp(mn - mx));
+  }
+};
 
 // lane-partial sum over this lane's valid slots, lane 0 seeded with init0, then butterfly
 template <int G, int DPL>

@@ -21,6 +21,7 @@ __device__ __forceinline__ double clamp200(double z) { return fmax(-200.0, fmin(
 // kStageDoubles: model data a single-workgroup kernel (the adaptation warmup) may copy into LDS
 // (Lane::xs); with one wavefront on the whole chip every global load is an exposed round trip.
 struct ModelDefaults {
+  static constexpr bool kVregMath = false;   // exp / log cores with VGPR-pinned coefficients
   static constexpr bool kCoop = false;
   static constexpr int kExtraLdsDoubles = 0;
   static constexpr int kStageDoubles = 0;
@@ -41,6 +42,8 @@ template <int G>
 struct EightSchools : ModelDefaults {
   static constexpr int D = 10;
   static constexpr int DPL = (D + G - 1) / G;
+  static constexpr bool kVregMath = (DPL <= 2);
+  using MM = Math<kVregMath>;
   using Consts = EightSchoolsConsts;
   struct Lane {
     double y[DPL], lsg[DPL];
@@ -75,7 +78,7 @@ struct EightSchools : ModelDefaults {
     const double mu = group_bcast_c<G, 0 % G>(q[0 / G]);
     const double zraw = group_bcast_c<G, 1 % G>(q[1 / G]);
     const double zc = clamp200(zraw);
-    const double tau = exmc_exp(zc);
+    const double tau = MM::exp(zc);
     dv.watch(mu);
     double L[DPL], A[DPL], B[DPL], T[DPL];
     bool valid[DPL];
@@ -111,7 +114,7 @@ struct EightSchools : ModelDefaults {
     const double t_mu = -0.5 * (zmu * zmu + c.c_mu);
     const double zt = dv(tau, ln.five);
     const double zt2 = zt * zt;
-    const double t_tau = (c.c_hc - exmc_log(1.0 + zt2)) + zc;
+    const double t_tau = (c.c_hc - MM::log(1.0 + zt2)) + zc;
     const double g_mu = (-dv(zmu, ln.five)) + sa;
     const double dhc = -dv(dv(2.0 * zt, ln.five), 1.0 + zt2);
     const bool in = (zraw > -200.0) && (zraw < 200.0);
@@ -182,20 +185,28 @@ struct SVConsts {
   double lam_s, lam_n, log_lam_s32, log_lam_n32;
 };
 
-__device__ __forceinline__ double lanczos_val_d(const SVConsts& c, double x, double& dx) {
+// Quotients (caller watches x in [2^-101, 2^100)): den = x + j >= x, the f32 Lanczos
+// coefficients lie in [2^-20, 2^11), so term in 2^(-121..112) and term / den in 2^(-221..213);
+// x - 0.5, ag and dag are watched here; t = x + 6.5 in [6.5, 2^101).
+template <class MM, class DV>
+__device__ __forceinline__ double lanczos_val_d(const SVConsts& c, double x, double& dx, DV& dv) {
   const double t = x + 6.5;
   double ag = c.lanczos[0];
   double dag = 0.0;
 #pragma unroll
   for (int i = 1; i < 9; i++) {
-    const double den = x + (double)(i - 1) * 1.0;
-    const double term = c.lanczos[i] / den;
+    const Recip den = make_recip(x + (double)(i - 1) * 1.0);
+    const double term = dv(c.lanczos[i], den);
     ag = ag + term;
-    dag = dag - term / den;
+    dag = dag - dv(term, den);
   }
-  const double lt = exmc_log(t);
-  dx = ((lt + (x - 0.5) / t) - 1.0) + dag / ag;
-  return ((c.half_log_2pi32 + (x - 0.5) * lt) - t) + exmc_log(ag);
+  const double lt = MM::log(t);
+  const double xm = x - 0.5;
+  dv.watch(xm);
+  dv.watch(ag);
+  dv.watch(dag);
+  dx = ((lt + dv(xm, t)) - 1.0) + dv(dag, ag);
+  return ((c.half_log_2pi32 + xm * lt) - t) + MM::log(ag);
 }
 
 template <int G>
@@ -215,23 +226,40 @@ struct SV : ModelDefaults {
       ln.r[k] = c.r[i < T ? i : 0];
     }
   }
+  static constexpr bool kVregMath = true;
+  using MM = Math<kVregMath>;
+
   __device__ static __forceinline__ double logp_grad(const Consts& c, const Lane& ln, int l,
                                                      const double (&q)[DPL], double (&g)[DPL]) {
+    return with_fast_div([&](auto& dv) -> double { return eval(c, ln, l, q, g, dv); });
+  }
+
+  // Quotients: sigma and nu are watched in [2^-100, 2^100), which puts the Lanczos arguments
+  // nu/2, (nu+1)/2 in [2^-101, 2^100); per slot the AR(1) residual and z^2 are watched in
+  // 2^+-250, so e = resid / sigma, w = z^2 / nu stay within 2^+-350, 1 + w in [1, 2^351),
+  // wr = w / (1 + w) in (2^-351, 1], hp1 * wr in (2^-352, 2^100): every operand of every
+  // quotient is inside the 2^+-380 window.
+  template <class DV>
+  __device__ static __forceinline__ double eval(const Consts& c, const Lane& ln, int l,
+                                                const double (&q)[DPL], double (&g)[DPL], DV& dv) {
     const double zs_raw = group_bcast_c<G, T % G>(q[T / G]);
     const double zn_raw = group_bcast_c<G, (T + 1) % G>(q[(T + 1) / G]);
     const double zs = clamp200(zs_raw), zn = clamp200(zn_raw);
-    const double sigma = exmc_exp(zs), nu = exmc_exp(zn);
+    const double sigma = MM::exp(zs), nu = MM::exp(zn);
     const double ss = fmax(sigma, c.tiny32);
     const double sdf = fmax(nu, c.tiny32);
+    dv.template watch_exp_if<-100, 100>(true, ss);
+    dv.template watch_exp_if<-100, 100>(true, sdf);
+    const Recip rss = make_recip(ss), rsdf = make_recip(sdf);
     const double t_sigma = (c.log_lam_s32 - c.lam_s * sigma) + zs;
     const double t_nu = (c.log_lam_n32 - c.lam_n * nu) + zn;
     const double hp1 = (sdf + 1.0) / 2.0, h = sdf / 2.0;
     double d1, d0;
-    const double lg1 = lanczos_val_d(c, hp1, d1);
-    const double lg0 = lanczos_val_d(c, h, d0);
-    const double An = (lg1 - lg0) - 0.5 * exmc_log(sdf * c.pi32);
-    const double dAn = (0.5 * d1 - 0.5 * d0) - 0.5 / sdf;
-    const double cn = c.log2pi32 + 2.0 * exmc_log(ss);
+    const double lg1 = lanczos_val_d<MM>(c, hp1, d1, dv);
+    const double lg0 = lanczos_val_d<MM>(c, h, d0, dv);
+    const double An = (lg1 - lg0) - 0.5 * MM::log(sdf * c.pi32);
+    const double dAn = (0.5 * d1 - 0.5 * d0) - dv(0.5, rsdf);
+    const double cn = c.log2pi32 + 2.0 * MM::log(ss);
     const int lane = threadIdx.x & 63;
     const int base = lane & ~(G - 1);
     const int prev_lane = base | ((l + G - 1) & (G - 1));
@@ -253,16 +281,20 @@ struct SV : ModelDefaults {
       const bool ist = i < T;
       const double qi = q[k];
       const double prev = (i == 0) ? 0.0 : qprev[k];
-      const double e = (qi - prev) / ss;
-      const double z = ln.r[k] * exmc_exp(-qi);
-      const double w = (z * z) / sdf;
-      const double lg = exmc_log(1.0 + w);
-      const double wr = w / (1.0 + w);
+      const double resid = qi - prev;
+      dv.template watch_exp_if<-250, 250>(ist, resid);
+      const double e = dv(resid, rss);
+      const double z = ln.r[k] * MM::exp(-qi);
+      const double zz = z * z;
+      dv.template watch_exp_if<-250, 250>(ist, zz);
+      const double w = dv(zz, rsdf);
+      const double lg = MM::log(1.0 + w);
+      const double wr = dv(w, 1.0 + w);
       P[k] = ist ? (-0.5 * (e * e + cn)) : 0.0;
       E2[k] = ist ? (e * e - 1.0) : 0.0;
-      de[k] = ist ? (-(e / ss)) : 0.0;
+      de[k] = ist ? (-dv(e, rss)) : 0.0;
       LL[k] = ist ? ((An - qi) - hp1 * lg) : 0.0;
-      DN[k] = ist ? ((dAn - 0.5 * lg) + (hp1 * wr) / sdf) : 0.0;
+      DN[k] = ist ? ((dAn - 0.5 * lg) + dv(hp1 * wr, rsdf)) : 0.0;
       g[k] = -1.0 + (sdf + 1.0) * wr;
     }
     // dP_{t+1}/ds_{t+1} from dim i+1: (lane l+1, slot k) or (lane 0, slot k+1) when l == G-1

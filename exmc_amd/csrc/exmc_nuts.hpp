@@ -225,6 +225,7 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
                                          int max_depth, Sink&& sink) {
   constexpr int DPL = M::DPL;
   constexpr int NSLOT = 5 * DPL + 3;
+  using MM = Math<M::kVregMath>;
   const int l = L.l;
   const auto& im = L.im;
   const auto& valid = L.valid;
@@ -328,7 +329,7 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
 #if EXMC_ABLATE == 4
             c_acc = fmin(1.0, 1.0 + fmin(dl, 0.0));
 #else
-            c_acc = fmin(1.0, exmc_exp(fmin(dl, 0.0)));
+            c_acc = fmin(1.0, MM::exp(fmin(dl, 0.0)));
 #endif
           } else {
             c_div = true;
@@ -363,9 +364,9 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
                 const double u = rng_uniform(trng);
                 const bool use_b = u < 0.5;
 #else
-                const double lsw = log_sum_exp(a_lsw, c_lsw);
+                const double lsw = MM::log_sum_exp(a_lsw, c_lsw);
                 const double u = rng_uniform(trng);
-                const bool use_b = u < exmc_exp(c_lsw - lsw);
+                const bool use_b = u < MM::exp(c_lsw - lsw);
 #endif
                 if (!use_b) {
                   c_logpP = a_logpP;
@@ -433,9 +434,9 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
             const double u = rng_uniform(trng);
             const bool use_sub = u < 0.5;
 #else
-            const double lsw = log_sum_exp(t_lsw, c_lsw);
+            const double lsw = MM::log_sum_exp(t_lsw, c_lsw);
             const double u = rng_uniform(trng);
-            const bool use_sub = exmc_log(u) < (c_lsw - t_lsw);
+            const bool use_sub = MM::log(u) < (c_lsw - t_lsw);
 #endif
             if (use_sub) {
               t_logpP = c_logpP;

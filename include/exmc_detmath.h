@@ -18,6 +18,12 @@
  * coefficient chains and the k*ln2 terms evaluated with fma (one rounding less per step
  * than the libm form, and one issue slot less on the GPU);
  * log1p = log(1+x) with the (x-(u-1))/u correction term.
+ *
+ * Device code has two spellings of the same arithmetic: exmc_exp / exmc_log leave instruction
+ * selection to the compiler; exmc_exp_v / exmc_log_v run the polynomial chains as one inline-asm
+ * block of three-address v_fma_f64 with the coefficients pinned in vector registers (fewer issue
+ * slots and no scalar-register pressure, at the price of ~40 VGPRs: for kernels with registers
+ * to spare). The bits are identical by construction (same IEEE operations in the same order).
  */
 #ifndef EXMC_DETMATH_H
 #define EXMC_DETMATH_H
@@ -41,15 +47,22 @@ EXMC_HD uint64_t exmc_to_bits(double d) {
   return u;
 }
 
+#define EXMC_INF_BITS 0x7FF0000000000000ULL
+#define EXMC_NAN_BITS 0x7FF8000000000000ULL
+
+EXMC_HD int exmc_isfinite(double x) {
+  return (exmc_to_bits(x) & EXMC_INF_BITS) != EXMC_INF_BITS;
+}
+
 #if defined(__HIPCC__)
 /* a / b, correctly rounded, for operands that need no range scaling (device only). The compiler
- * expands an f64 division into v_div_scale x2, v_rcp_f64, two Newton steps, quotient, residual,
- * v_div_fmas, v_div_fixup; scale / fmas / fixup only act when an operand or the quotient is zero,
- * denormal, huge, infinite or NaN, and they issue at quarter rate (a division costs ~25 issue
- * slots of a lone wave). These two functions are that sequence without the three range
- * instructions, so for in-range operands the bits are the hardware division's, i.e. IEEE
- * (tests/test_gpu_fastdiv.py checks them against `/` on the device). Callers own the range
- * argument. */
+ * expands an f64 division into v_div_scale x2, v_rcp_f64 (a 16-cycle instruction), two Newton
+ * steps, quotient, residual, v_div_fmas, v_div_fixup; scale / fmas / fixup only act when an
+ * operand or the quotient is zero, denormal, huge, infinite or NaN. These two functions are that
+ * sequence without the three range instructions, and exmc_div_core alone (3 operations) when the
+ * refined reciprocal of a reused divisor is kept. For in-range operands the bits are the
+ * hardware division's, i.e. IEEE (tests/test_gpu_fastdiv.py checks them against `/` on the
+ * device). Callers own the range argument. */
 static __device__ __forceinline__ double exmc_rcp_refined(double b) {
   double r = __builtin_amdgcn_rcp(b);
   double e = __builtin_fma(-b, r, 1.0);
@@ -65,16 +78,48 @@ static __device__ __forceinline__ double exmc_div_core(double a, double b, doubl
 }
 #endif
 
-/* The two polynomial kernels of exp and log. In gfx950 device code each is ONE inline-asm block of
- * three-address v_fma_f64 with every operand in a vector register. Left to the compiler a Horner
- * step acc*r + C becomes v_mov_b64 tmp, C; v_fmac_f64 tmp, acc, r (two issue slots, and the hoisted
- * coefficients fill the scarce scalar registers until loop state spills to v_writelane/v_readlane);
- * single-instruction asm statements are padded with an s_nop each (the hazard recogniser treats an
- * asm result as a possible transcendental). The host restatement is the same fma sequence, so the
- * bits are identical. The result of a block is only consumed by ordinary arithmetic in this file
- * (a function never returns an asm output: a DPP or lane-read consumer must see a plain VALU op). */
+/* log's s = f / (2 + f): f is 0 or 2^-53 <= |f| < 0.42, the denominator lies in [1.7, 2.42] */
 #if defined(__HIP_DEVICE_COMPILE__)
-static __device__ __forceinline__ void exmc_exp_core(double kf, double x, double* r_out, double* p_out) {
+#define EXMC_DIV_LOG(f, d) exmc_div_core((f), (d), exmc_rcp_refined(d))
+#else
+#define EXMC_DIV_LOG(f, d) ((f) / (d))
+#endif
+
+/* ---- polynomial cores, portable spelling ---- */
+EXMC_HD void exmc_exp_core(double kf, double x, double* r_out, double* p_out) {
+  double r = __builtin_fma(kf, -0x1.62e42fefa39efp-1, x);      /* - k*ln2_hi */
+  r = __builtin_fma(kf, -0x1.abc9e3b39803fp-56, r);            /* - k*ln2_lo */
+  double p = __builtin_fma(0x1.6124613a86d09p-33, r, 0x1.1eed8eff8d898p-29); /* 1/13!, 1/12! */
+  p = __builtin_fma(p, r, 0x1.ae64567f544e4p-26);              /* 1/11! */
+  p = __builtin_fma(p, r, 0x1.27e4fb7789f5cp-22);              /* 1/10! */
+  p = __builtin_fma(p, r, 0x1.71de3a556c734p-19);              /* 1/9!  */
+  p = __builtin_fma(p, r, 0x1.a01a01a01a01ap-16);              /* 1/8!  */
+  p = __builtin_fma(p, r, 0x1.a01a01a01a01ap-13);              /* 1/7!  */
+  p = __builtin_fma(p, r, 0x1.6c16c16c16c17p-10);              /* 1/6!  */
+  p = __builtin_fma(p, r, 0x1.1111111111111p-7);               /* 1/5!  */
+  p = __builtin_fma(p, r, 0x1.5555555555555p-5);               /* 1/4!  */
+  p = __builtin_fma(p, r, 0x1.5555555555555p-3);               /* 1/3!  */
+  *r_out = r;
+  *p_out = p;
+}
+EXMC_HD void exmc_log_core(double w, double* u1_out, double* u2_out) {
+  double u1 = __builtin_fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01);
+  double u2 = __builtin_fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01);
+  u1 = __builtin_fma(w, u1, 3.999999999940941908e-01);
+  u2 = __builtin_fma(w, u2, 2.857142874366239149e-01);
+  u2 = __builtin_fma(w, u2, 6.666666666666735130e-01);
+  *u1_out = u1;
+  *u2_out = u2;
+}
+
+/* ---- polynomial cores, gfx950 spelling: the same fma sequence as ONE asm block each. Left to the
+ * compiler a Horner step acc*r + C becomes v_mov_b64 tmp, C; v_fmac_f64 tmp, acc, r (two issue
+ * slots) and the hoisted coefficients fill the scalar registers until loop state spills to
+ * v_writelane/v_readlane; one-instruction asm statements are each padded with an s_nop. The result
+ * of a block is only consumed by ordinary arithmetic in this file: a function never returns an asm
+ * output, so a DPP or lane-read consumer always sees a plain VALU producer. ---- */
+#if defined(__HIP_DEVICE_COMPILE__)
+static __device__ __forceinline__ void exmc_exp_core_v(double kf, double x, double* r_out, double* p_out) {
   double p, r;
   __asm__("v_fma_f64 %1, %2, %4, %3\n\t"
           "v_fma_f64 %1, %2, %5, %1\n\t"
@@ -97,9 +142,7 @@ static __device__ __forceinline__ void exmc_exp_core(double kf, double x, double
   *r_out = r;
   *p_out = p;
 }
-/* log's s = f / (2 + f): f is 0 or 2^-53 <= |f| < 0.42, the denominator lies in [1.7, 2.42] */
-#define EXMC_DIV_LOG(f, d) exmc_div_core((f), (d), exmc_rcp_refined(d))
-static __device__ __forceinline__ void exmc_log_core(double w, double* u1_out, double* u2_out) {
+static __device__ __forceinline__ void exmc_log_core_v(double w, double* u1_out, double* u2_out) {
   double u1, u2;
   __asm__("v_fma_f64 %0, %2, %3, %4\n\t"
           "v_fma_f64 %1, %2, %6, %7\n\t"
@@ -114,97 +157,79 @@ static __device__ __forceinline__ void exmc_log_core(double w, double* u1_out, d
   *u1_out = u1;
   *u2_out = u2;
 }
-#else
-#define EXMC_DIV_LOG(f, d) ((f) / (d))
-static inline void exmc_exp_core(double kf, double x, double* r_out, double* p_out) {
-  double r = __builtin_fma(kf, -0x1.62e42fefa39efp-1, x);      /* - k*ln2_hi */
-  r = __builtin_fma(kf, -0x1.abc9e3b39803fp-56, r);            /* - k*ln2_lo */
-  double p = __builtin_fma(0x1.6124613a86d09p-33, r, 0x1.1eed8eff8d898p-29); /* 1/13!, 1/12! */
-  p = __builtin_fma(p, r, 0x1.ae64567f544e4p-26);              /* 1/11! */
-  p = __builtin_fma(p, r, 0x1.27e4fb7789f5cp-22);              /* 1/10! */
-  p = __builtin_fma(p, r, 0x1.71de3a556c734p-19);              /* 1/9!  */
-  p = __builtin_fma(p, r, 0x1.a01a01a01a01ap-16);              /* 1/8!  */
-  p = __builtin_fma(p, r, 0x1.a01a01a01a01ap-13);              /* 1/7!  */
-  p = __builtin_fma(p, r, 0x1.6c16c16c16c17p-10);              /* 1/6!  */
-  p = __builtin_fma(p, r, 0x1.1111111111111p-7);               /* 1/5!  */
-  p = __builtin_fma(p, r, 0x1.5555555555555p-5);               /* 1/4!  */
-  p = __builtin_fma(p, r, 0x1.5555555555555p-3);               /* 1/3!  */
-  *r_out = r;
-  *p_out = p;
+#elif defined(__HIPCC__)
+/* host pass of hipcc: the names must exist; the bodies are the portable ones */
+static __device__ __forceinline__ void exmc_exp_core_v(double kf, double x, double* r_out, double* p_out) {
+  exmc_exp_core(kf, x, r_out, p_out);
 }
-static inline void exmc_log_core(double w, double* u1_out, double* u2_out) {
-  double u1 = __builtin_fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01);
-  double u2 = __builtin_fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01);
-  u1 = __builtin_fma(w, u1, 3.999999999940941908e-01);
-  u2 = __builtin_fma(w, u2, 2.857142874366239149e-01);
-  u2 = __builtin_fma(w, u2, 6.666666666666735130e-01);
-  *u1_out = u1;
-  *u2_out = u2;
+static __device__ __forceinline__ void exmc_log_core_v(double w, double* u1_out, double* u2_out) {
+  exmc_log_core(w, u1_out, u2_out);
 }
 #endif
 
-#define EXMC_INF_BITS 0x7FF0000000000000ULL
-#define EXMC_NAN_BITS 0x7FF8000000000000ULL
-
-EXMC_HD int exmc_isfinite(double x) {
-  return (exmc_to_bits(x) & EXMC_INF_BITS) != EXMC_INF_BITS;
-}
-
-EXMC_HD double exmc_exp(double x) {
-  if (!(x == x)) return x;                       /* NaN */
-  if (x > 709.782712893384) return exmc_from_bits(EXMC_INF_BITS);
-  if (x < -745.1332191019412) return 0.0;
-  double kf = __builtin_rint(x * 0x1.71547652b82fep+0);      /* x * log2(e) */
-  double r, p;
-  exmc_exp_core(kf, x, &r, &p);                                /* reduction + 1/13! .. 1/3! */
-  p = __builtin_fma(p, r, 0.5);
-  p = __builtin_fma(p, r, 1.0);
-  p = __builtin_fma(p, r, 1.0);
-  int k = (int)kf;
-  int k1 = k >> 1;
-  int k2 = k - k1;
-  p *= exmc_from_bits((uint64_t)(k1 + 1023) << 52);
-  p *= exmc_from_bits((uint64_t)(k2 + 1023) << 52);
+/* ---- exp ---- */
+#define EXMC_EXP_BODY(CORE)                                                                  \
+  if (!(x == x)) return x;                       /* NaN */                                   \
+  if (x > 709.782712893384) return exmc_from_bits(EXMC_INF_BITS);                           \
+  if (x < -745.1332191019412) return 0.0;                                                   \
+  double kf = __builtin_rint(x * 0x1.71547652b82fep+0);      /* x * log2(e) */              \
+  double r, p;                                                                               \
+  CORE(kf, x, &r, &p);                                       /* reduction + 1/13! .. 1/3! */ \
+  p = __builtin_fma(p, r, 0.5);                                                              \
+  p = __builtin_fma(p, r, 1.0);                                                              \
+  p = __builtin_fma(p, r, 1.0);                                                              \
+  int k = (int)kf;                                                                           \
+  int k1 = k >> 1;                                                                           \
+  int k2 = k - k1;                                                                           \
+  p *= exmc_from_bits((uint64_t)(k1 + 1023) << 52);                                          \
+  p *= exmc_from_bits((uint64_t)(k2 + 1023) << 52);                                          \
   return p;
-}
 
-EXMC_HD double exmc_log(double x) {
-  uint64_t ix = exmc_to_bits(x);
-  int e = 0;
-  if (ix < 0x0010000000000000ULL || (ix >> 63)) {
-    if ((ix << 1) == 0) return -exmc_from_bits(EXMC_INF_BITS); /* +-0 */
-    if (ix >> 63) return exmc_from_bits(EXMC_NAN_BITS);        /* negative */
-    x *= 0x1p54;                                               /* subnormal */
-    ix = exmc_to_bits(x);
-    e = -54;
-  } else if (ix >= EXMC_INF_BITS) {
-    return x;                                                  /* +inf, NaN */
-  }
-  /* normalise mantissa into [sqrt(2)/2, sqrt(2)) */
-  uint64_t t = ix + (0x3FF0000000000000ULL - 0x3FE6A09E667F3BCDULL);
-  e += (int)(t >> 52) - 1023;
-  ix = (t & 0x000FFFFFFFFFFFFFULL) + 0x3FE6A09E667F3BCDULL;
-  double f = exmc_from_bits(ix) - 1.0;
-  double hfsq = 0.5 * f * f;
-  double dn = 2.0 + f;
-  double s = EXMC_DIV_LOG(f, dn);
-  double z = s * s;
-  double w = z * z;
-  double u1, u2;
-  exmc_log_core(w, &u1, &u2);
-  double t1 = w * u1;
-  double t2 = z * u2;
-  double R = t2 + t1;
-  double dk = (double)e;
-  double acc = __builtin_fma(dk, 1.90821492927058770002e-10, s * (hfsq + R));   /* + k*ln2_lo */
-  acc = (acc - hfsq) + f;
-  return __builtin_fma(dk, 6.93147180369123816490e-01, acc);                  /* + k*ln2_hi */
-}
+/* ---- log ---- */
+#define EXMC_LOG_BODY(CORE)                                                                  \
+  uint64_t ix = exmc_to_bits(x);                                                             \
+  int e = 0;                                                                                 \
+  if (ix < 0x0010000000000000ULL || (ix >> 63)) {                                            \
+    if ((ix << 1) == 0) return -exmc_from_bits(EXMC_INF_BITS); /* +-0 */                     \
+    if (ix >> 63) return exmc_from_bits(EXMC_NAN_BITS);        /* negative */                \
+    x *= 0x1p54;                                               /* subnormal */               \
+    ix = exmc_to_bits(x);                                                                    \
+    e = -54;                                                                                 \
+  } else if (ix >= EXMC_INF_BITS) {                                                          \
+    return x;                                                  /* +inf, NaN */               \
+  }                                                                                          \
+  /* normalise mantissa into [sqrt(2)/2, sqrt(2)) */                                         \
+  uint64_t t = ix + (0x3FF0000000000000ULL - 0x3FE6A09E667F3BCDULL);                         \
+  e += (int)(t >> 52) - 1023;                                                                \
+  ix = (t & 0x000FFFFFFFFFFFFFULL) + 0x3FE6A09E667F3BCDULL;                                  \
+  double f = exmc_from_bits(ix) - 1.0;                                                       \
+  double hfsq = 0.5 * f * f;                                                                 \
+  double dn = 2.0 + f;                                                                       \
+  double s = EXMC_DIV_LOG(f, dn);                                                            \
+  double z = s * s;                                                                          \
+  double w = z * z;                                                                          \
+  double u1, u2;                                                                             \
+  CORE(w, &u1, &u2);                                                                         \
+  double t1 = w * u1;                                                                        \
+  double t2 = z * u2;                                                                        \
+  double R = t2 + t1;                                                                        \
+  double dk = (double)e;                                                                     \
+  double acc = __builtin_fma(dk, 1.90821492927058770002e-10, s * (hfsq + R)); /* k*ln2_lo */ \
+  acc = (acc - hfsq) + f;                                                                    \
+  return __builtin_fma(dk, 6.93147180369123816490e-01, acc);                  /* k*ln2_hi */
+
+EXMC_HD double exmc_exp(double x) { EXMC_EXP_BODY(exmc_exp_core) }
+EXMC_HD double exmc_log(double x) { EXMC_LOG_BODY(exmc_log_core) }
 
 EXMC_HD double exmc_log1p(double x) {
   double u = 1.0 + x;
   if (u == 1.0) return x;
   return exmc_log(u) + (x - (u - 1.0)) / u;
 }
+
+#if defined(__HIPCC__)
+static __device__ __forceinline__ double exmc_exp_v(double x) { EXMC_EXP_BODY(exmc_exp_core_v) }
+static __device__ __forceinline__ double exmc_log_v(double x) { EXMC_LOG_BODY(exmc_log_core_v) }
+#endif
 
 #endif /* EXMC_DETMATH_H */
