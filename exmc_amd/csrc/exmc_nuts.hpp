@@ -163,48 +163,105 @@ __device__ __forceinline__ ZigTables stage_zig_tables(double* lds, const uint64_
   return ZigTables{(const uint64_t*)lz, lz + 256, lz + 512};
 }
 
-// sampler.ex:393-403: d sequential normal_s draws -> p = z / sqrt(M^-1). Fast path: the group
-// advances the stream d words, each lane scrambles and tests the word of its own dimension; if
-// every word is accepted at once (~86 % of transitions at d = 10) the stream position is exactly
-// d words further. Otherwise the draws are redone one by one, as normal_s consumes a
-// data-dependent number of words.
+// smallest `pos` over the chain groups of the wavefront (pos is uniform inside a group)
+template <int G>
+__device__ __forceinline__ int wave_min_pos(int pos) {
+  if constexpr (G == 64) {
+    return __builtin_amdgcn_readfirstlane(pos);
+  } else if constexpr (G >= 16) {
+    // an exited or masked group's register holds whatever it last wrote; 0 is always a safe bound
+    int m = __builtin_amdgcn_readlane(pos, 0);
+#pragma unroll
+    for (int b = G; b < 64; b += G) m = min(m, __builtin_amdgcn_readlane(pos, b));
+    return max(m, 0);
+  } else {
+    return 0;
+  }
+}
+
+// sampler.ex:393-403: d sequential normal_s draws -> p = z / sqrt(M^-1). normal_s accepts 98.5 %
+// of its 58-bit words at once (one word per variate) and otherwise consumes a data-dependent
+// number of further words, so the draws are sequential in principle. Here: the group advances a
+// copy of the stream over all remaining dimensions, lane l keeping the generator state in front
+// of its own dimensions, and every lane tests its own word at once. Up to the first dimension j
+// whose word is not accepted at once the variates are final; dimension j is then drawn the long
+// way from the state in front of it (taken from the lane that owns it), and the pass repeats from
+// j + 1. Expected passes: 1 + 0.015 d, against d sequential draws.
 template <class M, int G>
 __device__ __forceinline__ void draw_momentum(const NutsLane<M, G>& L, Rng& rng,
                                               double (&p)[M::DPL]) {
   constexpr int D = M::D, DPL = M::DPL;
-  Rng r2 = rng;
-  bool ok = true;
+  const int base = (threadIdx.x & 63) & ~(G - 1);
   double z[DPL];
-  uint64_t s0[DPL];
 #pragma unroll
-  for (int k = 0; k < DPL; k++) { z[k] = 0.0; s0[k] = 0; }
-  // kept rolled: unrolled, the D lane predicates (l == i) are hoisted into scalar register pairs
-  // for the whole kernel and the sampling loop pays for them in v_readlane spills
+  for (int k = 0; k < DPL; k++) z[k] = 0.0;
+  int pos = 0;   // dimensions [0, pos) are final and rng stands in front of dimension pos
+  for (;;) {
+    Rng r2 = rng;
+    uint64_t sa[DPL], sb[DPL];
+#pragma unroll
+    for (int k = 0; k < DPL; k++) { sa[k] = 0; sb[k] = 0; }
+    // kept rolled: unrolled, the D lane predicates (l == i) are hoisted into scalar register
+    // pairs for the whole kernel and the sampling loop pays for them in v_readlane spills
+    const int i0 = wave_min_pos<G>(pos);
 #pragma nounroll
-  for (int i = 0; i < D; i++) {
+    for (int i = i0; i < D; i++) {
+      const bool act = (G == 64) || (i >= pos);
 #pragma unroll
-    for (int k = 0; k < DPL; k++) s0[k] = (L.l + k * G == i) ? r2.b : s0[k];
-    rng_advance(r2);
-  }
+      for (int k = 0; k < DPL; k++) {
+        const bool mine = act && (L.l + k * G == i);
+        sa[k] = mine ? r2.a : sa[k];
+        sb[k] = mine ? r2.b : sb[k];
+      }
+      Rng nx = r2;
+      rng_advance(nx);
+      r2.a = act ? nx.a : r2.a;
+      r2.b = act ? nx.b : r2.b;
+    }
+    bool fail[DPL];
 #pragma unroll
-  for (int k = 0; k < DPL; k++) {
-    double zz;
-    const bool acc = normal_fast(rng_scramble(s0[k]), L.zt, zz);
-    ok = (acc || !L.valid[k]) && ok;
-    z[k] = zz;
-  }
-  if (group_all<G>(ok)) {
-    rng = r2;
+    for (int k = 0; k < DPL; k++) {
+      const bool live = L.valid[k] && (L.l + k * G >= pos);
+      double zz;
+      const bool acc = normal_fast(rng_scramble(sb[k]), L.zt, zz);
+      fail[k] = live && !acc;
+      z[k] = (live && acc) ? zz : z[k];
+    }
+    int j = D;   // first dimension of this group that needs the long way, D if none
 #pragma unroll
-    for (int k = 0; k < DPL; k++) p[k] = z[k] / L.sim[k];
-  } else {
-    for (int i = 0; i < D; i++) {
-      const double zz = rng_normal(rng, L.zt, L.nor_r);
+    for (int k = DPL - 1; k >= 0; k--) {
+      const unsigned long long m = __ballot(fail[k] ? 1 : 0);
+      const unsigned long long gm = (G == 64) ? m : ((m >> base) & ((1ULL << (G & 63)) - 1ULL));
+      j = (gm != 0) ? (k * G + __ffsll((long long)gm) - 1) : j;
+    }
+    if (__any((j < D) ? 1 : 0) == 0) {
+      rng = r2;
+      break;
+    }
+    if (j < D) {
+      const int ks = j / G;
+      uint64_t aj = 0, bj = 0;
 #pragma unroll
-      for (int k = 0; k < DPL; k++)
-        if (L.l + k * G == i) p[k] = zz / L.sim[k];
+      for (int k = 0; k < DPL; k++) {
+        aj = (k == ks) ? sa[k] : aj;
+        bj = (k == ks) ? sb[k] : bj;
+      }
+      const int src = base | (j & (G - 1));
+      Rng rj;
+      rj.a = __shfl(aj, src, 64);
+      rj.b = __shfl(bj, src, 64);
+      const double zz = rng_normal(rj, L.zt, L.nor_r);
+#pragma unroll
+      for (int k = 0; k < DPL; k++) z[k] = (L.l + k * G == j) ? zz : z[k];
+      rng = rj;
+      pos = j + 1;
+    } else {
+      rng = r2;
+      pos = D;
     }
   }
+#pragma unroll
+  for (int k = 0; k < DPL; k++) p[k] = z[k] / L.sim[k];
 }
 
 // n_draws NUTS transitions of this group's chain. sink(draw, q, logp, depth, n_steps, divergent,
