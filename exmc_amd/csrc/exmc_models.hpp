@@ -580,6 +580,7 @@ struct Radon : ModelDefaults {
   struct Lane {
     double u[DPL];
     int i0[DPL], i1[DPL];
+    Recip ten, five, c25;   // prior scales Normal(0, 10), Normal(0, 5), HalfCauchy(2.5)
   };
   __device__ static __forceinline__ void load(const Consts& c, int l, Lane& ln) {
 #pragma unroll
@@ -590,15 +591,31 @@ struct Radon : ModelDefaults {
       ln.i0[k] = cty ? (int)c.cs[j] : 0;
       ln.i1[k] = cty ? (int)c.cs[j + 1] : 0;
     }
+    ln.ten = make_recip_literal(10.0);
+    ln.five = make_recip_literal(5.0);
+    ln.c25 = make_recip_literal(2.5);
   }
-  __device__ static __forceinline__ double half_cauchy_d(const Consts& c, double x, double& dx) {
-    const double z = x / 2.5;
+  // x = exp(clamp200(.)) in [e^-200, e^200]: x / 2.5, 2z / 2.5 and the quotient by 1 + z^2 in
+  // [1, e^400] have operands within 2^+-580 of each other and quotients >= e^-201 (in range)
+  template <class DV>
+  __device__ static __forceinline__ double half_cauchy_d(const Consts& c, const Lane& ln, double x,
+                                                         double& dx, DV& dv) {
+    const double z = dv(x, ln.c25);
     const double z2 = z * z;
-    dx = -(((2.0 * z) / 2.5) / (1.0 + z2));
+    dx = -dv(dv(2.0 * z, ln.c25), 1.0 + z2);
     return c.c_hc - exmc_log(1.0 + z2);
   }
   __device__ static __forceinline__ double logp_grad(const Consts& c, const Lane& ln, int l,
                                                      const double (&q)[DPL], double (&g)[DPL]) {
+    return with_fast_div([&](auto& dv) -> double { return eval(c, ln, l, q, g, dv); });
+  }
+
+  // Quotients: sigma_y is watched in [2^-100, 2^100) and every residual y - mean in 2^+-250, so
+  // z = resid / sigma_y stays within 2^+-350 and is a legal numerator again; mu, gamma and beta
+  // are watched before their two quotients by the prior scale.
+  template <class DV>
+  __device__ static __forceinline__ double eval(const Consts& c, const Lane& ln, int l,
+                                                const double (&q)[DPL], double (&g)[DPL], DV& dv) {
     const double mu = group_bcast_c<G, J % G>(q[J / G]);
     const double gam = group_bcast_c<G, (J + 1) % G>(q[(J + 1) / G]);
     const double zsa_raw = group_bcast_c<G, (J + 2) % G>(q[(J + 2) / G]);
@@ -607,6 +624,11 @@ struct Radon : ModelDefaults {
     const double zsa = clamp200(zsa_raw), zsy = clamp200(zsy_raw);
     const double sa = exmc_exp(zsa), sy = exmc_exp(zsy);
     const double ssy = fmax(sy, c.tiny32);
+    dv.template watch_exp_if<-100, 100>(true, ssy);
+    dv.watch(mu);
+    dv.watch(gam);
+    dv.watch(beta);
+    const Recip rsy = make_recip(ssy);
     const double cn = c.log2pi32 + 2.0 * exmc_log(ssy);
     double s[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // lik, S, S*u, S*alpha_raw, F, Z2 partials
     double T[DPL];
@@ -621,8 +643,10 @@ struct Radon : ModelDefaults {
       for (int i = ln.i0[k]; i < ln.i1[k]; i++) {
         const double fi = c.fl[i];
         const double mean = alpha + beta * fi;
-        const double z = (c.y[i] - mean) / ssy;
-        const double a = z / ssy;
+        const double resid = c.y[i] - mean;
+        dv.template watch_exp_if<-250, 250>(true, resid);
+        const double z = dv(resid, rsy);
+        const double a = dv(z, rsy);
         lik = lik + (-0.5 * (z * z + cn));
         sj = sj + a;
         f = f + a * fi;
@@ -640,20 +664,20 @@ struct Radon : ModelDefaults {
       g[k] = (-ar) + sj * sa;
     }
     group_allsum_n<G, 6>(s);
-    const double zmu = (mu - 0.0) / 10.0, zg = (gam - 0.0) / 5.0, zb = (beta - 0.0) / 5.0;
+    const double zmu = dv(mu - 0.0, ln.ten), zg = dv(gam - 0.0, ln.five), zb = dv(beta - 0.0, ln.five);
     double dsa, dsy;
-    const double t_sa = half_cauchy_d(c, sa, dsa) + zsa;
-    const double t_sy = half_cauchy_d(c, sy, dsy) + zsy;
+    const double t_sa = half_cauchy_d(c, ln, sa, dsa, dv) + zsa;
+    const double t_sy = half_cauchy_d(c, ln, sy, dsy, dv) + zsy;
     const bool in_a = (zsa_raw > -200.0) && (zsa_raw < 200.0);
     const bool in_y = (zsy_raw > -200.0) && (zsy_raw < 200.0);
 #pragma unroll
     for (int k = 0; k < DPL; k++) {
       const int j = l + k * G;
-      if (j == J) { T[k] = -0.5 * (zmu * zmu + c.c_mu10); g[k] = (-(zmu / 10.0)) + s[1]; }
-      if (j == J + 1) { T[k] = -0.5 * (zg * zg + c.c_n5); g[k] = (-(zg / 5.0)) + s[2]; }
+      if (j == J) { T[k] = -0.5 * (zmu * zmu + c.c_mu10); g[k] = (-dv(zmu, ln.ten)) + s[1]; }
+      if (j == J + 1) { T[k] = -0.5 * (zg * zg + c.c_n5); g[k] = (-dv(zg, ln.five)) + s[2]; }
       if (j == J + 2) { T[k] = t_sa; g[k] = in_a ? ((dsa + s[3]) * sa + 1.0) : 0.0; }
       if (j == J + 3) { T[k] = t_sy; g[k] = in_y ? ((dsy * sy + s[5]) + 1.0) : 0.0; }
-      if (j == J + 4) { T[k] = -0.5 * (zb * zb + c.c_n5); g[k] = (-(zb / 5.0)) + s[4]; }
+      if (j == J + 4) { T[k] = -0.5 * (zb * zb + c.c_n5); g[k] = (-dv(zb, ln.five)) + s[4]; }
       if (j >= D) g[k] = 0.0;
     }
     return group_sum_slots<G, DPL>(T, valid, l, s[0]);
