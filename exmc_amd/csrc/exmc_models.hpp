@@ -25,7 +25,13 @@ struct ModelDefaults {
   static constexpr bool kCoop = false;
   static constexpr int kExtraLdsDoubles = 0;
   static constexpr int kStageDoubles = 0;
+  // kLdsDataDoubles: observations every NUTS workgroup keeps in LDS for the whole kernel
+  // (stage_data fills the image, Lane::xoff = its offset in the dynamic LDS array or -1)
+  static constexpr int kLdsDataDoubles = 0;
 };
+
+// the dynamic LDS of the running kernel (every extern __shared__ array names the same base)
+extern __shared__ double exmc_dyn_lds[];
 
 // ------------------------------------------------------------------------------------------
 // eight_schools, non-centered (benchmark/posteriordb/validate_posteriordb.exs:246-324).
@@ -577,12 +583,26 @@ struct Radon : ModelDefaults {
   static constexpr int D = J + 5;
   static constexpr int DPL = (D + G - 1) / G;
   using Consts = RadonConsts;
+  static constexpr int kObsCap = 1024;                 // observations an LDS image can hold
+  static constexpr int kLdsDataDoubles = 2 * kObsCap;  // [floor | y]
   struct Lane {
     double u[DPL];
     int i0[DPL], i1[DPL];
     Recip ten, five, c25;   // prior scales Normal(0, 10), Normal(0, 5), HalfCauchy(2.5)
+    int xoff;               // LDS image of floor / y (offset in doubles), or -1: read from global
   };
+  // cooperative (whole workgroup); the caller synchronises afterwards
+  __device__ static __forceinline__ bool stage_data(const Consts& c, double* dst) {
+    const int N = (int)c.cs[J];
+    if (N > kObsCap) return false;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+      dst[i] = c.fl[i];
+      dst[kObsCap + i] = c.y[i];
+    }
+    return true;
+  }
   __device__ static __forceinline__ void load(const Consts& c, int l, Lane& ln) {
+    ln.xoff = -1;
 #pragma unroll
     for (int k = 0; k < DPL; k++) {
       const int j = l + k * G;
@@ -640,10 +660,9 @@ struct Radon : ModelDefaults {
       const double ar = q[k];
       const double alpha = (mu + gam * ln.u[k]) + sa * ar;
       double lik = 0.0, sj = 0.0, f = 0.0, z2s = 0.0;
-      for (int i = ln.i0[k]; i < ln.i1[k]; i++) {
-        const double fi = c.fl[i];
+      auto obs = [&](double fi, double yi) {
         const double mean = alpha + beta * fi;
-        const double resid = c.y[i] - mean;
+        const double resid = yi - mean;
         dv.template watch_exp_if<-250, 250>(true, resid);
         const double z = dv(resid, rsy);
         const double a = dv(z, rsy);
@@ -651,6 +670,21 @@ struct Radon : ModelDefaults {
         sj = sj + a;
         f = f + a * fi;
         z2s = z2s + (z * z - 1.0);
+      };
+      if (ln.xoff >= 0) {
+        // LDS image, the next observation fetched while this one is used
+        const double* im = exmc_dyn_lds + ln.xoff;
+        int i = ln.i0[k];
+        const int iend = ln.i1[k];
+        double fn = 0.0, yn = 0.0;
+        if (i < iend) { fn = im[i]; yn = im[kObsCap + i]; }
+        for (; i < iend; i++) {
+          const double fi = fn, yi = yn;
+          if (i + 1 < iend) { fn = im[i + 1]; yn = im[kObsCap + i + 1]; }
+          obs(fi, yi);
+        }
+      } else {
+        for (int i = ln.i0[k]; i < ln.i1[k]; i++) obs(c.fl[i], c.y[i]);
       }
       if (valid[k]) {
         s[0] = s[0] + lik;

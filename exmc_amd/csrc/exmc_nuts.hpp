@@ -108,10 +108,31 @@ constexpr int kZigLdsBytes = 768 * 8;
 template <class M>
 __host__ __device__ constexpr int nuts_nslot() { return 5 * M::DPL + 3; }
 
+// dynamic LDS of a NUTS workgroup: [tree stack levels < LDSL][ziggurat tables][model scratch]
+// [model data image]
+template <class M, int LDSL>
+__host__ __device__ constexpr size_t nuts_lds_data_offset() {   // in doubles
+  return (size_t)LDSL * nuts_nslot<M>() * kNutsBlock + kZigLdsBytes / 8 +
+         (size_t)M::kExtraLdsDoubles;
+}
 template <class M, int LDSL>
 __host__ __device__ constexpr size_t nuts_lds_bytes() {
-  return (size_t)LDSL * nuts_nslot<M>() * kNutsBlock * 8 + kZigLdsBytes +
-         (size_t)M::kExtraLdsDoubles * 8;
+  return (nuts_lds_data_offset<M, LDSL>() + (size_t)M::kLdsDataDoubles) * 8;
+}
+
+// Models with kLdsDataDoubles > 0 keep their observations in LDS for the whole kernel
+// (M::stage_data fills the image, Lane::xoff is its offset in doubles or -1): with one wave per
+// SIMD every global load inside logp_grad is an exposed L2 round trip.
+template <class M, int G, int LDSL>
+__device__ __forceinline__ int stage_model_data(const typename M::Consts& mc, double* lds) {
+  if constexpr (M::kLdsDataDoubles > 0) {
+    const int off = (int)nuts_lds_data_offset<M, LDSL>();
+    const bool ok = M::stage_data(mc, lds + off);
+    __syncthreads();
+    return ok ? off : -1;
+  } else {
+    return -1;
+  }
 }
 
 template <int N>
@@ -626,10 +647,12 @@ __global__ void __launch_bounds__(kNutsBlock) nuts_kernel(NutsParams P, typename
   const bool has_chain = (tid / G) < C;
   const int chain = has_chain ? (tid / G) : (C - 1);   // surplus groups shadow the last chain
   const ZigTables zt = stage_zig_tables<LDSL, NSLOT>(lds, P.zig_ki, P.zig_wi, P.zig_fi);
+  const int xoff = stage_model_data<M, G, LDSL>(mc, lds);
   if (!M::kCoop && !has_chain) return;
 
   NutsLane<M, G> L;
   lane_setup<M, G, LDSL>(L, mc, lds, P.stack, P.inv_mass, P.sqrt_inv_mass, zt, P.nor_r);
+  if constexpr (M::kLdsDataDoubles > 0) L.ln.xoff = xoff;
   L.alive = has_chain;
   ChainRegs<DPL> st;
   chain_load<M, G>(P.st, C, chain, L.l, st);
@@ -811,6 +834,7 @@ __global__ void __launch_bounds__(kNutsBlock) warmup_kernel(WarmupParams P, type
       __syncthreads();
     }
   }
+  const int xoff = stage_model_data<M, G, LDSL>(mc, lds);
   // Wave-cooperative models: every lane group of the wave runs the same chain 0 redundantly (they
   // stay in lockstep, so the wave is fully populated at every logp_grad); group 0 writes.
   const bool writer = threadIdx.x < G;
@@ -819,6 +843,7 @@ __global__ void __launch_bounds__(kNutsBlock) warmup_kernel(WarmupParams P, type
   NutsLane<M, G> L;
   lane_setup<M, G, LDSL>(L, mc, lds, P.stack, nullptr, nullptr, zt, P.nor_r);
   if constexpr (M::kStageDoubles > 0) L.ln.xs = stage_ptr;
+  if constexpr (M::kLdsDataDoubles > 0) L.ln.xoff = xoff;
   ChainRegs<DPL> st;
   chain_load<M, G>(P.st, 1, 0, L.l, st);
 
