@@ -110,12 +110,23 @@ def radon_data(seed=42, n_counties=85, n_obs=919):
 
 
 def radon(data=None):
-    """Hierarchical radon, d = J+5 = 90. Kernel order alpha_raw_0..J-1, mu_alpha, gamma_u,
-    sigma_alpha, sigma_y, beta (the reference's flat order is the string sort)."""
+    """Hierarchical radon, d = J+5 = 90. Kernel order: the county intercepts alpha_raw_j by
+    DESCENDING observation count, then mu_alpha, gamma_u, sigma_alpha, sigma_y, beta (the
+    reference's flat order is the string sort; names carry the original county index). A lane of
+    the 64-lane chain group walks the observations of counties l and l + 64: with the 21 smallest
+    counties in the second slot a leapfrog costs max(slot 0) + max(slot 1) = 39 + 5 observation
+    steps instead of 28 + 39 in file order."""
     u, start, floor, y = data if data is not None else radon_data()
     J = len(u)
-    names = ["alpha_raw_%d" % j for j in range(J)] + ["mu_alpha", "gamma_u", "sigma_alpha",
-                                                        "sigma_y", "beta"]
+    u, start, floor, y = (np.asarray(u, float), np.asarray(start).astype(int),
+                          np.asarray(floor, float), np.asarray(y, float))
+    sizes = np.diff(start)
+    order = np.argsort(-sizes, kind="stable")
+    obs = np.concatenate([np.arange(start[j], start[j + 1]) for j in order])
+    u, floor, y = u[order], floor[obs], y[obs]
+    start = np.concatenate([[0], np.cumsum(sizes[order])])
+    names = ["alpha_raw_%d" % j for j in order] + ["mu_alpha", "gamma_u", "sigma_alpha",
+                                                     "sigma_y", "beta"]
     init = {nm: 0.0 for nm in names}
     init.update(sigma_alpha=1.0, sigma_y=1.0)
     blob = np.concatenate([np.asarray(u, float), np.asarray(start, float), np.asarray(floor, float),
