@@ -187,6 +187,24 @@ __device__ __forceinline__ double group_bcast_c(double v) {
   }
 }
 
+// One evaluation of f for N different group-uniform arguments: lane i of the group evaluates
+// x[i] (the other lanes x[0]) and the results are broadcast back. Scalar per-chain work is the same
+// instruction stream whatever its argument, so N calls of a 45-instruction log cost one call plus
+// the selects and broadcasts; each value is computed by exactly the operations of f (same bits).
+template <int G, class F, int... I>
+__device__ __forceinline__ void lane_batch_impl(double (&x)[sizeof...(I)], int l, F&& f,
+                                                std::integer_sequence<int, I...>) {
+  double a = x[0];
+  ((a = (l == I) ? x[I] : a), ...);
+  const double v = f(a);
+  ((x[I] = group_bcast_c<G, I>(v)), ...);
+}
+template <int G, int N, class F>
+__device__ __forceinline__ void lane_batch(double (&x)[N], int l, F&& f) {
+  static_assert(N <= G, "one lane per argument");
+  lane_batch_impl<G>(x, l, f, std::make_integer_sequence<int, N>{});
+}
+
 // true iff `ok` holds on every lane of this lane's group (the group's lanes are all active)
 template <int G>
 __device__ __forceinline__ bool group_all(bool ok) {

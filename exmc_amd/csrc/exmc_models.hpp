@@ -194,25 +194,48 @@ struct SVConsts {
 // Quotients (caller watches x in [2^-101, 2^100)): den = x + j >= x, the f32 Lanczos
 // coefficients lie in [2^-20, 2^11), so term in 2^(-121..112) and term / den in 2^(-221..213);
 // x - 0.5, ag and dag are watched here; t = x + 6.5 in [6.5, 2^101).
-template <class MM, class DV>
-__device__ __forceinline__ double lanczos_val_d(const SVConsts& c, double x, double& dx, DV& dv) {
-  const double t = x + 6.5;
-  double ag = c.lanczos[0];
-  double dag = 0.0;
-#pragma unroll
-  for (int i = 1; i < 9; i++) {
-    const Recip den = make_recip(x + (double)(i - 1) * 1.0);
-    const double term = dv(c.lanczos[i], den);
-    ag = ag + term;
-    dag = dag - dv(term, den);
-  }
-  const double lt = MM::log(t);
-  const double xm = x - 0.5;
-  dv.watch(xm);
-  dv.watch(ag);
-  dv.watch(dag);
-  dx = ((lt + dv(xm, t)) - 1.0) + dv(dag, ag);
-  return ((c.half_log_2pi32 + xm * lt) - t) + MM::log(ag);
+// Both lgamma evaluations of a leapfrog (x1 = (nu+1)/2, x0 = nu/2) at once. The 16 series terms
+// c_i / (x + i - 1) and their derivatives are one quotient pair on 16 different lanes (lane l:
+// call l / 8, term l % 8 + 1; lzc / lzj are that lane's coefficient and offset), summed in the
+// reference's order from broadcasts; the four logarithms of the two calls plus the two the
+// caller needs (extra[0..1] in, their logs out) are two lane-batched evaluations.
+template <class MM, int G, int... I>
+__device__ __forceinline__ void lanczos_sums(double term, double tdd, double c0, double& ag1,
+                                             double& dag1, double& ag0, double& dag0,
+                                             std::integer_sequence<int, I...>) {
+  ag1 = c0; dag1 = 0.0; ag0 = c0; dag0 = 0.0;
+  ((ag1 = ag1 + group_bcast_c<G, I>(term), dag1 = dag1 - group_bcast_c<G, I>(tdd)), ...);
+  ((ag0 = ag0 + group_bcast_c<G, 8 + I>(term), dag0 = dag0 - group_bcast_c<G, 8 + I>(tdd)), ...);
+}
+
+template <class MM, int G, class DV>
+__device__ __forceinline__ void lanczos_pair_d(const SVConsts& c, int l, double lzc, double lzj,
+                                               double x1, double x0, double (&extra)[2],
+                                               double& lg1, double& d1, double& lg0, double& d0,
+                                               DV& dv) {
+  static_assert(G >= 16, "one lane per series term of the two calls");
+  const double xs = ((l & 8) == 0) ? x1 : x0;
+  const Recip den = make_recip(xs + lzj * 1.0);
+  const double term = dv(lzc, den);
+  const double tdd = dv(term, den);
+  double ag1, dag1, ag0, dag0;
+  lanczos_sums<MM, G>(term, tdd, c.lanczos[0], ag1, dag1, ag0, dag0,
+                      std::make_integer_sequence<int, 8>{});
+  const double t1 = x1 + 6.5, t0 = x0 + 6.5;
+  double la[4] = {t1, t0, extra[0], extra[1]};
+  lane_batch<G, 4>(la, l, [](double v) { return MM::log(v); });
+  extra[0] = la[2];
+  extra[1] = la[3];
+  double lb[2] = {ag1, ag0};
+  lane_batch<G, 2>(lb, l, [](double v) { return MM::log(v); });
+  const double xm1 = x1 - 0.5, xm0 = x0 - 0.5;
+  dv.watch(xm1); dv.watch(xm0);
+  dv.watch(ag1); dv.watch(ag0);
+  dv.watch(dag1); dv.watch(dag0);
+  d1 = ((la[0] + dv(xm1, t1)) - 1.0) + dv(dag1, ag1);
+  d0 = ((la[1] + dv(xm0, t0)) - 1.0) + dv(dag0, ag0);
+  lg1 = ((c.half_log_2pi32 + xm1 * la[0]) - t1) + lb[0];
+  lg0 = ((c.half_log_2pi32 + xm0 * la[1]) - t0) + lb[1];
 }
 
 template <int G>
@@ -220,10 +243,11 @@ struct SV : ModelDefaults {
   static constexpr int T = 100;
   static constexpr int D = T + 2;
   static constexpr int DPL = (D + G - 1) / G;
-  static_assert(G >= 2, "sv spreads a chain over >= 2 lanes");
+  static_assert(G >= 16, "sv spreads a chain over >= 16 lanes (lane-batched lgamma series)");
   using Consts = SVConsts;
   struct Lane {
     double r[DPL];
+    double lzc, lzj;   // this lane's Lanczos coefficient and offset (lanczos_pair_d)
   };
   __device__ static __forceinline__ void load(const Consts& c, int l, Lane& ln) {
 #pragma unroll
@@ -231,6 +255,8 @@ struct SV : ModelDefaults {
       const int i = l + k * G;
       ln.r[k] = c.r[i < T ? i : 0];
     }
+    ln.lzc = c.lanczos[(l & 7) + 1];
+    ln.lzj = (double)(l & 7);
   }
   static constexpr bool kVregMath = true;
   using MM = Math<kVregMath>;
@@ -251,7 +277,9 @@ struct SV : ModelDefaults {
     const double zs_raw = group_bcast_c<G, T % G>(q[T / G]);
     const double zn_raw = group_bcast_c<G, (T + 1) % G>(q[(T + 1) / G]);
     const double zs = clamp200(zs_raw), zn = clamp200(zn_raw);
-    const double sigma = MM::exp(zs), nu = MM::exp(zn);
+    double ez[2] = {zs, zn};
+    lane_batch<G, 2>(ez, l, [](double v) { return MM::exp(v); });
+    const double sigma = ez[0], nu = ez[1];
     const double ss = fmax(sigma, c.tiny32);
     const double sdf = fmax(nu, c.tiny32);
     dv.template watch_exp_if<-100, 100>(true, ss);
@@ -260,12 +288,12 @@ struct SV : ModelDefaults {
     const double t_sigma = (c.log_lam_s32 - c.lam_s * sigma) + zs;
     const double t_nu = (c.log_lam_n32 - c.lam_n * nu) + zn;
     const double hp1 = (sdf + 1.0) / 2.0, h = sdf / 2.0;
-    double d1, d0;
-    const double lg1 = lanczos_val_d<MM>(c, hp1, d1, dv);
-    const double lg0 = lanczos_val_d<MM>(c, h, d0, dv);
-    const double An = (lg1 - lg0) - 0.5 * MM::log(sdf * c.pi32);
+    double d1, d0, lg1, lg0;
+    double lx[2] = {sdf * c.pi32, ss};   // in: arguments, out: their logarithms
+    lanczos_pair_d<MM, G>(c, l, ln.lzc, ln.lzj, hp1, h, lx, lg1, d1, lg0, d0, dv);
+    const double An = (lg1 - lg0) - 0.5 * lx[0];
     const double dAn = (0.5 * d1 - 0.5 * d0) - dv(0.5, rsdf);
-    const double cn = c.log2pi32 + 2.0 * MM::log(ss);
+    const double cn = c.log2pi32 + 2.0 * lx[1];
     const int lane = threadIdx.x & 63;
     const int base = lane & ~(G - 1);
     const int prev_lane = base | ((l + G - 1) & (G - 1));
@@ -594,7 +622,7 @@ struct Radon : ModelDefaults {
   // cooperative (whole workgroup); the caller synchronises afterwards
   __device__ static __forceinline__ bool stage_data(const Consts& c, double* dst) {
     const int N = (int)c.cs[J];
-    if (N > kObsCap) return false;
+    if (N >= kObsCap) return false;
     for (int i = threadIdx.x; i < N; i += blockDim.x) {
       dst[i] = c.fl[i];
       dst[kObsCap + i] = c.y[i];
@@ -680,7 +708,8 @@ struct Radon : ModelDefaults {
         if (i < iend) { fn = im[i]; yn = im[kObsCap + i]; }
         for (; i < iend; i++) {
           const double fi = fn, yi = yn;
-          if (i + 1 < iend) { fn = im[i + 1]; yn = im[kObsCap + i + 1]; }
+          fn = im[i + 1];            // one past the lane's last observation is still inside the
+          yn = im[kObsCap + i + 1];  // image (N < kObsCap) and never used
           obs(fi, yi);
         }
       } else {
