@@ -643,16 +643,6 @@ struct Radon : ModelDefaults {
     ln.five = make_recip_literal(5.0);
     ln.c25 = make_recip_literal(2.5);
   }
-  // x = exp(clamp200(.)) in [e^-200, e^200]: x / 2.5, 2z / 2.5 and the quotient by 1 + z^2 in
-  // [1, e^400] have operands within 2^+-580 of each other and quotients >= e^-201 (in range)
-  template <class DV>
-  __device__ static __forceinline__ double half_cauchy_d(const Consts& c, const Lane& ln, double x,
-                                                         double& dx, DV& dv) {
-    const double z = dv(x, ln.c25);
-    const double z2 = z * z;
-    dx = -dv(dv(2.0 * z, ln.c25), 1.0 + z2);
-    return c.c_hc - exmc_log(1.0 + z2);
-  }
   __device__ static __forceinline__ double logp_grad(const Consts& c, const Lane& ln, int l,
                                                      const double (&q)[DPL], double (&g)[DPL]) {
     return with_fast_div([&](auto& dv) -> double { return eval(c, ln, l, q, g, dv); });
@@ -660,7 +650,9 @@ struct Radon : ModelDefaults {
 
   // Quotients: sigma_y is watched in [2^-100, 2^100) and every residual y - mean in 2^+-250, so
   // z = resid / sigma_y stays within 2^+-350 and is a legal numerator again; mu, gamma and beta
-  // are watched before their two quotients by the prior scale.
+  // are watched before their two quotients by the prior scale. The HalfCauchy arguments
+  // x = exp(clamp200(.)) lie in [e^-200, e^200]: x / 2.5, 2z / 2.5 and the quotient by 1 + z^2
+  // in [1, e^400] have operands within 2^+-580 of each other and quotients >= e^-201 (in range).
   template <class DV>
   __device__ static __forceinline__ double eval(const Consts& c, const Lane& ln, int l,
                                                 const double (&q)[DPL], double (&g)[DPL], DV& dv) {
@@ -670,14 +662,27 @@ struct Radon : ModelDefaults {
     const double zsy_raw = group_bcast_c<G, (J + 3) % G>(q[(J + 3) / G]);
     const double beta = group_bcast_c<G, (J + 4) % G>(q[(J + 4) / G]);
     const double zsa = clamp200(zsa_raw), zsy = clamp200(zsy_raw);
-    const double sa = exmc_exp(zsa), sy = exmc_exp(zsy);
+    // the chain-scalar transcendentals as lane-batched evaluations: 2 exps, then the 3 logs
+    double ez[2] = {zsa, zsy};
+    lane_batch<G, 2>(ez, l, [](double v) { return exmc_exp(v); });
+    const double sa = ez[0], sy = ez[1];
     const double ssy = fmax(sy, c.tiny32);
     dv.template watch_exp_if<-100, 100>(true, ssy);
     dv.watch(mu);
     dv.watch(gam);
     dv.watch(beta);
     const Recip rsy = make_recip(ssy);
-    const double cn = c.log2pi32 + 2.0 * exmc_log(ssy);
+    // HalfCauchy(2.5) on sigma_alpha, sigma_y (half_cauchy.ex:19-27): z = x / 2.5,
+    // logp = c_hc - log(1 + z^2), d/dx = -((2z / 2.5) / (1 + z^2))
+    const double za = dv(sa, ln.c25), zy = dv(sy, ln.c25);
+    const double za2 = za * za, zy2 = zy * zy;
+    double lx[3] = {ssy, 1.0 + za2, 1.0 + zy2};
+    lane_batch<G, 3>(lx, l, [](double v) { return exmc_log(v); });
+    const double cn = c.log2pi32 + 2.0 * lx[0];
+    const double dsa = -dv(dv(2.0 * za, ln.c25), 1.0 + za2);
+    const double dsy = -dv(dv(2.0 * zy, ln.c25), 1.0 + zy2);
+    const double t_sa = (c.c_hc - lx[1]) + zsa;
+    const double t_sy = (c.c_hc - lx[2]) + zsy;
     double s[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // lik, S, S*u, S*alpha_raw, F, Z2 partials
     double T[DPL];
     bool valid[DPL];
@@ -728,9 +733,6 @@ struct Radon : ModelDefaults {
     }
     group_allsum_n<G, 6>(s);
     const double zmu = dv(mu - 0.0, ln.ten), zg = dv(gam - 0.0, ln.five), zb = dv(beta - 0.0, ln.five);
-    double dsa, dsy;
-    const double t_sa = half_cauchy_d(c, ln, sa, dsa, dv) + zsa;
-    const double t_sy = half_cauchy_d(c, ln, sy, dsy, dv) + zsy;
     const bool in_a = (zsa_raw > -200.0) && (zsa_raw < 200.0);
     const bool in_y = (zsy_raw > -200.0) && (zsy_raw < 200.0);
 #pragma unroll
