@@ -1016,9 +1016,14 @@ int exmc_hip_sample_chains_host(exmc_hip_model* m, const exmc_hip_tuning* tuning
                                 exmc_hip_opts o, exmc_hip_trace tr, int64_t* total_leapfrogs,
                                 int32_t* total_divergences) {
   if (check_model(m)) return EXMC_ERR_BADARG;
-  if (chain_hi <= chain_lo || o.num_samples < 1) return fail(EXMC_ERR_BADARG, "bad arguments");
+  if (chain_hi <= chain_lo || o.num_samples < 0) return fail(EXMC_ERR_BADARG, "bad arguments");
   HIP_TRY(hipSetDevice(m->device));
   const int C = chain_hi - chain_lo;
+  if (o.num_samples == 0) {   // nothing to draw: the chains are initialised, the traces stay empty
+    if (total_leapfrogs) *total_leapfrogs = 0;
+    if (total_divergences) *total_divergences = 0;
+    return exmc_hip_chains_init(m, tuning, init_q, n_chains, chain_lo, chain_hi, o);
+  }
   TraceLayout L = trace_layout(o.num_samples, m->d, C);
   int rc = m->trace.ensure(L.total);
   if (rc) return rc;

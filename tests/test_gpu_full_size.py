@@ -1,0 +1,110 @@
+"""BASELINE.json's full single-GPU configuration (eight_schools, 4096 chains x 1000 draws after
+the shared 1000-iteration warmup) through the C ABI, checked with properties that do not need the
+CPU checker to run 4 million transitions: a sample of chains bit for bit against the checker, shard
+independence, run-to-run determinism of the whole trace, convergence diagnostics. Plus the edge
+shapes of the entry points (no draws, depth 1, one chain, ragged last wavefront)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import oracle as O
+from exmc_amd import distributed, models, sampler
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("tree_depth", "n_steps", "divergent", "draws", "logp", "accept_prob", "energy")
+
+
+def _digest(raw):
+    h = hashlib.sha256()
+    for k in KEYS:
+        h.update(np.ascontiguousarray(raw[k]).tobytes())
+    return h.hexdigest()
+
+
+def test_eight_schools_4096_chains_1000_draws(hip):
+    spec = models.eight_schools()
+    comp = sampler.compile(spec)
+    om = O.eight_schools()
+    n_chains, n_draws = 4096, 1000
+    opts = dict(num_warmup=1000, num_samples=n_draws, seed=42, lanes_per_chain=16)
+    tuning = sampler.warmup(comp, spec.default_init, opts)
+    _, _, extra = sampler.sample_compiled_tuned(comp, tuning, spec.default_init, opts,
+                                                num_chains=n_chains)
+    raw = extra["raw"]
+    assert raw["draws"].shape == (n_chains, n_draws, spec.d)
+
+    # (1) chains from the first, a middle and the last wavefront equal the checker's, every output
+    q0 = spec.to_unconstrained(spec.default_init)
+    for lo in (0, 2050, n_chains - 3):
+        hi = lo + 3
+        t, st = O.sample_chains(om, n_chains, init_q=q0, num_warmup=1000, num_samples=n_draws,
+                                seed=42, chain_lo=lo, chain_hi=hi, cfg=O.Cfg(1, 16))
+        assert st.step_size == tuning["epsilon"]
+        for k in KEYS:
+            assert np.array_equal(t[k], raw[k][lo:hi]), (k, lo)
+
+    # (2) a shard run on its own reproduces the same rows (seed + 7919 i is shard independent)
+    _, _, ex2 = sampler.sample_compiled_tuned(comp, tuning, spec.default_init, opts,
+                                              num_chains=n_chains, chain_lo=1021, chain_hi=1031)
+    for k in KEYS:
+        assert np.array_equal(ex2["raw"][k], raw[k][1021:1031]), k
+
+    # (3) the counters the bench divides by are the trace's own sums
+    assert extra["total_leapfrogs"] == int(raw["n_steps"].astype(np.int64).sum())
+    assert extra["total_divergences"] == int(raw["divergent"].astype(np.int64).sum())
+
+    # (4) the whole 4096 x 1000 trace is reproducible bit for bit
+    _, _, ex3 = sampler.sample_compiled_tuned(comp, tuning, spec.default_init, opts,
+                                              num_chains=n_chains)
+    assert _digest(ex3["raw"]) == _digest(raw)
+
+    # (5) it is a sample of the posterior: split R-hat, acceptance, divergences, depth bound
+    import torch
+    draws = torch.from_numpy(np.ascontiguousarray(raw["draws"].transpose(1, 2, 0)))   # [S][d][C]
+    rhat = distributed.split_rhat(draws)
+    assert tuple(rhat.shape) == (spec.d,) and float(rhat.max()) < 1.01
+    assert 0.75 < float(raw["accept_prob"].mean()) < 0.95
+    assert float(raw["divergent"].mean()) < 0.005
+    assert int(raw["tree_depth"].max()) <= 10 and int(raw["tree_depth"].min()) >= 1
+    assert np.all(raw["n_steps"] <= (1 << raw["tree_depth"]) - 1)
+    assert np.isfinite(raw["draws"]).all() and np.isfinite(raw["energy"]).all()
+
+
+@pytest.mark.parametrize("n_chains,lanes", [(1, 16), (5, 16), (3, 1), (65, 1), (9, 8)])
+def test_ragged_chain_counts(hip, n_chains, lanes):
+    """Chain counts that leave the last wavefront partly empty (or nearly empty)."""
+    spec = models.eight_schools()
+    comp = sampler.compile(spec)
+    om = O.eight_schools()
+    opts = dict(num_warmup=0, num_samples=15, seed=5, lanes_per_chain=lanes)
+    tuning = dict(epsilon=0.4, inv_mass=np.ones(spec.d), chol_cov=None, warmup_divergences=0)
+    _, _, extra = sampler.sample_compiled_tuned(comp, tuning, spec.default_init, opts,
+                                                num_chains=n_chains)
+    assert extra["raw"]["draws"].shape == (n_chains, 15, spec.d)
+    q0 = spec.to_unconstrained(spec.default_init)
+    for c in sorted({0, n_chains // 2, n_chains - 1}):
+        t, _ = O.sample_tuned(om, 0.4, np.ones(spec.d), q0, num_samples=15, seed=5 + 7919 * c,
+                              cfg=O.Cfg(1, lanes))
+        for k in KEYS:
+            assert np.array_equal(t[k], extra["raw"][k][c]), (k, c)
+
+
+def test_no_draws_and_depth_one(hip):
+    spec = models.eight_schools()
+    comp = sampler.compile(spec)
+    om = O.eight_schools()
+    tuning = dict(epsilon=0.3, inv_mass=np.ones(spec.d), chol_cov=None, warmup_divergences=0)
+    # zero draws: empty traces, no leapfrogs, no error
+    _, _, ex0 = sampler.sample_compiled_tuned(comp, tuning, spec.default_init,
+                                              dict(num_warmup=0, num_samples=0, seed=1), num_chains=7)
+    assert ex0["raw"]["draws"].shape == (7, 0, spec.d) and ex0["total_leapfrogs"] == 0
+    # max_tree_depth 1: every transition is one doubling (n_steps == 1)
+    opts = dict(num_warmup=0, num_samples=25, seed=2, max_tree_depth=1, lanes_per_chain=16)
+    _, _, ex1 = sampler.sample_compiled_tuned(comp, tuning, spec.default_init, opts, num_chains=6)
+    assert np.all(ex1["raw"]["n_steps"] == 1) and np.all(ex1["raw"]["tree_depth"] == 1)
+    t, _ = O.sample_tuned(om, 0.3, np.ones(spec.d), spec.to_unconstrained(spec.default_init),
+                          num_samples=25, max_tree_depth=1, seed=2, cfg=O.Cfg(1, 16))
+    for k in KEYS:
+        assert np.array_equal(t[k], ex1["raw"][k][0]), k
