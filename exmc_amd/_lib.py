@@ -17,6 +17,9 @@ EXPORTS = [
     "exmc_hip_sample_chains", "exmc_hip_sample_chains_host", "exmc_hip_sample_host",
     "exmc_hip_chains_init", "exmc_hip_chains_advance", "exmc_hip_build_full_tree_host",
     "exmc_hip_ess", "exmc_hip_last_kernel_ms",
+    "exmc_hip_traj_create", "exmc_hip_traj_destroy", "exmc_hip_traj_get_endpoint_host",
+    "exmc_hip_traj_build_and_merge_host", "exmc_hip_traj_is_terminated_host",
+    "exmc_hip_traj_get_result_host", "exmc_hip_build_subtree_host",
 ]
 
 
@@ -85,6 +88,17 @@ def load():
     L.exmc_hip_build_full_tree_host.argtypes = [
         C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, dp, dp, C.c_int, dp, dp, dp, dp,
         C.c_int, dp, dp, C.c_int, C.POINTER(C.c_uint64), dp, dp, dp, ip, ip, dp, ip]
+    up = C.POINTER(C.c_uint64)
+    L.exmc_hip_traj_create.argtypes = [C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, C.POINTER(vp)]
+    L.exmc_hip_traj_destroy.argtypes = [vp]
+    L.exmc_hip_traj_destroy.restype = None
+    L.exmc_hip_traj_get_endpoint_host.argtypes = [vp, ip, dp, dp, dp]
+    L.exmc_hip_traj_build_and_merge_host.argtypes = [vp, dp, dp, dp, dp, C.c_int, dp, dp, ip, ip, up]
+    L.exmc_hip_traj_is_terminated_host.argtypes = [vp, ip]
+    L.exmc_hip_traj_get_result_host.argtypes = [vp, dp, dp, dp, ip, ip, dp, ip]
+    L.exmc_hip_build_subtree_host.argtypes = [
+        C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, C.c_int, dp, dp, ip, ip, up,
+        dp, dp, dp, dp, dp, dp, dp, dp, dp, dp, ip, ip, dp, ip, ip, dp]
     L.exmc_hip_ess.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
     L.exmc_hip_last_kernel_ms.argtypes = [vp]
     L.exmc_hip_last_kernel_ms.restype = C.c_double

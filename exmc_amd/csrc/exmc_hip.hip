@@ -1159,3 +1159,235 @@ int exmc_hip_ess(exmc_hip_model* m, const double* draws_dev, int n_draws, int d,
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------
+// The NIF's incremental trajectory interface, batched (include/exmc_hip.h; kernels in
+// exmc_native_tree.hpp). Blocking calls on the null stream: the interface is a compatibility
+// seam (one call per doubling), not a throughput path.
+// ------------------------------------------------------------------------------------------
+struct exmc_hip_traj {
+  int device = 0, C = 0, d = 0;
+  DevBuf state;
+  TrajDev T{};
+};
+
+namespace {
+
+// carve a TrajDev out of one allocation: 9 vectors [C][d], 3 scalars [C], 4 int32 [C]
+size_t traj_bytes(int C, int d) { return ((size_t)9 * C * d + 3 * (size_t)C) * 8 + 4 * (size_t)C * 4; }
+TrajDev traj_view(void* base, int C, int d) {
+  TrajDev t;
+  double* b = (double*)base;
+  const size_t v = (size_t)C * d;
+  t.qL = b; t.pL = b + v; t.gL = b + 2 * v; t.qR = b + 3 * v; t.pR = b + 4 * v; t.gR = b + 5 * v;
+  t.qP = b + 6 * v; t.gP = b + 7 * v; t.rho = b + 8 * v;
+  b += 9 * v;
+  t.logpP = b; t.lsw = b + C; t.acc = b + 2 * (size_t)C;
+  int32_t* ib = (int32_t*)(b + 3 * (size_t)C);
+  t.n = ib; t.depth = ib + C; t.div = ib + 2 * (size_t)C; t.turn = ib + 3 * (size_t)C;
+  return t;
+}
+
+int select_device(int device) {
+  const int ndev = exmc_hip_device_count();
+  if (ndev <= 0)
+    return fail(EXMC_ERR_NO_DEVICE, "no HIP device visible: libexmc_hip has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail(EXMC_ERR_BADARG, "device index out of range");
+  HIP_TRY(hipSetDevice(device));
+  return EXMC_OK;
+}
+
+// uploads of one subtree call: the four state arrays, inv_mass and the per-chain scalars
+struct SubtreeUpload {
+  DevBuf buf;
+  SubtreeParams P{};
+  int fill(int C, int d, const double* all_q, const double* all_p, const double* all_logp,
+           const double* all_g, int n_states, const double* inv_mass, const double* jlp0,
+           const int32_t* depth, const int32_t* go_right, const uint64_t* seeds) {
+    if (C < 1 || d < 1 || n_states < 1 || !all_q || !all_p || !all_logp || !all_g || !inv_mass ||
+        !jlp0 || !depth || !go_right || !seeds)
+      return fail(EXMC_ERR_BADARG, "bad arguments");
+    for (int c = 0; c < C; c++)
+      if (depth[c] >= kFtLevels || (depth[c] >= 0 && ((size_t)1 << depth[c]) > (size_t)n_states))
+        return fail(EXMC_ERR_BADARG, "depth needs more pre-computed states than were passed");
+    const size_t st = (size_t)C * n_states * d, sc = (size_t)C * n_states;
+    const size_t nd = 3 * st + sc + d + C /*jlp0*/ + C /*seeds*/ + (size_t)C * (kFtLevels + 2) * d;
+    int rc = buf.ensure(nd * 8 + 2 * (size_t)C * 4);
+    if (rc) return rc;
+    double* b = buf.as<double>();
+    auto up = [&](const void* src, size_t n_doubles) -> const double* {
+      double* dst = b;
+      if (hipMemcpy(dst, src, n_doubles * 8, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+      b += n_doubles;
+      return dst;
+    };
+    P.n_chains = C; P.d = d; P.n_states = n_states;
+    P.all_q = up(all_q, st); P.all_p = up(all_p, st); P.all_g = up(all_g, st);
+    P.all_logp = up(all_logp, sc);
+    P.inv_mass = up(inv_mass, d); P.jlp0 = up(jlp0, C);
+    P.seeds = (const uint64_t*)up(seeds, C);
+    P.scratch = b; b += (size_t)C * (kFtLevels + 2) * d;
+    int32_t* ib = (int32_t*)b;
+    if (!P.all_q || !P.all_p || !P.all_g || !P.all_logp || !P.inv_mass || !P.jlp0 || !P.seeds ||
+        hipMemcpy(ib, depth, (size_t)C * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(ib + C, go_right, (size_t)C * 4, hipMemcpyHostToDevice) != hipSuccess)
+      return fail(EXMC_ERR_HIP, "upload failed");
+    P.depth = ib; P.go_right = ib + C;
+    return EXMC_OK;
+  }
+};
+
+int down(void* dst, const void* src, size_t bytes) {
+  if (!dst) return EXMC_OK;
+  HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+  return EXMC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int exmc_hip_traj_create(int device, int C, int d, const double* q, const double* p,
+                         const double* grad, const double* logp, exmc_hip_traj** out) {
+  if (!out || C < 1 || d < 1 || !q || !p || !grad || !logp) return fail(EXMC_ERR_BADARG, "bad arguments");
+  *out = nullptr;
+  int rc = select_device(device);
+  if (rc) return rc;
+  exmc_hip_traj* t = new exmc_hip_traj();
+  t->device = device; t->C = C; t->d = d;
+  rc = t->state.ensure(traj_bytes(C, d));
+  if (rc) { delete t; return rc; }
+  t->T = traj_view(t->state.p, C, d);
+  const size_t v = (size_t)C * d * 8;
+  hipError_t e = hipMemset(t->state.p, 0, traj_bytes(C, d));   // lsw, acc, n, depth, div, turn = 0
+  // Trajectory::new (types.rs:136-152): both endpoints and the proposal are the start state, rho = p
+  const double* src[9] = {q, p, grad, q, p, grad, q, grad, p};
+  double* dst[9] = {t->T.qL, t->T.pL, t->T.gL, t->T.qR, t->T.pR, t->T.gR, t->T.qP, t->T.gP, t->T.rho};
+  for (int i = 0; i < 9 && e == hipSuccess; i++) e = hipMemcpy(dst[i], src[i], v, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(t->T.logpP, logp, (size_t)C * 8, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    t->state.release();
+    delete t;
+    return fail(EXMC_ERR_HIP, std::string("traj_create: ") + hipGetErrorString(e));
+  }
+  *out = t;
+  return EXMC_OK;
+}
+
+void exmc_hip_traj_destroy(exmc_hip_traj* t) {
+  if (!t) return;
+  (void)hipSetDevice(t->device);
+  t->state.release();
+  delete t;
+}
+
+int exmc_hip_traj_get_endpoint_host(exmc_hip_traj* t, const int32_t* go_right, double* q, double* p,
+                                    double* grad) {
+  if (!t || !go_right || !q || !p || !grad) return fail(EXMC_ERR_BADARG, "bad arguments");
+  HIP_TRY(hipSetDevice(t->device));
+  const size_t row = (size_t)t->d * 8;
+  for (int c = 0; c < t->C; c++) {
+    const size_t o = (size_t)c * t->d;
+    const bool r = go_right[c] != 0;
+    HIP_TRY(hipMemcpy(q + o, (r ? t->T.qR : t->T.qL) + o, row, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(p + o, (r ? t->T.pR : t->T.pL) + o, row, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(grad + o, (r ? t->T.gR : t->T.gL) + o, row, hipMemcpyDeviceToHost));
+  }
+  return EXMC_OK;
+}
+
+int exmc_hip_traj_build_and_merge_host(exmc_hip_traj* t, const double* all_q, const double* all_p,
+                                       const double* all_logp, const double* all_grad,
+                                       int n_states, const double* inv_mass, const double* jlp0,
+                                       const int32_t* depth, const int32_t* go_right,
+                                       const uint64_t* seeds) {
+  if (!t) return fail(EXMC_ERR_BADARG, "bad arguments");
+  HIP_TRY(hipSetDevice(t->device));
+  SubtreeUpload u;
+  int rc = u.fill(t->C, t->d, all_q, all_p, all_logp, all_grad, n_states, inv_mass, jlp0, depth,
+                  go_right, seeds);
+  if (rc == EXMC_OK) {
+    u.P.T = t->T;
+    hipLaunchKernelGGL(traj_build_and_merge_kernel, dim3((unsigned)((t->C + 63) / 64)), dim3(64), 0,
+                       0, u.P);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) rc = fail(EXMC_ERR_HIP, std::string("build_and_merge: ") + hipGetErrorString(e));
+  }
+  u.buf.release();
+  return rc;
+}
+
+int exmc_hip_traj_is_terminated_host(exmc_hip_traj* t, int32_t* out) {
+  if (!t || !out) return fail(EXMC_ERR_BADARG, "bad arguments");
+  HIP_TRY(hipSetDevice(t->device));
+  std::vector<int32_t> dv(t->C), tn(t->C);
+  HIP_TRY(hipMemcpy(dv.data(), t->T.div, (size_t)t->C * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(tn.data(), t->T.turn, (size_t)t->C * 4, hipMemcpyDeviceToHost));
+  for (int c = 0; c < t->C; c++) out[c] = (dv[c] || tn[c]) ? 1 : 0;   // types.rs:160-162
+  return EXMC_OK;
+}
+
+int exmc_hip_traj_get_result_host(exmc_hip_traj* t, double* q, double* logp, double* grad,
+                                  int32_t* n_steps, int32_t* divergent, double* accept_sum,
+                                  int32_t* depth) {
+  if (!t) return fail(EXMC_ERR_BADARG, "bad arguments");
+  HIP_TRY(hipSetDevice(t->device));
+  const size_t v = (size_t)t->C * t->d * 8, s8 = (size_t)t->C * 8, s4 = (size_t)t->C * 4;
+  int rc = down(q, t->T.qP, v);
+  if (!rc) rc = down(grad, t->T.gP, v);
+  if (!rc) rc = down(logp, t->T.logpP, s8);
+  if (!rc) rc = down(accept_sum, t->T.acc, s8);
+  if (!rc) rc = down(n_steps, t->T.n, s4);
+  if (!rc) rc = down(divergent, t->T.div, s4);
+  if (!rc) rc = down(depth, t->T.depth, s4);
+  return rc;
+}
+
+int exmc_hip_build_subtree_host(int device, int C, int d, const double* all_q, const double* all_p,
+                                const double* all_logp, const double* all_grad, int n_states,
+                                const double* inv_mass, const double* jlp0, const int32_t* depth,
+                                const int32_t* going_right, const uint64_t* seeds, double* q_left,
+                                double* p_left, double* grad_left, double* q_right, double* p_right,
+                                double* grad_right, double* q_prop, double* logp_prop,
+                                double* grad_prop, double* log_sum_weight, int32_t* n_steps,
+                                int32_t* divergent, double* accept_sum, int32_t* turning,
+                                int32_t* subtree_depth, double* rho) {
+  int rc = select_device(device);
+  if (rc) return rc;
+  SubtreeUpload u;
+  rc = u.fill(C, d, all_q, all_p, all_logp, all_grad, n_states, inv_mass, jlp0, depth, going_right,
+              seeds);
+  DevBuf outb;
+  if (rc == EXMC_OK) rc = outb.ensure(traj_bytes(C, d));
+  if (rc == EXMC_OK) {
+    u.P.out = traj_view(outb.p, C, d);
+    hipError_t e = hipMemset(outb.p, 0, traj_bytes(C, d));
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(build_subtree_kernel, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, 0, u.P);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) rc = fail(EXMC_ERR_HIP, std::string("build_subtree: ") + hipGetErrorString(e));
+  }
+  if (rc == EXMC_OK) {
+    const TrajDev& o = u.P.out;
+    const size_t v = (size_t)C * d * 8, s8 = (size_t)C * 8, s4 = (size_t)C * 4;
+    const std::pair<void*, const void*> vec[9] = {{q_left, o.qL}, {p_left, o.pL}, {grad_left, o.gL},
+                                                  {q_right, o.qR}, {p_right, o.pR}, {grad_right, o.gR},
+                                                  {q_prop, o.qP}, {grad_prop, o.gP}, {rho, o.rho}};
+    for (int i = 0; i < 9 && !rc; i++) rc = down(vec[i].first, vec[i].second, v);
+    if (!rc) rc = down(logp_prop, o.logpP, s8);
+    if (!rc) rc = down(log_sum_weight, o.lsw, s8);
+    if (!rc) rc = down(accept_sum, o.acc, s8);
+    if (!rc) rc = down(n_steps, o.n, s4);
+    if (!rc) rc = down(divergent, o.div, s4);
+    if (!rc) rc = down(turning, o.turn, s4);
+    if (!rc) rc = down(subtree_depth, o.depth, s4);
+  }
+  u.buf.release();
+  outb.release();
+  return rc;
+}
+
+}  // extern "C"

@@ -180,6 +180,59 @@ int exmc_hip_build_full_tree_host(int device, int n_chains, int d, const double*
                                   double* grad_out, int32_t* n_steps, int32_t* divergent,
                                   double* accept_sum, int32_t* depth);
 
+/* ---- The NIF's incremental trajectory interface, batched over n_chains trajectories ----
+ * (lib/exmc/nuts/native_tree.ex:19-110; native/exmc_tree/src/lib.rs:37-212, 345-434;
+ * types.rs:129-172). One handle = the `ResourceArc<TrajectoryResource>` of every chain of a batch,
+ * resident on the device between calls. Host buffers in the NIF's binary layout: native-endian
+ * f64, row-major [chain][dim] / [chain][state][dim]. */
+typedef struct exmc_hip_traj exmc_hip_traj;
+
+/* init_trajectory_bin/4 (lib.rs:37-50, Trajectory::new types.rs:129-152): q, p, grad [C][d];
+ * logp [C]. */
+int exmc_hip_traj_create(int device, int n_chains, int d, const double* q, const double* p,
+                         const double* grad, const double* logp, exmc_hip_traj** out);
+void exmc_hip_traj_destroy(exmc_hip_traj* t);
+
+/* get_endpoint_bin/2 (lib.rs:59-71): go_right [C] (0 = left); q, p, grad out [C][d]. */
+int exmc_hip_traj_get_endpoint_host(exmc_hip_traj* t, const int32_t* go_right, double* q,
+                                    double* p, double* grad);
+
+/* build_and_merge_bin/11 (lib.rs:73-112; build_subtree tree.rs:16-95, merge_into_trajectory
+ * tree.rs:194-265): per chain the 2^depth[c] pre-computed leapfrog states of one doubling in
+ * all_q, all_p, all_grad [C][n_states][d], all_logp [C][n_states] (n_states >= 2^max depth);
+ * inv_mass [d]; joint_logp_0, depth, go_right, rng_seed [C]. A chain with depth[c] < 0 is left
+ * untouched (e.g. already terminated). */
+int exmc_hip_traj_build_and_merge_host(exmc_hip_traj* t, const double* all_q, const double* all_p,
+                                       const double* all_logp, const double* all_grad,
+                                       int n_states, const double* inv_mass,
+                                       const double* joint_logp_0, const int32_t* depth,
+                                       const int32_t* go_right, const uint64_t* rng_seed);
+
+/* is_terminated/1 (lib.rs:52-57): out [C] = divergent || turning. */
+int exmc_hip_traj_is_terminated_host(exmc_hip_traj* t, int32_t* out);
+
+/* get_result_bin/1 (lib.rs:305-343, trajectory_to_result tree.rs:329-339): q, grad out [C][d];
+ * logp, accept_sum out [C]; n_steps, divergent, depth out int32 [C]. */
+int exmc_hip_traj_get_result_host(exmc_hip_traj* t, double* q, double* logp, double* grad,
+                                  int32_t* n_steps, int32_t* divergent, double* accept_sum,
+                                  int32_t* depth);
+
+/* build_subtree_bin/10 (lib.rs:114-212): the subtree record without a trajectory. Inputs as for
+ * build_and_merge; outputs per chain q_left, p_left, grad_left, q_right, p_right, grad_right,
+ * q_prop, grad_prop, rho [C][d]; logp_prop, log_sum_weight, accept_sum [C]; n_steps, divergent,
+ * turning, depth int32 [C]. */
+int exmc_hip_build_subtree_host(int device, int n_chains, int d, const double* all_q,
+                                const double* all_p, const double* all_logp,
+                                const double* all_grad, int n_states, const double* inv_mass,
+                                const double* joint_logp_0, const int32_t* depth,
+                                const int32_t* going_right, const uint64_t* rng_seed,
+                                double* q_left, double* p_left, double* grad_left,
+                                double* q_right, double* p_right, double* grad_right,
+                                double* q_prop, double* logp_prop, double* grad_prop,
+                                double* log_sum_weight, int32_t* n_steps, int32_t* divergent,
+                                double* accept_sum, int32_t* turning, int32_t* subtree_depth,
+                                double* rho);
+
 /* wall-clock of the last timed kernel region on the handle's stream, HIP events (ms) */
 double exmc_hip_last_kernel_ms(const exmc_hip_model* m);
 

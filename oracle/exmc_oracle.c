@@ -1454,6 +1454,29 @@ void exo_nt_build_and_merge(exo_nt_traj* tr, const double* aq, const double* ap,
   exo_xoshiro_seed_from_u64(rng, seed);
   nt_run_subtree(tr, aq, ap, alp, ag, im, jlp0, depth, d, go_right, rng);
 }
+void exo_nt_build_subtree(const double* aq, const double* ap, const double* alp, const double* ag,
+                          const double* im, double jlp0, int depth, int d, int going_right,
+                          uint64_t seed, double* vecs, double* scalars, int* ints) {
+  /* lib.rs:114-212: the subtree record. vecs = qL,pL,gL,qR,pR,gR,qP,gP,rho (9*d);
+   * scalars = logp_prop, log_sum_weight, accept_sum; ints = n_steps, divergent, turning, depth */
+  uint64_t rng[4];
+  exo_xoshiro_seed_from_u64(rng, seed);
+  ntctx t;
+  t.all_q = aq; t.all_p = ap; t.all_logp = alp; t.all_g = ag; t.im = im;
+  t.d = d; t.jlp0 = jlp0; t.rng = rng;
+  t.arena = (double*)malloc(sizeof(double) * 9 * d * (3 * (EXO_MAX_DEPTH + 2) + 2));
+  t.top = 0;
+  node sub;
+  nt_node_alloc(&t, &sub);
+  int counter = 0;
+  nt_build_subtree(&t, depth, going_right, &counter, &sub);
+  vcp(vecs, sub.qL, d); vcp(vecs + d, sub.pL, d); vcp(vecs + 2 * d, sub.gL, d);
+  vcp(vecs + 3 * d, sub.qR, d); vcp(vecs + 4 * d, sub.pR, d); vcp(vecs + 5 * d, sub.gR, d);
+  vcp(vecs + 6 * d, sub.qP, d); vcp(vecs + 7 * d, sub.gP, d); vcp(vecs + 8 * d, sub.rho, d);
+  scalars[0] = sub.logpP; scalars[1] = sub.lsw; scalars[2] = sub.acc;
+  ints[0] = sub.n; ints[1] = sub.div; ints[2] = sub.turn; ints[3] = sub.depth;
+  free(t.arena);
+}
 void exo_nt_get_result(const exo_nt_traj* t, double* q, double* g, exo_tree_result* res) {
   vcp(q, t->qP, t->d);
   vcp(g, t->gP, t->d);

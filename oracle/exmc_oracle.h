@@ -189,6 +189,12 @@ void exo_nt_build_and_merge(exo_nt_traj* t, const double* all_q, const double* a
                             const double* all_logp, const double* all_g, const double* inv_mass,
                             double jlp0, int depth, int d, int go_right, uint64_t seed);
 void exo_nt_get_result(const exo_nt_traj* t, double* q, double* g, exo_tree_result* res);
+/* build_subtree_bin (lib.rs:114-212): vecs = qL,pL,gL,qR,pR,gR,qP,gP,rho (9*d doubles);
+ * scalars = logp_prop, log_sum_weight, accept_sum; ints = n_steps, divergent, turning, depth */
+void exo_nt_build_subtree(const double* all_q, const double* all_p, const double* all_logp,
+                          const double* all_g, const double* inv_mass, double jlp0, int depth,
+                          int d, int going_right, uint64_t seed, double* vecs, double* scalars,
+                          int* ints);
 void exo_nt_build_full_tree(const double* q0, const double* p0, const double* g0, double logp0,
                             const double* fwd_q, const double* fwd_p, const double* fwd_logp,
                             const double* fwd_g, int n_fwd, const double* bwd_q,

@@ -156,6 +156,8 @@ def lib():
     L.exo_nt_build_and_merge.argtypes = [C.c_void_p, dp, dp, dp, dp, dp, C.c_double, C.c_int,
                                          C.c_int, C.c_int, C.c_uint64]
     L.exo_nt_get_result.argtypes = [C.c_void_p, dp, dp, C.POINTER(TreeResult)]
+    L.exo_nt_build_subtree.argtypes = [dp, dp, dp, dp, dp, C.c_double, C.c_int, C.c_int, C.c_int,
+                                       C.c_uint64, dp, dp, C.POINTER(C.c_int)]
     L.exo_nt_build_full_tree.argtypes = [dp, dp, dp, C.c_double, dp, dp, dp, dp, C.c_int, dp, dp,
                                          dp, dp, C.c_int, dp, C.c_double, C.c_int, C.c_int,
                                          C.c_uint64, dp, dp, C.POINTER(TreeResult)]

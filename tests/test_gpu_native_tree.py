@@ -112,3 +112,162 @@ def test_badarg_is_reported(hip):
                                         np.zeros((2, 1)), np.zeros((2, 1, 3)), np.zeros((2, 1, 3)),
                                         np.zeros((2, 1, 3)), np.zeros((2, 1)), np.zeros((2, 1, 3)),
                                         np.ones(3), np.zeros(2), 3, 3, [1, 2])
+
+
+def _ms_chain(om, q, p, g, eps, im, n, cfg):
+    aq, ap, alp, ag = om.multi_step(q, p, g, eps, im, n, cfg)
+    return aq, ap, alp, ag
+
+
+def test_incremental_trajectory_interface_bit_exact(hip):
+    """The NIF's resource interface (init_trajectory_bin, get_endpoint_bin, build_and_merge_bin,
+    is_terminated, get_result_bin; tree.ex:735-830 drives it one doubling at a time) for 40 chains
+    at once against the checker's restatement of lib.rs / tree.rs driven the same way: chains
+    terminate at different depths, terminated chains are skipped with depth -1."""
+    L = O.lib()
+    L.exo_nt_set_math_mode(1)
+    try:
+        om = O.eight_schools()
+        rng = np.random.default_rng(11)
+        Cn, d, eps, max_depth = 40, 10, 0.45, 6
+        cfg = O.Cfg(1, 1)
+        im = np.ascontiguousarray(rng.uniform(0.5, 2.0, size=d))
+        q0 = rng.normal(size=(Cn, d)) * 0.5
+        p0 = rng.normal(size=(Cn, d)) / np.sqrt(im)
+        g0 = np.zeros((Cn, d)); logp0 = np.zeros(Cn); jlp0 = np.zeros(Cn)
+        for c in range(Cn):
+            logp0[c], g0[c] = om.logp_grad(q0[c], cfg)
+            jlp0[c] = logp0[c] - L.exo_kinetic_energy(O.dptr(np.ascontiguousarray(p0[c])), O.dptr(im), d, cfg)
+        T = native_tree.Trajectories(q0, p0, g0, logp0)
+        refs = [L.exo_nt_init_trajectory(O.dptr(np.ascontiguousarray(q0[c])),
+                                         O.dptr(np.ascontiguousarray(p0[c])),
+                                         O.dptr(np.ascontiguousarray(g0[c])), float(logp0[c]), d)
+                for c in range(Cn)]
+        depth_now = np.zeros(Cn, np.int32)
+        finished_at = set()
+        for it in range(max_depth):
+            term = T.is_terminated()
+            assert [bool(L.exo_nt_is_terminated(r)) for r in refs] == term.tolist()
+            if term.all():
+                break
+            go_right = rng.integers(0, 2, size=Cn).astype(np.int32)
+            seeds = rng.integers(0, 10 ** 12, size=Cn).astype(np.uint64)
+            eq, ep, eg = T.get_endpoint_bin(go_right)
+            n = 1 << it
+            aq = np.zeros((Cn, n, d)); ap = np.zeros((Cn, n, d)); ag = np.zeros((Cn, n, d))
+            alp = np.zeros((Cn, n))
+            depth = np.where(term, -1, depth_now).astype(np.int32)
+            for c in range(Cn):
+                oq, op_, og = np.zeros(d), np.zeros(d), np.zeros(d)
+                L.exo_nt_get_endpoint(refs[c], int(go_right[c]), O.dptr(oq), O.dptr(op_), O.dptr(og))
+                assert np.array_equal(oq, eq[c]) and np.array_equal(op_, ep[c]) and np.array_equal(og, eg[c])
+                if term[c]:
+                    finished_at.add(int(depth_now[c]))
+                    continue
+                assert depth_now[c] == it
+                e = eps if go_right[c] else -eps
+                aq[c], ap[c], alp[c], ag[c] = _ms_chain(om, eq[c], ep[c], eg[c], e, im, n, cfg)
+                L.exo_nt_build_and_merge(refs[c], O.dptr(np.ascontiguousarray(aq[c])),
+                                         O.dptr(np.ascontiguousarray(ap[c])),
+                                         O.dptr(np.ascontiguousarray(alp[c])),
+                                         O.dptr(np.ascontiguousarray(ag[c])), O.dptr(im),
+                                         float(jlp0[c]), it, d, int(go_right[c]), int(seeds[c]))
+            assert T.build_and_merge_bin(aq, ap, alp, ag, im, jlp0, depth, d, go_right, seeds) == "ok"
+            depth_now = np.where(term, depth_now, depth_now + 1).astype(np.int32)
+        res = T.get_result_bin()
+        for c in range(Cn):
+            qo, go = np.zeros(d), np.zeros(d)
+            r = O.TreeResult()
+            L.exo_nt_get_result(refs[c], O.dptr(qo), O.dptr(go), C.byref(r))
+            assert (res["n_steps"][c], res["depth"][c], bool(res["divergent"][c])) == \
+                (r.n_steps, r.depth, bool(r.divergent)), c
+            assert res["accept_sum"][c] == r.accept_sum and res["logp"][c] == r.logp, c
+            assert np.array_equal(res["q_bin"][c], qo) and np.array_equal(res["grad_bin"][c], go), c
+            L.exo_nt_free(refs[c])
+        assert len(set(res["depth"].tolist())) > 1   # chains stopped at different depths
+    finally:
+        L.exo_nt_set_math_mode(0)
+
+
+@pytest.mark.parametrize("depth,eps", [(0, 0.3), (3, 0.3), (5, 0.6)])
+def test_build_subtree_bin_bit_exact(hip, depth, eps):
+    """build_subtree_bin (lib.rs:114-212) batched: every field of the subtree record, including
+    subtrees that stop early on a U-turn or a divergence (large eps)."""
+    L = O.lib()
+    L.exo_nt_set_math_mode(1)
+    try:
+        om = O.eight_schools()
+        rng = np.random.default_rng(depth + 3)
+        Cn, d, n = 33, 10, 1 << depth
+        cfg = O.Cfg(1, 1)
+        im = np.ascontiguousarray(rng.uniform(0.5, 2.0, size=d))
+        aq = np.zeros((Cn, n, d)); ap = np.zeros((Cn, n, d)); ag = np.zeros((Cn, n, d))
+        alp = np.zeros((Cn, n)); jlp0 = np.zeros(Cn)
+        going_right = rng.integers(0, 2, size=Cn).astype(np.int32)
+        seeds = rng.integers(0, 10 ** 12, size=Cn).astype(np.uint64)
+        for c in range(Cn):
+            q0 = rng.normal(size=d) * 0.5
+            p0 = rng.normal(size=d) / np.sqrt(im)
+            lp0, g0 = om.logp_grad(q0, cfg)
+            jlp0[c] = lp0 - L.exo_kinetic_energy(O.dptr(np.ascontiguousarray(p0)), O.dptr(im), d, cfg)
+            e = eps if going_right[c] else -eps
+            aq[c], ap[c], alp[c], ag[c] = _ms_chain(om, q0, p0, g0, e, im, n, cfg)
+        res = native_tree.build_subtree_bin(aq, ap, alp, ag, im, jlp0, depth, d, going_right, seeds)
+        keys = ["q_left_bin", "p_left_bin", "grad_left_bin", "q_right_bin", "p_right_bin",
+                "grad_right_bin", "q_prop_bin", "grad_prop_bin", "rho_bin"]
+        stopped_early = 0
+        for c in range(Cn):
+            vecs, sc, it = np.zeros(9 * d), np.zeros(3), np.zeros(4, np.int32)
+            L.exo_nt_build_subtree(O.dptr(np.ascontiguousarray(aq[c])), O.dptr(np.ascontiguousarray(ap[c])),
+                                   O.dptr(np.ascontiguousarray(alp[c])), O.dptr(np.ascontiguousarray(ag[c])),
+                                   O.dptr(im), float(jlp0[c]), depth, d, int(going_right[c]),
+                                   int(seeds[c]), O.dptr(vecs), O.dptr(sc),
+                                   it.ctypes.data_as(C.POINTER(C.c_int)))
+            for i, k in enumerate(keys):
+                assert np.array_equal(res[k][c], vecs[i * d:(i + 1) * d]), (k, c)
+            assert (res["logp_prop"][c], res["log_sum_weight"][c], res["accept_sum"][c]) == tuple(sc), c
+            assert (res["n_steps"][c], int(res["divergent"][c]), int(res["turning"][c]),
+                    res["depth"][c]) == tuple(int(x) for x in it), c
+            stopped_early += int(res["n_steps"][c] < n)
+        if depth == 5:
+            assert stopped_early > 0
+    finally:
+        L.exo_nt_set_math_mode(0)
+
+
+def test_trajectory_fixture_init_and_endpoints(hip):
+    """test/native_tree_test.exs:38-61: a fresh trajectory returns its start state from both ends."""
+    c = GOLD["init_get"]
+    T = native_tree.Trajectories([c["q"]], [c["p"]], [c["grad"]], [c["logp"]])
+    r = T.get_result_bin()
+    assert r["q_bin"][0].tolist() == c["q"] and r["grad_bin"][0].tolist() == c["grad"]
+    assert (r["logp"][0], r["n_steps"][0], bool(r["divergent"][0]), r["accept_sum"][0], r["depth"][0]) == \
+        (c["logp"], 0, False, 0.0, 0)
+    assert not T.is_terminated()[0]
+    for go_right in (1, 0):
+        q, p, g = T.get_endpoint_bin(go_right)
+        assert q[0].tolist() == c["q"] and p[0].tolist() == c["p"] and g[0].tolist() == c["grad"]
+
+
+@pytest.mark.parametrize("name", ["depth0", "depth1", "divergent"])
+def test_trajectory_fixture_build_and_merge(hip, name):
+    """test/native_tree_test.exs:63-178 through the GPU entry points: depth-0 merge => n_steps 1 and
+    depth 1; depth-1 => n_steps 2; logp -1e10 => divergent and terminated."""
+    c = GOLD[name]
+    d = c["d"]
+    T = native_tree.Trajectories([c["q"]], [c["p"]], [c["grad"]], [c["logp"]])
+    n = len(c["all_logp"])
+    shp = lambda k: np.array(c[k], dtype=np.float64).reshape(1, n, d)  # noqa: E731
+    assert T.build_and_merge_bin(shp("all_q"), shp("all_p"), np.array([c["all_logp"]]), shp("all_grad"),
+                                 c["inv_mass"], c["jlp0"], c["depth"], d, int(c["go_right"]),
+                                 c["seed"]) == "ok"
+    r = T.get_result_bin()
+    e = c["expect"]
+    if "n_steps" in e:
+        assert r["n_steps"][0] == e["n_steps"]
+    if "depth" in e:
+        assert r["depth"][0] == e["depth"]
+    if "divergent" in e:
+        assert bool(r["divergent"][0]) == e["divergent"]
+    if e.get("terminated"):
+        assert T.is_terminated()[0]
