@@ -20,6 +20,7 @@ EXPORTS = [
     "exmc_hip_traj_create", "exmc_hip_traj_destroy", "exmc_hip_traj_get_endpoint_host",
     "exmc_hip_traj_build_and_merge_host", "exmc_hip_traj_is_terminated_host",
     "exmc_hip_traj_get_result_host", "exmc_hip_build_subtree_host",
+    "exmc_hip_stream_begin", "exmc_hip_stream_next_host",
 ]
 
 
@@ -88,6 +89,8 @@ def load():
     L.exmc_hip_build_full_tree_host.argtypes = [
         C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, dp, dp, C.c_int, dp, dp, dp, dp,
         C.c_int, dp, dp, C.c_int, C.POINTER(C.c_uint64), dp, dp, dp, ip, ip, dp, ip]
+    L.exmc_hip_stream_begin.argtypes = [vp, dp, Opts, C.POINTER(Tuning)]
+    L.exmc_hip_stream_next_host.argtypes = [vp, C.c_int, Trace, ip]
     up = C.POINTER(C.c_uint64)
     L.exmc_hip_traj_create.argtypes = [C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, C.POINTER(vp)]
     L.exmc_hip_traj_destroy.argtypes = [vp]

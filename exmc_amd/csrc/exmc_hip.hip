@@ -1065,6 +1065,47 @@ int exmc_hip_sample_host(exmc_hip_model* m, const double* init_q, exmc_hip_opts 
   return download_trace(m, L, o.num_samples, 1, tr);
 }
 
+int exmc_hip_stream_begin(exmc_hip_model* m, const double* init_q, exmc_hip_opts o,
+                          exmc_hip_tuning* tuning_out) {
+  if (check_model(m)) return EXMC_ERR_BADARG;
+  exmc_hip_tuning tun;
+  int rc = exmc_hip_warmup(m, init_q, o, &tun);  // leaves chain 0's state in m->state
+  if (rc) return rc;
+  rc = upload_tuning(m, tun.inv_mass);
+  if (rc) return rc;
+  // the warmup chain stays resident and is advanced on demand (same state the one-launch
+  // exmc_hip_sample_host continues from)
+  m->res_C = 1;
+  m->res_lanes = resolve_lanes(m, o.lanes_per_chain);
+  m->res_eps = tun.epsilon;
+  m->res_max_depth = o.max_tree_depth;
+  if (tuning_out) *tuning_out = tun;
+  return EXMC_OK;
+}
+
+int exmc_hip_stream_next_host(exmc_hip_model* m, int n_draws, exmc_hip_trace tr,
+                              int32_t* divergences) {
+  if (check_model(m)) return EXMC_ERR_BADARG;
+  if (m->res_C != 1) return fail(EXMC_ERR_BADARG, "no stream: call exmc_hip_stream_begin");
+  if (n_draws < 1) return fail(EXMC_ERR_BADARG, "n_draws must be >= 1");
+  HIP_TRY(hipSetDevice(m->device));
+  TraceLayout L = trace_layout(n_draws, m->d, 1);
+  int rc = m->trace.ensure(L.total);
+  if (rc) return rc;
+  rc = reset_counters(m);
+  if (rc) return rc;
+  rc = launch_nuts(m, m->res_lanes, 1, n_draws, 0, m->res_eps, m->res_max_depth,
+                   trace_view(m->trace.p, L), true);
+  if (rc) return rc;
+  rc = finish_timing(m);
+  if (rc) return rc;
+  int32_t div = 0;
+  rc = read_counters(m, nullptr, &div);
+  if (rc) return rc;
+  if (divergences) *divergences = div;
+  return download_trace(m, L, n_draws, 1, tr);
+}
+
 int exmc_hip_build_full_tree_host(int device, int C, int d, const double* q0, const double* p0,
                                   const double* g0, const double* logp0, const double* fwd_q,
                                   const double* fwd_p, const double* fwd_logp, const double* fwd_g,

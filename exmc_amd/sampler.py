@@ -226,14 +226,31 @@ def sample_chains(ir, num_chains, opts=None):
 
 def sample_stream(ir, receiver, init_values=None, opts=None):
     """Exmc.NUTS.Sampler.sample_stream/4: `receiver` is called with the reference's messages,
-    ("exmc_sample", i, point_map, step_stat) for i = 1..n then ("exmc_done", n). Draws are produced
-    by one GPU launch and delivered in order (per-draw host notification is a later row)."""
+    ("exmc_sample", i, point_map, step_stat) for i = 1..n then ("exmc_done", n). The warmup runs
+    first; the draws are then produced `stream_chunk` (default 50) at a time by the resident chain
+    (exmc_hip_stream_begin / _next_host) and delivered as each chunk lands, so the receiver sees
+    samples while the chain is still running. The stream equals sample/3's draws bit for bit."""
     o = _merge_opts(opts)
-    trace, stats = sample(ir, init_values, o)
-    n = o["num_samples"]
-    names = list(trace.keys())
-    for i in range(n):
-        point_map = {k: float(trace[k][i]) for k in names}
-        receiver(("exmc_sample", i + 1, point_map, stats["sample_stats"][i]))
+    compiled = ir if isinstance(ir, Compiled) else Compiled(ir, device=o.get("device", 0))
+    spec = compiled.spec
+    L = _lib.load()
+    n = int(o["num_samples"])
+    chunk = max(1, int(o.get("stream_chunk", 50)))
+    tun = _lib.Tuning()
+    iq = _init_q(spec, init_values)
+    _lib.check(L.exmc_hip_stream_begin(compiled.h, None if iq is None else _dp(iq), _c_opts(o),
+                                       C.byref(tun)))
+    sent = 0
+    while sent < n:
+        m = min(chunk, n - sent)
+        t, tr = _host_trace(1, m, spec.d)
+        div = C.c_int32()
+        _lib.check(L.exmc_hip_stream_next_host(compiled.h, m, tr, C.byref(div)))
+        x = spec.constrain(t["draws"][0])
+        ss = SampleStats(t, 0)
+        for i in range(m):
+            point_map = {name: float(x[i, j]) for j, name in enumerate(spec.var_names)}
+            receiver(("exmc_sample", sent + i + 1, point_map, ss[i]))
+        sent += m
     receiver(("exmc_done", n))
     return "ok"

@@ -155,6 +155,16 @@ int exmc_hip_sample_host(exmc_hip_model* m, const double* init_q, exmc_hip_opts 
                          exmc_hip_trace trace_host, exmc_hip_tuning* tuning_out,
                          int32_t* divergences);
 
+/* Exmc.NUTS.Sampler.sample_stream/4 (sampler.ex:1186-1277), pull style: _begin runs the warmup
+ * and keeps the chain resident; each _next call draws the next n_draws transitions of that chain
+ * into host buffers [n_draws][..], so the binding can emit {:exmc_sample, i, point, stat} messages
+ * while later draws are still to come (the library itself never calls back into the VM). The
+ * concatenated draws equal exmc_hip_sample_host's bit for bit. */
+int exmc_hip_stream_begin(exmc_hip_model* m, const double* init_q, exmc_hip_opts opts,
+                          exmc_hip_tuning* tuning_out);
+int exmc_hip_stream_next_host(exmc_hip_model* m, int n_draws, exmc_hip_trace trace_host,
+                              int32_t* divergences);
+
 /* Exmc.Diagnostics.ess / rhat (lib/exmc/diagnostics.ex:42-52, 80-115) over a device trace
  * [draw][dim][chain]: ess_out dev [dim][chain]; rhat computed across all chains per dim. */
 int exmc_hip_ess(exmc_hip_model* m, const double* draws_dev, int n_draws, int d, int n_chains,

@@ -272,3 +272,20 @@ def test_bench_protocol_other_models_bit_exact(hip, name, factory, lanes, n_chai
     assert extra["total_leapfrogs"] == st.total_leapfrogs
     if name == "sv":
         assert t["tree_depth"].max() >= 7   # the global spill levels were exercised
+
+
+@pytest.mark.parametrize("chunk", [1, 7, 64])
+def test_sample_stream_equals_sample(hip, chunk):
+    """sample_stream/4 (sampler.ex:1186-1277): the messages ("exmc_sample", i, point, stat) for
+    i = 1..n then ("exmc_done", n), produced chunk by chunk from the resident chain, carry exactly
+    the draws and statistics of sample/3 under the same seed, whatever the chunk size."""
+    spec = models.eight_schools()
+    opts = dict(num_warmup=120, num_samples=45, seed=8, stream_chunk=chunk)
+    trace, stats = sampler.sample(spec, spec.default_init, opts)
+    msgs = []
+    assert sampler.sample_stream(spec, msgs.append, spec.default_init, opts) == "ok"
+    assert msgs[-1] == ("exmc_done", 45) and len(msgs) == 46
+    for i, (tag, idx, point, stat) in enumerate(msgs[:-1]):
+        assert tag == "exmc_sample" and idx == i + 1
+        assert all(point[k] == float(trace[k][i]) for k in trace)
+        assert stat == stats["sample_stats"][i]
