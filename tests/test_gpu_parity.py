@@ -289,3 +289,51 @@ def test_sample_stream_equals_sample(hip, chunk):
         assert tag == "exmc_sample" and idx == i + 1
         assert all(point[k] == float(trace[k][i]) for k in trace)
         assert stat == stats["sample_stats"][i]
+
+
+def _all_models():
+    return [("eight_schools", models.eight_schools, [16]),
+            ("sv", lambda: __import__("bench").make_spec("sv")[0], [64]),
+            ("logistic", models.logistic, [16]),
+            ("radon", models.radon, [64])]
+
+
+@pytest.mark.parametrize("name,factory,lane_list", _all_models(), ids=lambda x: x if isinstance(x, str) else "")
+def test_logp_grad_extreme_operands_bit_exact(hip, name, factory, lane_list):
+    """The kernels divide without the hardware's range instructions only while every watched
+    operand is inside 2^+-380 (exmc_device.hpp: Div); outside it a wavefront re-evaluates with the
+    ordinary division. Positions that push scales, residuals and prior arguments to zero, to the
+    clamp of the log transform, to 1e+-150 and beyond must give the checker's bits either way
+    (NaN where the checker gives NaN)."""
+    spec = factory()
+    comp = sampler.compile(spec)
+    om = O.Model(spec.kind, spec.d, spec.data)
+    rng = np.random.default_rng(17)
+    d = spec.d
+    rows = [np.zeros(d), np.full(d, 1e-300), np.full(d, -1e-300), np.full(d, 1e-160),
+            np.full(d, 345.0), np.full(d, -345.0), np.full(d, 1e150), np.full(d, -1e150),
+            np.full(d, 199.999), np.full(d, -199.999), np.full(d, 200.0), np.full(d, -250.0)]
+    for scale in (1e-200, 1e-8, 30.0, 150.0, 400.0, 1e100):
+        rows.append(rng.normal(size=d) * scale)
+    base = rng.normal(size=d) * 0.3
+    for i in range(0, d, max(1, d // 12)):      # one extreme coordinate in an ordinary position
+        for v in (0.0, 1e-310, 700.0, -700.0, 1e308):
+            r = base.copy()
+            r[i] = v
+            rows.append(r)
+    for i in range(max(0, d - 5), d):           # the scale / hyper-parameters sit at the end
+        for v in (0.0, 150.0, -150.0, 260.0, -260.0):
+            r = base.copy()
+            r[i] = v
+            rows.append(r)
+    q = np.ascontiguousarray(np.array(rows))
+    C_ = q.shape[0]
+    for lanes in lane_list:
+        lp = np.zeros(C_)
+        g = np.zeros((C_, d))
+        _lib.check(hip.exmc_hip_logp_grad_host(comp.h, _dp(q), C_, lanes, _dp(lp), _dp(g)))
+        cfg = O.Cfg(1, lanes)
+        for c in range(C_):
+            olp, og = om.logp_grad(q[c], cfg)
+            assert np.array_equal(np.array([olp]), np.array([lp[c]]), equal_nan=True), (name, c, olp, lp[c])
+            assert np.array_equal(og, g[c], equal_nan=True), (name, c, og, g[c])
