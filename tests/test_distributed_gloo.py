@@ -46,8 +46,13 @@ def _worker(rank, world, port, n_chains, S, out_dir):
     lf = xd.reduce_sum(torch.tensor([float(st.total_leapfrogs)], dtype=torch.float64), dist)
     tmax = xd.reduce_max(torch.tensor([float(rank + 1)], dtype=torch.float64), dist)
     rhat = xd.split_rhat(allt)
+    # the default bench path: all-gather of per-chain half-chain statistics instead of the traces
+    hm, hv, hn = xd.half_chain_stats(local)
+    rhat_stats = xd.split_rhat_from_stats(xd.gather_chain_stats(hm, dist),
+                                          xd.gather_chain_stats(hv, dist), hn)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), all=allt.numpy(), ess=ess_t.numpy(),
-             lf=lf.numpy(), tmax=tmax.numpy(), rhat=rhat.numpy(), eps=st.step_size)
+             lf=lf.numpy(), tmax=tmax.numpy(), rhat=rhat.numpy(), rhat_stats=rhat_stats.numpy(),
+             eps=st.step_size)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -86,4 +91,5 @@ def test_two_rank_gloo_sharding_matches_single_process(tmp_path):
         assert z["tmax"][0] == world
         assert float(z["eps"]) == st.step_size               # every rank re-derives the same tuning
         assert np.allclose(z["rhat"], xd.split_rhat(torch.from_numpy(ref)).numpy())
+        assert np.allclose(z["rhat_stats"], z["rhat"], rtol=1e-12, atol=0.0)
         assert np.all(np.abs(z["rhat"] - 1.0) < 0.5)
