@@ -187,6 +187,27 @@ __device__ __forceinline__ double group_bcast_c(double v) {
   }
 }
 
+// the value held by the previous / next lane of the chain group, wrapping inside the group:
+// DPP row rotates for G = 16, wavefront rotates for G = 64, ds_bpermute otherwise
+template <int G>
+__device__ __forceinline__ double group_rot_prev(double v) {   // lane l <- lane (l - 1) mod G
+  if constexpr (G == 64) return dpp_move<0x13C>(v);             // wave_ror:1
+  else if constexpr (G == 16) return dpp_move<0x121>(v);        // row_ror:1
+  else {
+    const int lane = threadIdx.x & 63;
+    return __shfl(v, (lane & ~(G - 1)) | ((lane + G - 1) & (G - 1)), 64);
+  }
+}
+template <int G>
+__device__ __forceinline__ double group_rot_next(double v) {   // lane l <- lane (l + 1) mod G
+  if constexpr (G == 64) return dpp_move<0x134>(v);             // wave_rol:1
+  else if constexpr (G == 16) return dpp_move<0x12F>(v);        // row_ror:15
+  else {
+    const int lane = threadIdx.x & 63;
+    return __shfl(v, (lane & ~(G - 1)) | ((lane + 1) & (G - 1)), 64);
+  }
+}
+
 // One evaluation of f for N different group-uniform arguments: lane i of the group evaluates
 // x[i] (the other lanes x[0]) and the results are broadcast back. Scalar per-chain work is the same
 // instruction stream whatever its argument, so N calls of a 45-instruction log cost one call plus

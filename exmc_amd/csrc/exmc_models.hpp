@@ -294,20 +294,15 @@ struct SV : ModelDefaults {
     const double An = (lg1 - lg0) - 0.5 * lx[0];
     const double dAn = (0.5 * d1 - 0.5 * d0) - dv(0.5, rsdf);
     const double cn = c.log2pi32 + 2.0 * lx[1];
-    const int lane = threadIdx.x & 63;
-    const int base = lane & ~(G - 1);
-    const int prev_lane = base | ((l + G - 1) & (G - 1));
-    const int next_lane = base | ((l + 1) & (G - 1));
     double P[DPL], LL[DPL], E2[DPL], DN[DPL], de[DPL];
     bool valid[DPL];
-    // previous-state values: dim i-1 is (lane l-1, slot k) or (lane G-1, slot k-1) when l == 0
-    double qprev[DPL];
+    // previous-state values: dim i-1 is (lane l-1, slot k) or (lane G-1, slot k-1) when l == 0:
+    // one rotate of the group per slot delivers both (lane 0 receives lane G-1's value)
+    double qrot[DPL], qprev[DPL];
 #pragma unroll
-    for (int k = 0; k < DPL; k++) {
-      const double same = __shfl(q[k], prev_lane, 64);
-      const double lower = (k > 0) ? __shfl(q[k > 0 ? k - 1 : 0], prev_lane, 64) : 0.0;
-      qprev[k] = (l > 0) ? same : lower;
-    }
+    for (int k = 0; k < DPL; k++) qrot[k] = group_rot_prev<G>(q[k]);
+#pragma unroll
+    for (int k = 0; k < DPL; k++) qprev[k] = (l > 0) ? qrot[k] : ((k > 0) ? qrot[k > 0 ? k - 1 : 0] : 0.0);
 #pragma unroll
     for (int k = 0; k < DPL; k++) {
       const int i = l + k * G;
@@ -332,11 +327,14 @@ struct SV : ModelDefaults {
       g[k] = -1.0 + (sdf + 1.0) * wr;
     }
     // dP_{t+1}/ds_{t+1} from dim i+1: (lane l+1, slot k) or (lane 0, slot k+1) when l == G-1
+    double drot[DPL];
+#pragma unroll
+    for (int k = 0; k < DPL; k++) drot[k] = group_rot_next<G>(de[k]);
 #pragma unroll
     for (int k = 0; k < DPL; k++) {
       const int i = l + k * G;
-      const double same = __shfl(de[k], next_lane, 64);
-      const double upper = (k + 1 < DPL) ? __shfl(de[k + 1 < DPL ? k + 1 : k], next_lane, 64) : 0.0;
+      const double same = drot[k];
+      const double upper = (k + 1 < DPL) ? drot[k + 1 < DPL ? k + 1 : k] : 0.0;
       double nxt = (l < G - 1) ? same : upper;
       nxt = (i + 1 < T) ? nxt : 0.0;
       g[k] = g[k] + (de[k] - nxt);
