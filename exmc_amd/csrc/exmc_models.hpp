@@ -382,8 +382,20 @@ struct Logistic : ModelDefaults {
   static constexpr int D = K + 1;
   static constexpr int DPL = (D + G - 1) / G;
   using Consts = LogisticConsts;
-  struct Lane {};
-  __device__ static __forceinline__ void load(const Consts&, int, Lane&) {}
+  // LDS image of X and y for single-workgroup kernels (the adaptation warmup): with one wave on
+  // the whole chip every row of X is otherwise an exposed L2 round trip, 32 times per leapfrog
+  static constexpr int kObsCap = 512;
+  static constexpr int kRowStride = K + 1;   // 21 doubles: rows 16 apart fall in different LDS banks
+  static constexpr int kStageDoubles = kObsCap * kRowStride + kObsCap;
+  struct Lane {
+    const double* xs;   // LDS image [N][kRowStride] then y, or null (rows stream from L2)
+  };
+  __device__ static __forceinline__ void load(const Consts&, int, Lane& ln) { ln.xs = nullptr; }
+  // cooperative (whole workgroup); the caller synchronises afterwards and guarantees N <= kObsCap
+  __device__ static __forceinline__ void stage(const Consts& c, double* dst) {
+    for (int i = threadIdx.x; i < c.N * K; i += blockDim.x) dst[(i / K) * kRowStride + i % K] = c.X[i];
+    for (int i = threadIdx.x; i < c.N; i += blockDim.x) dst[kObsCap * kRowStride + i] = c.y[i];
+  }
 
   // every lane needs the whole coefficient vector: dim i lives in slot i / G of lane i % G
   template <int... I>
@@ -392,19 +404,28 @@ struct Logistic : ModelDefaults {
     ((qf[I] = group_bcast_c<G, I % G>(q[I / G])), ...);
   }
 
-  __device__ static __forceinline__ double logp_grad(const Consts& c, const Lane&, int l,
+  __device__ static __forceinline__ double logp_grad(const Consts& c, const Lane& ln, int l,
                                                      const double (&q)[DPL], double (&g)[DPL]) {
     double qf[D];
     bcast_all(q, qf, std::make_integer_sequence<int, D>{});
     double s[D + 1];   // s[0..D-1] gradient partials, s[D] likelihood partial
 #pragma unroll
     for (int j = 0; j <= D; j++) s[j] = 0.0;
+    const bool staged = ln.xs != nullptr;                     // wave-uniform
+    const int xoff = staged ? (int)(ln.xs - exmc_dyn_lds) : 0;
     for (int n = l; n < c.N; n += G) {
-      const double* x = c.X + (size_t)n * K;
-      double xr[K];
+      double xr[K], yn;
+      if (staged) {
+        const double* x = exmc_dyn_lds + xoff + n * kRowStride;
 #pragma unroll
-      for (int j = 0; j < K; j++) xr[j] = x[j];
-      const double yn = c.y[n];
+        for (int j = 0; j < K; j++) xr[j] = x[j];
+        yn = exmc_dyn_lds[xoff + kObsCap * kRowStride + n];
+      } else {
+        const double* x = c.X + (size_t)n * K;
+#pragma unroll
+        for (int j = 0; j < K; j++) xr[j] = x[j];
+        yn = c.y[n];
+      }
       double eta = __builtin_fma(1.0, qf[0], 0.0);
 #pragma unroll
       for (int j = 0; j < K; j++) eta = __builtin_fma(xr[j], qf[1 + j], eta);
