@@ -263,6 +263,12 @@ def main():
         torch.cuda.synchronize()
         gather_s = time.perf_counter() - t0
         rhat = xd.split_rhat_from_stats(hm, hv, hn)
+        if world == 1:
+            # one GPU holds every chain: Diagnostics.rhat in the reference's summation order on
+            # the device (bit-identical to the checker, tests/test_gpu_diagnostics.py)
+            rk = torch.empty((d,), dtype=torch.float64, device=dev)
+            _lib.check(L.exmc_hip_rhat(comp.h, draws.data_ptr(), K, d, Cper, rk.data_ptr()))
+            rhat = rk
     ess_min = float(ess_sum.min())
     total_s = adapt_s + elapsed + gather_s
     value = leapfrogs / elapsed

@@ -1199,6 +1199,22 @@ int exmc_hip_ess(exmc_hip_model* m, const double* draws_dev, int n_draws, int d,
   return finish_timing(m);
 }
 
+int exmc_hip_rhat(exmc_hip_model* m, const double* draws_dev, int n_draws, int d, int n_chains,
+                  double* rhat_dev) {
+  if (check_model(m)) return EXMC_ERR_BADARG;
+  if (!draws_dev || !rhat_dev || n_draws < 4 || d < 1 || n_chains < 1)
+    return fail(EXMC_ERR_BADARG, "bad arguments");
+  HIP_TRY(hipSetDevice(m->device));
+  int rc = m->io.ensure((size_t)d * 4 * n_chains * 8);   // half-chain means and variances
+  if (rc) return rc;
+  HIP_TRY(hipEventRecord(m->ev0, m->stream));
+  hipLaunchKernelGGL(rhat_kernel, dim3((unsigned)d), dim3(256), 0, m->stream, draws_dev, n_draws, d,
+                     n_chains, m->io.as<double>(), rhat_dev);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(m->ev1, m->stream));
+  return finish_timing(m);
+}
+
 }  // extern "C"
 
 // ------------------------------------------------------------------------------------------

@@ -279,4 +279,50 @@ ess_kernel(const double* draws, int S, int D, int C, double* ess_out) {
   }
 }
 
+// Diagnostics.rhat (diagnostics.ex:80-115), split R-hat of one dimension per workgroup over a
+// [S][D][C] trace: each chain split at S/2, both halves trimmed to the shorter length; half-chain
+// means and variances summed left to right over draws (one thread per half-chain, coalesced over
+// chains), then the between / within sums over the 2C half-chains in the reference's order
+// (chain 0 first half, chain 0 second half, chain 1 ...) by one thread. stats: scratch [D][2][2C].
+__global__ void __launch_bounds__(256)
+rhat_kernel(const double* draws, int S, int D, int C, double* stats, double* rhat_out) {
+  const int dim = blockIdx.x;
+  const int mid = S / 2;
+  const int len = mid < (S - mid) ? mid : (S - mid);
+  const int m = 2 * C;
+  double* means = stats + (size_t)dim * 2 * m;
+  double* vars = means + m;
+  const size_t stride = (size_t)D * C;
+  for (int h = threadIdx.x; h < m; h += blockDim.x) {
+    const int c = h % C, half = h / C;     // threads sweep chains first: coalesced loads
+    const double* x = draws + (size_t)(half ? mid : 0) * stride + (size_t)dim * C + c;
+    double sum = 0.0;
+    for (int i = 0; i < len; i++) sum += x[(size_t)i * stride];
+    const double cm = sum / len;
+    double ss = 0.0;
+    for (int i = 0; i < len; i++) {
+      const double dv = x[(size_t)i * stride] - cm;
+      ss += dv * dv;
+    }
+    means[2 * c + half] = cm;
+    vars[2 * c + half] = ss / (len - 1);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double gm = 0.0;
+    for (int k = 0; k < m; k++) gm += means[k];
+    gm /= m;
+    double b = 0.0, w = 0.0;
+    for (int k = 0; k < m; k++) {
+      const double dm = means[k] - gm;
+      b += dm * dm;
+      w += vars[k];
+    }
+    b = (double)len / (m - 1) * b;
+    w /= m;
+    const double var_hat = (double)(len - 1) / len * w + b / len;
+    rhat_out[dim] = __dsqrt_rn(var_hat / w);
+  }
+}
+
 }  // namespace exmc

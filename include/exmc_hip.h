@@ -155,6 +155,11 @@ int exmc_hip_sample_host(exmc_hip_model* m, const double* init_q, exmc_hip_opts 
                          exmc_hip_trace trace_host, exmc_hip_tuning* tuning_out,
                          int32_t* divergences);
 
+/* Exmc.Diagnostics.rhat (lib/exmc/diagnostics.ex:80-115): split R-hat per dimension across the
+ * n_chains chains of a device trace [draw][dim][chain] (n_draws >= 4): rhat_dev [dim]. */
+int exmc_hip_rhat(exmc_hip_model* m, const double* draws_dev, int n_draws, int d, int n_chains,
+                  double* rhat_dev);
+
 /* Exmc.NUTS.Sampler.sample_stream/4 (sampler.ex:1186-1277), pull style: _begin runs the warmup
  * and keeps the chain resident; each _next call draws the next n_draws transitions of that chain
  * into host buffers [n_draws][..], so the binding can emit {:exmc_sample, i, point, stat} messages
@@ -165,8 +170,8 @@ int exmc_hip_stream_begin(exmc_hip_model* m, const double* init_q, exmc_hip_opts
 int exmc_hip_stream_next_host(exmc_hip_model* m, int n_draws, exmc_hip_trace trace_host,
                               int32_t* divergences);
 
-/* Exmc.Diagnostics.ess / rhat (lib/exmc/diagnostics.ex:42-52, 80-115) over a device trace
- * [draw][dim][chain]: ess_out dev [dim][chain]; rhat computed across all chains per dim. */
+/* Exmc.Diagnostics.ess (lib/exmc/diagnostics.ex:42-52, 123-167) of every (dim, chain) series of
+ * a device trace [draw][dim][chain]: ess_dev [dim][chain]. */
 int exmc_hip_ess(exmc_hip_model* m, const double* draws_dev, int n_draws, int d, int n_chains,
                  double* ess_dev);
 
