@@ -108,3 +108,31 @@ def test_no_draws_and_depth_one(hip):
                           num_samples=25, max_tree_depth=1, seed=2, cfg=O.Cfg(1, 16))
     for k in KEYS:
         assert np.array_equal(t[k], ex1["raw"][k][0]), k
+
+
+@pytest.mark.parametrize("name,lanes,n_chains,n_draws", [("eight_schools", 16, 2048, 150),
+                                                        ("logistic", 16, 96, 40),
+                                                        ("radon", 64, 48, 40), ("sv", 64, 12, 12)])
+def test_every_chain_of_a_batch_bit_exact(hip, name, lanes, n_chains, n_draws):
+    """Every chain of a batch against the checker (not a sample of chains): hundreds of thousands of
+    transitions exercise the rare paths of the lock-step walk — subtrees ending early on a U-turn
+    or a divergence while their wave neighbours continue, several ziggurat words of one momentum
+    draw needing the long way, trees of different depth in one wavefront."""
+    import bench
+    spec = bench.make_spec(name)[0]
+    comp = sampler.compile(spec)
+    om = O.Model(spec.kind, spec.d, spec.data)
+    opts = dict(num_warmup=1000, num_samples=n_draws, seed=123, lanes_per_chain=lanes)
+    tuning = sampler.warmup(comp, spec.default_init, opts)
+    _, _, extra = sampler.sample_compiled_tuned(comp, tuning, spec.default_init, opts,
+                                                num_chains=n_chains)
+    t, st = O.sample_chains(om, n_chains, init_q=spec.to_unconstrained(spec.default_init),
+                            num_warmup=1000, num_samples=n_draws, seed=123, n_threads=8,
+                            cfg=O.Cfg(1, lanes))
+    assert st.step_size == tuning["epsilon"]
+    for k in KEYS:
+        assert np.array_equal(t[k], extra["raw"][k]), k
+    assert extra["total_leapfrogs"] == st.total_leapfrogs
+    if name == "eight_schools":
+        ns = extra["raw"]["n_steps"]
+        assert (ns != (1 << extra["raw"]["tree_depth"]) - 1).sum() > 50   # early-ended subtrees occurred
