@@ -50,14 +50,30 @@ __global__ void k(double* out, long long* cyc, double seed) {
   TIME(27, "v_fma_f32 %2, %3, %3, %3\n\t")
   TIME(28, "s_mov_b64 s[20:21], exec\n\t")
   TIME(29, "v_xor_b32 %2, %3, %3\n\t")
+  // branches: 256 taken s_branch to the next instruction / 256 not-taken s_cbranch_execz /
+  // 256 s_cbranch_execz taken over one skipped instruction (exec = 0 inside a saveexec region)
+  t0 = clock64();
+  asm volatile(REP256("s_branch 1f\n\t1:\n\t") ::: "memory");
+  t1 = clock64();
+  cyc[30] = t1 - t0;
+  t0 = clock64();
+  asm volatile(REP256("s_cbranch_execz 1f\n\t1:\n\t") ::: "memory");
+  t1 = clock64();
+  cyc[31] = t1 - t0;
+  t0 = clock64();
+  asm volatile("s_mov_b64 s[22:23], exec\n\t s_mov_b64 exec, 0\n\t"
+               REP256("s_cbranch_execz 1f\n\t v_mov_b32 %0, %0\n\t1:\n\t")
+               "s_mov_b64 exec, s[22:23]\n\t" : "+v"(x) :: "s22", "s23", "memory");
+  t1 = clock64();
+  cyc[32] = t1 - t0;
   out[threadIdx.x] = a + b + x + y + (double)u + (double)w;
 }
 
 int main() {
   double* out; long long* cyc;
-  (void)hipMalloc(&out, 64 * 8); (void)hipMalloc(&cyc, 32 * 8);
+  (void)hipMalloc(&out, 64 * 8); (void)hipMalloc(&cyc, 40 * 8);
   for (int it = 0; it < 2; it++) hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, out, cyc, 1.0);
-  long long h[32];
+  long long h[40];
   (void)hipMemcpy(h, cyc, sizeof h, hipMemcpyDeviceToHost);
   const char* nm[30] = {"v_fma_f64", "v_mul_f64", "v_add_f64", "v_rndne_f64", "v_cvt_i32_f64", "v_cvt_f64_i32",
                         "v_cvt_f64_u32", "v_ldexp_f64", "v_rcp_f64", "v_div_scale_f64", "v_div_fmas_f64",
@@ -66,5 +82,8 @@ int main() {
                         "v_mov_b64", "v_readlane_b32", "v_mov_b32_dpp", "v_frexp_mant_f64",
                         "v_frexp_exp_i32_f64", "v_sqrt_f64", "v_fma_f32", "s_mov_b64", "v_xor_b32"};
   for (int i = 0; i < 30; i++) printf("%-22s %6.2f clocks/instr\n", nm[i], (double)h[i] / 256.0);
+  printf("%-34s %6.2f clocks each\n", "s_branch taken (to next instr)", (double)h[30] / 256.0);
+  printf("%-34s %6.2f clocks each\n", "s_cbranch_execz not taken", (double)h[31] / 256.0);
+  printf("%-34s %6.2f clocks each\n", "s_cbranch_execz taken (skip 1)", (double)h[32] / 256.0);
   return 0;
 }
