@@ -271,3 +271,41 @@ def test_trajectory_fixture_build_and_merge(hip, name):
         assert bool(r["divergent"][0]) == e["divergent"]
     if e.get("terminated"):
         assert T.is_terminated()[0]
+
+
+def test_merge_invariants_on_the_gpu_subtree_records(hip):
+    """test/nuts/statham_merge_test.exs:135-170 (merge_subtrees postconditions) on records produced
+    by the GPU: a depth-3 subtree against the two depth-2 subtrees over the halves of the same
+    states: log_sum_weight = log_sum_exp of the children (1e-10, as the reference asserts), n_steps
+    additive, depth = max + 1, rho additive (exactly: the merge adds the two vectors), divergent
+    monotonic, accept_sum additive; endpoints are the outer endpoints of the children."""
+    om = O.eight_schools()
+    rng = np.random.default_rng(99)
+    Cn, d, n, eps = 24, 10, 8, 0.05     # small step: no U-turn, no early end
+    cfg = O.Cfg(1, 1)
+    L = O.lib()
+    im = np.ascontiguousarray(rng.uniform(0.5, 2.0, size=d))
+    aq = np.zeros((Cn, n, d)); ap = np.zeros((Cn, n, d)); ag = np.zeros((Cn, n, d))
+    alp = np.zeros((Cn, n)); jlp0 = np.zeros(Cn)
+    for c in range(Cn):
+        q0 = rng.normal(size=d) * 0.5
+        p0 = rng.normal(size=d) / np.sqrt(im)
+        lp0, g0 = om.logp_grad(q0, cfg)
+        jlp0[c] = lp0 - L.exo_kinetic_energy(O.dptr(np.ascontiguousarray(p0)), O.dptr(im), d, cfg)
+        aq[c], ap[c], alp[c], ag[c] = _ms_chain(om, q0, p0, g0, eps, im, n, cfg)
+    seeds = rng.integers(0, 10 ** 12, size=Cn).astype(np.uint64)
+    full = native_tree.build_subtree_bin(aq, ap, alp, ag, im, jlp0, 3, d, 1, seeds)
+    a = native_tree.build_subtree_bin(aq[:, :4], ap[:, :4], alp[:, :4], ag[:, :4], im, jlp0, 2, d, 1, seeds)
+    b = native_tree.build_subtree_bin(aq[:, 4:], ap[:, 4:], alp[:, 4:], ag[:, 4:], im, jlp0, 2, d, 1, seeds)
+    assert not full["turning"].any() and not full["divergent"].any()
+    for c in range(Cn):
+        lse = L.exo_log_sum_exp(float(a["log_sum_weight"][c]), float(b["log_sum_weight"][c]), 1)
+        assert abs(full["log_sum_weight"][c] - lse) < 1.0e-10
+    assert np.array_equal(full["n_steps"], a["n_steps"] + b["n_steps"]) and (full["n_steps"] == 8).all()
+    assert np.array_equal(full["depth"], np.maximum(a["depth"], b["depth"]) + 1)
+    assert np.array_equal(full["rho_bin"], a["rho_bin"] + b["rho_bin"])
+    assert np.array_equal(full["divergent"], a["divergent"] | b["divergent"])
+    assert np.allclose(full["accept_sum"], a["accept_sum"] + b["accept_sum"], rtol=1e-14, atol=0)
+    assert np.array_equal(full["q_left_bin"], a["q_left_bin"]) and np.array_equal(full["p_left_bin"], a["p_left_bin"])
+    assert np.array_equal(full["q_right_bin"], b["q_right_bin"]) and np.array_equal(full["p_right_bin"], b["p_right_bin"])
+    assert np.array_equal(full["q_left_bin"], aq[:, 0]) and np.array_equal(full["q_right_bin"], aq[:, 7])
