@@ -11,6 +11,9 @@
 // moves inside a 16-lane row) and, above 16 lanes, on v_readlane: after the row stages every
 // lane of a row holds the row sum, so mirror moves deliver exactly the operands the xor pattern
 // would, and the result is bit-identical to `v[l] + v[l ^ m]` for m = 1, 2, 4, ...
+// Also here: group broadcasts and rotates on DPP / v_readlane, lane-batched evaluation of
+// chain-scalar functions, the division policy (IEEE quotients without the range instructions),
+// the two spellings of exp / log, OTP's exsss generator and its ziggurat normal.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -224,17 +227,6 @@ template <int G, int N, class F>
 __device__ __forceinline__ void lane_batch(double (&x)[N], int l, F&& f) {
   static_assert(N <= G, "one lane per argument");
   lane_batch_impl<G>(x, l, f, std::make_integer_sequence<int, N>{});
-}
-
-// true iff `ok` holds on every lane of this lane's group (the group's lanes are all active)
-template <int G>
-__device__ __forceinline__ bool group_all(bool ok) {
-  if (G == 1) return ok;
-  const unsigned long long b = __ballot(ok);
-  const int lane = threadIdx.x & 63;
-  const int base = lane & ~(G - 1);
-  const unsigned long long m = (G == 64) ? ~0ULL : (((1ULL << G) - 1) << base);
-  return (b & m) == m;
 }
 
 // ---- OTP :rand exsss (Xorshift116**, 58-bit words); call sites sampler.ex:154,343,396,836,897,
