@@ -49,10 +49,18 @@ def make_spec(name):
         return models.logistic(), 1016
     if name == "radon":
         return models.radon(), 4328
+    if name == "gen_eight_schools":
+        # the same posterior written as 26 Builder nodes and compiled by exmc_amd/codegen.py
+        # (one lane per chain, generated value + gradient); not a BASELINE config
+        from exmc_amd import codegen
+        init = {n: 0.0 for n in ["mu"] + ["theta_%d" % j for j in range(8)]}
+        init["tau"] = 1.0
+        return codegen.compile_ir(codegen.eight_schools_ir(), name=name, default_init=init), 488
     raise SystemExit("unknown model %s" % name)
 
 
-DEFAULT_CHAINS_PER_GPU = {"eight_schools": 4096, "logistic": 8192, "sv": 2048, "radon": 1024}
+DEFAULT_CHAINS_PER_GPU = {"eight_schools": 4096, "logistic": 8192, "sv": 2048, "radon": 1024,
+                          "gen_eight_schools": 4096}
 
 
 def measured_traffic(model, chains, steps, lanes):
@@ -72,7 +80,7 @@ def multi_step_roofline(comp, spec, dev, n_chains=262144, n_steps=32, lanes=1, r
     Bytes per launch are algorithmic: reads 3*d*8*C, writes (3*d+1)*8*n*C. Kernel time from the HIP
     events the library records on its own stream."""
     d = spec.d
-    L = _lib.load()
+    L = comp.L
     g = torch.Generator(device=dev).manual_seed(1)
     q = 0.3 * torch.randn((d, n_chains), dtype=torch.float64, device=dev, generator=g)
     p = torch.randn((d, n_chains), dtype=torch.float64, device=dev, generator=g)
@@ -86,7 +94,7 @@ def multi_step_roofline(comp, spec, dev, n_chains=262144, n_steps=32, lanes=1, r
     torch.cuda.synchronize()
     times = []
     for i in range(reps + 1):                      # first launch is untimed warmup
-        _lib.check(L.exmc_hip_multi_step(comp.h, q.data_ptr(), p.data_ptr(), gr.data_ptr(), 0.05, imp,
+        comp.check(L.exmc_hip_multi_step(comp.h, q.data_ptr(), p.data_ptr(), gr.data_ptr(), 0.05, imp,
                                          n_steps, n_chains, lanes, aq.data_ptr(), ap.data_ptr(),
                                          al.data_ptr(), ag.data_ptr()))
         if i:
@@ -111,9 +119,14 @@ def cpu_baseline(spec, init, K, n_chains_total, budget_s=15.0):
     thread) on a bounded sample of the same workload. A reported baseline, not the target."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle as O
-    om = O.Model(spec.kind, spec.d, spec.data)
+    if hasattr(spec, "gen"):
+        # a generated model's CPU form is its own generated text compiled for the host; it only
+        # exists in the deterministic-math spelling
+        import gen_checker
+        om, cfg = gen_checker.model(spec.gen), O.Cfg(1, 1)
+    else:
+        om, cfg = O.Model(spec.kind, spec.d, spec.data), O.Cfg(0, 1)
     q0 = spec.to_unconstrained(init)
-    cfg = O.Cfg(0, 1)
     cores = min(os.cpu_count() or 1, 64)
     t0 = time.perf_counter()
     O.sample_chains(om, 1, init_q=q0, num_warmup=1000, num_samples=K, seed=42, cfg=cfg)
@@ -141,8 +154,9 @@ def cpu_baseline(spec, init, K, n_chains_total, budget_s=15.0):
         "unit": "leapfrog_steps/s",
         "cores": cores,
         "kind": "port",
-        "sample": "%d chains x %d draws after the shared 1000-iteration warmup, oracle libm mode, "
-                  "%d host threads, wall %.2f s (includes the serial warmup)" % (n, K, cores, wall),
+        "sample": "%d chains x %d draws after the shared 1000-iteration warmup, oracle %s mode, "
+                  "%d host threads, wall %.2f s (includes the serial warmup)"
+                  % (n, K, "libm" if cfg.math_mode == 0 else "deterministic-math", cores, wall),
         "ess_per_s": ess_min / wall,
         "chains": n,
         "wall_s": wall,
@@ -194,7 +208,7 @@ def main():
     opts = sampler._merge_opts(dict(num_warmup=args.adapt, num_samples=K, seed=42,
                                     lanes_per_chain=lanes))
     init = spec.default_init
-    L = _lib.load()
+    L = comp.L
 
     # --- shared adaptation warmup: every rank runs it with the same seed (deterministic, so no
     # broadcast is needed) ---
@@ -220,15 +234,15 @@ def main():
     iq = np.ascontiguousarray(spec.to_unconstrained(init))
     iqp = iq.ctypes.data_as(C.POINTER(C.c_double))
     lo, hi = rank * Cper, (rank + 1) * Cper
-    _lib.check(L.exmc_hip_chains_init(comp.h, C.byref(tun), iqp, Ctot, lo, hi, sampler._c_opts(opts)))
+    comp.check(L.exmc_hip_chains_init(comp.h, C.byref(tun), iqp, Ctot, lo, hi, sampler._c_opts(opts)))
     lf, dv = C.c_int64(), C.c_int32()
     if W > 0:
-        _lib.check(L.exmc_hip_chains_advance(comp.h, min(W, K), 0, tr, C.byref(lf), C.byref(dv)))
+        comp.check(L.exmc_hip_chains_advance(comp.h, min(W, K), 0, tr, C.byref(lf), C.byref(dv)))
 
     # --- timed region: exactly K draws for every chain ---
     barrier()
     t0 = time.perf_counter()
-    _lib.check(L.exmc_hip_chains_advance(comp.h, K, 0, tr, C.byref(lf), C.byref(dv)))
+    comp.check(L.exmc_hip_chains_advance(comp.h, K, 0, tr, C.byref(lf), C.byref(dv)))
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = comp.last_kernel_ms
@@ -245,7 +259,7 @@ def main():
     # --- diagnostics: per-chain Geyer ESS on device, summed over chains; RCCL all-gather of the
     # finished traces for split R-hat (the only collective on the path) ---
     ess = torch.empty((d, Cper), dtype=torch.float64, device=dev)
-    _lib.check(L.exmc_hip_ess(comp.h, draws.data_ptr(), K, d, Cper, ess.data_ptr()))
+    comp.check(L.exmc_hip_ess(comp.h, draws.data_ptr(), K, d, Cper, ess.data_ptr()))
     ess_ms = comp.last_kernel_ms
     ess_sum = ess.sum(dim=1)
     if not args.gather_traces:
@@ -270,7 +284,7 @@ def main():
             # one GPU holds every chain: Diagnostics.rhat in the reference's summation order on
             # the device (bit-identical to the checker, tests/test_gpu_diagnostics.py)
             rk = torch.empty((d,), dtype=torch.float64, device=dev)
-            _lib.check(L.exmc_hip_rhat(comp.h, draws.data_ptr(), K, d, Cper, rk.data_ptr()))
+            comp.check(L.exmc_hip_rhat(comp.h, draws.data_ptr(), K, d, Cper, rk.data_ptr()))
             rhat = rk
     ess_min = float(ess_sum.min())
     total_s = adapt_s + elapsed + gather_s

@@ -44,20 +44,25 @@ class Trace(C.Structure):
                 ("energy", C.c_void_p)]
 
 
-_lib = None
+_libs = {}
 
 
 def load():
     """Load libexmc_hip.so. torch (if used in the same process) must be imported first so both
     share one HIP runtime; exmc_amd/__init__ takes care of the order."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+    return bind(LIB_PATH)
+
+
+def bind(path):
+    """Load a library with the include/exmc_hip.h ABI: libexmc_hip.so itself or a plug-in build
+    made for one generated model (exmc_amd/codegen.py)."""
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
         raise ExmcHipError(
-            "libexmc_hip.so is not built (%s): run `python -m exmc_amd.build`; there is no "
-            "CPU fallback" % LIB_PATH)
-    L = C.CDLL(LIB_PATH)
+            "%s is not built: run `python -m exmc_amd.build` (or codegen.build_plugin for a "
+            "generated model); there is no CPU fallback" % path)
+    L = C.CDLL(path)
     dp = C.POINTER(C.c_double)
     vp = C.c_void_p
     L.exmc_hip_last_error.restype = C.c_char_p
@@ -106,11 +111,11 @@ def load():
     L.exmc_hip_rhat.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
     L.exmc_hip_last_kernel_ms.argtypes = [vp]
     L.exmc_hip_last_kernel_ms.restype = C.c_double
-    _lib = L
+    _libs[path] = L
     return L
 
 
-def check(rc):
+def check(rc, L=None):
     if rc != OK:
-        msg = load().exmc_hip_last_error()
+        msg = (L or load()).exmc_hip_last_error()
         raise ExmcHipError("libexmc_hip error %d: %s" % (rc, msg.decode() if msg else ""))

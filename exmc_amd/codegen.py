@@ -1,0 +1,727 @@
+"""Builder IR -> HIP kernel source (restricted first cut).
+
+The reference turns a Builder IR into a logp closure by walking the nodes (compiler.ex:200-269,
+one term per free RV and per obs node, summed by sum_logps :394-395) and leaves the gradient to
+Nx.Defn reverse-mode AD (compiler.ex:131-141); EXLA then JIT-compiles the graph. Here the same
+walk emits straight-line C for value + gradient, hipcc compiles it into a copy of the NUTS
+kernels (one lane per chain, the whole position in registers), and the result is loaded as a
+plug-in library with the same C ABI as libexmc_hip.so (include/exmc_hip.h, kind
+EXMC_MODEL_CUSTOM).
+
+What is covered (everything else raises CodegenError -- there is no interpreter fallback):
+  * scalar free RVs (a vector free RV with an elementwise distribution does not compile in the
+    reference either: sum_logps reshapes every term to {});
+  * Normal, HalfNormal, HalfCauchy, Exponential, Cauchy, Laplace, Lognormal, StudentT and
+    (as an observation) Bernoulli, each restated operation by operation from lib/exmc/dist/;
+  * transforms nil, :log, :softplus, :logit (transform.ex:15-66);
+  * params that are numbers, vectors (observation targets only) or string refs to free RVs
+    (resolve_params_constrained, compiler.ex:436-463), the non-centred rewrite of
+    Normal(ref, ref) RVs included (rewrite/non_centered_parameterization.ex:50-55);
+  * obs nodes with scalar or vector values and reduce :sum (builder.ex:97-102).
+
+Numeric contract of the generated code:
+  * forward value: the reference's Nx operation sequence with its f32-rounded literals
+    (Nx.tensor(<float>) is f32), sums left to right from the first element as Nx.sum on the
+    BinaryBackend, exp/log/log1p from include/exmc_detmath.h;
+  * terms in Map.values order of the node map = ids sorted as strings (exact for <= 32 nodes,
+    where Erlang maps are sorted; larger maps iterate in hash order, which is not restated);
+  * gradient: reverse-mode accumulation over the same graph with the local rules listed at
+    `_Grad` below. Nx's own AD rewrites are not restated ("parity unpinned"), so the
+    checker for a generated model is the same generated C compiled for the host
+    (tests/gen_checker.py), not a hand-derived gradient.
+  * everything that depends only on the model's data is evaluated once on the host at
+    exmc_hip_model_create (exmc_gen_fold) and read by the kernels through uniform scalar loads.
+"""
+import hashlib
+import math
+import os
+import subprocess
+
+import numpy as np
+
+from . import build as _build
+from .models import ModelSpec
+
+CUSTOM = 6
+MAX_D = 20   # one lane per chain: 5*D+3 doubles per tree node, one level must fit LDS
+MAX_NODES_SORTED = 32
+
+
+class CodegenError(ValueError):
+    pass
+
+
+def _f32(x):
+    return float(np.float32(x))
+
+
+LOG_2PI_F32 = _f32(math.log(_f32(2.0 * math.pi)))   # Nx.log(Nx.tensor(2*pi)), normal.ex:19,22
+LOG_2_OVER_PI_F32 = _f32(math.log(2.0 / math.pi))   # half_cauchy.ex:22
+NEG_LOG_PI_F32 = _f32(-math.log(math.pi))           # cauchy.ex:21
+LOG_2_F32 = _f32(math.log(_f32(2.0)))               # half_normal.ex:21
+PI_F32 = _f32(math.pi)                              # student_t.ex:27
+TINY_F32 = _f32(1.0e-30)
+HALF_LOG_2PI_F32 = _f32(0.5 * math.log(2.0 * math.pi))   # math.ex:30
+BERN_LO = _f32(1.0e-7)                              # bernoulli.ex:20-21 (f32 arithmetic)
+BERN_HI = _f32(np.float32(1.0) - np.float32(1.0e-7))
+LANCZOS = [0.99999999999980993, 676.5203681218851, -1259.1392167224028, 771.32342877765313,
+           -176.61502916214059, 12.507343278686905, -0.13857109526572012, 9.9843695780195716e-6,
+           1.5056327351493116e-7]                   # math.ex:10-20 (Nx.tensor(c) is f32)
+
+
+# ---------------------------------------------------------------------------------------------
+# Builder mirror (lib/exmc/builder.ex:34-67)
+# ---------------------------------------------------------------------------------------------
+class IR:
+    def __init__(self):
+        self.nodes = {}
+
+    def _add(self, id_, node):
+        if not isinstance(id_, str):
+            raise CodegenError("node ids are strings")
+        if id_ in self.nodes:
+            raise CodegenError("duplicate node id %r" % id_)
+        self.nodes[id_] = node
+        return self
+
+    def rv(self, id_, dist, params, transform=None):
+        return self._add(id_, dict(op="rv", dist=dist, params=dict(params), transform=transform))
+
+    def obs(self, id_, rv_id, value, **opts):
+        for k in opts:
+            if k not in ("reduce",):
+                raise CodegenError("obs option %r is not covered by the generator" % k)
+        v = np.asarray(value, dtype=np.float64)
+        reduce_ = opts.get("reduce")
+        if v.ndim > 0 and reduce_ is None:
+            reduce_ = "sum"                      # builder.ex:97-102
+        if v.ndim > 1:
+            raise CodegenError("obs values are scalars or vectors")
+        if v.ndim == 1 and reduce_ != "sum":
+            raise CodegenError("vector obs needs reduce :sum")
+        return self._add(id_, dict(op="obs", target=rv_id, value=v))
+
+
+def simple_ir(y=None):
+    """The reference README's first model: mu ~ N(0,5), sigma ~ Exponential(1) [:log],
+    y ~ N(mu, sigma) observed."""
+    from .models import SIMPLE_Y
+    ir = IR()
+    ir.rv("mu", "normal", dict(mu=0.0, sigma=5.0))
+    ir.rv("sigma", "exponential", {"lambda": 1.0}, transform="log")
+    ir.rv("y", "normal", dict(mu="mu", sigma="sigma"))
+    ir.obs("y_obs", "y", SIMPLE_Y if y is None else y)
+    return ir
+
+
+def eight_schools_ir(y=None, sigma=None):
+    """Eight schools as plain Builder nodes (26 of them): theta_j ~ N("mu","tau") is what the
+    non-centred rewrite turns into theta_j_raw ~ N(0,1) with theta_j = mu + tau*raw
+    (rewrite/non_centered_parameterization.ex:50-55)."""
+    from .models import EIGHT_SCHOOLS_SIGMA, EIGHT_SCHOOLS_Y
+    y = EIGHT_SCHOOLS_Y if y is None else y
+    sigma = EIGHT_SCHOOLS_SIGMA if sigma is None else sigma
+    ir = IR()
+    ir.rv("mu", "normal", dict(mu=0.0, sigma=5.0))
+    ir.rv("tau", "half_cauchy", dict(scale=5.0), transform="log")
+    for j in range(len(y)):
+        ir.rv("theta_%d" % j, "normal", dict(mu="mu", sigma="tau"))
+        ir.rv("y_%d" % j, "normal", dict(mu="theta_%d" % j, sigma=sigma[j]))
+        ir.obs("y_obs_%d" % j, "y_%d" % j, y[j])
+    return ir
+
+
+# ---------------------------------------------------------------------------------------------
+# expression graph (hash-consed; a vector is a python list of scalar nodes)
+# ---------------------------------------------------------------------------------------------
+class _Graph:
+    def __init__(self):
+        self.ops = []      # (op, args) with args = tuple of node indices / payload
+        self.const = []    # depends on data only
+        self.key = {}
+        self.data = []     # raw model data, in first-use order
+
+    def _node(self, op, *args):
+        k = (op,) + args
+        i = self.key.get(k)
+        if i is None:
+            i = len(self.ops)
+            self.ops.append(k)
+            if op == "lit" or op == "data":
+                c = True
+            elif op == "q":
+                c = False
+            else:
+                c = all(self.const[a] for a in args)
+            self.const.append(c)
+            self.key[k] = i
+        return i
+
+    def lit(self, x):
+        return self._node("lit", float(x).hex())
+
+    def lit_value(self, i):
+        return float.fromhex(self.ops[i][1]) if self.ops[i][0] == "lit" else None
+
+    def datum(self, x):
+        self.data.append(float(x))
+        return self._node("data", len(self.data) - 1)
+
+    def q(self, i):
+        return self._node("q", i)
+
+    def add(self, a, b): return self._node("add", a, b)
+    def sub(self, a, b): return self._node("sub", a, b)
+    def div(self, a, b): return self._node("div", a, b)
+    def exp(self, a): return self._node("exp", a)
+    def log(self, a): return self._node("log", a)
+    def log1p(self, a): return self._node("log1p", a)
+    def max(self, a, b): return self._node("max", a, b)
+    def min(self, a, b): return self._node("min", a, b)
+    def abs(self, a): return self._node("abs", a)
+    def sel_gt(self, a, b, x, y): return self._node("sel_gt", a, b, x, y)
+
+    def neg(self, a):
+        if self.ops[a][0] == "neg":
+            return self.ops[a][1]
+        return self._node("neg", a)
+
+    def mul(self, a, b):
+        # only rewrites that are exact in IEEE arithmetic
+        for x, y in ((a, b), (b, a)):
+            v = self.lit_value(x)
+            if v == 1.0:
+                return y
+            if v == -1.0:
+                return self.neg(y)
+        return self._node("mul", a, b)
+
+    def recip(self, a):
+        return self.div(self.lit(1.0), a)
+
+
+class _Grad:
+    """Reverse-mode accumulation. Local rules (g = adjoint of the result y):
+         a+b: g, g        a-b: g, -g        a*b: g*b, g*a        -a: -g
+         a/b: g*r, -((g*r)*y) with r = 1/b (one reciprocal per distinct denominator)
+         exp a: g*y       log a: g*(1/a)    log1p a: g*(1/(1+a))
+         max(a,b): g where a > b / g where b > a (nothing on a tie, as the clamps in
+                   exmc_models.hpp); min likewise; |a|: g, -g or 0 by the sign of a
+       Contributions to one node are added in decreasing order of the consumer's index."""
+
+    def __init__(self, g, root):
+        self.g = g
+        self.adj = {root: g.lit(1.0)}
+
+    def _acc(self, node, contrib):
+        if self.g.const[node]:
+            return
+        cur = self.adj.get(node)
+        self.adj[node] = contrib if cur is None else self.g.add(cur, contrib)
+
+    def run(self, n_forward):
+        g = self.g
+        zero = g.lit(0.0)
+        for y in range(n_forward - 1, -1, -1):
+            gy = self.adj.get(y)
+            if gy is None or g.const[y]:
+                continue
+            op = g.ops[y][0]
+            a = g.ops[y][1:]
+            if op == "add":
+                self._acc(a[0], gy); self._acc(a[1], gy)
+            elif op == "sub":
+                self._acc(a[0], gy); self._acc(a[1], g.neg(gy))
+            elif op == "mul":
+                self._acc(a[0], g.mul(gy, a[1])); self._acc(a[1], g.mul(gy, a[0]))
+            elif op == "neg":
+                self._acc(a[0], g.neg(gy))
+            elif op == "div":
+                gr = g.mul(gy, g.recip(a[1]))
+                self._acc(a[0], gr)
+                if not g.const[a[1]]:
+                    self._acc(a[1], g.neg(g.mul(gr, y)))
+            elif op == "exp":
+                self._acc(a[0], g.mul(gy, y))
+            elif op == "log":
+                self._acc(a[0], g.mul(gy, g.recip(a[0])))
+            elif op == "log1p":
+                self._acc(a[0], g.mul(gy, g.recip(g.add(g.lit(1.0), a[0]))))
+            elif op == "max":
+                self._acc(a[0], g.sel_gt(a[0], a[1], gy, zero))
+                self._acc(a[1], g.sel_gt(a[1], a[0], gy, zero))
+            elif op == "min":
+                self._acc(a[0], g.sel_gt(a[1], a[0], gy, zero))
+                self._acc(a[1], g.sel_gt(a[0], a[1], gy, zero))
+            elif op == "abs":
+                self._acc(a[0], g.sel_gt(a[0], zero, gy, g.sel_gt(zero, a[0], g.neg(gy), zero)))
+            elif op == "q":
+                pass
+            else:
+                raise CodegenError("no gradient rule for %s" % op)
+
+
+# ---------------------------------------------------------------------------------------------
+# distributions and transforms, operation by operation
+# ---------------------------------------------------------------------------------------------
+def _softplus(g, x):
+    # transform.ex:293-296
+    return g.add(g.max(x, g.lit(0.0)), g.log1p(g.exp(g.neg(g.abs(x)))))
+
+
+def _clamp200(g, z):
+    # transform.ex:27,53: max(lo, min(z, hi)), f64 range (jit.ex precision :f64)
+    return g.max(g.lit(-200.0), g.min(z, g.lit(200.0)))
+
+
+def _apply_transform(g, t, z):
+    if t is None:
+        return z
+    if t == "log":
+        return g.exp(_clamp200(g, z))
+    if t == "softplus":
+        return _softplus(g, z)
+    if t == "logit":
+        return g.exp(g.neg(_softplus(g, g.neg(z))))
+    raise CodegenError("transform %r is not covered" % (t,))
+
+
+def _log_abs_det_jacobian(g, t, z):
+    if t is None:
+        return g.lit(0.0)
+    if t == "log":
+        return _clamp200(g, z)
+    if t == "softplus":
+        return g.neg(_softplus(g, g.neg(z)))
+    if t == "logit":
+        return g.add(g.neg(_softplus(g, g.neg(z))), g.neg(_softplus(g, z)))
+    raise CodegenError("transform %r is not covered" % (t,))
+
+
+def _lgamma(g, x):
+    # math.ex:27-52
+    t = g.add(x, g.lit(6.5))
+    ag = g.lit(_f32(LANCZOS[0]))
+    for i, c in enumerate(LANCZOS[1:]):
+        ag = g.add(ag, g.div(g.lit(_f32(c)), g.add(x, g.lit(float(i)))))
+    r = g.add(g.lit(HALF_LOG_2PI_F32), g.mul(g.sub(x, g.lit(0.5)), g.log(t)))
+    return g.add(g.sub(r, t), g.log(ag))
+
+
+def _need(params, dist, *names):
+    if sorted(params) != sorted(names):
+        raise CodegenError("%s takes params %s, got %s" % (dist, sorted(names), sorted(params)))
+    return [params[n] for n in names]
+
+
+def _logpdf(g, dist, x, p):
+    tiny = g.lit(TINY_F32)
+    if dist == "normal":          # normal.ex:15-24
+        mu, sigma = _need(p, dist, "mu", "sigma")
+        ss = g.max(sigma, tiny)
+        z = g.div(g.sub(x, mu), ss)
+        log_term = g.add(g.lit(LOG_2PI_F32), g.mul(g.lit(2.0), g.log(ss)))
+        return g.mul(g.lit(-0.5), g.add(g.mul(z, z), log_term))
+    if dist == "half_normal":     # half_normal.ex:15-22
+        (sigma,) = _need(p, dist, "sigma")
+        ss = g.max(sigma, tiny)
+        z = g.div(x, ss)
+        base = g.mul(g.lit(-0.5), g.add(g.mul(z, z), g.lit(LOG_2PI_F32)))
+        return g.add(base, g.sub(g.lit(LOG_2_F32), g.log(ss)))
+    if dist == "half_cauchy":     # half_cauchy.ex:17-25
+        (scale,) = _need(p, dist, "scale")
+        ss = g.max(scale, tiny)
+        z = g.div(x, ss)
+        r = g.sub(g.lit(LOG_2_OVER_PI_F32), g.log(ss))
+        return g.sub(r, g.log(g.add(g.lit(1.0), g.mul(z, z))))
+    if dist == "exponential":     # exponential.ex:15-17
+        (lam,) = _need(p, dist, "lambda")
+        return g.sub(g.log(lam), g.mul(lam, x))
+    if dist == "cauchy":          # cauchy.ex:15-24
+        loc, scale = _need(p, dist, "loc", "scale")
+        ss = g.max(scale, tiny)
+        z = g.div(g.sub(x, loc), ss)
+        r = g.sub(g.lit(NEG_LOG_PI_F32), g.log(ss))
+        return g.sub(r, g.log(g.add(g.lit(1.0), g.mul(z, z))))
+    if dist == "laplace":         # laplace.ex:15-21
+        mu, b = _need(p, dist, "mu", "b")
+        sb = g.max(b, tiny)
+        return g.sub(g.neg(g.log(g.mul(g.lit(2.0), sb))), g.div(g.abs(g.sub(x, mu)), sb))
+    if dist == "lognormal":       # lognormal.ex:15-25
+        mu, sigma = _need(p, dist, "mu", "sigma")
+        ss = g.max(sigma, tiny)
+        lx = g.log(x)
+        z = g.div(g.sub(lx, mu), ss)
+        log_term = g.add(g.lit(LOG_2PI_F32), g.mul(g.lit(2.0), g.log(ss)))
+        return g.sub(g.mul(g.lit(-0.5), g.add(g.mul(z, z), log_term)), lx)
+    if dist == "student_t":       # student_t.ex:15-29
+        df, loc, scale = _need(p, dist, "df", "loc", "scale")
+        ss = g.max(scale, tiny)
+        sdf = g.max(df, tiny)
+        z = g.div(g.sub(x, loc), ss)
+        z2 = g.mul(z, z)
+        hp1 = g.div(g.add(sdf, g.lit(1.0)), g.lit(2.0))
+        h = g.div(sdf, g.lit(2.0))
+        r = g.sub(_lgamma(g, hp1), _lgamma(g, h))
+        r = g.sub(r, g.mul(g.lit(0.5), g.log(g.mul(sdf, g.lit(PI_F32)))))
+        r = g.sub(r, g.log(ss))
+        return g.sub(r, g.mul(hp1, g.log(g.add(g.lit(1.0), g.div(z2, sdf)))))
+    if dist == "bernoulli":       # bernoulli.ex:17-27
+        (pp,) = _need(p, dist, "p")
+        pc = g.min(g.max(pp, g.lit(BERN_LO)), g.lit(BERN_HI))
+        return g.add(g.mul(x, g.log(pc)),
+                     g.mul(g.sub(g.lit(1.0), x), g.log(g.sub(g.lit(1.0), pc))))
+    raise CodegenError("distribution %r is not covered" % (dist,))
+
+
+# ---------------------------------------------------------------------------------------------
+# the term walk
+# ---------------------------------------------------------------------------------------------
+class Generated:
+    """d, var_names (flat order, point_map.ex:37), transforms, ncp_info, data (what
+    exmc_hip_model_create receives), header (the generated source) and its digest."""
+
+
+def _observed_targets(ir):
+    return {n["target"] for n in ir.nodes.values() if n["op"] == "obs"}
+
+
+def _apply_ncp(ir, ncp):
+    """rewrite/non_centered_parameterization.ex:26-55"""
+    nodes, info = dict(ir.nodes), {}
+    if not ncp:
+        return nodes, info
+    observed = _observed_targets(ir)
+    for id_, n in ir.nodes.items():
+        if (n["op"] == "rv" and n["dist"] == "normal" and n["transform"] is None
+                and id_ not in observed and isinstance(n["params"].get("mu"), str)
+                and isinstance(n["params"].get("sigma"), str)):
+            info[id_] = dict(mu=n["params"]["mu"], sigma=n["params"]["sigma"])
+            nodes[id_] = dict(op="rv", dist="normal", params=dict(mu=0.0, sigma=1.0), transform=None)
+    return nodes, info
+
+
+def generate(ir, ncp=True):
+    """Compiler.compile_for_sampling (compiler.ex:46-58) as source text."""
+    nodes, ncp_info = _apply_ncp(ir, ncp)
+    if len(nodes) > MAX_NODES_SORTED:
+        raise CodegenError("more than %d nodes: the reference's term order is the hash order of "
+                           "an Erlang map, which is not restated" % MAX_NODES_SORTED)
+    for id_, n in nodes.items():
+        if n["op"] == "obs" and n["target"] not in nodes:
+            raise CodegenError("obs %r targets unknown node %r" % (id_, n["target"]))
+    observed = _observed_targets(ir)
+    free = sorted(i for i, n in nodes.items() if n["op"] == "rv" and i not in observed)
+    if not free:
+        raise CodegenError("no free random variables")
+    if len(free) > MAX_D:
+        raise CodegenError("%d free variables; the one-lane-per-chain kernels take at most %d"
+                           % (len(free), MAX_D))
+    offset = {id_: k for k, id_ in enumerate(free)}
+    g = _Graph()
+
+    def resolve_ref(id_, stack=()):
+        # compiler.ex:447-463
+        if id_ not in offset:
+            raise CodegenError("param ref %r is not a free random variable" % id_)
+        if id_ in stack:
+            raise CodegenError("cyclic non-centred reference through %r" % id_)
+        z = g.q(offset[id_])
+        if id_ in ncp_info:
+            mu = resolve_value(ncp_info[id_]["mu"], stack + (id_,))
+            sigma = resolve_value(ncp_info[id_]["sigma"], stack + (id_,))
+            return g.add(mu, g.mul(sigma, z))
+        return _apply_transform(g, nodes[id_]["transform"], z)
+
+    def resolve_value(v, stack=()):
+        if isinstance(v, str):
+            return resolve_ref(v, stack)
+        a = np.asarray(v, dtype=np.float64)
+        if a.ndim == 0:
+            return g.datum(float(a))
+        if a.ndim == 1:
+            return [g.datum(float(x)) for x in a]
+        raise CodegenError("params are scalars, vectors or refs")
+
+    def elementwise(dist, x, params):
+        n = max([len(v) for v in [x] + list(params.values()) if isinstance(v, list)] + [0])
+        if n == 0:
+            return _logpdf(g, dist, x, params), False
+        for v in [x] + list(params.values()):
+            if isinstance(v, list) and len(v) != n:
+                raise CodegenError("vector lengths differ")
+        pick = lambda v, i: v[i] if isinstance(v, list) else v   # noqa: E731
+        return [_logpdf(g, dist, pick(x, i), {k: pick(v, i) for k, v in params.items()})
+                for i in range(n)], True
+
+    terms = []
+    for id_ in sorted(nodes):                     # Map.values order, compiler.ex:176-180
+        n = nodes[id_]
+        if n["op"] == "rv":
+            if id_ not in offset:
+                continue
+            params = {k: resolve_value(v) for k, v in n["params"].items()}
+            if any(isinstance(v, list) for v in params.values()):
+                raise CodegenError("free RV %r has a vector param" % id_)
+            z = g.q(offset[id_])
+            x = _apply_transform(g, n["transform"], z)
+            t = _logpdf(g, n["dist"], x, params)
+            if n["transform"] is not None:
+                t = g.add(t, _log_abs_det_jacobian(g, n["transform"], z))   # compiler.ex:222-229
+            terms.append(t)
+        else:
+            tgt = nodes[n["target"]]
+            if tgt["op"] != "rv":
+                raise CodegenError("obs %r does not target an rv" % id_)
+            if tgt["transform"] is not None:
+                raise CodegenError("obs of a transformed rv is not covered")
+            params = {k: resolve_value(v) for k, v in tgt["params"].items()}
+            val = n["value"]
+            x = g.datum(float(val)) if val.ndim == 0 else [g.datum(float(v)) for v in val]
+            t, vec = elementwise(tgt["dist"], x, params)
+            if vec:
+                if val.ndim == 0:
+                    raise CodegenError("scalar obs %r of a vector-valued target" % id_)
+                acc = t[0]                        # Nx.sum on the BinaryBackend: left to right
+                for e in t[1:]:
+                    acc = g.add(acc, e)
+                t = acc
+            terms.append(t)
+    total = terms[0]                              # sum_logps, compiler.ex:394-395
+    for t in terms[1:]:
+        total = g.add(t, total)
+    if g.const[total]:
+        raise CodegenError("the log-density does not depend on the free variables")
+
+    n_fwd = len(g.ops)
+    ad = _Grad(g, total)
+    ad.run(n_fwd)
+    grads = [ad.adj.get(g.key.get(("q", k))) for k in range(len(free))]
+
+    out = Generated()
+    out.d = len(free)
+    out.var_names = free
+    out.transforms = {i: nodes[i]["transform"] for i in free if nodes[i]["transform"]}
+    out.ncp_info = ncp_info
+    out.data = np.asarray(g.data, dtype=np.float64)
+    out.header = _emit(g, total, grads, out.d)
+    out.digest = hashlib.sha256(out.header.encode()).hexdigest()[:16]
+    out.n_ops = out.header.count("\n")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# emission
+# ---------------------------------------------------------------------------------------------
+_BIN = {"add": "+", "sub": "-", "mul": "*", "div": "/"}
+_FN1 = {"exp": "EXMC_GEN_EXP", "log": "EXMC_GEN_LOG", "log1p": "EXMC_GEN_LOG1P", "abs": "fabs"}
+_FN2 = {"max": "fmax", "min": "fmin"}
+
+
+def _lds_levels(d):
+    per_level = (5 * d + 3) * 64 * 8
+    return max(1, min(6, (56 * 1024) // per_level))
+
+
+def _emit(g, total, grads, d):
+    outputs = [total] + [x for x in grads if x is not None]
+    # liveness: everything reachable from the outputs
+    live = set()
+    stack = list(outputs)
+    while stack:
+        i = stack.pop()
+        if i in live:
+            continue
+        live.add(i)
+        op = g.ops[i]
+        if op[0] not in ("lit", "data", "q"):
+            stack.extend(op[1:])
+    # folded constants: const non-literal nodes read by a dynamic node (or being an output)
+    slot = {}
+    for a in outputs:
+        if g.const[a] and g.ops[a][0] != "lit" and a not in slot:
+            slot[a] = len(slot)
+    for i in sorted(live):
+        if g.const[i]:
+            continue
+        for a in (g.ops[i][1:] if g.ops[i][0] != "q" else ()):
+            if g.const[a] and g.ops[a][0] != "lit" and a not in slot:
+                slot[a] = len(slot)
+    # host-side nodes needed for the slots
+    host = set()
+    stack = list(slot)
+    while stack:
+        i = stack.pop()
+        if i in host:
+            continue
+        host.add(i)
+        op = g.ops[i]
+        if op[0] not in ("lit", "data"):
+            stack.extend(op[1:])
+
+    def ref(i, dyn):
+        op = g.ops[i]
+        if op[0] == "lit":
+            s = repr(float.fromhex(op[1]))
+            if "inf" in s or "nan" in s:
+                raise CodegenError("non-finite literal")
+            return "(%s)" % s if s.startswith("-") else s
+        if dyn and i in slot:
+            return "c[%d]" % slot[i]
+        if op[0] == "data":
+            return "data[%d]" % op[1]
+        if op[0] == "q":
+            return "q[%d]" % op[1]
+        return "t%d" % i
+
+    def stmt(i, dyn):
+        op = g.ops[i]
+        a = [ref(x, dyn) for x in op[1:]] if op[0] not in ("lit", "data", "q") else []
+        if op[0] in _BIN:
+            e = "%s %s %s" % (a[0], _BIN[op[0]], a[1])
+        elif op[0] == "neg":
+            e = "-%s" % a[0]
+        elif op[0] in _FN1:
+            e = "%s(%s)" % (_FN1[op[0]], a[0])
+        elif op[0] in _FN2:
+            e = "%s(%s, %s)" % (_FN2[op[0]], a[0], a[1])
+        elif op[0] == "sel_gt":
+            e = "(%s > %s) ? %s : %s" % tuple(a)
+        else:
+            raise CodegenError("cannot emit %s" % op[0])
+        return "  const double t%d = %s;" % (i, e)
+
+    L = []
+    L.append("/* generated by exmc_amd/codegen.py -- do not edit. Included twice over: by")
+    L.append(" * exmc_amd/csrc/exmc_models.hpp (device functor Custom<1>, -DEXMC_CUSTOM_HEADER) and by")
+    L.append(" * the host checker tests build from the same text. */")
+    L.append("#define EXMC_GEN_D %d" % d)
+    L.append("#define EXMC_GEN_NDATA %d" % len(g.data))
+    L.append("#define EXMC_GEN_NCONST %d" % max(1, len(slot)))
+    L.append("#define EXMC_GEN_LDS_LEVELS %d" % _lds_levels(d))
+    L.append("")
+    L.append("EXMC_GEN_HOST void exmc_gen_fold(const double* data, double* c) {")
+    for i in sorted(host):
+        if g.ops[i][0] not in ("lit", "data"):
+            L.append(stmt(i, False))
+    for i, k in sorted(slot.items(), key=lambda kv: kv[1]):
+        L.append("  c[%d] = %s;" % (k, ref(i, False)))
+    if not slot:
+        L.append("  c[0] = 0.0;")
+    L.append("  (void)data;")
+    L.append("}")
+    L.append("")
+    L.append("EXMC_GEN_FN double exmc_gen_logp_grad(const double* c, const double* q, double* g) {")
+    for i in sorted(live):
+        if not g.const[i] and g.ops[i][0] != "q":
+            L.append(stmt(i, True))
+    for k, x in enumerate(grads):
+        L.append("  g[%d] = %s;" % (k, "0.0" if x is None else ref(x, True)))
+    L.append("  (void)c;")
+    L.append("  return %s;" % ref(total, True))
+    L.append("}")
+    return "\n".join(L) + "\n"
+
+
+# ---------------------------------------------------------------------------------------------
+# plug-in build + ModelSpec
+# ---------------------------------------------------------------------------------------------
+GEN_DIR = os.path.join(_build.OUT_DIR, "gen")
+
+
+def _extra_flags():
+    return os.environ.get("EXMC_GEN_EXTRA_FLAGS", "").split()
+
+
+def plugin_paths(gen):
+    tag = gen.digest
+    if _extra_flags():
+        tag += "_" + hashlib.sha256(" ".join(_extra_flags()).encode()).hexdigest()[:8]
+    d = os.path.join(GEN_DIR, tag)
+    return d, os.path.join(d, "exmc_gen_model.h"), os.path.join(d, "libexmc_hip_gen.so")
+
+
+def build_plugin(gen, force=False, verbose=False):
+    """hipcc the NUTS kernels around the generated functor (the analogue of the EXLA JIT step,
+    jit.ex). Cached by the digest of the generated text and the kernel sources' mtimes."""
+    d, hdr, so = plugin_paths(gen)
+    os.makedirs(d, exist_ok=True)
+    if not os.path.exists(hdr) or open(hdr).read() != gen.header:
+        with open(hdr, "w") as f:
+            f.write(gen.header)
+    if not force and os.path.exists(so):
+        t = os.path.getmtime(so)
+        if all(os.path.getmtime(p) <= t for p in _build.DEPS + [hdr]):
+            return so
+    cmd = [_build.hipcc()] + _build.FLAGS + _extra_flags() + ["-DEXMC_ONLY_CUSTOM", '-DEXMC_CUSTOM_HEADER="%s"' % hdr,
+                                              "-o", so, _build.SRC]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=os.path.dirname(_build.SRC))
+    return so
+
+
+class GeneratedSpec(ModelSpec):
+    """ModelSpec of a generated model; `lib_path` names the plug-in library sampler.Compiled
+    loads instead of libexmc_hip.so."""
+
+    def __init__(self, gen, lib_path, name="generated", default_init=None):
+        super().__init__(CUSTOM, name, gen.data, gen.var_names, gen.transforms, default_init)
+        self.gen = gen
+        self.lib_path = lib_path
+
+    def to_unconstrained(self, init_values):
+        # invert_ncp_init + PointMap.to_unconstrained (sampler.ex:351-392)
+        vals = {k: float(v) for k, v in init_values.items()}
+        raw = {}
+        for id_, src in self.gen.ncp_info.items():
+            if id_ in vals:
+                res = lambda s: vals[s] if isinstance(s, str) else float(s)   # noqa: E731
+                raw[id_] = (vals[id_] - res(src["mu"])) / res(src["sigma"])
+        vals.update(raw)
+        q = np.zeros(self.d)
+        for i, name in enumerate(self.var_names):
+            x = vals[name]
+            t = self.transforms.get(name)
+            if t == "log":
+                q[i] = math.log(x)
+            elif t == "softplus":
+                q[i] = math.log(math.expm1(x))
+            elif t == "logit":
+                q[i] = math.log(x) - math.log1p(-x)
+            else:
+                q[i] = x
+        return q
+
+    def constrain(self, q):
+        # build_trace: Transform.apply per entry, then reconstruct_ncp (sampler.ex:1281-1313)
+        x = np.array(q, dtype=np.float64, copy=True)
+        sp = lambda v: np.maximum(v, 0.0) + np.log1p(np.exp(-np.abs(v)))   # noqa: E731
+        for i, name in enumerate(self.var_names):
+            t = self.transforms.get(name)
+            if t == "log":
+                x[..., i] = np.exp(np.clip(x[..., i], -200.0, 200.0))
+            elif t == "softplus":
+                x[..., i] = sp(x[..., i])
+            elif t == "logit":
+                x[..., i] = np.exp(-sp(-x[..., i]))
+        idx = {n: i for i, n in enumerate(self.var_names)}
+        done, pending = set(), dict(self.gen.ncp_info)
+        while pending:
+            ready = [i for i, s in pending.items()
+                     if all(not (isinstance(v, str) and v in pending) for v in s.values())]
+            if not ready:
+                raise CodegenError("cyclic non-centred references")
+            for id_ in ready:
+                s = pending.pop(id_)
+                val = lambda v: x[..., idx[v]] if isinstance(v, str) else float(v)   # noqa: E731
+                x[..., idx[id_]] = val(s["mu"]) + val(s["sigma"]) * x[..., idx[id_]]
+                done.add(id_)
+        return x
+
+
+def compile_ir(ir, ncp=True, name="generated", default_init=None, verbose=False):
+    """IR -> GeneratedSpec with its plug-in library built. Needs hipcc (no fallback)."""
+    gen = generate(ir, ncp=ncp)
+    so = build_plugin(gen, verbose=verbose)
+    return GeneratedSpec(gen, so, name=name, default_init=default_init)

@@ -75,6 +75,9 @@ struct exmc_hip_model {
   SVConsts sv{};
   LogisticConsts lg{};
   RadonConsts rd{};
+#ifdef EXMC_CUSTOM_HEADER
+  CustomConsts cu{};
+#endif
   DevBuf data;      // model data kept in HBM (logistic X,y; radon u,starts,floor,y)
   DevBuf zig;       // ki[256] u64, wi[256], fi[256]
   DevBuf tuning;    // inv_mass[D], sqrt_inv_mass[D]
@@ -136,6 +139,12 @@ struct Tag {
 template <class F>
 int dispatch(exmc_hip_model* m, int lanes, F&& f) {
   switch (m->kind) {
+#ifdef EXMC_CUSTOM_HEADER
+    case EXMC_MODEL_CUSTOM:   // a generated model (exmc_amd/codegen.py), one lane per chain
+      if (lanes == 1) return f(Tag<Custom<1>, 1, EXMC_GEN_LDS_LEVELS>{}, m->cu);
+      break;
+#endif
+#ifndef EXMC_ONLY_CUSTOM      // plug-in builds carry the generated model only
     case EXMC_MODEL_EIGHT_SCHOOLS:
       switch (lanes) {
         case 1: return f(Tag<EightSchools<1>, 1, 2>{}, m->es);
@@ -171,6 +180,7 @@ int dispatch(exmc_hip_model* m, int lanes, F&& f) {
         default: break;
       }
       break;
+#endif
     default: break;
   }
   return fail(EXMC_ERR_UNSUPPORTED, "model kind / lanes_per_chain combination not compiled in");
@@ -628,6 +638,10 @@ int exmc_hip_model_create(int kind, int d, const double* data, int n_data, int d
   if (ndev <= 0)
     return fail(EXMC_ERR_NO_DEVICE, "no HIP device visible: libexmc_hip has no CPU fallback");
   if (device < 0 || device >= ndev) return fail(EXMC_ERR_BADARG, "device index out of range");
+#ifdef EXMC_ONLY_CUSTOM
+  if (kind != EXMC_MODEL_CUSTOM)
+    return fail(EXMC_ERR_UNSUPPORTED, "this plug-in build carries one generated model (EXMC_MODEL_CUSTOM) only");
+#endif
   exmc_hip_model* m = new exmc_hip_model();
   m->kind = kind;
   m->device = device;
@@ -701,6 +715,13 @@ int exmc_hip_model_create(int kind, int d, const double* data, int n_data, int d
       m->rd.c_hc = f32r(std::log(2.0 / M_PI)) - std::log(2.5);
       break;
     }
+#ifdef EXMC_CUSTOM_HEADER
+    case EXMC_MODEL_CUSTOM: {
+      if (n_data != EXMC_GEN_NDATA || (n_data > 0 && !data)) { delete m; return fail(EXMC_ERR_BADARG, "generated model: data length differs from the one it was generated for"); }
+      m->d = EXMC_GEN_D;
+      break;
+    }
+#endif
     default:
       delete m;
       return fail(EXMC_ERR_UNSUPPORTED, "model kind not compiled into libexmc_hip");
@@ -763,6 +784,18 @@ int exmc_hip_model_create(int kind, int d, const double* data, int n_data, int d
       m->rd.y = base + 2 * J + 1 + N;
     }
   }
+#ifdef EXMC_CUSTOM_HEADER
+  if (kind == EXMC_MODEL_CUSTOM) {
+    // everything that depends on the data only, evaluated once (same arithmetic as the kernels)
+    std::vector<double> folded(EXMC_GEN_NCONST);
+    exmc_gen_fold(data, folded.data());
+    rc = m->data.ensure(folded.size() * 8);
+    if (rc) return bail(rc);
+    if (hipMemcpy(m->data.p, folded.data(), folded.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
+      return bail(fail(EXMC_ERR_HIP, "model data upload failed"));
+    m->cu.c = m->data.as<double>();
+  }
+#endif
   *out = m;
   return EXMC_OK;
 }

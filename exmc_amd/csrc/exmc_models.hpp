@@ -769,3 +769,49 @@ struct Radon : ModelDefaults {
 };
 
 }  // namespace exmc
+
+// ------------------------------------------------------------------------------------------
+// A model generated from Builder IR (exmc_amd/codegen.py; the reference's compiler.ex term walk
+// + Nx.Defn value_and_grad, compiler.ex:131-141,200-269). The generated header is straight-line
+// code over the whole position, so a chain is one lane and q / g stay in registers; c[] (the
+// data-only subexpressions, folded on the host at model create) is read with scalar loads.
+// ------------------------------------------------------------------------------------------
+#ifdef EXMC_CUSTOM_HEADER
+#define EXMC_GEN_HOST static inline
+#define EXMC_GEN_FN static __host__ __device__ __forceinline__
+// exp / log / log1p are real calls here, not inlined. A generated body holds tens of them; inlined
+// at -O3, each brings its special-case branches, the folded constants already fill the scalar
+// registers, and the resulting scalar-register spill code produced run-to-run different results
+// on gfx950 (ROCm 7.2; a d = 9 model with 30 calls: step-size search off by 2x, lanes 1.. of a
+// wave differing from lane 0, while -O1 and the called form agree with the CPU checker bit for
+// bit -- tools/gen_debug.py). The call form also cuts the VGPR spills of the NUTS kernel 12x.
+static __host__ __device__ __noinline__ double exmc_gen_exp_call(double x) { return exmc_exp(x); }
+static __host__ __device__ __noinline__ double exmc_gen_log_call(double x) { return exmc_log(x); }
+static __host__ __device__ __noinline__ double exmc_gen_log1p_call(double x) { return exmc_log1p(x); }
+#define EXMC_GEN_EXP exmc_gen_exp_call
+#define EXMC_GEN_LOG exmc_gen_log_call
+#define EXMC_GEN_LOG1P exmc_gen_log1p_call
+#include EXMC_CUSTOM_HEADER
+
+namespace exmc {
+
+struct CustomConsts {
+  const double* c;
+};
+
+template <int G>
+struct Custom : ModelDefaults {
+  static_assert(G == 1, "generated models are one lane per chain");
+  static constexpr int D = EXMC_GEN_D;
+  static constexpr int DPL = D;
+  using Consts = CustomConsts;
+  struct Lane {};
+  __device__ static __forceinline__ void load(const Consts&, int, Lane&) {}
+  __device__ static __forceinline__ double logp_grad(const Consts& c, const Lane&, int,
+                                                     const double (&q)[DPL], double (&g)[DPL]) {
+    return exmc_gen_logp_grad(c.c, q, g);
+  }
+};
+
+}  // namespace exmc
+#endif

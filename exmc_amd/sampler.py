@@ -30,17 +30,19 @@ class Compiled:
         if not isinstance(spec, ModelSpec):
             raise TypeError("expected a ModelSpec")
         self.spec = spec
-        L = _lib.load()
+        # a generated model brings its own build of the library (codegen.GeneratedSpec.lib_path)
+        lib_path = getattr(spec, "lib_path", None)
+        L = self.L = _lib.bind(lib_path) if lib_path else _lib.load()
         h = C.c_void_p()
         _lib.check(L.exmc_hip_model_create(spec.kind, spec.d, _dp(spec.data), int(spec.data.size),
-                                           int(device), C.byref(h)))
+                                           int(device), C.byref(h)), L)
         self.h = h
         self.d = spec.d
         self.device = device
 
     def close(self):
         if getattr(self, "h", None):
-            _lib.load().exmc_hip_model_destroy(self.h)
+            self.L.exmc_hip_model_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -49,13 +51,16 @@ class Compiled:
         except Exception:
             pass
 
+    def check(self, rc):
+        _lib.check(rc, self.L)
+
     @property
     def default_lanes(self):
-        return _lib.load().exmc_hip_model_default_lanes(self.h)
+        return self.L.exmc_hip_model_default_lanes(self.h)
 
     @property
     def last_kernel_ms(self):
-        return _lib.load().exmc_hip_last_kernel_ms(self.h)
+        return self.L.exmc_hip_last_kernel_ms(self.h)
 
 
 def compile(ir, opts=None):  # noqa: A001  (name mirrors Sampler.compile/2)
@@ -140,12 +145,12 @@ def sample_compiled(compiled, init_values=None, opts=None):
     """sample_from_compiled (sampler.ex:126-257), cold start, diagonal mass."""
     o = _merge_opts(opts)
     spec = compiled.spec
-    L = _lib.load()
+    L = compiled.L
     t, tr = _host_trace(1, o["num_samples"], spec.d)
     tun = _lib.Tuning()
     div = C.c_int32()
     iq = _init_q(spec, init_values)
-    _lib.check(L.exmc_hip_sample_host(compiled.h, None if iq is None else _dp(iq), _c_opts(o), tr,
+    compiled.check(L.exmc_hip_sample_host(compiled.h, None if iq is None else _dp(iq), _c_opts(o), tr,
                                       C.byref(tun), C.byref(div)))
     trace = _build_trace(spec, t["draws"][0])
     stats = dict(step_size=tun.epsilon, inv_mass_diag=np.array(tun.inv_mass[:spec.d]),
@@ -164,10 +169,10 @@ def sample(ir, init_values=None, opts=None):
 def warmup(compiled, init_values=None, opts=None):
     """Shared warmup on chain 0 (sampler.ex:1053-1080); returns the tuning map."""
     o = _merge_opts(opts)
-    L = _lib.load()
+    L = compiled.L
     tun = _lib.Tuning()
     iq = _init_q(compiled.spec, init_values)
-    _lib.check(L.exmc_hip_warmup(compiled.h, None if iq is None else _dp(iq), _c_opts(o),
+    compiled.check(L.exmc_hip_warmup(compiled.h, None if iq is None else _dp(iq), _c_opts(o),
                                  C.byref(tun)))
     return dict(epsilon=tun.epsilon, inv_mass=np.array(tun.inv_mass[:compiled.d]), chol_cov=None,
                 warmup_divergences=tun.warmup_divergences)
@@ -179,7 +184,7 @@ def sample_compiled_tuned(compiled, tuning, init_values=None, opts=None, num_cha
     uses seed + 7919*i (sampler.ex:1083)."""
     o = _merge_opts(opts)
     spec = compiled.spec
-    L = _lib.load()
+    L = compiled.L
     chain_hi = num_chains if chain_hi is None else chain_hi
     nc = chain_hi - chain_lo
     t, tr = _host_trace(nc, o["num_samples"], spec.d)
@@ -187,7 +192,7 @@ def sample_compiled_tuned(compiled, tuning, init_values=None, opts=None, num_cha
     lf = C.c_int64()
     dv = C.c_int32()
     iq = _init_q(spec, init_values)
-    _lib.check(L.exmc_hip_sample_chains_host(compiled.h, C.byref(tun),
+    compiled.check(L.exmc_hip_sample_chains_host(compiled.h, C.byref(tun),
                                              None if iq is None else _dp(iq), num_chains,
                                              chain_lo, chain_hi, _c_opts(o), tr, C.byref(lf),
                                              C.byref(dv)))
@@ -233,19 +238,19 @@ def sample_stream(ir, receiver, init_values=None, opts=None):
     o = _merge_opts(opts)
     compiled = ir if isinstance(ir, Compiled) else Compiled(ir, device=o.get("device", 0))
     spec = compiled.spec
-    L = _lib.load()
+    L = compiled.L
     n = int(o["num_samples"])
     chunk = max(1, int(o.get("stream_chunk", 50)))
     tun = _lib.Tuning()
     iq = _init_q(spec, init_values)
-    _lib.check(L.exmc_hip_stream_begin(compiled.h, None if iq is None else _dp(iq), _c_opts(o),
+    compiled.check(L.exmc_hip_stream_begin(compiled.h, None if iq is None else _dp(iq), _c_opts(o),
                                        C.byref(tun)))
     sent = 0
     while sent < n:
         m = min(chunk, n - sent)
         t, tr = _host_trace(1, m, spec.d)
         div = C.c_int32()
-        _lib.check(L.exmc_hip_stream_next_host(compiled.h, m, tr, C.byref(div)))
+        compiled.check(L.exmc_hip_stream_next_host(compiled.h, m, tr, C.byref(div)))
         x = spec.constrain(t["draws"][0])
         ss = SampleStats(t, 0)
         for i in range(m):

@@ -44,7 +44,10 @@ enum {
   EXMC_MODEL_EIGHT_SCHOOLS = 2,
   EXMC_MODEL_SV = 3,
   EXMC_MODEL_LOGISTIC = 4,
-  EXMC_MODEL_RADON = 5
+  EXMC_MODEL_RADON = 5,
+  /* a model generated from Builder IR (compiler.ex:46-58 -> exmc_amd/codegen.py); present only
+   * in a plug-in build of this library made for that model; data = the generator's data vector */
+  EXMC_MODEL_CUSTOM = 6
 };
 
 typedef struct exmc_hip_model exmc_hip_model;

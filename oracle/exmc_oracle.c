@@ -174,11 +174,11 @@ double exo_dist_exponential(double x, double lambda, int mm) {
   return exo_log(lambda, mm) - lambda * x;
 }
 double exo_dist_half_normal(double x, double sigma, int mm) {
-  /* half_normal.ex:15-22: log(2) - 0.5*log(2*pi) - log(sigma) - 0.5*(x/sigma)^2 */
+  /* half_normal.ex:15-22: -0.5*(z^2 + log(2pi)) + (log(2) - log(sigma)), literals f32 */
   double ss = fmax(sigma, TINY_F32());
   double z = x / ss;
-  double c = f32r(0.5 * log(2.0 / M_PI));
-  return (c - exo_log(ss, mm)) - 0.5 * (z * z);
+  double base = -0.5 * (z * z + LOG_2PI_F32());
+  return base + (f32r(log(2.0)) - exo_log(ss, mm));
 }
 double exo_dist_bernoulli(double x, double p, int mm) {
   /* bernoulli.ex:17-27: p clipped to [1e-7, 1-1e-7] */
@@ -235,6 +235,7 @@ struct exo_model {
   int kind, d, n;
   double* data;     /* model-specific */
   double* aux;      /* derived constants */
+  exo_custom_fn custom;
 };
 
 exo_model* exo_model_create(int kind, int d, const double* data, int n_data) {
@@ -268,6 +269,9 @@ exo_model* exo_model_create(int kind, int d, const double* data, int n_data) {
       if (d < 2 || n_data % d != 0) { exo_model_free(m); return 0; }
       m->d = d;
       break;
+    case EXO_MODEL_CUSTOM:
+      m->d = d;
+      break;
     case EXO_MODEL_RADON:
       /* data = u[J], county_start[J+1], floor[N], y[N] (observations sorted by county); d = J+5 */
       if (d < 6 || (n_data - (2 * (d - 5) + 1)) % 2 != 0) { exo_model_free(m); return 0; }
@@ -289,6 +293,7 @@ void exo_model_free(exo_model* m) {
   free(m);
 }
 int exo_model_dim(const exo_model* m) { return m->d; }
+void exo_model_set_custom(exo_model* m, exo_custom_fn fn) { m->custom = fn; }
 
 static double clamp200(double z) { return fmax(-200.0, fmin(z, 200.0)); } /* transform.ex:17-29 */
 
@@ -564,6 +569,7 @@ double exo_logp_grad(const exo_model* m, const double* q, double* grad, exo_cfg 
     case EXO_MODEL_SIMPLE: return logp_simple(m, q, grad, cfg);
     case EXO_MODEL_EIGHT_SCHOOLS: return logp_eight_schools(m, q, grad, cfg);
     case EXO_MODEL_SV: return logp_sv(m, q, grad, cfg);
+    case EXO_MODEL_CUSTOM: return m->custom ? m->custom(m->data, q, grad) : NAN;
     default: return NAN;
   }
 }

@@ -39,7 +39,8 @@ enum {
   EXO_MODEL_EIGHT_SCHOOLS = 2,/* d=10: non-centered, validate_posteriordb.exs:246-324 */
   EXO_MODEL_SV = 3,           /* d=T+2: stochastic volatility, STANDARD_BENCHMARKS.md:51-61 */
   EXO_MODEL_LOGISTIC = 4,     /* d=K+1: logistic regression, STANDARD_BENCHMARKS.md:41-49 */
-  EXO_MODEL_RADON = 5         /* d=J+5: hierarchical radon, notebooks/09_radon_bhm.livemd */
+  EXO_MODEL_RADON = 5,        /* d=J+5: hierarchical radon, notebooks/09_radon_bhm.livemd */
+  EXO_MODEL_CUSTOM = 6        /* a generated model (exmc_amd/codegen.py): logp+grad via a function pointer */
 };
 
 typedef struct {
@@ -76,6 +77,10 @@ double exo_log_sum_exp(double a, double b, int math_mode);   /* tree.ex:1597-160
 exo_model* exo_model_create(int kind, int d, const double* data, int n_data);
 void exo_model_free(exo_model* m);
 int exo_model_dim(const exo_model* m);
+/* EXO_MODEL_CUSTOM: fn(data, q, grad) -> logp is the C restatement emitted by the code generator
+ * from the same expression graph as the HIP functor (deterministic-math contract only). */
+typedef double (*exo_custom_fn)(const double* data, const double* q, double* grad);
+void exo_model_set_custom(exo_model* m, exo_custom_fn fn);
 double exo_logp_grad(const exo_model* m, const double* q, double* grad, exo_cfg cfg);
 void exo_constrain(const exo_model* m, const double* q, double* x); /* Transform.apply per entry */
 /* distribution known answers (dist/<name>.ex doctests) */

@@ -1,0 +1,36 @@
+"""Builder-IR test models for the generator (exmc_amd/codegen.py), shared by CPU and GPU tests."""
+import numpy as np
+
+from exmc_amd import codegen as cg
+
+
+simple_ir = cg.simple_ir
+eight_schools_ir = cg.eight_schools_ir
+
+
+def zoo_ir(seed=5):
+    """Every covered distribution and transform at least once; d = 9."""
+    rng = np.random.default_rng(seed)
+    ir = cg.IR()
+    ir.rv("a_loc", "cauchy", dict(loc=0.5, scale=2.0))
+    ir.rv("b_scale", "half_normal", dict(sigma=2.0), transform="softplus")
+    ir.rv("c_df", "exponential", {"lambda": 0.2}, transform="log")
+    ir.rv("d_p", "normal", dict(mu=0.0, sigma=1.5), transform="logit")
+    ir.rv("e_lap", "laplace", dict(mu="a_loc", b="b_scale"))
+    ir.rv("f_ln", "lognormal", dict(mu=0.1, sigma=0.7), transform="log")
+    ir.rv("g_t", "student_t", dict(df="c_df", loc="a_loc", scale="f_ln"))
+    ir.rv("h_hc", "half_cauchy", dict(scale="b_scale"), transform="log")
+    ir.rv("i_centered", "normal", dict(mu="a_loc", sigma=1.0))   # one ref only: no NCP
+    ir.rv("t_obs_rv", "student_t", dict(df=4.0, loc="e_lap", scale="h_hc"))
+    ir.obs("t_obs", "t_obs_rv", rng.normal(size=7) * 2.0)
+    ir.rv("n_obs_rv", "normal", dict(mu="i_centered", sigma=np.abs(rng.normal(size=5)) + 0.5))
+    ir.obs("n_obs", "n_obs_rv", rng.normal(size=5))
+    ir.rv("bern_rv", "bernoulli", dict(p="d_p"))
+    ir.obs("bern", "bern_rv", (rng.uniform(size=9) < 0.4).astype(float))
+    ir.rv("l_obs_rv", "laplace", dict(mu="g_t", b=1.3))
+    ir.obs("l_obs", "l_obs_rv", 0.25)
+    return ir
+
+
+ZOO_INIT = dict(a_loc=0.3, b_scale=1.2, c_df=5.0, d_p=0.4, e_lap=-0.2, f_ln=0.9, g_t=0.1, h_hc=1.5,
+                i_centered=0.0)

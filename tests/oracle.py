@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(ROOT, "oracle", "build", "libexmc_oracle.so")
 
 MAX_D = 256
 STD_NORMAL, SIMPLE, EIGHT_SCHOOLS, SV, LOGISTIC, RADON = range(6)
+EXO_MODEL_CUSTOM = 6
 
 
 class Cfg(C.Structure):
@@ -98,6 +99,8 @@ def lib():
     L.exo_model_create.argtypes = [C.c_int, C.c_int, dp, C.c_int]
     L.exo_model_create.restype = C.c_void_p
     L.exo_model_free.argtypes = [C.c_void_p]
+    L.exo_model_set_custom.argtypes = [C.c_void_p, C.c_void_p]
+    L.exo_model_set_custom.restype = None
     L.exo_model_dim.argtypes = [C.c_void_p]
     L.exo_logp_grad.argtypes = [C.c_void_p, dp, dp, Cfg]
     L.exo_logp_grad.restype = C.c_double
