@@ -725,3 +725,50 @@ def compile_ir(ir, ncp=True, name="generated", default_init=None, verbose=False)
     gen = generate(ir, ncp=ncp)
     so = build_plugin(gen, verbose=verbose)
     return GeneratedSpec(gen, so, name=name, default_init=default_init)
+
+
+# ---------------------------------------------------------------------------------------------
+# language-neutral front door: python -m exmc_amd.codegen model.json out_dir [--no-build]
+#   model.json: {"ncp": true, "nodes": {"mu": {"op": "rv", "dist": "normal",
+#                "params": {"mu": 0.0, "sigma": 5.0}, "transform": null}, ...,
+#                "y_obs": {"op": "obs", "target": "y", "value": [2.1, 1.8]}}}
+#   out_dir gets exmc_gen_model.h, libexmc_hip_gen.so and model.json (d, var_names = the flat
+#   order, transforms, ncp_info, data = what exmc_hip_model_create takes with EXMC_MODEL_CUSTOM).
+# ---------------------------------------------------------------------------------------------
+def ir_from_json(doc):
+    ir = IR()
+    for id_, n in doc["nodes"].items():
+        if n.get("op") == "rv":
+            ir.rv(id_, n["dist"], n["params"], transform=n.get("transform"))
+        elif n.get("op") == "obs":
+            opts = {k: n[k] for k in ("reduce", "weight", "mask", "censored") if n.get(k) is not None}
+            ir.obs(id_, n["target"], n["value"], **opts)
+        else:
+            raise CodegenError("node %r: op %r is not covered" % (id_, n.get("op")))
+    return ir
+
+
+def main(argv=None):
+    import json
+    import shutil
+    import sys
+    argv = sys.argv[1:] if argv is None else argv
+    if len(argv) < 2:
+        raise SystemExit("usage: python -m exmc_amd.codegen model.json out_dir [--no-build]")
+    doc = json.load(open(argv[0]))
+    gen = generate(ir_from_json(doc), ncp=doc.get("ncp", True))
+    os.makedirs(argv[1], exist_ok=True)
+    with open(os.path.join(argv[1], "exmc_gen_model.h"), "w") as f:
+        f.write(gen.header)
+    meta = dict(kind=CUSTOM, d=gen.d, var_names=gen.var_names, transforms=gen.transforms,
+                ncp_info=gen.ncp_info, data=gen.data.tolist(), digest=gen.digest)
+    if "--no-build" not in argv:
+        shutil.copyfile(build_plugin(gen), os.path.join(argv[1], "libexmc_hip_gen.so"))
+        meta["library"] = "libexmc_hip_gen.so"
+    with open(os.path.join(argv[1], "model.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print(os.path.join(argv[1], "model.json"))
+
+
+if __name__ == "__main__":
+    main()

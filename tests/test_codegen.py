@@ -10,7 +10,7 @@ import pytest
 import gen_checker as GC
 import gen_models as GM
 import oracle as O
-from exmc_amd import _lib, codegen as cg
+from exmc_amd import _lib, codegen as cg, models
 
 DET = O.Cfg(1, 1)
 
@@ -150,3 +150,22 @@ def test_plugin_library_builds_and_exports_the_c_abi():
     L = C.CDLL(so)
     for name in _lib.EXPORTS:
         getattr(L, name)
+
+
+def test_json_front_door(tmp_path):
+    """python -m exmc_amd.codegen model.json out_dir: the same generator for a non-Python host."""
+    import json
+    doc = {"ncp": True, "nodes": {
+        "mu": {"op": "rv", "dist": "normal", "params": {"mu": 0.0, "sigma": 5.0}},
+        "sigma": {"op": "rv", "dist": "exponential", "params": {"lambda": 1.0}, "transform": "log"},
+        "y": {"op": "rv", "dist": "normal", "params": {"mu": "mu", "sigma": "sigma"}},
+        "y_obs": {"op": "obs", "target": "y", "value": list(models.SIMPLE_Y)}}}
+    src = tmp_path / "m.json"
+    src.write_text(json.dumps(doc))
+    cg.main([str(src), str(tmp_path / "out"), "--no-build"])
+    meta = json.loads((tmp_path / "out" / "model.json").read_text())
+    ref = cg.generate(GM.simple_ir())
+    assert meta["digest"] == ref.digest and meta["d"] == 2 and meta["var_names"] == ["mu", "sigma"]
+    assert (tmp_path / "out" / "exmc_gen_model.h").read_text() == ref.header
+    with pytest.raises(cg.CodegenError):
+        cg.ir_from_json({"nodes": {"x": {"op": "det"}}})
