@@ -590,6 +590,22 @@ int run_warmup_device(exmc_hip_model* m, int lanes, exmc_hip_opts o, exmc_hip_tu
       P.stage_model = 1;
       lds_bytes += (size_t)M::kStageDoubles * 8;
     }
+    // two-wave form (tree wave + integrator wave, exmc_nuts.hpp PipeBox) unless switched off
+    const char* pe = std::getenv("EXMC_HIP_WARMUP_PIPE");
+    const bool pipe = !(pe && pe[0] == '0') &&
+                      lds_bytes + pipe_lds_doubles<M::DPL>() * 8 <= 160 * 1024;
+    if (pipe) {
+      lds_bytes += pipe_lds_doubles<M::DPL>() * 8;
+      if (lds_bytes > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void*)warmup_kernel<M, T::G, T::LDSL, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+      HIP_TRY(hipEventRecord(m->ev0, m->stream));
+      hipLaunchKernelGGL((warmup_kernel<M, T::G, T::LDSL, true>), dim3(1), dim3(2 * kNutsBlock),
+                         lds_bytes, m->stream, P, mc);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipEventRecord(m->ev1, m->stream));
+      return (int)EXMC_OK;
+    }
     if (lds_bytes > 64 * 1024)
       HIP_TRY(hipFuncSetAttribute((const void*)warmup_kernel<M, T::G, T::LDSL>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));

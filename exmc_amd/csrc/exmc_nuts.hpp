@@ -32,6 +32,8 @@
 // dot products run on DPP butterflies (exmc_device.hpp), six at a time per merge.
 #pragma once
 
+#include <type_traits>
+
 #include "exmc_models.hpp"
 
 // EXMC_ABLATE = 1..4 builds timing-only variants (U-turn reductions / merge transcendentals /
@@ -285,6 +287,139 @@ __device__ __forceinline__ void draw_momentum(const NutsLane<M, G>& L, Rng& rng,
   for (int k = 0; k < DPL; k++) p[k] = z[k] / L.sim[k];
 }
 
+// ------------------------------------------------------------------------------------------
+// Two-wave pipeline for a single chain (the serial warmup): wave 0 keeps the tree (nuts_run with
+// a PipeBox), wave 1 integrates. Both walk the same skeleton -- transition, doubling, leaf -- and
+// meet at one workgroup barrier per step; between two barriers the tree wave merges leaf k while
+// the integrator computes leaf k+1 into the other of two LDS slots. Everything either side
+// decides on (alive, direction) is published in LDS before the barrier that precedes its use,
+// double-buffered by the parity of the barrier count, so both waves always take the same number
+// of barriers. The arithmetic of a leaf is the one nuts_run performs itself: results are
+// bit-identical to the one-wave kernel.
+// Mailbox rows (each row = 64 doubles, one column per lane of the wave):
+//   start  q0[DPL] p0[DPL] g0[DPL] im[DPL] eps jlp0
+//   ctrl   [parity][alive, go_right]
+//   slot   [parity][q[DPL] p[DPL] g[DPL] logp jlp]
+// ------------------------------------------------------------------------------------------
+struct NoPipe {
+  static constexpr bool kOn = false;
+};
+
+template <int DPL>
+struct PipeBox {
+  static constexpr bool kOn = true;
+  static constexpr int kCtrl = 4 * DPL + 2;
+  static constexpr int kSlot = kCtrl + 4;
+  static constexpr int kSlotRows = 3 * DPL + 2;
+  static constexpr int kRows = kSlot + 2 * kSlotRows;
+  double* box;   // this lane's column
+  int seq;       // barriers passed (identical on both waves)
+
+  __device__ __forceinline__ double& row(int r) const { return box[(size_t)r * 64]; }
+  __device__ __forceinline__ void sync() {
+    __syncthreads();
+    seq++;
+  }
+  // ---- tree wave ----
+  __device__ __forceinline__ void put_start(const double (&q)[DPL], const double (&p)[DPL],
+                                            const double (&g)[DPL], const double (&im)[DPL],
+                                            double eps, double jlp0) const {
+#pragma unroll
+    for (int k = 0; k < DPL; k++) {
+      row(k) = q[k]; row(DPL + k) = p[k]; row(2 * DPL + k) = g[k]; row(3 * DPL + k) = im[k];
+    }
+    row(4 * DPL) = eps;
+    row(4 * DPL + 1) = jlp0;
+  }
+  __device__ __forceinline__ void put_ctrl(bool alive, bool go_right) const {
+    const int b = kCtrl + 2 * ((seq + 1) & 1);
+    row(b) = alive ? 1.0 : 0.0;
+    row(b + 1) = go_right ? 1.0 : 0.0;
+  }
+  __device__ __forceinline__ void put_alive(bool alive) const {
+    row(kCtrl + 2 * ((seq + 1) & 1)) = alive ? 1.0 : 0.0;
+  }
+  __device__ __forceinline__ void get_leaf(double (&q)[DPL], double (&p)[DPL], double (&g)[DPL],
+                                           double& logp, double& jlp) const {
+    const int b = kSlot + kSlotRows * (seq & 1);
+#pragma unroll
+    for (int k = 0; k < DPL; k++) { q[k] = row(b + k); p[k] = row(b + DPL + k); g[k] = row(b + 2 * DPL + k); }
+    logp = row(b + 3 * DPL);
+    jlp = row(b + 3 * DPL + 1);
+  }
+  // ---- integrator wave ----
+  __device__ __forceinline__ bool get_alive() const { return row(kCtrl + 2 * (seq & 1)) != 0.0; }
+  __device__ __forceinline__ bool get_right() const { return row(kCtrl + 2 * (seq & 1) + 1) != 0.0; }
+  __device__ __forceinline__ void put_leaf(const double (&q)[DPL], const double (&p)[DPL],
+                                           const double (&g)[DPL], double logp, double jlp) const {
+    const int b = kSlot + kSlotRows * ((seq + 1) & 1);
+#pragma unroll
+    for (int k = 0; k < DPL; k++) { row(b + k) = q[k]; row(b + DPL + k) = p[k]; row(b + 2 * DPL + k) = g[k]; }
+    row(b + 3 * DPL) = logp;
+    row(b + 3 * DPL + 1) = jlp;
+  }
+};
+
+template <int DPL>
+__host__ __device__ constexpr size_t pipe_lds_doubles() { return (size_t)PipeBox<DPL>::kRows * 64; }
+
+// the integrator wave's side of one transition (mirror of nuts_run's skeleton)
+template <class M, int G>
+__device__ __forceinline__ void pipe_integrate_transition(const typename M::Consts& mc,
+                                                          const NutsLane<M, G>& L,
+                                                          PipeBox<M::DPL>& pb) {
+  constexpr int DPL = M::DPL;
+  double q[DPL], p[DPL], g[DPL], qL[DPL], pL[DPL], gL[DPL], qR[DPL], pR[DPL], gR[DPL], im[DPL];
+  pb.sync();   // the tree wave has published the start of the transition
+#pragma unroll
+  for (int k = 0; k < DPL; k++) {
+    qL[k] = qR[k] = q[k] = pb.row(k);
+    pL[k] = pR[k] = p[k] = pb.row(DPL + k);
+    gL[k] = gR[k] = g[k] = pb.row(2 * DPL + k);
+    im[k] = pb.row(3 * DPL + k);
+  }
+  const double eps = pb.row(4 * DPL);
+  auto leap = [&](double eps_dir) {
+    // batched_leapfrog.ex:79-85, the same operations in the same order as nuts_run's leaf pass
+    const double h = eps_dir / 2.0;
+#pragma unroll
+    for (int k = 0; k < DPL; k++) {
+      const double ph = p[k] + h * g[k];
+      p[k] = ph;
+      q[k] = q[k] + eps_dir * (im[k] * ph);
+    }
+    const double logp_new = M::logp_grad(mc, L.ln, L.l, q, g);
+#pragma unroll
+    for (int k = 0; k < DPL; k++) p[k] = p[k] + h * g[k];
+    const double jlp = logp_new - kinetic_energy<G, DPL>(p, im, L.valid);
+    pb.put_leaf(q, p, g, logp_new, jlp);
+  };
+  for (int depth = 0;; depth++) {
+    pb.sync();   // direction of this doubling (or the end of the transition) is published
+    const bool go_right = pb.get_right();
+    if (__any(pb.get_alive() ? 1 : 0) == 0) break;
+    const double eps_dir = go_right ? eps : -eps;
+#pragma unroll
+    for (int k = 0; k < DPL; k++) {
+      q[k] = go_right ? qR[k] : qL[k];
+      p[k] = go_right ? pR[k] : pL[k];
+      g[k] = go_right ? gR[k] : gL[k];
+    }
+    const int nleaf = 1 << depth;
+    leap(eps_dir);
+    for (int leaf = 0; leaf < nleaf; leaf++) {
+      pb.sync();   // leaf `leaf` is in its slot; the tree wave is done with leaf - 1
+      if (leaf > 0 && __any(pb.get_alive() ? 1 : 0) == 0) break;
+      if (leaf + 1 < nleaf) leap(eps_dir);
+    }
+#pragma unroll
+    for (int k = 0; k < DPL; k++) {
+      if (go_right) { qR[k] = q[k]; pR[k] = p[k]; gR[k] = g[k]; }
+      else { qL[k] = q[k]; pL[k] = p[k]; gL[k] = g[k]; }
+    }
+  }
+}
+
 // n_draws NUTS transitions of this group's chain. sink(draw, q, logp, depth, n_steps, divergent,
 // accept_sum, jlp0) is called once per finished transition.
 // stack slots of one pending node: rho, p_in, p_out, q_prop, g_prop (DPL each), lsw, logp_prop, acc
@@ -297,10 +432,10 @@ __device__ __forceinline__ void draw_momentum(const NutsLane<M, G>& L, Rng& rng,
 // tree.ex:1175-1177 path, handled by the same level loop) idles until the deepest tree of the
 // wavefront is finished: for eight_schools E[max of 4 trees] / E[tree] = 1.18 extra passes buy a
 // pass that costs ~0.6x of the asynchronous one (no union of divergent paths, no exec juggling).
-template <class M, int G, int LDSL, class Sink>
+template <class M, int G, int LDSL, class Sink, class Pipe = NoPipe>
 __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const NutsLane<M, G>& L,
                                          ChainRegs<M::DPL>& st, int n_draws, double eps,
-                                         int max_depth, Sink&& sink) {
+                                         int max_depth, Sink&& sink, Pipe* pipe = nullptr) {
   constexpr int DPL = M::DPL;
   constexpr int NSLOT = 5 * DPL + 3;
   using MM = Math<M::kVregMath>;
@@ -350,9 +485,13 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
       t_div = t_turn = false;
       t_depth = 0;
     }
+    if constexpr (Pipe::kOn) {
+      pipe->put_start(st.q, pL, st.g, im, eps, jlp0);
+      pipe->sync();
+    }
     EXMC_PROF(0)
 
-    for (int depth = 0; __any(alive ? 1 : 0) != 0; depth++) {   // depth is wave-uniform
+    for (int depth = 0; Pipe::kOn || __any(alive ? 1 : 0) != 0; depth++) {   // depth is wave-uniform
       if (alive) {
         // tree.ex:403-413 direction + outward endpoint
         const double u = rng_uniform(trng);
@@ -365,34 +504,48 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
           g[k] = go_right ? gR[k] : gL[k];
         }
       }
+      if constexpr (Pipe::kOn) {
+        pipe->put_ctrl(alive, go_right);
+        pipe->sync();
+        if (__any(alive ? 1 : 0) == 0) break;
+      }
       EXMC_PROF(1)
 
       const int nleaf = 1 << depth;
       for (int leaf = 0; leaf < nleaf; leaf++) {
+        if constexpr (Pipe::kOn) pipe->sync();
         if (leaf > 0 && __any(alive ? 1 : 0) == 0) break;
         EXMC_PROF_COUNT(9)
-        // ---- one leapfrog on every lane (batched_leapfrog.ex:79-85); idle groups integrate
-        // scratch registers so that wave-cooperative models see all 64 lanes ----
-        const double h = eps_dir / 2.0;
+        double logp_new, jlp;
+        if constexpr (Pipe::kOn) {
+          // the integrator wave computed this leaf while the previous one was merged here
 #pragma unroll
-        for (int k = 0; k < DPL; k++) {
-          qold[k] = q[k];
-          gold[k] = g[k];
-          const double ph = p[k] + h * g[k];
-          p[k] = ph;
-          q[k] = q[k] + eps_dir * (im[k] * ph);
-        }
+          for (int k = 0; k < DPL; k++) { qold[k] = q[k]; gold[k] = g[k]; }
+          pipe->get_leaf(q, p, g, logp_new, jlp);
+        } else {
+          // ---- one leapfrog on every lane (batched_leapfrog.ex:79-85); idle groups integrate
+          // scratch registers so that wave-cooperative models see all 64 lanes ----
+          const double h = eps_dir / 2.0;
+#pragma unroll
+          for (int k = 0; k < DPL; k++) {
+            qold[k] = q[k];
+            gold[k] = g[k];
+            const double ph = p[k] + h * g[k];
+            p[k] = ph;
+            q[k] = q[k] + eps_dir * (im[k] * ph);
+          }
 #if EXMC_ABLATE == 3
-        double logp_new = 0.0;
+          logp_new = 0.0;
 #pragma unroll
-        for (int k = 0; k < DPL; k++) { g[k] = -q[k]; logp_new = logp_new - 0.5 * q[k] * q[k]; }
-        logp_new = group_allsum<G>(logp_new);
+          for (int k = 0; k < DPL; k++) { g[k] = -q[k]; logp_new = logp_new - 0.5 * q[k] * q[k]; }
+          logp_new = group_allsum<G>(logp_new);
 #else
-        const double logp_new = M::logp_grad(mc, L.ln, l, q, g);
+          logp_new = M::logp_grad(mc, L.ln, l, q, g);
 #endif
 #pragma unroll
-        for (int k = 0; k < DPL; k++) p[k] = p[k] + h * g[k];
-        const double jlp = logp_new - kinetic_energy<G, DPL>(p, im, valid);
+          for (int k = 0; k < DPL; k++) p[k] = p[k] + h * g[k];
+          jlp = logp_new - kinetic_energy<G, DPL>(p, im, valid);
+        }
         EXMC_PROF(2)
 
         if (alive) {
@@ -560,6 +713,7 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
           }
           EXMC_PROF(5)
         }
+        if constexpr (Pipe::kOn) pipe->put_alive(alive);
       }
     }
 
@@ -819,17 +973,21 @@ struct DualAvgDev {
   }
 };
 
-template <class M, int G, int LDSL>
-__global__ void __launch_bounds__(kNutsBlock) warmup_kernel(WarmupParams P, typename M::Consts mc) {
+// kPipe: two waves, the second one integrating one leaf ahead of the tree (see PipeBox above).
+template <class M, int G, int LDSL, bool kPipe = false>
+__global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock)
+    warmup_kernel(WarmupParams P, typename M::Consts mc) {
   constexpr int D = M::D, DPL = M::DPL;
   constexpr int NSLOT = 5 * DPL + 3;
   extern __shared__ double lds[];
   const ZigTables zt = stage_zig_tables<LDSL, NSLOT>(lds, P.zig_ki, P.zig_wi, P.zig_fi);
   // single workgroup on an otherwise idle chip: keep the model data in LDS when it offers an image
   double* stage_ptr = nullptr;
+  size_t lds_used = nuts_lds_bytes<M, LDSL>() / 8;
   if constexpr (M::kStageDoubles > 0) {
     if (P.stage_model) {
-      stage_ptr = lds + nuts_lds_bytes<M, LDSL>() / 8;
+      stage_ptr = lds + lds_used;
+      lds_used += (size_t)M::kStageDoubles;
       M::stage(mc, stage_ptr);
       __syncthreads();
     }
@@ -837,13 +995,30 @@ __global__ void __launch_bounds__(kNutsBlock) warmup_kernel(WarmupParams P, type
   const int xoff = stage_model_data<M, G, LDSL>(mc, lds);
   // Wave-cooperative models: every lane group of the wave runs the same chain 0 redundantly (they
   // stay in lockstep, so the wave is fully populated at every logp_grad); group 0 writes.
-  const bool writer = threadIdx.x < G;
+  const int lane = threadIdx.x & 63;
+  const bool writer = lane < G;
   if (blockIdx.x != 0 || (!M::kCoop && !writer)) return;
 
   NutsLane<M, G> L;
   lane_setup<M, G, LDSL>(L, mc, lds, P.stack, nullptr, nullptr, zt, P.nor_r);
   if constexpr (M::kStageDoubles > 0) L.ln.xs = stage_ptr;
   if constexpr (M::kLdsDataDoubles > 0) L.ln.xoff = xoff;
+  using Pipe = std::conditional_t<kPipe, PipeBox<DPL>, NoPipe>;
+  Pipe pipe;
+  if constexpr (kPipe) {
+    // both waves index the stack and the mailbox by their lane, not by threadIdx.x
+    L.lstk = lds + lane;
+    L.gstk = P.stack + lane;
+    L.nthreads = kNutsBlock;
+    pipe.box = lds + lds_used + lane;
+    pipe.seq = 0;
+    if (threadIdx.x >= kNutsBlock) {
+      const bool windows = P.adapt_end > P.init_buffer;
+      const int n = (P.num_warmup > 0) ? (windows ? P.num_warmup : P.init_buffer) : 0;
+      for (int i = 0; i < n; i++) pipe_integrate_transition<M, G>(mc, L, pipe);
+      return;
+    }
+  }
   ChainRegs<DPL> st;
   chain_load<M, G>(P.st, 1, 0, L.l, st);
 
@@ -886,7 +1061,8 @@ __global__ void __launch_bounds__(kNutsBlock) warmup_kernel(WarmupParams P, type
       }
       // sampler.ex:709: depth cap 8 for absolute warmup index < 200, Phase II only
       const int cap = (in_window && i < 200) ? (P.max_depth < 8 ? P.max_depth : 8) : P.max_depth;
-      nuts_run<M, G, LDSL>(mc, L, st, 1, exmc_exp(da.log_epsilon), cap, sink);
+      if constexpr (kPipe) nuts_run<M, G, LDSL>(mc, L, st, 1, exmc_exp(da.log_epsilon), cap, sink, &pipe);
+      else nuts_run<M, G, LDSL>(mc, L, st, 1, exmc_exp(da.log_epsilon), cap, sink);
       divergences += diverged ? 1 : 0;
       da.update(accept);
       if (in_window) {
