@@ -290,16 +290,21 @@ __device__ __forceinline__ void draw_momentum(const NutsLane<M, G>& L, Rng& rng,
 // ------------------------------------------------------------------------------------------
 // Two-wave pipeline for a single chain (the serial warmup): wave 0 keeps the tree (nuts_run with
 // a PipeBox), wave 1 integrates. Both walk the same skeleton -- transition, doubling, leaf -- and
-// meet at one workgroup barrier per step; between two barriers the tree wave merges leaf k while
-// the integrator computes leaf k+1 into the other of two LDS slots. Everything either side
-// decides on (alive, direction) is published in LDS before the barrier that precedes its use,
+// meet at one workgroup barrier per leaf; between two barriers the tree wave merges leaf k while
+// the integrator computes leaf k+1 (leapfrog, model gradient, the leaf's weight and accept
+// statistic) into the other of two LDS slots. The integrator does not wait for the end of a
+// doubling either: a complete doubling j consumes exactly 2^j uniforms after its direction draw
+// (2^j - 1 inner merges, one outer merge; tree.ex:403, 1397, 1489), so it advances a copy of the
+// tree's generator, knows the next direction, and has the first leaf of the next doubling ready
+// while the tree wave is still in the outer merge (wasted when the tree stops there).
+// What either side decides (alive) is published in LDS before the barrier that precedes its use,
 // double-buffered by the parity of the barrier count, so both waves always take the same number
 // of barriers. The arithmetic of a leaf is the one nuts_run performs itself: results are
 // bit-identical to the one-wave kernel.
 // Mailbox rows (each row = 64 doubles, one column per lane of the wave):
-//   start  q0[DPL] p0[DPL] g0[DPL] im[DPL] eps jlp0
+//   start  q0[DPL] p0[DPL] g0[DPL] im[DPL] eps jlp0 rng.a rng.b
 //   ctrl   [parity][alive, go_right]
-//   slot   [parity][q[DPL] p[DPL] g[DPL] logp jlp]
+//   slot   [parity][q[DPL] p[DPL] g[DPL] logp lsw acc div]
 // ------------------------------------------------------------------------------------------
 struct NoPipe {
   static constexpr bool kOn = false;
@@ -308,9 +313,9 @@ struct NoPipe {
 template <int DPL>
 struct PipeBox {
   static constexpr bool kOn = true;
-  static constexpr int kCtrl = 4 * DPL + 2;
+  static constexpr int kCtrl = 4 * DPL + 4;
   static constexpr int kSlot = kCtrl + 4;
-  static constexpr int kSlotRows = 3 * DPL + 2;
+  static constexpr int kSlotRows = 3 * DPL + 4;
   static constexpr int kRows = kSlot + 2 * kSlotRows;
   double* box;   // this lane's column
   int seq;       // barriers passed (identical on both waves)
@@ -323,13 +328,15 @@ struct PipeBox {
   // ---- tree wave ----
   __device__ __forceinline__ void put_start(const double (&q)[DPL], const double (&p)[DPL],
                                             const double (&g)[DPL], const double (&im)[DPL],
-                                            double eps, double jlp0) const {
+                                            double eps, double jlp0, const Rng& trng) const {
 #pragma unroll
     for (int k = 0; k < DPL; k++) {
       row(k) = q[k]; row(DPL + k) = p[k]; row(2 * DPL + k) = g[k]; row(3 * DPL + k) = im[k];
     }
     row(4 * DPL) = eps;
     row(4 * DPL + 1) = jlp0;
+    row(4 * DPL + 2) = __longlong_as_double((long long)trng.a);
+    row(4 * DPL + 3) = __longlong_as_double((long long)trng.b);
   }
   __device__ __forceinline__ void put_ctrl(bool alive, bool go_right) const {
     const int b = kCtrl + 2 * ((seq + 1) & 1);
@@ -340,23 +347,27 @@ struct PipeBox {
     row(kCtrl + 2 * ((seq + 1) & 1)) = alive ? 1.0 : 0.0;
   }
   __device__ __forceinline__ void get_leaf(double (&q)[DPL], double (&p)[DPL], double (&g)[DPL],
-                                           double& logp, double& jlp) const {
+                                           double& logp, double& lsw, double& acc, bool& div) const {
     const int b = kSlot + kSlotRows * (seq & 1);
 #pragma unroll
     for (int k = 0; k < DPL; k++) { q[k] = row(b + k); p[k] = row(b + DPL + k); g[k] = row(b + 2 * DPL + k); }
     logp = row(b + 3 * DPL);
-    jlp = row(b + 3 * DPL + 1);
+    lsw = row(b + 3 * DPL + 1);
+    acc = row(b + 3 * DPL + 2);
+    div = row(b + 3 * DPL + 3) != 0.0;
   }
   // ---- integrator wave ----
   __device__ __forceinline__ bool get_alive() const { return row(kCtrl + 2 * (seq & 1)) != 0.0; }
-  __device__ __forceinline__ bool get_right() const { return row(kCtrl + 2 * (seq & 1) + 1) != 0.0; }
   __device__ __forceinline__ void put_leaf(const double (&q)[DPL], const double (&p)[DPL],
-                                           const double (&g)[DPL], double logp, double jlp) const {
+                                           const double (&g)[DPL], double logp, double lsw,
+                                           double acc, bool div) const {
     const int b = kSlot + kSlotRows * ((seq + 1) & 1);
 #pragma unroll
     for (int k = 0; k < DPL; k++) { row(b + k) = q[k]; row(b + DPL + k) = p[k]; row(b + 2 * DPL + k) = g[k]; }
     row(b + 3 * DPL) = logp;
-    row(b + 3 * DPL + 1) = jlp;
+    row(b + 3 * DPL + 1) = lsw;
+    row(b + 3 * DPL + 2) = acc;
+    row(b + 3 * DPL + 3) = div ? 1.0 : 0.0;
   }
 };
 
@@ -369,6 +380,7 @@ __device__ __forceinline__ void pipe_integrate_transition(const typename M::Cons
                                                           const NutsLane<M, G>& L,
                                                           PipeBox<M::DPL>& pb) {
   constexpr int DPL = M::DPL;
+  using MM = Math<M::kVregMath>;
   double q[DPL], p[DPL], g[DPL], qL[DPL], pL[DPL], gL[DPL], qR[DPL], pR[DPL], gR[DPL], im[DPL];
   pb.sync();   // the tree wave has published the start of the transition
 #pragma unroll
@@ -379,8 +391,13 @@ __device__ __forceinline__ void pipe_integrate_transition(const typename M::Cons
     im[k] = pb.row(3 * DPL + k);
   }
   const double eps = pb.row(4 * DPL);
+  const double jlp0 = pb.row(4 * DPL + 1);
+  Rng prng;   // copy of the tree's generator, used for the direction draws only
+  prng.a = (uint64_t)__double_as_longlong(pb.row(4 * DPL + 2));
+  prng.b = (uint64_t)__double_as_longlong(pb.row(4 * DPL + 3));
   auto leap = [&](double eps_dir) {
-    // batched_leapfrog.ex:79-85, the same operations in the same order as nuts_run's leaf pass
+    // batched_leapfrog.ex:79-85 and the leaf's scalars (tree.ex:1042-1109): the same operations
+    // in the same order as nuts_run's own leaf pass
     const double h = eps_dir / 2.0;
 #pragma unroll
     for (int k = 0; k < DPL; k++) {
@@ -392,31 +409,51 @@ __device__ __forceinline__ void pipe_integrate_transition(const typename M::Cons
 #pragma unroll
     for (int k = 0; k < DPL; k++) p[k] = p[k] + h * g[k];
     const double jlp = logp_new - kinetic_energy<G, DPL>(p, im, L.valid);
-    pb.put_leaf(q, p, g, logp_new, jlp);
+    bool c_div;
+    double c_lsw, c_acc;
+    if (exmc_isfinite(jlp)) {
+      const double dl = jlp - jlp0;
+      c_div = dl < -1000.0;
+      c_lsw = dl;
+      c_acc = fmin(1.0, MM::exp(fmin(dl, 0.0)));
+    } else {
+      c_div = true;
+      c_lsw = -1001.0;
+      c_acc = 0.0;
+    }
+    c_acc = c_div ? 0.0 : c_acc;
+    pb.put_leaf(q, p, g, logp_new, c_lsw, c_acc, c_div);
   };
+  bool go_right = rng_uniform(prng) > 0.5;   // tree.ex:403
+  leap(go_right ? eps : -eps);               // first leaf of doubling 0
   for (int depth = 0;; depth++) {
-    pb.sync();   // direction of this doubling (or the end of the transition) is published
-    const bool go_right = pb.get_right();
+    pb.sync();   // the tree wave says whether this doubling happens; its first leaf is in the slot
     if (__any(pb.get_alive() ? 1 : 0) == 0) break;
     const double eps_dir = go_right ? eps : -eps;
+    const int nleaf = 1 << depth;
+    bool stopped = false;
+    for (int leaf = 1; leaf < nleaf; leaf++) {
+      leap(eps_dir);
+      pb.sync();   // leaf `leaf` is in its slot; the tree wave is done with leaf - 1
+      if (__any(pb.get_alive() ? 1 : 0) == 0) { stopped = true; break; }
+    }
+    if (stopped) continue;   // the next barrier carries alive = false
+    // this doubling is complete on this side: the new endpoint, the next direction (2^depth
+    // uniforms later in the tree's stream) and, ahead of the tree wave, the next first leaf
+#pragma unroll
+    for (int k = 0; k < DPL; k++) {
+      if (go_right) { qR[k] = q[k]; pR[k] = p[k]; gR[k] = g[k]; }
+      else { qL[k] = q[k]; pL[k] = p[k]; gL[k] = g[k]; }
+    }
+    for (int i = 0; i < nleaf; i++) rng_advance(prng);
+    go_right = rng_uniform(prng) > 0.5;
 #pragma unroll
     for (int k = 0; k < DPL; k++) {
       q[k] = go_right ? qR[k] : qL[k];
       p[k] = go_right ? pR[k] : pL[k];
       g[k] = go_right ? gR[k] : gL[k];
     }
-    const int nleaf = 1 << depth;
-    leap(eps_dir);
-    for (int leaf = 0; leaf < nleaf; leaf++) {
-      pb.sync();   // leaf `leaf` is in its slot; the tree wave is done with leaf - 1
-      if (leaf > 0 && __any(pb.get_alive() ? 1 : 0) == 0) break;
-      if (leaf + 1 < nleaf) leap(eps_dir);
-    }
-#pragma unroll
-    for (int k = 0; k < DPL; k++) {
-      if (go_right) { qR[k] = q[k]; pR[k] = p[k]; gR[k] = g[k]; }
-      else { qL[k] = q[k]; pL[k] = p[k]; gL[k] = g[k]; }
-    }
+    leap(go_right ? eps : -eps);
   }
 }
 
@@ -486,7 +523,7 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
       t_depth = 0;
     }
     if constexpr (Pipe::kOn) {
-      pipe->put_start(st.q, pL, st.g, im, eps, jlp0);
+      pipe->put_start(st.q, pL, st.g, im, eps, jlp0, trng);
       pipe->sync();
     }
     EXMC_PROF(0)
@@ -513,15 +550,19 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
 
       const int nleaf = 1 << depth;
       for (int leaf = 0; leaf < nleaf; leaf++) {
-        if constexpr (Pipe::kOn) pipe->sync();
+        if constexpr (Pipe::kOn) {
+          if (leaf > 0) pipe->sync();   // leaf 0 arrived with the doubling's barrier
+        }
         if (leaf > 0 && __any(alive ? 1 : 0) == 0) break;
         EXMC_PROF_COUNT(9)
-        double logp_new, jlp;
+        double logp_new, jlp = 0.0;
+        bool pc_div = false;
+        double pc_lsw = 0.0, pc_acc = 0.0;
         if constexpr (Pipe::kOn) {
           // the integrator wave computed this leaf while the previous one was merged here
 #pragma unroll
           for (int k = 0; k < DPL; k++) { qold[k] = q[k]; gold[k] = g[k]; }
-          pipe->get_leaf(q, p, g, logp_new, jlp);
+          pipe->get_leaf(q, p, g, logp_new, pc_lsw, pc_acc, pc_div);
         } else {
           // ---- one leapfrog on every lane (batched_leapfrog.ex:79-85); idle groups integrate
           // scratch registers so that wave-cooperative models see all 64 lanes ----
@@ -553,7 +594,11 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
           bool c_div, c_turn = false;
           double c_lsw, c_acc, c_logpP;
           int c_n = 1;
-          if (exmc_isfinite(jlp)) {
+          if constexpr (Pipe::kOn) {
+            c_div = pc_div;
+            c_lsw = pc_lsw;
+            c_acc = pc_acc;
+          } else if (exmc_isfinite(jlp)) {
             const double dl = jlp - jlp0;
             c_div = dl < -1000.0;
             c_lsw = dl;
