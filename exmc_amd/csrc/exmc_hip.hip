@@ -573,7 +573,7 @@ int run_warmup_device(exmc_hip_model* m, int lanes, exmc_hip_opts o, exmc_hip_tu
   }
   P.zig_ki = zig_ki(m); P.zig_wi = zig_wi(m); P.zig_fi = zig_fi(m);
   P.nor_r = EXMC_NOR_R;
-  int rc = m->io.ensure((size_t)(3 + d) * 8);
+  int rc = m->io.ensure((size_t)(8 + d) * 8);
   if (rc) return rc;
   P.out = m->io.as<double>();
   rc = dispatch(m, lanes, [&](auto tag, const auto& mc) {
@@ -590,9 +590,10 @@ int run_warmup_device(exmc_hip_model* m, int lanes, exmc_hip_opts o, exmc_hip_tu
       P.stage_model = 1;
       lds_bytes += (size_t)M::kStageDoubles * 8;
     }
-    // two-wave form (tree wave + integrator wave, exmc_nuts.hpp PipeBox) unless switched off
+    // two-wave form (tree wave + integrator wave, exmc_nuts.hpp PipeBox) where the model gains
+    // from it; EXMC_HIP_WARMUP_PIPE=0 / 1 forces the one-wave / two-wave kernel
     const char* pe = std::getenv("EXMC_HIP_WARMUP_PIPE");
-    const bool pipe = !(pe && pe[0] == '0') &&
+    const bool pipe = ((pe && pe[0] == '1') || (M::kPipeWarmup && !(pe && pe[0] == '0'))) &&
                       lds_bytes + pipe_lds_doubles<M::DPL>() * 8 <= 160 * 1024;
     if (pipe) {
       lds_bytes += pipe_lds_doubles<M::DPL>() * 8;
@@ -617,11 +618,15 @@ int run_warmup_device(exmc_hip_model* m, int lanes, exmc_hip_opts o, exmc_hip_tu
     return (int)EXMC_OK;
   });
   if (rc) return rc;
-  std::vector<double> h(3 + d);
+  std::vector<double> h(8 + d);
   HIP_TRY(hipMemcpyAsync(h.data(), m->io.p, h.size() * 8, hipMemcpyDeviceToHost, m->stream));
   HIP_TRY(hipStreamSynchronize(m->stream));
   rc = finish_timing(m);
   if (rc) return rc;
+#ifdef EXMC_XCC_PROBE
+  fprintf(stderr, "[xcc probe] warmup ran on xcc/cu/se %d, %.3f ms  shader clocks %.0f  wall ticks %.0f\n",
+          (int)h[2], m->last_ms, h[3 + d], h[4 + d]);
+#endif
   tun->epsilon = h[0];
   tun->warmup_divergences = (int)h[1];
   for (int i = 0; i < d; i++) tun->inv_mass[i] = h[3 + i];

@@ -28,6 +28,10 @@ struct ModelDefaults {
   // kLdsDataDoubles: observations every NUTS workgroup keeps in LDS for the whole kernel
   // (stage_data fills the image, Lane::xoff = its offset in the dynamic LDS array or -1)
   static constexpr int kLdsDataDoubles = 0;
+  // single-chain warmup as two waves (tree + integrator, exmc_nuts.hpp PipeBox). Pays when the
+  // tree bookkeeping is a real share of a leaf pass: sv 900 -> 695 ms, radon 194 -> 169 ms,
+  // eight_schools ~20 -> ~17 ms; not for logistic, whose pass is nearly all model (158 -> 162 ms)
+  static constexpr bool kPipeWarmup = true;
 };
 
 // the dynamic LDS of the running kernel (every extern __shared__ array names the same base)
@@ -378,6 +382,7 @@ struct LogisticConsts {
 
 template <int G>
 struct Logistic : ModelDefaults {
+  static constexpr bool kPipeWarmup = false;
   static constexpr int K = 20;
   static constexpr int D = K + 1;
   static constexpr int DPL = (D + G - 1) / G;
@@ -474,6 +479,7 @@ typedef double exmc_v4d __attribute__((ext_vector_type(4)));
 
 template <>
 struct Logistic<4> : ModelDefaults {
+  static constexpr bool kPipeWarmup = false;
   static constexpr int G = 4;
   static constexpr int K = 20;
   static constexpr int D = K + 1;

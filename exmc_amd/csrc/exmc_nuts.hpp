@@ -1066,6 +1066,9 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock)
   }
   ChainRegs<DPL> st;
   chain_load<M, G>(P.st, 1, 0, L.l, st);
+#ifdef EXMC_XCC_PROBE
+  const long long probe_c0 = clock64(), probe_w0 = wall_clock64();
+#endif
 
   double accept = 0.0;
   bool diverged = false;
@@ -1155,6 +1158,16 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock)
     P.out[0] = eps_final;
     P.out[1] = (double)divergences;
     P.out[2] = (double)leapfrogs;
+#ifdef EXMC_XCC_PROBE   // development: which XCD / CU / SE the single workgroup ran on
+    {
+      unsigned xcc, hw;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      P.out[2] = (double)((xcc & 0xf) * 1000 + ((hw >> 8) & 0xf) * 10 + ((hw >> 13) & 0x7));
+      P.out[3 + D] = (double)(clock64() - probe_c0);
+      P.out[4 + D] = (double)(wall_clock64() - probe_w0);
+    }
+#endif
   }
 #pragma unroll
   for (int k = 0; k < DPL; k++) {

@@ -199,13 +199,18 @@ def test_device_warmup_equals_host_driven_and_oracle(es, hip, num_warmup, monkey
     adapt_end <= init_buffer, sampler.ex:580-582)."""
     spec, comp, om = es
     opts = dict(num_warmup=num_warmup, num_samples=1, seed=9, lanes_per_chain=16)
-    dev = sampler.warmup(comp, spec.default_init, opts)
+    dev = sampler.warmup(comp, spec.default_init, opts)      # two-wave pipeline (the default)
+    monkeypatch.setenv("EXMC_HIP_WARMUP_PIPE", "0")
+    one = sampler.warmup(comp, spec.default_init, opts)      # one wave does both jobs
+    monkeypatch.delenv("EXMC_HIP_WARMUP_PIPE")
     monkeypatch.setenv("EXMC_HIP_HOST_WARMUP", "1")
     host = sampler.warmup(comp, spec.default_init, opts)
     monkeypatch.delenv("EXMC_HIP_HOST_WARMUP")
     st = O.warmup(om, spec.to_unconstrained(spec.default_init), num_warmup=num_warmup, seed=9,
                   cfg=O.Cfg(1, 16))
-    assert dev["epsilon"] == host["epsilon"] == st.step_size
+    assert dev["epsilon"] == one["epsilon"] == host["epsilon"] == st.step_size
+    assert np.array_equal(dev["inv_mass"], one["inv_mass"])
+    assert dev["warmup_divergences"] == one["warmup_divergences"]
     assert np.array_equal(dev["inv_mass"], host["inv_mass"])
     assert np.array_equal(dev["inv_mass"], np.array(st.inv_mass[:spec.d]))
     assert dev["warmup_divergences"] == host["warmup_divergences"] == st.divergences
