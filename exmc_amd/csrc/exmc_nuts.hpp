@@ -313,7 +313,8 @@ struct NoPipe {
 template <int DPL>
 struct PipeBox {
   static constexpr bool kOn = true;
-  static constexpr int kCtrl = 4 * DPL + 4;
+  static constexpr int kQuit = 4 * DPL + 4;   // start row: the tree wave abandons the kernel
+  static constexpr int kCtrl = 4 * DPL + 5;
   static constexpr int kSlot = kCtrl + 4;
   static constexpr int kSlotRows = 3 * DPL + 4;
   static constexpr int kRows = kSlot + 2 * kSlotRows;
@@ -337,6 +338,12 @@ struct PipeBox {
     row(4 * DPL + 1) = jlp0;
     row(4 * DPL + 2) = __longlong_as_double((long long)trng.a);
     row(4 * DPL + 3) = __longlong_as_double((long long)trng.b);
+    row(kQuit) = 0.0;
+  }
+  // instead of a transition: tell the integrator wave to leave (it waits at the start barrier)
+  __device__ __forceinline__ void quit() {
+    row(kQuit) = 1.0;
+    sync();
   }
   __device__ __forceinline__ void put_ctrl(bool alive, bool go_right) const {
     const int b = kCtrl + 2 * ((seq + 1) & 1);
@@ -376,13 +383,14 @@ __host__ __device__ constexpr size_t pipe_lds_doubles() { return (size_t)PipeBox
 
 // the integrator wave's side of one transition (mirror of nuts_run's skeleton)
 template <class M, int G>
-__device__ __forceinline__ void pipe_integrate_transition(const typename M::Consts& mc,
+__device__ __forceinline__ bool pipe_integrate_transition(const typename M::Consts& mc,
                                                           const NutsLane<M, G>& L,
                                                           PipeBox<M::DPL>& pb) {
   constexpr int DPL = M::DPL;
   using MM = Math<M::kVregMath>;
   double q[DPL], p[DPL], g[DPL], qL[DPL], pL[DPL], gL[DPL], qR[DPL], pR[DPL], gR[DPL], im[DPL];
   pb.sync();   // the tree wave has published the start of the transition
+  if (__any(pb.row(PipeBox<DPL>::kQuit) != 0.0 ? 1 : 0) != 0) return false;
 #pragma unroll
   for (int k = 0; k < DPL; k++) {
     qL[k] = qR[k] = q[k] = pb.row(k);
@@ -455,6 +463,7 @@ __device__ __forceinline__ void pipe_integrate_transition(const typename M::Cons
     }
     leap(go_right ? eps : -eps);
   }
+  return true;
 }
 
 // n_draws NUTS transitions of this group's chain. sink(draw, q, logp, depth, n_steps, divergent,
@@ -985,6 +994,9 @@ struct WarmupParams {
   int n_windows;
   int win_start[32], win_end[32];   // build_windows (sampler.ex:764-785), computed on the host
   double* stack;
+  size_t stack_stride;      // doubles of spill stack per workgroup (replicas, see `race`)
+  int* race;                // null, or a zeroed word: the workgroups are replicas of the same
+                            // deterministic chain and the first to finish publishes the result
   int stage_model;          // 1: dynamic LDS includes M::kStageDoubles for the model's LDS image
   double* out;              // [0] eps_final, [1] divergences, [2] leapfrogs, [3..3+D) inv_mass
   const uint64_t* zig_ki;
@@ -1042,7 +1054,7 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock)
   // stay in lockstep, so the wave is fully populated at every logp_grad); group 0 writes.
   const int lane = threadIdx.x & 63;
   const bool writer = lane < G;
-  if (blockIdx.x != 0 || (!M::kCoop && !writer)) return;
+  if (!M::kCoop && !writer) return;
 
   NutsLane<M, G> L;
   lane_setup<M, G, LDSL>(L, mc, lds, P.stack, nullptr, nullptr, zt, P.nor_r);
@@ -1053,14 +1065,15 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock)
   if constexpr (kPipe) {
     // both waves index the stack and the mailbox by their lane, not by threadIdx.x
     L.lstk = lds + lane;
-    L.gstk = P.stack + lane;
+    L.gstk = P.stack + (size_t)blockIdx.x * P.stack_stride + lane;
     L.nthreads = kNutsBlock;
     pipe.box = lds + lds_used + lane;
     pipe.seq = 0;
     if (threadIdx.x >= kNutsBlock) {
       const bool windows = P.adapt_end > P.init_buffer;
       const int n = (P.num_warmup > 0) ? (windows ? P.num_warmup : P.init_buffer) : 0;
-      for (int i = 0; i < n; i++) pipe_integrate_transition<M, G>(mc, L, pipe);
+      for (int i = 0; i < n; i++)
+        if (!pipe_integrate_transition<M, G>(mc, L, pipe)) break;
       return;
     }
   }
@@ -1082,6 +1095,7 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock)
   };
 
   const int W = P.num_warmup;
+  bool lost = false;
   double eps = find_eps_dev<M, G>(mc, L, st, P.log_half);
   double eps_final = eps;
   if (W > 0) {
@@ -1096,6 +1110,13 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock)
 #pragma unroll
     for (int k = 0; k < DPL; k++) wmean[k] = wm2[k] = 0.0;
     for (int i = 0; i < n_iter; i++) {
+      // another replica of this chain has already finished: leave (the integrator wave is told
+      // through the mailbox, at the barrier it is waiting at)
+      if (P.race && __hip_atomic_load(P.race, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        lost = true;
+        if constexpr (kPipe) pipe.quit();
+        break;
+      }
       if (has_windows) {
         if (win < P.n_windows && i == P.win_start[win]) {
           if (win == 0) eps = exmc_exp(da.log_epsilon);   // sampler.ex:578
@@ -1153,6 +1174,13 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock)
   }
 
   if (!writer) return;
+  if (P.race) {
+    // the first replica to get here owns the outputs
+    int won = 0;
+    if (!lost && lane == 0) won = (atomicCAS(P.race, 0, 1) == 0) ? 1 : 0;
+    won = __builtin_amdgcn_readfirstlane(won);
+    if (!won) return;
+  }
   chain_store<M, G>(P.st, 1, 0, L.l, st);
   if (L.l == 0) {
     P.out[0] = eps_final;
