@@ -262,6 +262,27 @@ int launch_nuts(exmc_hip_model* m, int lanes, int C, int n_draws, int draw_offse
     P.scratch = m->misc.as<double>() + 3;
     P.zig_ki = zig_ki(m); P.zig_wi = zig_wi(m); P.zig_fi = zig_fi(m);
     P.nor_r = EXMC_NOR_R;
+    if constexpr (M::kPipeNutsLevels > 0) {
+      // wave pairs (tree + integrator), fewer stack levels in LDS to make room for the mailbox.
+      // Opt-in (EXMC_HIP_NUTS_PIPE=1): bit-identical, but with the chip already full the pair
+      // executes ~10 % more instructions (mailbox, barriers) than it hides in stalls --
+      // eight_schools 4096 x 1000: 1.81e9 leapfrog/s against 1.90e9 for one wave per SIMD.
+      const char* pe = std::getenv("EXMC_HIP_NUTS_PIPE");
+      if (pe && pe[0] == '1') {
+        constexpr int PL = M::kPipeNutsLevels;
+        constexpr int kSpillP = (kMaxLevels > PL) ? (kMaxLevels - PL) : 1;
+        rc = m->stack.ensure((size_t)kSpillP * nuts_nslot<M>() * nthreads * 8);
+        if (rc) return rc;
+        P.stack = m->stack.as<double>();
+        if (timed) HIP_TRY(hipEventRecord(m->ev0, m->stream));
+        const size_t lds_p = nuts_lds_bytes<M, PL>() + pipe_lds_doubles<M::DPL>() * 8;
+        hipLaunchKernelGGL((nuts_kernel<M, T::G, PL, true>), grid, dim3(2 * kNutsBlock), lds_p,
+                           m->stream, P, mc);
+        HIP_TRY(hipGetLastError());
+        if (timed) HIP_TRY(hipEventRecord(m->ev1, m->stream));
+        return (int)EXMC_OK;
+      }
+    }
     if (timed) HIP_TRY(hipEventRecord(m->ev0, m->stream));
     const size_t lds_bytes = nuts_lds_bytes<M, T::LDSL>();
     hipLaunchKernelGGL((nuts_kernel<M, T::G, T::LDSL>), grid, dim3(kNutsBlock), lds_bytes,
@@ -290,6 +311,17 @@ int finish_timing(exmc_hip_model* m) {
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, m->ev0, m->ev1));
   m->last_ms = ms;
+#ifdef EXMC_XCC_PROBE
+  if (const char* path = std::getenv("EXMC_WAVE_PROBE_OUT")) {
+    static std::vector<double> h(4096 * 3);
+    HIP_TRY(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_wave_probe), h.size() * 8));
+    if (FILE* f = std::fopen(path, "w")) {   // rewritten after every timed launch: the last one stays
+      std::fprintf(f, "%.3f\n", ms);
+      for (int i = 0; i < 4096; i++) std::fprintf(f, "%d %.0f %.0f %.0f\n", i, h[i * 3], h[i * 3 + 1], h[i * 3 + 2]);
+      std::fclose(f);
+    }
+  }
+#endif
 #if EXMC_PROFILE_SECTIONS
   {
     unsigned long long h[16], z[16] = {0};

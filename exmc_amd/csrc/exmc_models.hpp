@@ -32,6 +32,8 @@ struct ModelDefaults {
   // tree bookkeeping is a real share of a leaf pass: sv 900 -> 695 ms, radon 194 -> 169 ms,
   // eight_schools ~20 -> ~17 ms; not for logistic, whose pass is nearly all model (158 -> 162 ms)
   static constexpr bool kPipeWarmup = true;
+  // > 0: the sampling kernel runs as wave pairs too, with this many tree-stack levels in LDS
+  static constexpr int kPipeNutsLevels = 0;
 };
 
 // the dynamic LDS of the running kernel (every extern __shared__ array names the same base)
@@ -53,6 +55,7 @@ struct EightSchools : ModelDefaults {
   static constexpr int D = 10;
   static constexpr int DPL = (D + G - 1) / G;
   static constexpr bool kVregMath = (DPL <= 2);
+  static constexpr int kPipeNutsLevels = (G == 16) ? 4 : 0;
   using MM = Math<kVregMath>;
   using Consts = EightSchoolsConsts;
   struct Lane {

@@ -51,6 +51,10 @@
 
 namespace exmc {
 
+#ifdef EXMC_XCC_PROBE
+__device__ double g_wave_probe[4096 * 3];   // per workgroup of nuts_kernel: placement, clocks, leapfrogs
+#endif
+
 #if EXMC_PROFILE_SECTIONS
 __device__ unsigned long long g_prof[16];
 #define EXMC_PROF_DECL long long prof_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long prof_t_ = clock64();
@@ -845,12 +849,18 @@ __device__ __forceinline__ void chain_store(const ChainState& s, int C, int chai
   }
 }
 
-template <class M, int G, int LDSL>
-__global__ void __launch_bounds__(kNutsBlock) nuts_kernel(NutsParams P, typename M::Consts mc) {
+// kPipe: every workgroup is a pair of waves over the same 64/G chains -- wave 0 keeps the trees,
+// wave 1 integrates one leaf ahead (PipeBox above). With two waves per SIMD the barrier waits and
+// the bubbles of one wave (taken branches, > 4-clock issues, LDS round trips) are the other's
+// issue slots.
+template <class M, int G, int LDSL, bool kPipe = false>
+__global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock)
+    nuts_kernel(NutsParams P, typename M::Consts mc) {
   constexpr int D = M::D, DPL = M::DPL;
   constexpr int NSLOT = 5 * DPL + 3;
   extern __shared__ double lds[];
-  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int tid = blockIdx.x * kNutsBlock + lane;   // both waves of a pair see the same chains
   const int C = P.n_chains;
   const bool has_chain = (tid / G) < C;
   const int chain = has_chain ? (tid / G) : (C - 1);   // surplus groups shadow the last chain
@@ -862,6 +872,20 @@ __global__ void __launch_bounds__(kNutsBlock) nuts_kernel(NutsParams P, typename
   lane_setup<M, G, LDSL>(L, mc, lds, P.stack, P.inv_mass, P.sqrt_inv_mass, zt, P.nor_r);
   if constexpr (M::kLdsDataDoubles > 0) L.ln.xoff = xoff;
   L.alive = has_chain;
+  using Pipe = std::conditional_t<kPipe, PipeBox<DPL>, NoPipe>;
+  Pipe pipe;
+  if constexpr (kPipe) {
+    L.lstk = lds + lane;
+    L.gstk = P.stack + tid;
+    L.nthreads = (size_t)gridDim.x * kNutsBlock;
+    pipe.box = lds + nuts_lds_bytes<M, LDSL>() / 8 + lane;
+    pipe.seq = 0;
+    if (threadIdx.x >= kNutsBlock) {
+      for (int i = 0; i < P.n_draws; i++)
+        if (!pipe_integrate_transition<M, G>(mc, L, pipe)) break;
+      return;
+    }
+  }
   ChainRegs<DPL> st;
   chain_load<M, G>(P.st, C, chain, L.l, st);
 
@@ -918,7 +942,21 @@ __global__ void __launch_bounds__(kNutsBlock) nuts_kernel(NutsParams P, typename
     lf_total += (unsigned long long)t_n;
     div_total += t_div ? 1u : 0u;
   };
-  nuts_run<M, G, LDSL>(mc, L, st, P.n_draws, P.eps, P.max_depth, sink);
+#ifdef EXMC_XCC_PROBE
+  const long long wave_c0 = clock64();
+#endif
+  if constexpr (kPipe) nuts_run<M, G, LDSL>(mc, L, st, P.n_draws, P.eps, P.max_depth, sink, &pipe);
+  else nuts_run<M, G, LDSL>(mc, L, st, P.n_draws, P.eps, P.max_depth, sink);
+#ifdef EXMC_XCC_PROBE   // development: per-wave clocks and placement of the sampling kernel
+  if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096) {
+    unsigned xcc, hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    g_wave_probe[blockIdx.x * 3 + 0] = (double)((xcc & 0xf) * 1000 + ((hw >> 8) & 0xf) * 10 + ((hw >> 13) & 0x7));
+    g_wave_probe[blockIdx.x * 3 + 1] = (double)(clock64() - wave_c0);
+    g_wave_probe[blockIdx.x * 3 + 2] = (double)lf_total;
+  }
+#endif
 
   if (!has_chain) return;
   chain_store<M, G>(P.st, C, chain, l, st);

@@ -342,3 +342,18 @@ def test_logp_grad_extreme_operands_bit_exact(hip, name, factory, lane_list):
             olp, og = om.logp_grad(q[c], cfg)
             assert np.array_equal(np.array([olp]), np.array([lp[c]]), equal_nan=True), (name, c, olp, lp[c])
             assert np.array_equal(og, g[c], equal_nan=True), (name, c, og, g[c])
+
+
+def test_wave_pair_sampling_kernel_equals_default(es, hip, monkeypatch):
+    """EXMC_HIP_NUTS_PIPE=1: every workgroup of nuts_kernel is a tree wave + an integrator wave
+    (the warmup's pipeline applied to the sampling phase; opt-in, slower on a full chip)."""
+    spec, comp, _ = es
+    opts = dict(num_warmup=120, num_samples=150, seed=5, lanes_per_chain=16)
+    tuning = sampler.warmup(comp, spec.default_init, opts)
+    _, _, a = sampler.sample_compiled_tuned(comp, tuning, spec.default_init, opts, num_chains=37)
+    monkeypatch.setenv("EXMC_HIP_NUTS_PIPE", "1")
+    _, _, b = sampler.sample_compiled_tuned(comp, tuning, spec.default_init, opts, num_chains=37)
+    monkeypatch.delenv("EXMC_HIP_NUTS_PIPE")
+    for k in ("draws", "logp", "tree_depth", "n_steps", "divergent", "accept_prob", "energy"):
+        assert np.array_equal(a["raw"][k], b["raw"][k]), k
+    assert a["total_leapfrogs"] == b["total_leapfrogs"]
