@@ -255,7 +255,10 @@ class _Grad:
                 self._acc(a[1], g.sel_gt(a[0], a[1], gy, zero))
             elif op == "abs":
                 self._acc(a[0], g.sel_gt(a[0], zero, gy, g.sel_gt(zero, a[0], g.neg(gy), zero)))
-            elif op == "q":
+            elif op == "sel_gt":
+                self._acc(a[2], g.sel_gt(a[0], a[1], gy, zero))
+                self._acc(a[3], g.sel_gt(a[0], a[1], zero, gy))
+            elif op in ("q", "qown"):
                 pass
             else:
                 raise CodegenError("no gradient rule for %s" % op)
@@ -401,7 +404,7 @@ def _apply_ncp(ir, ncp):
     return nodes, info
 
 
-def generate(ir, ncp=True):
+def generate(ir, ncp=True, vectorize=True):
     """Compiler.compile_for_sampling (compiler.ex:46-58) as source text."""
     nodes, ncp_info = _apply_ncp(ir, ncp)
     if len(nodes) > MAX_NODES_SORTED:
@@ -505,6 +508,15 @@ def generate(ir, ncp=True):
     out.ncp_info = ncp_info
     out.data = np.asarray(g.data, dtype=np.float64)
     out.header = _emit(g, total, grads, out.d)
+    # the 16-lane layout, when the model has plates to spread over lanes (codegen_vec.py): the
+    # plug-in then carries Custom<16> next to Custom<1> and defaults to it
+    from . import codegen_vec
+    out.vec = codegen_vec.generate(ir, ncp=ncp) if vectorize else None
+    out.lanes = 1
+    if out.vec is not None:
+        out.header += "\n" + out.vec["text"]
+        out.data = np.concatenate([out.data, out.vec["vdata"]])
+        out.lanes = codegen_vec.G
     out.digest = hashlib.sha256(out.header.encode()).hexdigest()[:16]
     out.n_ops = out.header.count("\n")
     return out

@@ -142,6 +142,9 @@ int dispatch(exmc_hip_model* m, int lanes, F&& f) {
 #ifdef EXMC_CUSTOM_HEADER
     case EXMC_MODEL_CUSTOM:   // a generated model (exmc_amd/codegen.py), one lane per chain
       if (lanes == 1) return f(Tag<Custom<1>, 1, EXMC_GEN_LDS_LEVELS>{}, m->cu);
+#ifdef EXMC_GEN_VEC
+      if (lanes == 16) return f(Tag<Custom<16>, 16, 6>{}, m->cu);   // plates across lanes
+#endif
       break;
 #endif
 #ifndef EXMC_ONLY_CUSTOM      // plug-in builds carry the generated model only
@@ -193,6 +196,9 @@ int default_lanes(int kind) {
     case EXMC_MODEL_SV: return 64;
     case EXMC_MODEL_LOGISTIC: return 16;
     case EXMC_MODEL_RADON: return 64;
+#ifdef EXMC_GEN_VEC
+    case EXMC_MODEL_CUSTOM: return 16;
+#endif
     default: return 1;
   }
 }
@@ -783,7 +789,12 @@ int exmc_hip_model_create(int kind, int d, const double* data, int n_data, int d
     }
 #ifdef EXMC_CUSTOM_HEADER
     case EXMC_MODEL_CUSTOM: {
-      if (n_data != EXMC_GEN_NDATA || (n_data > 0 && !data)) { delete m; return fail(EXMC_ERR_BADARG, "generated model: data length differs from the one it was generated for"); }
+#ifdef EXMC_GEN_VEC
+      constexpr int kGenData = EXMC_GEN_NDATA + EXMC_GEN_NVU + 16 * EXMC_GEN_NLR;
+#else
+      constexpr int kGenData = EXMC_GEN_NDATA;
+#endif
+      if (n_data != kGenData || (n_data > 0 && !data)) { delete m; return fail(EXMC_ERR_BADARG, "generated model: data length differs from the one it was generated for"); }
       m->d = EXMC_GEN_D;
       break;
     }
@@ -853,13 +864,26 @@ int exmc_hip_model_create(int kind, int d, const double* data, int n_data, int d
 #ifdef EXMC_CUSTOM_HEADER
   if (kind == EXMC_MODEL_CUSTOM) {
     // everything that depends on the data only, evaluated once (same arithmetic as the kernels)
+#ifdef EXMC_GEN_VEC
+    std::vector<double> folded(EXMC_GEN_NCONST + EXMC_GEN_NVC + 16 * EXMC_GEN_NLC);
+    {
+      const double* vdata = data + EXMC_GEN_NDATA;
+      double* vc = folded.data() + EXMC_GEN_NCONST;
+      exmc_gen_vfold(vdata, vc);
+      for (int l = 0; l < 16; l++)
+        exmc_gen_vfold_lane(vc, vdata + EXMC_GEN_NVU + l * EXMC_GEN_NLR,
+                            vc + EXMC_GEN_NVC + l * EXMC_GEN_NLC);
+    }
+#else
     std::vector<double> folded(EXMC_GEN_NCONST);
+#endif
     exmc_gen_fold(data, folded.data());
     rc = m->data.ensure(folded.size() * 8);
     if (rc) return bail(rc);
     if (hipMemcpy(m->data.p, folded.data(), folded.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
       return bail(fail(EXMC_ERR_HIP, "model data upload failed"));
     m->cu.c = m->data.as<double>();
+    m->cu.vc = m->data.as<double>() + EXMC_GEN_NCONST;
   }
 #endif
   *out = m;

@@ -805,12 +805,13 @@ static __host__ __device__ __noinline__ double exmc_gen_log1p_call(double x) { r
 namespace exmc {
 
 struct CustomConsts {
-  const double* c;
+  const double* c;    // folded constants of the one-lane form
+  const double* vc;   // 16-lane form: [EXMC_GEN_NVC uniform][16][EXMC_GEN_NLC per lane]
 };
 
 template <int G>
 struct Custom : ModelDefaults {
-  static_assert(G == 1, "generated models are one lane per chain");
+  static_assert(G == 1, "the generic form of a generated model is one lane per chain");
   static constexpr int D = EXMC_GEN_D;
   static constexpr int DPL = D;
   using Consts = CustomConsts;
@@ -821,6 +822,48 @@ struct Custom : ModelDefaults {
     return exmc_gen_logp_grad(c.c, q, g);
   }
 };
+
+#ifdef EXMC_GEN_VEC
+// Plates across lanes (exmc_amd/codegen_vec.py): lane l owns dimension l and evaluates the units
+// of the vectorised families assigned to it with its own row of constants; the partial
+// log-density and the partial adjoints of the shared variables cross the group in one butterfly.
+template <>
+struct Custom<16> : ModelDefaults {
+  static constexpr int G = 16;
+  static constexpr int D = EXMC_GEN_D;
+  static constexpr int DPL = 1;
+  static_assert(D <= G, "one dimension per lane");
+  using Consts = CustomConsts;
+  struct Lane {
+    double lc[EXMC_GEN_NLC];
+  };
+  __device__ static __forceinline__ void load(const Consts& c, int l, Lane& ln) {
+#pragma unroll
+    for (int k = 0; k < EXMC_GEN_NLC; k++) ln.lc[k] = c.vc[EXMC_GEN_NVC + l * EXMC_GEN_NLC + k];
+  }
+  template <int... I>
+  __device__ static __forceinline__ void bcast_all(double x, double (&qs)[D],
+                                                   std::integer_sequence<int, I...>) {
+    ((qs[I] = group_bcast_c<G, I>(x)), ...);
+  }
+  __device__ static __forceinline__ double logp_grad(const Consts& c, const Lane& ln, int l,
+                                                     const double (&q)[DPL], double (&g)[DPL]) {
+    double qs[D], s[EXMC_GEN_NS], sg[D], gown, slp;
+    bcast_all(q[0], qs, std::make_integer_sequence<int, D>{});
+    exmc_gen_lane(c.vc, ln.lc, qs, q[0], s, &gown, sg, &slp);
+    group_allsum_n<G, EXMC_GEN_NS>(s);
+    constexpr int smap[D] = EXMC_GEN_SMAP;
+    double gi = 0.0;
+#pragma unroll
+    for (int i = 0; i < D; i++) {
+      const double tot = (smap[i] > 0) ? (sg[i] + s[smap[i] > 0 ? smap[i] : 0]) : sg[i];
+      gi = (l == i) ? tot : gi;
+    }
+    g[0] = gi + gown;
+    return slp + s[0];
+  }
+};
+#endif
 
 }  // namespace exmc
 #endif

@@ -2,8 +2,10 @@
 
 The text exmc_amd/codegen.py emits is compiled here with gcc into a small shared object and
 hooked into the CPU oracle as EXO_MODEL_CUSTOM, so the oracle's leapfrog / tree / sampler run
-over exactly the expression list the HIP functor Custom<1> was compiled from (deterministic
-math, no contraction). Product code never imports this file.
+over exactly the expression list the HIP functors Custom<1> / Custom<16> were compiled from
+(deterministic math, no contraction). For the 16-lane layout the per-lane function runs in a loop
+over 16 virtual lanes and the partials are added in the order of the device's xor butterfly.
+Product code never imports this file.
 """
 import ctypes as C
 import os
@@ -18,6 +20,7 @@ OUT_DIR = os.path.join(ROOT, "oracle", "build")
 
 WRAPPER = """
 #include <math.h>
+#include <string.h>
 #include "exmc_detmath.h"
 #define EXMC_GEN_HOST static inline
 #define EXMC_GEN_FN static inline
@@ -26,12 +29,48 @@ WRAPPER = """
 #define EXMC_GEN_LOG1P exmc_log1p
 #include "%(header)s"
 int exmc_gen_check_dim(void) { return EXMC_GEN_D; }
-int exmc_gen_check_ndata(void) { return EXMC_GEN_NDATA; }
+int exmc_gen_check_ndata(void) {
+#ifdef EXMC_GEN_VEC
+  return EXMC_GEN_NDATA + EXMC_GEN_NVU + 16 * EXMC_GEN_NLR;
+#else
+  return EXMC_GEN_NDATA;
+#endif
+}
 double exmc_gen_check(const double* data, const double* q, double* g) {
   double c[EXMC_GEN_NCONST];
   exmc_gen_fold(data, c);
   return exmc_gen_logp_grad(c, q, g);
 }
+#ifdef EXMC_GEN_VEC
+/* Custom<16> of exmc_amd/csrc/exmc_models.hpp on 16 virtual lanes */
+double exmc_gen_check16(const double* data, const double* q, double* g) {
+  const double* vdata = data + EXMC_GEN_NDATA;
+  double vc[EXMC_GEN_NVC];
+  double S[16][EXMC_GEN_NS], gown[16], sg[EXMC_GEN_D], slp = 0.0, R[EXMC_GEN_NS];
+  static const int smap[EXMC_GEN_D] = EXMC_GEN_SMAP;
+  exmc_gen_vfold(vdata, vc);
+  for (int l = 0; l < 16; l++) {
+    double lc[EXMC_GEN_NLC], sgl[EXMC_GEN_D], slpl;
+    exmc_gen_vfold_lane(vc, vdata + EXMC_GEN_NVU + l * EXMC_GEN_NLR, lc);
+    exmc_gen_lane(vc, lc, q, l < EXMC_GEN_D ? q[l] : 0.0, S[l], &gown[l], sgl, &slpl);
+    if (l == 0) { memcpy(sg, sgl, sizeof sg); slp = slpl; }
+  }
+  for (int k = 0; k < EXMC_GEN_NS; k++) {   /* group_allsum_n: xor butterfly over the 16 lanes */
+    double part[16], nxt[16];
+    for (int l = 0; l < 16; l++) part[l] = S[l][k];
+    for (int m = 1; m < 16; m <<= 1) {
+      for (int l = 0; l < 16; l++) nxt[l] = part[l] + part[l ^ m];
+      memcpy(part, nxt, sizeof part);
+    }
+    R[k] = part[0];
+  }
+  for (int i = 0; i < EXMC_GEN_D; i++) {
+    const double tot = smap[i] > 0 ? sg[i] + R[smap[i]] : sg[i];
+    g[i] = tot + gown[i];
+  }
+  return slp + R[0];
+}
+#endif
 """
 
 _keep = []
@@ -54,24 +93,35 @@ def build(gen):
     return so
 
 
-def model(gen):
-    """oracle Model running the generated value+gradient."""
+def _lib(gen):
     L = C.CDLL(build(gen))
+    for name in ("exmc_gen_check", "exmc_gen_check16"):
+        if hasattr(L, name):
+            f = getattr(L, name)
+            f.restype = C.c_double
+            f.argtypes = [C.POINTER(C.c_double)] * 3
+    _keep.append(L)
+    return L
+
+
+def model(gen, lanes=None):
+    """oracle Model running the generated value+gradient; lanes 1 or 16 (default: the layout the
+    plug-in defaults to). Use with O.Cfg(1, lanes)."""
+    lanes = gen.lanes if lanes is None else lanes
+    L = _lib(gen)
     assert L.exmc_gen_check_dim() == gen.d and L.exmc_gen_check_ndata() == gen.data.size
     m = O.Model(O.EXO_MODEL_CUSTOM, gen.d, gen.data)
-    fn = C.cast(L.exmc_gen_check, C.c_void_p)
+    fn = C.cast(L.exmc_gen_check16 if lanes == 16 else L.exmc_gen_check, C.c_void_p)
     O.lib().exo_model_set_custom(m.h, fn)
-    _keep.append(L)
     m.gen_lib = L
+    m.lanes = lanes
     return m
 
 
-def logp_grad(gen, q):
-    L = C.CDLL(build(gen))
-    L.exmc_gen_check.restype = C.c_double
-    L.exmc_gen_check.argtypes = [C.POINTER(C.c_double)] * 3
+def logp_grad(gen, q, lanes=1):
+    L = _lib(gen)
     q = np.ascontiguousarray(q, dtype=np.float64)
     g = np.zeros(gen.d)
     data = np.ascontiguousarray(gen.data)
-    lp = L.exmc_gen_check(O.dptr(data), O.dptr(q), O.dptr(g))
-    return lp, g
+    f = L.exmc_gen_check16 if lanes == 16 else L.exmc_gen_check
+    return f(O.dptr(data), O.dptr(q), O.dptr(g)), g

@@ -20,7 +20,7 @@ def test_simple_matches_handwritten_oracle_model():
     the generator's reverse-mode rules vs the hand-derived form -> a few ulp."""
     gen = cg.generate(GM.simple_ir())
     assert gen.d == 2 and gen.var_names == ["mu", "sigma"] and gen.transforms == {"sigma": "log"}
-    m, mh = GC.model(gen), O.simple()
+    m, mh = GC.model(gen, 1), O.simple()
     rng = np.random.default_rng(0)
     for i in range(50):
         q = rng.normal(size=2) * (1.0 + i % 3)
@@ -40,7 +40,7 @@ def test_eight_schools_builder_ir_matches_handwritten_gradient():
     script's Custom-dist model up to its dropped 8*0.5*log(2pi) constant."""
     gen = cg.generate(GM.eight_schools_ir())
     assert gen.d == 10 and sorted(gen.ncp_info) == ["theta_%d" % j for j in range(8)]
-    m, mh = GC.model(gen), O.eight_schools()
+    m, mh = GC.model(gen, 1), O.eight_schools()
     rng = np.random.default_rng(1)
     diffs = []
     for _ in range(20):
@@ -59,7 +59,7 @@ def test_eight_schools_builder_ir_matches_handwritten_gradient():
 def test_every_distribution_and_transform_against_central_differences():
     gen = cg.generate(GM.zoo_ir())
     assert gen.d == 9
-    m = GC.model(gen)
+    m = GC.model(gen, 1)
     rng = np.random.default_rng(2)
     for _ in range(10):
         q = rng.normal(size=gen.d) * 0.8
@@ -169,3 +169,31 @@ def test_json_front_door(tmp_path):
     assert (tmp_path / "out" / "exmc_gen_model.h").read_text() == ref.header
     with pytest.raises(cg.CodegenError):
         cg.ir_from_json({"nodes": {"x": {"op": "det"}}})
+
+
+def test_plates_across_lanes_agree_with_the_one_lane_form():
+    """codegen_vec: families of identical terms run on different lanes with per-lane constants
+    (eight schools: the nine Normal priors and the eight likelihood terms; shared mu, tau reduced
+    in one butterfly). Same value and gradient as the scalar form up to the summation order."""
+    from exmc_amd import codegen_vec
+    gen = cg.generate(GM.eight_schools_ir())
+    assert gen.lanes == 16 and gen.vec["n_families"] == 2 and gen.vec["n_reduced"] == 3
+    assert cg.generate(GM.eight_schools_ir(), vectorize=False).lanes == 1
+    rng = np.random.default_rng(4)
+    for ir in (GM.eight_schools_ir(), GM.simple_ir(), GM.zoo_ir()):
+        g2 = cg.generate(ir)
+        assert g2.vec is not None
+        for _ in range(25):
+            q = rng.normal(size=g2.d) * 1.3
+            a, ga = GC.logp_grad(g2, q, 1)
+            b, gb = GC.logp_grad(g2, q, 16)
+            assert abs(a - b) <= 1e-13 * max(1.0, abs(a))
+            np.testing.assert_allclose(ga, gb, rtol=1e-12, atol=1e-12)
+    # nothing to spread: a single term per shape, or more dimensions than lanes
+    ir = cg.IR().rv("x", "normal", dict(mu=0.0, sigma=1.0)).rv("s", "half_cauchy", dict(scale=1.0),
+                                                             transform="log")
+    assert codegen_vec.generate(ir) is None and cg.generate(ir).lanes == 1
+    big = cg.IR()
+    for i in range(18):
+        big.rv("x%02d" % i, "normal", dict(mu=0.0, sigma=1.0))
+    assert cg.generate(big).lanes == 1

@@ -1,6 +1,7 @@
-"""GPU parity for generated models (exmc_amd/codegen.py): the plug-in HIP library, through the C
-ABI, against the CPU oracle running the same generated text compiled with gcc
-(tests/gen_checker.py). Bit for bit, as for the hand-written kinds."""
+"""GPU parity for generated models (exmc_amd/codegen.py, codegen_vec.py): the plug-in HIP library,
+through the C ABI, against the CPU oracle running the same generated text compiled with gcc
+(tests/gen_checker.py). Bit for bit, as for the hand-written kinds, in both layouts: one lane per
+chain and plates across 16 lanes."""
 import ctypes as C
 
 import numpy as np
@@ -13,8 +14,6 @@ from exmc_amd import codegen as cg, models, sampler
 
 pytestmark = pytest.mark.gpu
 
-DET = O.Cfg(1, 1)
-
 
 def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
@@ -22,7 +21,8 @@ def _dp(a):
 
 def _compiled(ir, init, name):
     spec = cg.compile_ir(ir, name=name, default_init=init)
-    return spec, sampler.compile(spec), GC.model(spec.gen)
+    assert spec.gen.lanes == 16
+    return spec, sampler.compile(spec), {1: GC.model(spec.gen, 1), 16: GC.model(spec.gen, 16)}
 
 
 @pytest.fixture(scope="module")
@@ -42,9 +42,11 @@ def zoo(hip):
     return _compiled(GM.zoo_ir(), GM.ZOO_INIT, "gen_zoo")
 
 
+@pytest.mark.parametrize("lanes", [1, 16])
 @pytest.mark.parametrize("which", ["simple", "schools", "zoo"])
-def test_generated_logp_grad_bit_exact(which, request):
-    spec, comp, om = request.getfixturevalue(which)
+def test_generated_logp_grad_bit_exact(which, lanes, request):
+    spec, comp, oms = request.getfixturevalue(which)
+    assert comp.default_lanes == 16
     rng = np.random.default_rng(11)
     n = 193
     q = np.ascontiguousarray(rng.normal(size=(n, spec.d)) * 1.2)
@@ -54,21 +56,24 @@ def test_generated_logp_grad_bit_exact(which, request):
     q[3, :] = 0.0
     lp = np.zeros(n)
     g = np.zeros((n, spec.d))
-    comp.check(comp.L.exmc_hip_logp_grad_host(comp.h, _dp(q), n, 1, _dp(lp), _dp(g)))
+    comp.check(comp.L.exmc_hip_logp_grad_host(comp.h, _dp(q), n, lanes, _dp(lp), _dp(g)))
+    cfg = O.Cfg(1, lanes)
     for c in range(n):
-        olp, og = om.logp_grad(q[c], DET)
+        olp, og = oms[lanes].logp_grad(q[c], cfg)
         assert olp == lp[c] or (np.isnan(olp) and np.isnan(lp[c])), (which, c, olp, lp[c])
         assert np.array_equal(og, g[c], equal_nan=True), (which, c, og, g[c])
 
 
+@pytest.mark.parametrize("lanes", [1, 16])
 @pytest.mark.parametrize("which", ["simple", "schools", "zoo"])
-def test_generated_sample_bit_exact(which, request):
+def test_generated_sample_bit_exact(which, lanes, request):
     """Sampler.sample/3 end to end (warmup adaptation + sampling) on the generated kernels."""
-    spec, comp, om = request.getfixturevalue(which)
-    opts = dict(num_warmup=150, num_samples=120, seed=17)
+    spec, comp, oms = request.getfixturevalue(which)
+    opts = dict(num_warmup=150, num_samples=120, seed=17, lanes_per_chain=lanes)
     trace, stats = sampler.sample_compiled(comp, spec.default_init, opts)
     q0 = spec.to_unconstrained(spec.default_init)
-    t, st = O.sample(om, init_q=q0, num_warmup=150, num_samples=120, seed=17, cfg=DET)
+    t, st = O.sample(oms[lanes], init_q=q0, num_warmup=150, num_samples=120, seed=17,
+                     cfg=O.Cfg(1, lanes))
     assert stats["step_size"] == st.step_size
     raw = stats["raw"]
     assert np.array_equal(raw["tree_depth"][0], t["tree_depth"])
@@ -82,18 +87,18 @@ def test_generated_sample_bit_exact(which, request):
 
 
 def test_generated_eight_schools_chains_bit_exact_and_same_posterior(schools, hip):
-    spec, comp, om = schools
+    """The default (16-lane) layout over a batch of chains; same posterior as the hand-written
+    kind."""
+    spec, comp, oms = schools
     opts = dict(num_warmup=200, num_samples=200, seed=42, init_values=spec.default_init)
     traces, stats = sampler.sample_chains_compiled(comp, 96, opts)
     q0 = spec.to_unconstrained(spec.default_init)
-    t, st = O.sample_chains(om, 96, init_q=q0, num_warmup=200, num_samples=200, seed=42, cfg=DET,
-                            n_threads=8)
+    t, st = O.sample_chains(oms[16], 96, init_q=q0, num_warmup=200, num_samples=200, seed=42,
+                            cfg=O.Cfg(1, 16), n_threads=8)
     raw = stats[0]["extra"]["raw"]
     assert stats[0]["step_size"] == st.step_size
     assert np.array_equal(raw["n_steps"], t["n_steps"])
     assert np.array_equal(raw["draws"], t["draws"])
-    # same posterior as the hand-written kind (different parameterisation of the same model:
-    # compare constrained mu, tau, theta_0 means within Monte-Carlo error)
     hs = models.eight_schools()
     hcomp = sampler.compile(hs)
     htr, hst = sampler.sample_chains_compiled(hcomp, 96, dict(num_warmup=200, num_samples=200, seed=43,
