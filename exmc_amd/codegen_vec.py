@@ -189,11 +189,14 @@ def plan(ir, ncp=True):
         groups.setdefault(tuple(r.g.ops), []).append(k)
     families, scalar_units = [], []
     for sig, members in groups.items():
-        fam = _family(members, recs, D) if len(members) >= 2 else None
-        if fam is None:
-            scalar_units.extend(members)
-        else:
-            families.append(fam)
+        # more units than lanes (a long observation vector): 16 at a time
+        for lo in range(0, len(members), G):
+            part = members[lo:lo + G]
+            fam = _family(part, recs, D) if len(part) >= 2 else None
+            if fam is None:
+                scalar_units.extend(part)
+            else:
+                families.append(fam)
     if not families:
         return None
     families.sort(key=lambda f: f["members"][0])

@@ -832,6 +832,7 @@ struct Custom<16> : ModelDefaults {
   static constexpr int G = 16;
   static constexpr int D = EXMC_GEN_D;
   static constexpr int DPL = 1;
+  static constexpr bool kVregMath = true;   // the tree's own exp / log (nuts_run), as EightSchools<16>
   static_assert(D <= G, "one dimension per lane");
   using Consts = CustomConsts;
   struct Lane {

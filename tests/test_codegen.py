@@ -197,3 +197,13 @@ def test_plates_across_lanes_agree_with_the_one_lane_form():
     for i in range(18):
         big.rv("x%02d" % i, "normal", dict(mu=0.0, sigma=1.0))
     assert cg.generate(big).lanes == 1
+    # an observation vector longer than the lane group is taken 16 elements at a time
+    y = rng.normal(size=40) * 2.0 + 1.0
+    g3 = cg.generate(GM.simple_ir(y=y))
+    assert g3.lanes == 16 and g3.vec["n_families"] == 3
+    for _ in range(10):
+        q = rng.normal(size=2)
+        a, ga = GC.logp_grad(g3, q, 1)
+        b, gb = GC.logp_grad(g3, q, 16)
+        assert abs(a - b) <= 1e-13 * max(1.0, abs(a))
+        np.testing.assert_allclose(ga, gb, rtol=1e-12, atol=1e-12)
