@@ -357,3 +357,22 @@ def test_wave_pair_sampling_kernel_equals_default(es, hip, monkeypatch):
     for k in ("draws", "logp", "tree_depth", "n_steps", "divergent", "accept_prob", "energy"):
         assert np.array_equal(a["raw"][k], b["raw"][k]), k
     assert a["total_leapfrogs"] == b["total_leapfrogs"]
+
+
+@pytest.mark.parametrize("pipe", ["1", "0"])
+def test_warmup_replicas_race_to_the_same_result(es, hip, monkeypatch, pipe):
+    """EXMC_HIP_WARMUP_REPLICAS: the warmup launch is N workgroups running the same deterministic
+    chain, the first to finish publishes; 1, the default 32 and 200 replicas give the same tuning
+    and leave the same chain state behind (the next sampling run is identical)."""
+    spec, comp, _ = es
+    opts = dict(num_warmup=130, num_samples=40, seed=21, lanes_per_chain=16)
+    monkeypatch.setenv("EXMC_HIP_WARMUP_PIPE", pipe)
+    out = []
+    for reps in ("1", "32", "200"):
+        monkeypatch.setenv("EXMC_HIP_WARMUP_REPLICAS", reps)
+        trace, stats = sampler.sample_compiled(comp, spec.default_init, opts)
+        out.append((stats["step_size"], stats["inv_mass_diag"].copy(), stats["raw"]["draws"].copy(),
+                    stats["divergences"]))
+    for o in out[1:]:
+        assert o[0] == out[0][0] and np.array_equal(o[1], out[0][1])
+        assert np.array_equal(o[2], out[0][2]) and o[3] == out[0][3]
