@@ -8,7 +8,10 @@
 //   nuts_kernel  nuts_run for every resident chain (sampling phase, sampler.ex:929-973).
 //   warmup_kernel  run_warmup (sampler.ex:537-762) for chain 0 in ONE launch: dual averaging
 //                (step_size.ex:13-50), Welford windows (mass_matrix.ex:40-97),
-//                find_reasonable_epsilon (sampler.ex:451-530) all on the device.
+//                find_reasonable_epsilon (sampler.ex:451-530) all on the device. By default a
+//                two-wave workgroup (PipeBox: the integrator wave runs one leaf ahead of the tree
+//                wave) launched as several replicas of the same deterministic chain, of which
+//                the first to finish publishes the result.
 //
 // The tree is built iteratively. The reference recursion (tree.ex:1144-1203) is unrolled into a
 // per-level stack of pending "first halves": after leaf k completes, one inner merge fires for

@@ -16,6 +16,13 @@
  * Numeric contract: IEEE f64 throughout (lib/exmc/jit.ex:90-98 => :f64); exp/log through
  * include/exmc_detmath.h; reductions over a chain's dimensions in the G-lane order documented
  * in DESIGN.md (G = lanes_per_chain; G = 1 is the reference's left-to-right order).
+ *
+ * Environment switches (read at call time; every setting gives bit-identical results):
+ *   EXMC_HIP_HOST_WARMUP=1       adaptation driven from the host, one launch per transition
+ *   EXMC_HIP_WARMUP_PIPE=0|1     one-wave / two-wave (tree + integrator) warmup kernel;
+ *                                default: two-wave where the model gains from it
+ *   EXMC_HIP_WARMUP_REPLICAS=N   workgroups racing through the same warmup chain (default 32)
+ *   EXMC_HIP_NUTS_PIPE=1         wave pairs in the sampling kernel too (eight_schools, 16 lanes)
  */
 #ifndef EXMC_HIP_H
 #define EXMC_HIP_H
