@@ -20,7 +20,7 @@ EXPORTS = [
     "exmc_hip_traj_create", "exmc_hip_traj_destroy", "exmc_hip_traj_get_endpoint_host",
     "exmc_hip_traj_build_and_merge_host", "exmc_hip_traj_is_terminated_host",
     "exmc_hip_traj_get_result_host", "exmc_hip_build_subtree_host",
-    "exmc_hip_stream_begin", "exmc_hip_stream_next_host", "exmc_hip_rhat",
+    "exmc_hip_stream_begin", "exmc_hip_stream_next_host", "exmc_hip_rhat", "exmc_hip_ess_bulk",
 ]
 
 
@@ -109,6 +109,7 @@ def bind(path):
         dp, dp, dp, dp, dp, dp, dp, dp, dp, dp, ip, ip, dp, ip, ip, dp]
     L.exmc_hip_ess.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
     L.exmc_hip_rhat.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
+    L.exmc_hip_ess_bulk.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
     L.exmc_hip_last_kernel_ms.argtypes = [vp]
     L.exmc_hip_last_kernel_ms.restype = C.c_double
     _libs[path] = L

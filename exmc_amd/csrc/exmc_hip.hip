@@ -1316,7 +1316,22 @@ int exmc_hip_ess(exmc_hip_model* m, const double* draws_dev, int n_draws, int d,
   HIP_TRY(hipSetDevice(m->device));
   HIP_TRY(hipEventRecord(m->ev0, m->stream));
   hipLaunchKernelGGL(ess_kernel, dim3((unsigned)(d * n_chains)), dim3(256), (size_t)n_draws * 16,
-                     m->stream, draws_dev, n_draws, d, n_chains, ess_dev);
+                     m->stream, draws_dev, n_draws, d, n_chains, ess_dev, 0);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(m->ev1, m->stream));
+  return finish_timing(m);
+}
+
+int exmc_hip_ess_bulk(exmc_hip_model* m, const double* draws_dev, int n_draws, int d, int n_chains,
+                      double* ess_dev) {
+  if (check_model(m)) return EXMC_ERR_BADARG;
+  if (!draws_dev || !ess_dev || n_draws < 1 || d < 1 || n_chains < 1)
+    return fail(EXMC_ERR_BADARG, "bad arguments");
+  if ((size_t)n_draws * 24 > 64 * 1024) return fail(EXMC_ERR_UNSUPPORTED, "n_draws too large for the LDS ess kernel");
+  HIP_TRY(hipSetDevice(m->device));
+  HIP_TRY(hipEventRecord(m->ev0, m->stream));
+  hipLaunchKernelGGL(ess_kernel, dim3((unsigned)(d * n_chains)), dim3(256), (size_t)n_draws * 24,
+                     m->stream, draws_dev, n_draws, d, n_chains, ess_dev, 1);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(m->ev1, m->stream));
   return finish_timing(m);

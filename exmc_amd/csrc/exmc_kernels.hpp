@@ -227,22 +227,54 @@ __global__ void __launch_bounds__(kNutsBlock) find_eps_kernel(FindEpsParams P,
 
 // Diagnostics.ess (diagnostics.ex:42-52, 123-167): one workgroup per (dim, chain) series of a
 // [S][D][C] trace; lag sums are left-to-right per lag as the reference computes them.
+// bulk != 0: Diagnostics.ess_bulk (diagnostics.ex:60-72, 186-219) -- the series is first replaced
+// by the normal scores of its ranks (average rank for ties, (r - 3/8) / (n + 1/4), the
+// reference's rational probit approximation with sqrt IEEE and log from exmc_detmath.h); the
+// ranks are counted (every thread compares its elements with the whole series in LDS).
+__device__ __forceinline__ double probit_inner_dev(double p) {
+  const double t = __dsqrt_rn(-2.0 * exmc_log(p));
+  return t - (2.515517 + 0.802853 * t + 0.010328 * t * t) /
+                 (1.0 + 1.432788 * t + 0.189269 * t * t + 0.001308 * t * t * t);
+}
+
 __global__ void __launch_bounds__(256)
-ess_kernel(const double* draws, int S, int D, int C, double* ess_out) {
-  extern __shared__ double sh[];  // S centred values + S acf values
+ess_kernel(const double* draws, int S, int D, int C, double* ess_out, int bulk) {
+  extern __shared__ double sh[];  // S centred values + S acf values (+ S raw values when bulk)
   double* c = sh;
   double* acf = sh + S;
+  double* raw = sh + 2 * (size_t)S;
   const int series = blockIdx.x;  // dim * C + chain
   const double* x = draws + series;
   const size_t stride = (size_t)D * C;
   __shared__ double s_mean, s_var;
+  if (bulk && S >= 4) {
+    for (int i = threadIdx.x; i < S; i += blockDim.x) raw[i] = x[(size_t)i * stride];
+    __syncthreads();
+    for (int i = threadIdx.x; i < S; i += blockDim.x) {
+      const double xi = raw[i];
+      int lo = 0, eq = 0;
+      for (int j = 0; j < S; j++) {
+        const double xj = raw[j];
+        lo += (xj < xi) ? 1 : 0;
+        eq += (xj == xi) ? 1 : 0;
+      }
+      const double avg = (double)(lo + 1) + (double)(eq - 1) / 2.0;
+      const double pr = (avg - 0.375) / ((double)S + 0.25);
+      acf[i] = (pr < 0.5) ? -probit_inner_dev(pr) : probit_inner_dev(1.0 - pr);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < S; i += blockDim.x) raw[i] = acf[i];
+    __syncthreads();
+  }
   if (threadIdx.x == 0) {
     double sum = 0.0;
-    for (int i = 0; i < S; i++) sum += x[(size_t)i * stride];
+    if (bulk && S >= 4) for (int i = 0; i < S; i++) sum += raw[i];
+    else for (int i = 0; i < S; i++) sum += x[(size_t)i * stride];
     s_mean = sum / S;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < S; i += blockDim.x) c[i] = x[(size_t)i * stride] - s_mean;
+  for (int i = threadIdx.x; i < S; i += blockDim.x)
+    c[i] = ((bulk && S >= 4) ? raw[i] : x[(size_t)i * stride]) - s_mean;
   __syncthreads();
   if (threadIdx.x == 0) {
     double v = 0.0;

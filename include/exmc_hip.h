@@ -184,6 +184,10 @@ int exmc_hip_stream_next_host(exmc_hip_model* m, int n_draws, exmc_hip_trace tra
  * a device trace [draw][dim][chain]: ess_dev [dim][chain]. */
 int exmc_hip_ess(exmc_hip_model* m, const double* draws_dev, int n_draws, int d, int n_chains,
                  double* ess_dev);
+/* Exmc.Diagnostics.ess_bulk (lib/exmc/diagnostics.ex:60-72, 186-219): the same on the
+ * rank-normalised series (average ranks, probit of (r - 3/8) / (n + 1/4)). */
+int exmc_hip_ess_bulk(exmc_hip_model* m, const double* draws_dev, int n_draws, int d, int n_chains,
+                      double* ess_dev);
 
 /* Exmc.NUTS.NativeTree.build_full_tree_bin/17 (lib/exmc/nuts/native_tree.ex:55-75,
  * native/exmc_tree/src/lib.rs:219-302, tree.rs:276-326), batched over n_chains independent

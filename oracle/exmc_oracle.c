@@ -1202,8 +1202,9 @@ double exo_ess(const double* x, int n) {
   if (n < 4) return n * 1.0;
   return ess_from_acf_direct(x, n);
 }
+static int g_probit_mode = 0;   /* 1: log from exmc_detmath.h, as the device kernel */
 static double probit_inner(double p) {
-  double t = sqrt(-2.0 * log(p));
+  double t = sqrt(-2.0 * exo_log(p, g_probit_mode));
   return t - (2.515517 + 0.802853 * t + 0.010328 * t * t) /
                  (1.0 + 1.432788 * t + 0.189269 * t * t + 0.001308 * t * t * t);
 }
@@ -1233,6 +1234,12 @@ double exo_ess_bulk(const double* x, int n) {
   double r = ess_from_acf_direct(z, n);
   free(s);
   free(z);
+  return r;
+}
+double exo_ess_bulk_mode(const double* x, int n, int math_mode) {
+  g_probit_mode = math_mode;
+  double r = exo_ess_bulk(x, n);
+  g_probit_mode = 0;
   return r;
 }
 double exo_rhat(const double* chains, int nch, int n) {

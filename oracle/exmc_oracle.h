@@ -179,6 +179,7 @@ int exo_sample_tuned(const exo_model* m, const double* init_q, double epsilon,
 /* ---- diagnostics (diagnostics.ex:42-167) */
 double exo_ess(const double* x, int n);
 double exo_ess_bulk(const double* x, int n);
+double exo_ess_bulk_mode(const double* x, int n, int math_mode);  /* 1: deterministic log */
 double exo_rhat(const double* chains, int n_chains, int n);  /* chains [n_chains][n] */
 
 /* ---- NativeTree NIF semantics (native/exmc_tree/src/{tree,lib}.rs) */

@@ -148,6 +148,8 @@ def lib():
     L.exo_ess.restype = C.c_double
     L.exo_ess_bulk.argtypes = [dp, C.c_int]
     L.exo_ess_bulk.restype = C.c_double
+    L.exo_ess_bulk_mode.argtypes = [dp, C.c_int, C.c_int]
+    L.exo_ess_bulk_mode.restype = C.c_double
     L.exo_rhat.argtypes = [dp, C.c_int, C.c_int]
     L.exo_rhat.restype = C.c_double
     L.exo_nt_init_trajectory.argtypes = [dp, dp, dp, C.c_double, C.c_int]
