@@ -307,7 +307,11 @@ def generate(ir, ncp=True):
     vdata = list(g.data)
     for l in range(G):
         vdata.extend(table[c][l] for c in range(ncol))
+    qmask = 0
+    for m in __import__("re").finditer(r"qs\[(\d+)\]", text):
+        qmask |= 1 << int(m.group(1))
     macros = ["#define EXMC_GEN_VEC 1", "#define EXMC_GEN_NS %d" % len(s_out),
+              "#define EXMC_GEN_QMASK %du   /* dimensions the lane function reads through qs[] */" % qmask,
               "#define EXMC_GEN_NVU %d" % nvu, "#define EXMC_GEN_NLR %d" % ncol,
               "#define EXMC_GEN_NVC %d" % nvc, "#define EXMC_GEN_NLC %d" % nlc,
               "#define EXMC_GEN_SMAP {%s}" % ", ".join(str(v) for v in smap)]

@@ -845,7 +845,8 @@ struct Custom<16> : ModelDefaults {
   template <int... I>
   __device__ static __forceinline__ void bcast_all(double x, double (&qs)[D],
                                                    std::integer_sequence<int, I...>) {
-    ((qs[I] = group_bcast_c<G, I>(x)), ...);
+    // only the dimensions the generated code reads as shared variables are broadcast
+    ((qs[I] = ((EXMC_GEN_QMASK >> I) & 1u) ? group_bcast_c<G, I>(x) : 0.0), ...);
   }
   __device__ static __forceinline__ double logp_grad(const Consts& c, const Lane& ln, int l,
                                                      const double (&q)[DPL], double (&g)[DPL]) {
