@@ -112,6 +112,27 @@ def test_generated_eight_schools_chains_bit_exact_and_same_posterior(schools, hi
     assert abs(xg[:, 2].mean() - h_theta0.mean()) < 0.35
 
 
+def test_generated_eight_schools_at_the_bench_size(schools, hip):
+    """4096 chains x 1000 draws on the generated 16-lane kernels (what bench.py --model
+    gen_eight_schools times): chains from the first, a middle and the last wavefront equal the
+    checker's on every output; the counters are the trace's own sums."""
+    spec, comp, oms = schools
+    n_chains, n_draws = 4096, 1000
+    opts = dict(num_warmup=1000, num_samples=n_draws, seed=42)
+    tuning = sampler.warmup(comp, spec.default_init, opts)
+    _, _, extra = sampler.sample_compiled_tuned(comp, tuning, spec.default_init, opts,
+                                                num_chains=n_chains)
+    raw = extra["raw"]
+    q0 = spec.to_unconstrained(spec.default_init)
+    for lo in (0, 2050, n_chains - 2):
+        t, st = O.sample_chains(oms[16], n_chains, init_q=q0, num_warmup=1000, num_samples=n_draws,
+                                seed=42, chain_lo=lo, chain_hi=lo + 2, cfg=O.Cfg(1, 16))
+        assert st.step_size == tuning["epsilon"]
+        for k in ("draws", "logp", "tree_depth", "n_steps", "divergent", "accept_prob", "energy"):
+            assert np.array_equal(t[k], raw[k][lo:lo + 2]), (k, lo)
+    assert extra["total_leapfrogs"] == int(raw["n_steps"].astype(np.int64).sum())
+
+
 def test_plugin_refuses_other_kinds_and_wrong_data(simple):
     spec, comp, _ = simple
     h = C.c_void_p()
