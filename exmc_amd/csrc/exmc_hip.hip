@@ -1346,8 +1346,11 @@ int exmc_hip_rhat(exmc_hip_model* m, const double* draws_dev, int n_draws, int d
   int rc = m->io.ensure((size_t)d * 4 * n_chains * 8);   // half-chain means and variances
   if (rc) return rc;
   HIP_TRY(hipEventRecord(m->ev0, m->stream));
-  hipLaunchKernelGGL(rhat_kernel, dim3((unsigned)d), dim3(256), 0, m->stream, draws_dev, n_draws, d,
-                     n_chains, m->io.as<double>(), rhat_dev);
+  const unsigned slices = (unsigned)((2 * n_chains + 255) / 256);
+  hipLaunchKernelGGL(rhat_kernel, dim3((unsigned)d, slices), dim3(256), 0, m->stream, draws_dev,
+                     n_draws, d, n_chains, m->io.as<double>(), rhat_dev, 0);
+  hipLaunchKernelGGL(rhat_kernel, dim3((unsigned)d), dim3(64), 0, m->stream, draws_dev, n_draws, d,
+                     n_chains, m->io.as<double>(), rhat_dev, 1);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(m->ev1, m->stream));
   return finish_timing(m);
