@@ -125,7 +125,7 @@ def cpu_baseline(spec, init, K, n_chains_total, budget_s=15.0):
         import gen_checker
         om, cfg = gen_checker.model(spec.gen), O.Cfg(1, 1)
     else:
-        om, cfg = O.Model(spec.kind, spec.d, spec.data), O.Cfg(0, 1)
+        om, cfg = O.model_for(spec), O.Cfg(0, 1)
     q0 = spec.to_unconstrained(init)
     cores = min(os.cpu_count() or 1, 64)
     t0 = time.perf_counter()

@@ -21,6 +21,7 @@ EXPORTS = [
     "exmc_hip_traj_build_and_merge_host", "exmc_hip_traj_is_terminated_host",
     "exmc_hip_traj_get_result_host", "exmc_hip_build_subtree_host",
     "exmc_hip_stream_begin", "exmc_hip_stream_next_host", "exmc_hip_rhat", "exmc_hip_ess_bulk",
+    "exmc_hip_model_set_flat_order",
 ]
 
 
@@ -71,6 +72,7 @@ def bind(path):
     L.exmc_hip_model_destroy.argtypes = [vp]
     L.exmc_hip_model_destroy.restype = None
     L.exmc_hip_model_dim.argtypes = [vp]
+    L.exmc_hip_model_set_flat_order.argtypes = [vp, C.POINTER(C.c_int32), C.c_int]
     L.exmc_hip_model_default_lanes.argtypes = [vp]
     L.exmc_hip_model_stream.argtypes = [vp]
     L.exmc_hip_model_stream.restype = vp

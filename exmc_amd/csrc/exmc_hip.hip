@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -80,6 +81,8 @@ struct exmc_hip_model {
 #endif
   DevBuf data;      // model data kept in HBM (logistic X,y; radon u,starts,floor,y)
   DevBuf zig;       // ki[256] u64, wi[256], fi[256]
+  DevBuf flat;      // perm[D], rank[D] (int32) when the kernel order is not the reference's flat order
+  bool flat_set = false;
   DevBuf tuning;    // inv_mass[D], sqrt_inv_mass[D]
   DevBuf state;     // q[D][C], g[D][C], logp[C], rng[2][C]
   DevBuf stack;
@@ -212,6 +215,57 @@ dim3 grid_for(int n_chains, int lanes, int block) {
 
 constexpr int kBlock = 64;
 
+FlatOrder flat_order(exmc_hip_model* m) {
+  FlatOrder f;
+  if (m->flat_set) {
+    f.perm = m->flat.as<int32_t>();
+    f.rank = m->flat.as<int32_t>() + m->d;
+  }
+  return f;
+}
+
+// perm[r] = kernel dimension of flat entry r; identity clears the table
+int set_flat_order(exmc_hip_model* m, const int32_t* perm) {
+  const int d = m->d;
+  std::vector<int32_t> h(2 * (size_t)d, -1);
+  bool identity = true;
+  for (int r = 0; r < d; r++) {
+    if (perm[r] < 0 || perm[r] >= d || h[d + perm[r]] >= 0)
+      return fail(EXMC_ERR_BADARG, "flat order is not a permutation of 0..d-1");
+    h[r] = perm[r];
+    h[d + perm[r]] = r;
+    identity = identity && perm[r] == r;
+  }
+  if (identity) {
+    m->flat_set = false;
+    return EXMC_OK;
+  }
+  int rc = m->flat.ensure(h.size() * 4);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpy(m->flat.p, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+  m->flat_set = true;
+  return EXMC_OK;
+}
+
+// the kinds whose free-RV names the kind fixes: ids sorted as strings (point_map.ex:37)
+int default_flat_order(exmc_hip_model* m) {
+  std::vector<std::string> names;
+  if (m->kind == EXMC_MODEL_SV) {          // kernel order s_1..s_T, sigma, nu
+    for (int t = 1; t <= m->d - 2; t++) names.push_back("s_" + std::to_string(t));
+    names.push_back("sigma");
+    names.push_back("nu");
+  } else if (m->kind == EXMC_MODEL_LOGISTIC) {   // kernel order alpha, beta_1..beta_K
+    names.push_back("alpha");
+    for (int j = 1; j < m->d; j++) names.push_back("beta_" + std::to_string(j));
+  } else {
+    return EXMC_OK;   // sorted already (eight_schools, simple, generated models) or caller-defined (radon)
+  }
+  std::vector<int32_t> perm(m->d);
+  for (int i = 0; i < m->d; i++) perm[i] = i;
+  std::sort(perm.begin(), perm.end(), [&](int32_t a, int32_t b) { return names[a] < names[b]; });
+  return set_flat_order(m, perm.data());
+}
+
 const uint64_t* zig_ki(exmc_hip_model* m) { return m->zig.as<uint64_t>(); }
 const double* zig_wi(exmc_hip_model* m) { return m->zig.as<double>() + 256; }
 const double* zig_fi(exmc_hip_model* m) { return m->zig.as<double>() + 512; }
@@ -232,6 +286,7 @@ int launch_init(exmc_hip_model* m, int lanes, int C, int chain_lo, uint64_t seed
   P.init_q = init_dev;
   P.zig_ki = zig_ki(m); P.zig_wi = zig_wi(m); P.zig_fi = zig_fi(m);
   P.nor_r = EXMC_NOR_R;
+  P.flat = flat_order(m);
   return dispatch(m, lanes, [&](auto tag, const auto& mc) {
     using T = decltype(tag);
     const size_t xlds = aux_lds_bytes<typename T::M>();
@@ -268,6 +323,7 @@ int launch_nuts(exmc_hip_model* m, int lanes, int C, int n_draws, int draw_offse
     P.scratch = m->misc.as<double>() + 3;
     P.zig_ki = zig_ki(m); P.zig_wi = zig_wi(m); P.zig_fi = zig_fi(m);
     P.nor_r = EXMC_NOR_R;
+    P.flat = flat_order(m);
     if constexpr (M::kPipeNutsLevels > 0) {
       // wave pairs (tree + integrator), fewer stack levels in LDS to make room for the mailbox.
       // Opt-in (EXMC_HIP_NUTS_PIPE=1): bit-identical, but with the chip already full the pair
@@ -516,6 +572,7 @@ int find_eps(exmc_hip_model* m, int lanes, double* eps) {
   P.eps_out = m->misc.as<double>();
   P.zig_ki = zig_ki(m); P.zig_wi = zig_wi(m); P.zig_fi = zig_fi(m);
   P.nor_r = EXMC_NOR_R;
+  P.flat = flat_order(m);
   int rc = dispatch(m, lanes, [&](auto tag, const auto& mc) {
     using T = decltype(tag);
     const size_t lds_bytes = nuts_lds_bytes<typename T::M, 0>();
@@ -611,6 +668,7 @@ int run_warmup_device(exmc_hip_model* m, int lanes, exmc_hip_opts o, exmc_hip_tu
   }
   P.zig_ki = zig_ki(m); P.zig_wi = zig_wi(m); P.zig_fi = zig_fi(m);
   P.nor_r = EXMC_NOR_R;
+  P.flat = flat_order(m);
   int rc = m->io.ensure((size_t)(8 + d) * 8);
   if (rc) return rc;
   P.out = m->io.as<double>();
@@ -886,15 +944,25 @@ int exmc_hip_model_create(int kind, int d, const double* data, int n_data, int d
     m->cu.vc = m->data.as<double>() + EXMC_GEN_NCONST;
   }
 #endif
+  rc = default_flat_order(m);
+  if (rc) return bail(rc);
   *out = m;
   return EXMC_OK;
+}
+
+int exmc_hip_model_set_flat_order(exmc_hip_model* m, const int32_t* perm, int d) {
+  if (check_model(m)) return EXMC_ERR_BADARG;
+  if (!perm || d != m->d) return fail(EXMC_ERR_BADARG, "flat order needs d entries");
+  HIP_TRY(hipSetDevice(m->device));
+  m->res_C = 0;   // resident chains were initialised under the previous order
+  return set_flat_order(m, perm);
 }
 
 void exmc_hip_model_destroy(exmc_hip_model* m) {
   if (!m) return;
   (void)hipSetDevice(m->device);
   m->zig.release(); m->tuning.release(); m->state.release(); m->stack.release();
-  m->misc.release(); m->trace.release(); m->io.release(); m->data.release();
+  m->misc.release(); m->trace.release(); m->io.release(); m->data.release(); m->flat.release();
   if (m->ev0) (void)hipEventDestroy(m->ev0);
   if (m->ev1) (void)hipEventDestroy(m->ev1);
   if (m->stream) (void)hipStreamDestroy(m->stream);

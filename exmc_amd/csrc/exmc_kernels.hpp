@@ -135,6 +135,7 @@ struct InitParams {
   const double* zig_wi;
   const double* zig_fi;
   double nor_r;
+  FlatOrder flat;
 };
 
 template <class M, int G>
@@ -164,11 +165,18 @@ __global__ void __launch_bounds__(kAuxBlock) init_chains_kernel(InitParams P,
       if (i < D) q[k] = P.init_q[i];
     }
   } else {
-    for (int i = 0; i < D; i++) {
+    // sampler.ex:339-349: variate r fills entry r of the reference's flat vector
+    int rank[DPL];
+#pragma unroll
+    for (int k = 0; k < DPL; k++) {
+      const int i = l + k * G;
+      rank[k] = (i < D) ? (P.flat.rank ? P.flat.rank[i] : i) : D;
+    }
+    for (int r = 0; r < D; r++) {
       const double z = rng_normal(rng, zt, P.nor_r);
 #pragma unroll
       for (int k = 0; k < DPL; k++)
-        if (l + k * G == i) q[k] = z * 0.1;
+        if (rank[k] == r) q[k] = z * 0.1;
     }
   }
   const double lp = M::logp_grad(mc, ln, l, q, g);
@@ -202,6 +210,7 @@ struct FindEpsParams {
   const double* zig_wi;
   const double* zig_fi;
   double nor_r;
+  FlatOrder flat;
 };
 
 template <class M, int G>
@@ -214,7 +223,7 @@ __global__ void __launch_bounds__(kNutsBlock) find_eps_kernel(FindEpsParams P,
   const bool writer = threadIdx.x < G;
   if (blockIdx.x != 0 || (!M::kCoop && !writer)) return;
   NutsLane<M, G> L;
-  lane_setup<M, G, 0>(L, mc, lds, nullptr, P.inv_mass, P.sqrt_inv_mass, zt, P.nor_r);
+  lane_setup<M, G, 0>(L, mc, lds, nullptr, P.inv_mass, P.sqrt_inv_mass, zt, P.nor_r, P.flat);
   ChainRegs<DPL> st;
   chain_load<M, G>(P.st, P.n_chains, 0, L.l, st);
   const double eps = find_eps_dev<M, G>(mc, L, st, P.log_half);

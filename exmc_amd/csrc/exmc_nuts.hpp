@@ -74,6 +74,16 @@ __device__ unsigned long long g_prof[16];
 #define EXMC_PROF_FLUSH
 #endif
 
+// The reference's flat vector is the free RVs sorted by id as strings (point_map.ex:30-60) and
+// the RNG-consuming steps fill it front to back (init_position sampler.ex:339-349,
+// sample_momentum_fast sampler.ex:393-403). The kernels keep their own compute layout; a model
+// whose kernel order is not the sorted one carries the permutation: perm[r] = kernel dimension of
+// flat entry r, rank[i] = flat position of kernel dimension i (both null = identity).
+struct FlatOrder {
+  const int32_t* perm = nullptr;   // dev [D]
+  const int32_t* rank = nullptr;   // dev [D]
+};
+
 struct ChainState {
   double* q;       // [D][C]
   double* g;       // [D][C]
@@ -108,6 +118,7 @@ struct NutsParams {
   const double* zig_wi;
   const double* zig_fi;
   double nor_r;
+  FlatOrder flat;
 };
 
 constexpr int kMaxLevels = 12;
@@ -162,6 +173,8 @@ struct NutsLane {
   typename M::Lane ln;
   double im[DPL], sim[DPL];
   bool valid[DPL];
+  int rank[DPL];     // flat (draw) position of this lane's dimensions; M::D for slots past D
+  const int32_t* perm;   // flat position -> kernel dimension, null = identity
   int l;
   double* lstk;      // this lane's column of the LDS stack
   double* gstk;      // this lane's column of the global spill stack
@@ -209,14 +222,33 @@ __device__ __forceinline__ int wave_min_pos(int pos) {
   }
 }
 
-// sampler.ex:393-403: d sequential normal_s draws -> p = z / sqrt(M^-1). normal_s accepts 98.5 %
-// of its 58-bit words at once (one word per variate) and otherwise consumes a data-dependent
-// number of further words, so the draws are sequential in principle. Here: the group advances a
-// copy of the stream over all remaining dimensions, lane l keeping the generator state in front
-// of its own dimensions, and every lane tests its own word at once. Up to the first dimension j
-// whose word is not accepted at once the variates are final; dimension j is then drawn the long
-// way from the state in front of it (taken from the lane that owns it), and the pass repeats from
-// j + 1. Expected passes: 1 + 0.015 d, against d sequential draws.
+// smallest value over the G-lane chain group (32-bit, DPP inside a row, v_readlane across rows)
+template <int G>
+__device__ __forceinline__ int group_min_i32(int v) {
+  if (G >= 2) v = min(v, __builtin_amdgcn_mov_dpp(v, kDppXor1, 0xF, 0xF, true));
+  if (G >= 4) v = min(v, __builtin_amdgcn_mov_dpp(v, kDppXor2, 0xF, 0xF, true));
+  if (G >= 8) v = min(v, __builtin_amdgcn_mov_dpp(v, kDppHalfMirror, 0xF, 0xF, true));
+  if (G >= 16) v = min(v, __builtin_amdgcn_mov_dpp(v, kDppRowMirror, 0xF, 0xF, true));
+  if (G >= 32) {
+    const int r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
+    const int r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+    const int h0 = min(r0, r1), h1 = min(r2, r3);
+    if (G == 32) v = ((threadIdx.x & 63) < 32) ? h0 : h1;
+    else v = min(h0, h1);
+  }
+  return v;
+}
+
+// sampler.ex:393-403: d sequential normal_s draws -> p = z / sqrt(M^-1), variate r going to the
+// r-th entry of the reference's flat vector (L.rank / L.perm, see FlatOrder). normal_s accepts
+// 98.5 % of its 58-bit words at once (one word per variate) and otherwise consumes a
+// data-dependent number of further words, so the draws are sequential in principle. Here: the
+// group advances a copy of the stream over all remaining draws, each lane keeping the generator
+// state in front of the draws of its own dimensions, and every lane tests its own word at once.
+// Up to the first draw j whose word is not accepted at once the variates are final; draw j is then
+// made the long way from the state in front of it (taken from the lane that owns that
+// dimension), and the pass repeats from j + 1. Expected passes: 1 + 0.015 d, against d sequential
+// draws.
 template <class M, int G>
 __device__ __forceinline__ void draw_momentum(const NutsLane<M, G>& L, Rng& rng,
                                               double (&p)[M::DPL]) {
@@ -225,13 +257,13 @@ __device__ __forceinline__ void draw_momentum(const NutsLane<M, G>& L, Rng& rng,
   double z[DPL];
 #pragma unroll
   for (int k = 0; k < DPL; k++) z[k] = 0.0;
-  int pos = 0;   // dimensions [0, pos) are final and rng stands in front of dimension pos
+  int pos = 0;   // draws [0, pos) are final and rng stands in front of draw pos
   for (;;) {
     Rng r2 = rng;
     uint64_t sa[DPL], sb[DPL];
 #pragma unroll
     for (int k = 0; k < DPL; k++) { sa[k] = 0; sb[k] = 0; }
-    // kept rolled: unrolled, the D lane predicates (l == i) are hoisted into scalar register
+    // kept rolled: unrolled, the D lane predicates (rank == i) are hoisted into scalar register
     // pairs for the whole kernel and the sampling loop pays for them in v_readlane spills
     const int i0 = wave_min_pos<G>(pos);
 #pragma nounroll
@@ -239,7 +271,7 @@ __device__ __forceinline__ void draw_momentum(const NutsLane<M, G>& L, Rng& rng,
       const bool act = (G == 64) || (i >= pos);
 #pragma unroll
       for (int k = 0; k < DPL; k++) {
-        const bool mine = act && (L.l + k * G == i);
+        const bool mine = act && (L.rank[k] == i);
         sa[k] = mine ? r2.a : sa[k];
         sb[k] = mine ? r2.b : sb[k];
       }
@@ -251,38 +283,46 @@ __device__ __forceinline__ void draw_momentum(const NutsLane<M, G>& L, Rng& rng,
     bool fail[DPL];
 #pragma unroll
     for (int k = 0; k < DPL; k++) {
-      const bool live = L.valid[k] && (L.l + k * G >= pos);
+      const bool live = L.valid[k] && (L.rank[k] >= pos);
       double zz;
       const bool acc = normal_fast(rng_scramble(sb[k]), L.zt, zz);
       fail[k] = live && !acc;
       z[k] = (live && acc) ? zz : z[k];
     }
-    int j = D;   // first dimension of this group that needs the long way, D if none
+    int j = D;   // first draw of this group that needs the long way, D if none
+    if (L.perm == nullptr) {
+      // identity order: the first failing dimension is the first set bit of the group's ballot
 #pragma unroll
-    for (int k = DPL - 1; k >= 0; k--) {
-      const unsigned long long m = __ballot(fail[k] ? 1 : 0);
-      const unsigned long long gm = (G == 64) ? m : ((m >> base) & ((1ULL << (G & 63)) - 1ULL));
-      j = (gm != 0) ? (k * G + __ffsll((long long)gm) - 1) : j;
+      for (int k = DPL - 1; k >= 0; k--) {
+        const unsigned long long m = __ballot(fail[k] ? 1 : 0);
+        const unsigned long long gm = (G == 64) ? m : ((m >> base) & ((1ULL << (G & 63)) - 1ULL));
+        j = (gm != 0) ? (k * G + __ffsll((long long)gm) - 1) : j;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < DPL; k++) j = fail[k] ? min(j, L.rank[k]) : j;
+      j = group_min_i32<G>(j);
     }
     if (__any((j < D) ? 1 : 0) == 0) {
       rng = r2;
       break;
     }
     if (j < D) {
-      const int ks = j / G;
+      const int dim = (L.perm == nullptr) ? j : L.perm[j];   // the dimension draw j belongs to
+      const int ks = dim / G;
       uint64_t aj = 0, bj = 0;
 #pragma unroll
       for (int k = 0; k < DPL; k++) {
         aj = (k == ks) ? sa[k] : aj;
         bj = (k == ks) ? sb[k] : bj;
       }
-      const int src = base | (j & (G - 1));
+      const int src = base | (dim & (G - 1));
       Rng rj;
       rj.a = __shfl(aj, src, 64);
       rj.b = __shfl(bj, src, 64);
       const double zz = rng_normal(rj, L.zt, L.nor_r);
 #pragma unroll
-      for (int k = 0; k < DPL; k++) z[k] = (L.l + k * G == j) ? zz : z[k];
+      for (int k = 0; k < DPL; k++) z[k] = (L.rank[k] == j) ? zz : z[k];
       rng = rj;
       pos = j + 1;
     } else {
@@ -796,7 +836,7 @@ template <class M, int G, int LDSL>
 __device__ __forceinline__ void lane_setup(NutsLane<M, G>& L, const typename M::Consts& mc,
                                            double* lds, double* stack, const double* inv_mass,
                                            const double* sqrt_inv_mass, const ZigTables& zt,
-                                           double nor_r) {
+                                           double nor_r, const FlatOrder& flat = FlatOrder{}) {
   constexpr int D = M::D, DPL = M::DPL;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   L.l = threadIdx.x & (G - 1);
@@ -815,7 +855,9 @@ __device__ __forceinline__ void lane_setup(NutsLane<M, G>& L, const typename M::
     L.valid[k] = i < D;
     L.im[k] = (L.valid[k] && inv_mass) ? inv_mass[i] : 1.0;
     L.sim[k] = (L.valid[k] && sqrt_inv_mass) ? sqrt_inv_mass[i] : 1.0;
+    L.rank[k] = L.valid[k] ? (flat.rank ? flat.rank[i] : i) : D;
   }
+  L.perm = flat.perm;
 }
 
 template <class M, int G>
@@ -872,7 +914,7 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock)
   if (!M::kCoop && !has_chain) return;
 
   NutsLane<M, G> L;
-  lane_setup<M, G, LDSL>(L, mc, lds, P.stack, P.inv_mass, P.sqrt_inv_mass, zt, P.nor_r);
+  lane_setup<M, G, LDSL>(L, mc, lds, P.stack, P.inv_mass, P.sqrt_inv_mass, zt, P.nor_r, P.flat);
   if constexpr (M::kLdsDataDoubles > 0) L.ln.xoff = xoff;
   L.alive = has_chain;
   using Pipe = std::conditional_t<kPipe, PipeBox<DPL>, NoPipe>;
@@ -1044,6 +1086,7 @@ struct WarmupParams {
   const double* zig_wi;
   const double* zig_fi;
   double nor_r;
+  FlatOrder flat;
 };
 
 struct DualAvgDev {
@@ -1098,7 +1141,7 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock)
   if (!M::kCoop && !writer) return;
 
   NutsLane<M, G> L;
-  lane_setup<M, G, LDSL>(L, mc, lds, P.stack, nullptr, nullptr, zt, P.nor_r);
+  lane_setup<M, G, LDSL>(L, mc, lds, P.stack, nullptr, nullptr, zt, P.nor_r, P.flat);
   if constexpr (M::kStageDoubles > 0) L.ln.xs = stage_ptr;
   if constexpr (M::kLdsDataDoubles > 0) L.ln.xoff = xoff;
   using Pipe = std::conditional_t<kPipe, PipeBox<DPL>, NoPipe>;

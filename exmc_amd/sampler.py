@@ -39,6 +39,11 @@ class Compiled:
         self.h = h
         self.d = spec.d
         self.device = device
+        # PointMap.build's layout (point_map.ex:30-60): the RNG-consuming steps draw in the flat
+        # order of the sorted ids; the kernels keep their own compute layout
+        order = np.ascontiguousarray(spec.flat_order(), dtype=np.int32)
+        _lib.check(L.exmc_hip_model_set_flat_order(
+            h, order.ctypes.data_as(C.POINTER(C.c_int32)), int(order.size)), L)
 
     def close(self):
         if getattr(self, "h", None):

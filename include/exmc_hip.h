@@ -100,6 +100,15 @@ int exmc_hip_device_count(void);
 int exmc_hip_model_create(int kind, int d, const double* data, int n_data, int device,
                           exmc_hip_model** out);
 void exmc_hip_model_destroy(exmc_hip_model* m);
+/* Replaces PointMap.build's layout decision (lib/exmc/point_map.ex:30-60: free RVs sorted by id
+ * as strings) for the RNG-consuming steps: init_position (sampler.ex:339-349) and
+ * sample_momentum_fast (sampler.ex:393-403) draw one normal_s per entry of that flat vector, front
+ * to back. perm[r] = kernel dimension of flat entry r (d entries). The compute layout, traces and
+ * inv_mass stay in kernel order. Defaults at create: the string sort of the kind's own names for
+ * SV (nu, s_1, s_10, s_100, s_11, ...) and LOGISTIC (alpha, beta_1, beta_10, ...); identity for
+ * the kinds whose kernel order is sorted already; RADON's county order depends on its data, so its
+ * caller passes the order. Evicts resident chains. */
+int exmc_hip_model_set_flat_order(exmc_hip_model* m, const int32_t* perm, int d);
 int exmc_hip_model_dim(const exmc_hip_model* m);
 int exmc_hip_model_default_lanes(const exmc_hip_model* m);
 /* the model handle's HIP stream (hipStream_t as void*) */

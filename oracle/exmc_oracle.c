@@ -236,7 +236,43 @@ struct exo_model {
   double* data;     /* model-specific */
   double* aux;      /* derived constants */
   exo_custom_fn custom;
+  /* flat[r] = kernel dimension of the r-th entry of the reference's flat vector: PointMap.build
+   * sorts the free RVs by id as strings (point_map.ex:30-60) and init_position /
+   * sample_momentum_fast consume one normal_s per flat entry in that order (sampler.ex:339-349,
+   * 393-403). Identity when the kernel order already is the sorted one. */
+  int flat[EXO_MAX_D];
 };
+
+/* ids of a kind whose names the kind fixes, sorted as the reference sorts them (byte order) */
+static int cmp_names(const void* a, const void* b) {
+  return strcmp(((const char* const*)a)[0], ((const char* const*)b)[0]);
+}
+static void flat_from_names(exo_model* m, char (*names)[24]) {
+  const char* ptr[EXO_MAX_D];
+  for (int i = 0; i < m->d; i++) ptr[i] = names[i];
+  qsort(ptr, (size_t)m->d, sizeof(ptr[0]), cmp_names);
+  for (int r = 0; r < m->d; r++) m->flat[r] = (int)((ptr[r] - names[0]) / 24);
+}
+static void default_flat_order(exo_model* m) {
+  char names[EXO_MAX_D][24];
+  for (int i = 0; i < EXO_MAX_D; i++) m->flat[i] = i;
+  if (m->kind == EXO_MODEL_SV) {
+    /* kernel order s_1..s_T, sigma, nu (STANDARD_BENCHMARKS.md:51-61 names) */
+    int T = m->d - 2;
+    for (int t = 0; t < T; t++) snprintf(names[t], 24, "s_%d", t + 1);
+    snprintf(names[T], 24, "sigma");
+    snprintf(names[T + 1], 24, "nu");
+    flat_from_names(m, names);
+  } else if (m->kind == EXO_MODEL_LOGISTIC) {
+    /* kernel order alpha, beta_1..beta_K */
+    snprintf(names[0], 24, "alpha");
+    for (int j = 1; j < m->d; j++) snprintf(names[j], 24, "beta_%d", j);
+    flat_from_names(m, names);
+  }
+  /* radon: the county order of the kernel layout depends on the data (descending county size);
+   * its caller passes the order with exo_model_set_flat_order. eight_schools (mu, tau,
+   * theta_trans_0..7) and simple (mu, sigma) are sorted already. */
+}
 
 exo_model* exo_model_create(int kind, int d, const double* data, int n_data) {
   exo_model* m = (exo_model*)calloc(1, sizeof(exo_model));
@@ -284,7 +320,21 @@ exo_model* exo_model_create(int kind, int d, const double* data, int n_data) {
     exo_model_free(m);
     return 0;
   }
+  default_flat_order(m);
   return m;
+}
+int exo_model_set_flat_order(exo_model* m, const int* flat) {
+  char seen[EXO_MAX_D];
+  memset(seen, 0, sizeof(seen));
+  for (int r = 0; r < m->d; r++) {
+    if (flat[r] < 0 || flat[r] >= m->d || seen[flat[r]]) return -1;   /* not a permutation */
+    seen[flat[r]] = 1;
+  }
+  for (int r = 0; r < m->d; r++) m->flat[r] = flat[r];
+  return 0;
+}
+void exo_model_get_flat_order(const exo_model* m, int* flat) {
+  for (int r = 0; r < m->d; r++) flat[r] = m->flat[r];
 }
 void exo_model_free(exo_model* m) {
   if (!m) return;
@@ -932,9 +982,10 @@ typedef struct {
   int divergences;
 } cstate;
 
-static void sample_momentum(exo_rng* rng, const double* im, int d, double* p, int mm) {
-  /* sampler.ex:393-403 */
-  for (int i = 0; i < d; i++) {
+static void sample_momentum(const exo_model* m, exo_rng* rng, const double* im, double* p, int mm) {
+  /* sampler.ex:393-403: one normal_s per entry of the flat vector, in flat (sorted-id) order */
+  for (int r = 0; r < m->d; r++) {
+    int i = m->flat[r];
     double z = exo_rng_normal(rng, mm);
     p[i] = z / sqrt(im[i]);
   }
@@ -950,7 +1001,7 @@ static void nuts_step(const exo_model* m, cstate* s, double eps, const double* i
   /* sampler.ex:794-925 */
   int d = m->d;
   double p[EXO_MAX_D], qn[EXO_MAX_D], gn[EXO_MAX_D];
-  sample_momentum(&s->rng, im, d, p, c.math_mode);
+  sample_momentum(m, &s->rng, im, p, c.math_mode);
   double jlp0 = s->logp - exo_kinetic_energy(p, im, d, c);
   exo_tree_result r;
   exo_tree_build(m, s->q, p, s->logp, s->g, eps, im, max_depth, s->rng, jlp0, qn, gn, &r, c);
@@ -967,7 +1018,7 @@ static double find_reasonable_epsilon(const exo_model* m, cstate* s, const doubl
   /* sampler.ex:451-530 */
   int d = m->d;
   double p[EXO_MAX_D];
-  sample_momentum(&s->rng, im, d, p, c.math_mode);
+  sample_momentum(m, &s->rng, im, p, c.math_mode);
   double jlp0 = s->logp - exo_kinetic_energy(p, im, d, c);
   double eps = 1.0;
   double q[EXO_MAX_D], pp[EXO_MAX_D], g[EXO_MAX_D], jlp;
@@ -995,7 +1046,8 @@ static void init_chain(const exo_model* m, const double* init_q, uint64_t seed, 
   if (init_q) {
     vcp(s->q, init_q, d);
   } else {
-    for (int i = 0; i < d; i++) s->q[i] = exo_rng_normal(&s->rng, c.math_mode) * 0.1;
+    /* sampler.ex:339-349: d normal_s draws fill the flat vector front to back */
+    for (int r = 0; r < d; r++) s->q[m->flat[r]] = exo_rng_normal(&s->rng, c.math_mode) * 0.1;
   }
   s->logp = exo_logp_grad(m, s->q, s->g, c);
   s->divergences = 0;

@@ -81,6 +81,12 @@ int exo_model_dim(const exo_model* m);
  * from the same expression graph as the HIP functor (deterministic-math contract only). */
 typedef double (*exo_custom_fn)(const double* data, const double* q, double* grad);
 void exo_model_set_custom(exo_model* m, exo_custom_fn fn);
+/* flat[r] = kernel dimension of the r-th entry of the reference's flat vector (PointMap.build sorts
+ * free-RV ids as strings, point_map.ex:30-60); the RNG-consuming steps (init_position,
+ * sample_momentum_fast: sampler.ex:339-349, 393-403) draw in that order. Defaults: the string sort
+ * of the kind's names for sv and logistic, identity otherwise. Returns -1 if not a permutation. */
+int exo_model_set_flat_order(exo_model* m, const int* flat);
+void exo_model_get_flat_order(const exo_model* m, int* flat);
 double exo_logp_grad(const exo_model* m, const double* q, double* grad, exo_cfg cfg);
 void exo_constrain(const exo_model* m, const double* q, double* x); /* Transform.apply per entry */
 /* distribution known answers (dist/<name>.ex doctests) */

@@ -61,7 +61,7 @@ def model_for(name):
         return O.simple()
     if name in ("logistic", "radon"):
         spec = spec_for(name)
-        return O.Model(spec.kind, spec.d, spec.data)
+        return O.model_for(spec)
     return O.Model(O.SV, 102, sv_returns())
 
 

@@ -102,6 +102,10 @@ def lib():
     L.exo_model_set_custom.argtypes = [C.c_void_p, C.c_void_p]
     L.exo_model_set_custom.restype = None
     L.exo_model_dim.argtypes = [C.c_void_p]
+    L.exo_model_set_flat_order.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    L.exo_model_set_flat_order.restype = C.c_int
+    L.exo_model_get_flat_order.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    L.exo_model_get_flat_order.restype = None
     L.exo_logp_grad.argtypes = [C.c_void_p, dp, dp, Cfg]
     L.exo_logp_grad.restype = C.c_double
     L.exo_constrain.argtypes = [C.c_void_p, dp, dp]
@@ -196,6 +200,18 @@ class Model:
                 self.h = None
         except Exception:
             pass
+
+    def set_flat_order(self, order):
+        """order[r] = kernel dimension of the r-th entry of the reference's flat vector."""
+        a = np.ascontiguousarray(order, dtype=np.int32)
+        assert a.size == self.d
+        if lib().exo_model_set_flat_order(self.h, a.ctypes.data_as(C.POINTER(C.c_int))) != 0:
+            raise ValueError("flat order is not a permutation")
+
+    def flat_order(self):
+        a = np.zeros(self.d, dtype=np.int32)
+        lib().exo_model_get_flat_order(self.h, a.ctypes.data_as(C.POINTER(C.c_int)))
+        return [int(v) for v in a]
 
     def logp_grad(self, q, cfg=None):
         cfg = cfg or Cfg(0, 1)
@@ -294,6 +310,14 @@ def sample_chains(model, n_chains, init_q=None, num_warmup=1000, num_samples=100
     for k in t:
         t[k] = t[k].reshape((nc, num_samples) + t[k].shape[1:])
     return t, st
+
+
+def model_for(spec):
+    """The checker's model for an exmc_amd ModelSpec, drawing in the spec's flat order
+    (ModelSpec.flat_order = PointMap.build's sorted ids, point_map.ex:30-60)."""
+    m = Model(spec.kind, spec.d, spec.data)
+    m.set_flat_order(spec.flat_order())
+    return m
 
 
 EIGHT_SCHOOLS_Y = [28.0, 8.0, -3.0, 7.0, -1.0, 1.0, 18.0, 12.0]

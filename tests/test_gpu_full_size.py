@@ -121,7 +121,7 @@ def test_every_chain_of_a_batch_bit_exact(hip, name, lanes, n_chains, n_draws):
     import bench
     spec = bench.make_spec(name)[0]
     comp = sampler.compile(spec)
-    om = O.Model(spec.kind, spec.d, spec.data)
+    om = O.model_for(spec)
     opts = dict(num_warmup=1000, num_samples=n_draws, seed=123, lanes_per_chain=lanes)
     tuning = sampler.warmup(comp, spec.default_init, opts)
     _, _, extra = sampler.sample_compiled_tuned(comp, tuning, spec.default_init, opts,

@@ -63,7 +63,7 @@ def test_model_logp_grad_bit_exact(hip, name, factory, lane_list):
     N=500 dense X@beta), radon (d=90, 919 observations in 85 counties)."""
     spec = factory()
     comp = sampler.compile(spec)
-    om = O.Model(spec.kind, spec.d, spec.data)
+    om = O.model_for(spec)
     rng = np.random.default_rng(3)
     C_ = 37
     q = _rand_q(rng, C_, spec.d, 0.4)
@@ -229,6 +229,36 @@ def test_random_init_bit_exact(es, hip):
     assert np.array_equal(t["tree_depth"], extra["raw"]["tree_depth"])
 
 
+def _permuted_models():
+    import bench
+    return [("sv", lambda: bench.make_spec("sv")[0], 64), ("sv32", lambda: bench.make_spec("sv")[0], 32),
+            ("radon", lambda: bench.make_spec("radon")[0], 64),
+            ("logistic", lambda: bench.make_spec("logistic")[0], 16),
+            ("logistic8", lambda: bench.make_spec("logistic")[0], 8),
+            ("logistic_mfma", lambda: bench.make_spec("logistic")[0], 4)]
+
+
+@pytest.mark.parametrize("name,factory,lanes", _permuted_models(),
+                         ids=lambda x: x if isinstance(x, str) else "")
+def test_random_init_and_momentum_in_flat_order_bit_exact(hip, name, factory, lanes):
+    """Models whose kernel layout is not the sorted-id order: the 0.1 * normal_s init
+    (sampler.ex:339-349), the step-size search and every momentum draw (sampler.ex:393-403) consume
+    the stream in PointMap's flat order (point_map.ex:30-60) on both sides."""
+    spec = factory()
+    assert spec.flat_order() != list(range(spec.d))
+    comp = sampler.compile(spec)
+    om = O.model_for(spec)
+    opts = dict(num_warmup=30, num_samples=6, seed=5, lanes_per_chain=lanes, max_tree_depth=5)
+    tuning = sampler.warmup(comp, None, opts)
+    t, st = O.sample_chains(om, 5, init_q=None, num_warmup=30, num_samples=6, seed=5,
+                            max_tree_depth=5, cfg=O.Cfg(1, lanes))
+    assert st.step_size == tuning["epsilon"]
+    assert np.array_equal(np.array(st.inv_mass[:spec.d]), tuning["inv_mass"])
+    _, _, extra = sampler.sample_compiled_tuned(comp, tuning, None, opts, num_chains=5)
+    for k in ("tree_depth", "n_steps", "divergent", "draws", "energy"):
+        assert np.array_equal(t[k], extra["raw"][k]), k
+
+
 def test_single_chain_sample_bit_exact(hip):
     """Sampler.sample/3 on the d=2 plumbing config (BASELINE configs[0])."""
     spec = models.simple()
@@ -261,7 +291,7 @@ def test_bench_protocol_other_models_bit_exact(hip, name, factory, lanes, n_chai
     per-draw output identical to the checker."""
     spec = factory()
     comp = sampler.compile(spec)
-    om = O.Model(spec.kind, spec.d, spec.data)
+    om = O.model_for(spec)
     opts = dict(num_warmup=1000, num_samples=n_draws, seed=42, lanes_per_chain=lanes)
     tuning = sampler.warmup(comp, spec.default_init, opts)
     q0 = spec.to_unconstrained(spec.default_init)
@@ -312,7 +342,7 @@ def test_logp_grad_extreme_operands_bit_exact(hip, name, factory, lane_list):
     (NaN where the checker gives NaN)."""
     spec = factory()
     comp = sampler.compile(spec)
-    om = O.Model(spec.kind, spec.d, spec.data)
+    om = O.model_for(spec)
     rng = np.random.default_rng(17)
     d = spec.d
     rows = [np.zeros(d), np.full(d, 1e-300), np.full(d, -1e-300), np.full(d, 1e-160),

@@ -25,7 +25,7 @@ def all_models():
     lg, rd = models.logistic(), models.radon()
     return [("std_normal", O.std_normal(7)), ("simple", O.simple()),
             ("eight_schools", O.eight_schools()), ("sv", O.Model(O.SV, 102, sv_returns())),
-            ("logistic", O.Model(lg.kind, lg.d, lg.data)), ("radon", O.Model(rd.kind, rd.d, rd.data))]
+            ("logistic", O.model_for(lg)), ("radon", O.model_for(rd))]
 
 
 def fd_grad(m, q, cfg, h=1e-6):

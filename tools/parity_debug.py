@@ -21,7 +21,7 @@ def main():
     nw = int(sys.argv[5]) if len(sys.argv) > 5 else 1000
     spec, _ = bench.make_spec(name)
     comp = sampler.compile(spec)
-    om = O.Model(spec.kind, spec.d, spec.data)
+    om = O.model_for(spec)
     opts = dict(num_warmup=nw, num_samples=n_draws, seed=42, lanes_per_chain=lanes)
     tuning = sampler.warmup(comp, spec.default_init, opts)
     q0 = spec.to_unconstrained(spec.default_init)

@@ -23,7 +23,7 @@ def main():
     lanes = int(sys.argv[2]) if len(sys.argv) > 2 else comp.default_lanes
     nw = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
     tun = sampler.warmup(comp, spec.default_init, dict(num_warmup=nw, seed=42, lanes_per_chain=lanes))
-    om = O.Model(spec.kind, spec.d, spec.data)
+    om = O.model_for(spec)
     st = O.warmup(om, spec.to_unconstrained(spec.default_init), num_warmup=nw, seed=42,
                   cfg=O.Cfg(1, lanes))
     im = np.array(st.inv_mass[:spec.d])
