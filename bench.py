@@ -1,13 +1,17 @@
 #!/usr/bin/env python3
 """bench.py — leapfrog steps/s and ESS/s of the NUTS hot path on MI355X.
 
-A "step" is one NUTS transition (draw) for every resident chain. After the shared adaptation
-warmup (sampler.ex:1053-1080, run once, untimed for `value`, wall time reported) the chains are
-initialised in HBM, W untimed draws are taken, then exactly K draws are timed between
+A "step" is one pass of the hot path over one batch: --draws-per-step (default 50) NUTS
+transitions for every resident chain, so the driver's `--steps 20` is SURVEY 8(d)'s protocol --
+1000 draws per chain after one shared 1000-iteration warmup. After the shared adaptation warmup
+(sampler.ex:1053-1080, run once, untimed for `value`, wall time reported and counted in ESS/s) W
+untimed steps are taken on throw-away chains, the chains are initialised again, and exactly K steps
+(one launch of the NUTS kernel, one trace of K * draws-per-step rows) are timed between
 barrier + synchronize pairs. value = useful leapfrogs (sum of n_steps, tree.ex:1612) per second
-over all GPUs; ESS/s, the roofline of the NUTS kernel and the CPU checker's numbers ride along.
+over all GPUs; ESS/s (adaptation + sampling + the ESS kernel + the gather), the roofline of the
+NUTS kernel and the CPU checker's numbers ride along.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W      (N > 1 without a launcher: spawns the ranks)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 """
 import argparse
@@ -114,6 +118,22 @@ def multi_step_roofline(comp, spec, dev, n_chains=262144, n_steps=32, lanes=1, r
             "bytes_per_launch": nbytes}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children through
+    torch.distributed.run (before anything in this process touches a GPU; never exec in place, a
+    profiler may already have initialised the device) and relay their output and exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def cpu_baseline(spec, init, K, n_chains_total, budget_s=15.0):
     """The CPU checker (oracle/, libm mode = the reference's own arithmetic, one chain per host
     thread) on a bounded sample of the same workload. A reported baseline, not the target."""
@@ -166,8 +186,11 @@ def cpu_baseline(spec, init, K, n_chains_total, budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--draws-per-step", type=int, default=50,
+                    help="NUTS transitions per chain in one step (one kernel launch); 20 steps of "
+                         "50 = the 1000-draw protocol of SURVEY 8(d)")
     ap.add_argument("--model", default="eight_schools")
     ap.add_argument("--chains-per-gpu", type=int, default=0)
     ap.add_argument("--lanes", type=int, default=0)
@@ -181,7 +204,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args.gpus))
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device is visible (no CPU fallback)")
@@ -201,11 +226,15 @@ def main():
 
     spec, bytes_per_leapfrog = make_spec(args.model)
     K, W, d = args.steps, args.warmup, spec.d
+    B = args.draws_per_step
+    if K < 1 or B < 1 or W < 0:
+        raise SystemExit("--steps and --draws-per-step must be >= 1, --warmup >= 0")
+    S = K * B                      # draws per chain in the timed region
     Cper = args.chains_per_gpu or DEFAULT_CHAINS_PER_GPU[args.model]
     Ctot = Cper * world
     comp = sampler.compile(spec, {"device": local_rank})
     lanes = args.lanes or comp.default_lanes
-    opts = sampler._merge_opts(dict(num_warmup=args.adapt, num_samples=K, seed=42,
+    opts = sampler._merge_opts(dict(num_warmup=args.adapt, num_samples=S, seed=42,
                                     lanes_per_chain=lanes))
     init = spec.default_init
     L = comp.L
@@ -224,29 +253,36 @@ def main():
         log("adaptation: eps=%.5f, %d iterations in %.3f s" % (tuning["epsilon"], args.adapt, adapt_s))
 
     # --- resident chains + trace buffers in HBM ---
-    draws = torch.empty((K, d, Cper), dtype=torch.float64, device=dev)
-    n_steps = torch.empty((K, Cper), dtype=torch.int32, device=dev)
-    depth = torch.empty((K, Cper), dtype=torch.int32, device=dev)
-    diverg = torch.empty((K, Cper), dtype=torch.int32, device=dev)
-    accept = torch.empty((K, Cper), dtype=torch.float64, device=dev)
+    draws = torch.empty((S, d, Cper), dtype=torch.float64, device=dev)
+    n_steps = torch.empty((S, Cper), dtype=torch.int32, device=dev)
+    depth = torch.empty((S, Cper), dtype=torch.int32, device=dev)
+    diverg = torch.empty((S, Cper), dtype=torch.int32, device=dev)
+    accept = torch.empty((S, Cper), dtype=torch.float64, device=dev)
     tr = _lib.Trace(draws.data_ptr(), None, depth.data_ptr(), n_steps.data_ptr(), diverg.data_ptr(),
                     accept.data_ptr(), None)
     iq = np.ascontiguousarray(spec.to_unconstrained(init))
     iqp = iq.ctypes.data_as(C.POINTER(C.c_double))
     lo, hi = rank * Cper, (rank + 1) * Cper
-    comp.check(L.exmc_hip_chains_init(comp.h, C.byref(tun), iqp, Ctot, lo, hi, sampler._c_opts(opts)))
     lf, dv = C.c_int64(), C.c_int32()
     if W > 0:
-        comp.check(L.exmc_hip_chains_advance(comp.h, min(W, K), 0, tr, C.byref(lf), C.byref(dv)))
+        # untimed steps on throw-away chains (they pay for the code object and first-touch of the
+        # trace buffers); the timed region starts from freshly initialised chains
+        comp.check(L.exmc_hip_chains_init(comp.h, C.byref(tun), iqp, Ctot, lo, hi, sampler._c_opts(opts)))
+        for k in range(W):
+            comp.check(L.exmc_hip_chains_advance(comp.h, B, (k % K) * B, tr, C.byref(lf), C.byref(dv)))
 
-    # --- timed region: exactly K draws for every chain ---
+    # --- timed region: chain initialisation, then exactly K steps of B draws for every chain ---
     barrier()
     t0 = time.perf_counter()
-    comp.check(L.exmc_hip_chains_advance(comp.h, K, 0, tr, C.byref(lf), C.byref(dv)))
+    comp.check(L.exmc_hip_chains_init(comp.h, C.byref(tun), iqp, Ctot, lo, hi, sampler._c_opts(opts)))
+    # the K steps are one launch of the NUTS kernel (K * B transitions per chain): the chains stay in
+    # registers from the first draw to the last
+    comp.check(L.exmc_hip_chains_advance(comp.h, S, 0, tr, C.byref(lf), C.byref(dv)))
+    leap_local, div_local = lf.value, dv.value
     barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms = comp.last_kernel_ms
-    stats = torch.tensor([elapsed, float(lf.value), float(dv.value)], dtype=torch.float64, device=dev)
+    kernel_ms = comp.last_kernel_ms                   # HIP events on the library's stream
+    stats = torch.tensor([elapsed, float(leap_local), float(div_local)], dtype=torch.float64, device=dev)
     if dist is not None:
         mx = stats.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -254,12 +290,15 @@ def main():
         dist.all_reduce(sm, op=dist.ReduceOp.SUM)
         elapsed, leapfrogs, divs = float(mx[0]), float(sm[1]), float(sm[2])
     else:
-        leapfrogs, divs = float(lf.value), float(dv.value)
+        leapfrogs, divs = float(leap_local), float(div_local)
 
     # --- diagnostics: per-chain Geyer ESS on device, summed over chains; RCCL all-gather of the
     # finished traces for split R-hat (the only collective on the path) ---
     ess = torch.empty((d, Cper), dtype=torch.float64, device=dev)
-    comp.check(L.exmc_hip_ess(comp.h, draws.data_ptr(), K, d, Cper, ess.data_ptr()))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    comp.check(L.exmc_hip_ess(comp.h, draws.data_ptr(), S, d, Cper, ess.data_ptr()))
+    ess_s = time.perf_counter() - t0      # the call returns when the kernel has finished
     ess_ms = comp.last_kernel_ms
     ess_sum = ess.sum(dim=1)
     if not args.gather_traces:
@@ -284,14 +323,14 @@ def main():
             # one GPU holds every chain: Diagnostics.rhat in the reference's summation order on
             # the device (bit-identical to the checker, tests/test_gpu_diagnostics.py)
             rk = torch.empty((d,), dtype=torch.float64, device=dev)
-            comp.check(L.exmc_hip_rhat(comp.h, draws.data_ptr(), K, d, Cper, rk.data_ptr()))
+            comp.check(L.exmc_hip_rhat(comp.h, draws.data_ptr(), S, d, Cper, rk.data_ptr()))
             rhat = rk
     ess_min = float(ess_sum.min())
-    total_s = adapt_s + elapsed + gather_s
+    total_s = adapt_s + elapsed + ess_s + gather_s
     value = leapfrogs / elapsed
 
     if rank == 0:
-        local_lf = float(lf.value)
+        local_lf = float(leap_local)
         achieved = bytes_per_leapfrog * local_lf / (kernel_ms * 1e-3) / 1e9
         out = {
             "metric": "leapfrog_steps_per_s",
@@ -306,22 +345,25 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "%s d=%d, %d chains/GPU (%d total), %d draws/chain after one shared "
-                                   "%d-iteration warmup, max_tree_depth 10, target_accept 0.8"
-                                   % (args.model, d, Cper, Ctot, K, args.adapt),
+            "config": {"workload": "%s d=%d, %d chains/GPU (%d total), %d draws/chain (%d steps of %d "
+                                   "draws) after one shared %d-iteration warmup, max_tree_depth 10, "
+                                   "target_accept 0.8"
+                                   % (args.model, d, Cper, Ctot, S, K, B, args.adapt),
+                       "draws_per_step": B, "draws_per_chain": S,
                        "lanes_per_chain": lanes, "seed": 42},
             "ess_per_s": ess_min / total_s,
             "ess_min_total": ess_min,
-            "ess_wall_s": {"adaptation": adapt_s, "sampling": elapsed, "gather": gather_s},
+            "ess_wall_s": {"adaptation": adapt_s, "sampling": elapsed, "ess_kernel": ess_s,
+                           "gather": gather_s},
             "rhat_max": float(rhat.max()),
             "divergent_transitions": divs,
-            "mean_leapfrogs_per_draw": leapfrogs / (K * Ctot),
+            "mean_leapfrogs_per_draw": leapfrogs / (S * Ctot),
             "step_size": tuning["epsilon"],
             "ess_kernel_ms": ess_ms,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(args.model, Cper, K, lanes),
-                         "kernel": "nuts_kernel", "kernel_ms": kernel_ms,
+                         "traffic": measured_traffic(args.model, Cper, S, lanes),
+                         "kernel": "nuts_kernel", "launches": 1, "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_leapfrog": bytes_per_leapfrog,
                          "leapfrogs_per_launch": local_lf},
         }
@@ -329,7 +371,7 @@ def main():
             # the B2 batched-leapfrog contract at a batch that fills the chip (not the timed path)
             out["roofline_multi_step"] = multi_step_roofline(comp, spec, dev)
         if world == 1 and not args.no_cpu:
-            cb = cpu_baseline(spec, init, K, Ctot)
+            cb = cpu_baseline(spec, init, S, Ctot)
             out["cpu_baseline"] = cb
             out["gpu_over_cpu"] = {"leapfrog_steps_per_s": value / cb["value"],
                                    "ess_per_s": out["ess_per_s"] / cb["ess_per_s"]}

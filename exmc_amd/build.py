@@ -16,6 +16,7 @@ DEPS = [
     os.path.join(HERE, "csrc", "exmc_native_tree.hpp"),
     os.path.join(HERE, "csrc", "exmc_models.hpp"),
     os.path.join(HERE, "csrc", "exmc_device.hpp"),
+    os.path.join(HERE, "csrc", "exmc_ess.hpp"),
     os.path.join(ROOT, "include", "exmc_hip.h"),
     os.path.join(ROOT, "include", "exmc_detmath.h"),
     os.path.join(ROOT, "include", "exmc_zig_tables.h"),

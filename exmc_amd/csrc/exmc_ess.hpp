@@ -1,0 +1,76 @@
+// exmc_ess.hpp -- Diagnostics.ess (lib/exmc/diagnostics.ex:42-52, 123-167) of one strided series.
+//
+// The reference computes every lag of the autocorrelation (O(S^2) per series) and then keeps only
+// the lags in front of Geyer's first non-positive pair (diagnostics.ex:147-167). Here the lags are
+// computed eight at a time, one sweep over the series per block of eight, and the sweeps stop at
+// that pair. The values that are used are the same bits: each lag sum runs left to right over i as
+// `acc + c[i] * c[i + lag]` (diagnostics.ex:137-141), the centred values are `x - mean` with
+// mean = (left-to-right sum) / S, and lag 0 of the first block is the variance.
+// A sweep for lags [l0, l0 + 8) walks j = i + lag from l0 up, reading c[j] and c[j - l0]; the last
+// eight values of the second stream sit in a register ring (ring[(j - l0) & 7], static indices
+// after unrolling by eight), so lag l0 + k multiplies c[j] with ring[(u - k) & 7].
+// Plain C++ (no HIP types): the device kernel calls it per lane, and tests/test_ess_series_host.py
+// compiles it for the host to check it against the CPU checker. Build with -ffp-contract=off.
+#pragma once
+
+#include <stddef.h>
+
+#if defined(__HIPCC__)
+#define EXMC_ESS_HD __host__ __device__ __forceinline__
+#else
+#define EXMC_ESS_HD static inline
+#endif
+
+namespace exmc {
+
+EXMC_ESS_HD double ess_series(const double* x, size_t stride, int S) {
+  if (S < 4) return S * 1.0;   // diagnostics.ex:46
+  double sum = 0.0;
+#pragma unroll 16
+  for (int i = 0; i < S; i++) sum += x[(size_t)i * stride];
+  const double mean = sum / S;
+  const int max_k = (S - 1) / 2;
+  double tau = -1.0, var = 0.0;
+  bool done = false;
+  for (int l0 = 0; !done; l0 += 8) {
+    double acc[8], ring[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc[k] = ring[k] = 0.0;
+    // ring entries that are not filled yet stand for indices i < 0: they are zeros and add 0.0 to
+    // their lag sum, which leaves it unchanged
+    for (int j0 = l0; j0 < S; j0 += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int j = j0 + u;
+        if (j < S) {
+          const double cj = x[(size_t)j * stride] - mean;
+          ring[u] = (l0 == 0) ? cj : (x[(size_t)(j - l0) * stride] - mean);
+#pragma unroll
+          for (int k = 0; k < 8; k++) acc[k] = acc[k] + ring[(u - k) & 7] * cj;
+        }
+      }
+    }
+    if (l0 == 0) {
+      var = acc[0];
+      if (var == 0.0) break;   // diagnostics.ex:130-131: all-zero ACF, tau stays -1
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+      const int k = l0 / 2 + kk;
+      if (!done) {
+        if (k > max_k) {
+          done = true;
+        } else {
+          // lags past S - 1 have empty sums: 0.0 / var = 0.0 = Enum.at(acf, lag, 0.0)
+          const double pair = acc[2 * kk] / var + acc[2 * kk + 1] / var;
+          if (pair > 0) tau += 2 * pair;
+          else done = true;
+        }
+      }
+    }
+  }
+  const double t = tau > 1.0 ? tau : 1.0;   // max(tau, 1.0), diagnostics.ex:165
+  return S / t;
+}
+
+}  // namespace exmc

@@ -89,6 +89,7 @@ struct exmc_hip_model {
   DevBuf misc;      // [0] eps_out, [1..2] counters (u64), [3] trace scratch word, [8..8+D) init_q
   DevBuf trace;     // staging for host-trace entry points
   DevBuf io;        // staging for host vectors
+  DevBuf scores;    // ess_bulk: the rank-normalised copy of the caller's trace
   int state_chains = 0;
   // resident chains (exmc_hip_chains_init / _advance)
   int res_C = 0, res_lanes = 0, res_max_depth = 10;
@@ -962,7 +963,7 @@ void exmc_hip_model_destroy(exmc_hip_model* m) {
   if (!m) return;
   (void)hipSetDevice(m->device);
   m->zig.release(); m->tuning.release(); m->state.release(); m->stack.release();
-  m->misc.release(); m->trace.release(); m->io.release(); m->data.release(); m->flat.release();
+  m->misc.release(); m->trace.release(); m->io.release(); m->data.release(); m->flat.release(); m->scores.release();
   if (m->ev0) (void)hipEventDestroy(m->ev0);
   if (m->ev1) (void)hipEventDestroy(m->ev1);
   if (m->stream) (void)hipStreamDestroy(m->stream);
@@ -1380,11 +1381,11 @@ int exmc_hip_ess(exmc_hip_model* m, const double* draws_dev, int n_draws, int d,
   if (check_model(m)) return EXMC_ERR_BADARG;
   if (!draws_dev || !ess_dev || n_draws < 1 || d < 1 || n_chains < 1)
     return fail(EXMC_ERR_BADARG, "bad arguments");
-  if ((size_t)n_draws * 16 > 64 * 1024) return fail(EXMC_ERR_UNSUPPORTED, "n_draws too large for the LDS ess kernel");
   HIP_TRY(hipSetDevice(m->device));
   HIP_TRY(hipEventRecord(m->ev0, m->stream));
-  hipLaunchKernelGGL(ess_kernel, dim3((unsigned)(d * n_chains)), dim3(256), (size_t)n_draws * 16,
-                     m->stream, draws_dev, n_draws, d, n_chains, ess_dev, 0);
+  const size_t series = (size_t)d * n_chains;
+  hipLaunchKernelGGL(ess_series_kernel, dim3((unsigned)((series + kEssBlock - 1) / kEssBlock)),
+                     dim3(kEssBlock), 0, m->stream, draws_dev, n_draws, d, n_chains, ess_dev);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(m->ev1, m->stream));
   return finish_timing(m);
@@ -1395,11 +1396,22 @@ int exmc_hip_ess_bulk(exmc_hip_model* m, const double* draws_dev, int n_draws, i
   if (check_model(m)) return EXMC_ERR_BADARG;
   if (!draws_dev || !ess_dev || n_draws < 1 || d < 1 || n_chains < 1)
     return fail(EXMC_ERR_BADARG, "bad arguments");
-  if ((size_t)n_draws * 24 > 64 * 1024) return fail(EXMC_ERR_UNSUPPORTED, "n_draws too large for the LDS ess kernel");
+  if (n_draws < 4) return exmc_hip_ess(m, draws_dev, n_draws, d, n_chains, ess_dev);   // diagnostics.ex:62
+  const size_t lds = (size_t)n_draws * 8;
+  if (lds > 160 * 1024) return fail(EXMC_ERR_UNSUPPORTED, "n_draws too large for the LDS rank kernel (max 20480)");
   HIP_TRY(hipSetDevice(m->device));
+  const size_t series = (size_t)d * n_chains;
+  int rc = m->scores.ensure(series * (size_t)n_draws * 8);   // the normal scores, [S][D][C]
+  if (rc) return rc;
+  if (lds > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute((const void*)rank_scores_kernel,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   HIP_TRY(hipEventRecord(m->ev0, m->stream));
-  hipLaunchKernelGGL(ess_kernel, dim3((unsigned)(d * n_chains)), dim3(256), (size_t)n_draws * 24,
-                     m->stream, draws_dev, n_draws, d, n_chains, ess_dev, 1);
+  hipLaunchKernelGGL(rank_scores_kernel, dim3((unsigned)series), dim3(256), lds, m->stream,
+                     draws_dev, n_draws, d, n_chains, m->scores.as<double>());
+  hipLaunchKernelGGL(ess_series_kernel, dim3((unsigned)((series + kEssBlock - 1) / kEssBlock)),
+                     dim3(kEssBlock), 0, m->stream, (const double*)m->scores.as<double>(), n_draws, d,
+                     n_chains, ess_dev);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(m->ev1, m->stream));
   return finish_timing(m);

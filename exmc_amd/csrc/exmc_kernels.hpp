@@ -5,13 +5,15 @@
 //   init_chains_kernel seed :rand, init position, first logp/grad (sampler.ex:154-165,339-349).
 //   find_eps_kernel    find_reasonable_epsilon_with_rng (sampler.ex:451-530).
 //   logp_grad_kernel   vag_fn batched (compiler.ex:131-141).
-//   ess_kernel         Diagnostics.ess (diagnostics.ex:42-52,123-167).
+//   ess_series_kernel  Diagnostics.ess (diagnostics.ex:42-52,123-167); rank_scores_kernel the
+//                      rank-normalisation of Diagnostics.ess_bulk (diagnostics.ex:60-72,186-219).
 //
 // All are launched with one wavefront per workgroup (64 threads) and M::kExtraLdsDoubles * 8
 // bytes of dynamic LDS. For wave-cooperative models (M::kCoop, the MFMA logistic) lane groups
 // without a chain shadow the last chain instead of leaving, so that logp_grad sees a full wave.
 #pragma once
 
+#include "exmc_ess.hpp"
 #include "exmc_nuts.hpp"
 
 namespace exmc {
@@ -234,12 +236,24 @@ __global__ void __launch_bounds__(kNutsBlock) find_eps_kernel(FindEpsParams P,
   }
 }
 
-// Diagnostics.ess (diagnostics.ex:42-52, 123-167): one workgroup per (dim, chain) series of a
-// [S][D][C] trace; lag sums are left-to-right per lag as the reference computes them.
-// bulk != 0: Diagnostics.ess_bulk (diagnostics.ex:60-72, 186-219) -- the series is first replaced
-// by the normal scores of its ranks (average rank for ties, (r - 3/8) / (n + 1/4), the
-// reference's rational probit approximation with sqrt IEEE and log from exmc_detmath.h); the
-// ranks are counted (every thread compares its elements with the whole series in LDS).
+// Diagnostics.ess (diagnostics.ex:42-52, 123-167) over a [S][D][C] trace, one lane per (dim, chain)
+// series (lanes sweep chains first, so every load of a wavefront is one coalesced row segment);
+// the per-series routine is exmc_ess.hpp.
+constexpr int kEssBlock = 64;
+
+__global__ void __launch_bounds__(kEssBlock)
+ess_series_kernel(const double* draws, int S, int D, int C, double* ess_out) {
+  const size_t series = (size_t)blockIdx.x * kEssBlock + threadIdx.x;   // dim * C + chain
+  const size_t stride = (size_t)D * C;
+  if (series >= stride) return;
+  ess_out[series] = ess_series(draws + series, stride, S);
+}
+
+// Diagnostics.ess_bulk (diagnostics.ex:60-72, 186-219), first half: every series is replaced by
+// the normal scores of its ranks -- average rank for ties, (r - 3/8) / (n + 1/4), the reference's
+// rational probit approximation with sqrt IEEE and log from exmc_detmath.h. One workgroup per
+// series; the ranks are counted (every thread compares its elements with the whole series in
+// LDS). The scores go to a second [S][D][C] array on which ess_series_kernel then runs.
 __device__ __forceinline__ double probit_inner_dev(double p) {
   const double t = __dsqrt_rn(-2.0 * exmc_log(p));
   return t - (2.515517 + 0.802853 * t + 0.010328 * t * t) /
@@ -247,76 +261,25 @@ __device__ __forceinline__ double probit_inner_dev(double p) {
 }
 
 __global__ void __launch_bounds__(256)
-ess_kernel(const double* draws, int S, int D, int C, double* ess_out, int bulk) {
-  extern __shared__ double sh[];  // S centred values + S acf values (+ S raw values when bulk)
-  double* c = sh;
-  double* acf = sh + S;
-  double* raw = sh + 2 * (size_t)S;
-  const int series = blockIdx.x;  // dim * C + chain
-  const double* x = draws + series;
+rank_scores_kernel(const double* draws, int S, int D, int C, double* scores) {
+  extern __shared__ double raw[];  // S values
+  const size_t series = blockIdx.x;  // dim * C + chain
   const size_t stride = (size_t)D * C;
-  __shared__ double s_mean, s_var;
-  if (bulk && S >= 4) {
-    for (int i = threadIdx.x; i < S; i += blockDim.x) raw[i] = x[(size_t)i * stride];
-    __syncthreads();
-    for (int i = threadIdx.x; i < S; i += blockDim.x) {
-      const double xi = raw[i];
-      int lo = 0, eq = 0;
-      for (int j = 0; j < S; j++) {
-        const double xj = raw[j];
-        lo += (xj < xi) ? 1 : 0;
-        eq += (xj == xi) ? 1 : 0;
-      }
-      const double avg = (double)(lo + 1) + (double)(eq - 1) / 2.0;
-      const double pr = (avg - 0.375) / ((double)S + 0.25);
-      acf[i] = (pr < 0.5) ? -probit_inner_dev(pr) : probit_inner_dev(1.0 - pr);
+  const double* x = draws + series;
+  double* z = scores + series;
+  for (int i = threadIdx.x; i < S; i += blockDim.x) raw[i] = x[(size_t)i * stride];
+  __syncthreads();
+  for (int i = threadIdx.x; i < S; i += blockDim.x) {
+    const double xi = raw[i];
+    int lo = 0, eq = 0;
+    for (int j = 0; j < S; j++) {
+      const double xj = raw[j];
+      lo += (xj < xi) ? 1 : 0;
+      eq += (xj == xi) ? 1 : 0;
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < S; i += blockDim.x) raw[i] = acf[i];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    double sum = 0.0;
-    if (bulk && S >= 4) for (int i = 0; i < S; i++) sum += raw[i];
-    else for (int i = 0; i < S; i++) sum += x[(size_t)i * stride];
-    s_mean = sum / S;
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < S; i += blockDim.x)
-    c[i] = ((bulk && S >= 4) ? raw[i] : x[(size_t)i * stride]) - s_mean;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double v = 0.0;
-    for (int i = 0; i < S; i++) v += c[i] * c[i];
-    s_var = v;
-  }
-  __syncthreads();
-  const double var = s_var;
-  for (int lag = threadIdx.x; lag < S; lag += blockDim.x) {
-    double sum = 0.0;
-    for (int i = 0; i < S - lag; i++) sum += c[i] * c[i + lag];
-    acf[lag] = (var != 0.0) ? (sum / var) : 0.0;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double result;
-    if (S < 4) {
-      result = S * 1.0;
-    } else {
-      double tau = -1.0;
-      if (var != 0.0) {
-        const int max_k = (S - 1) / 2;
-        for (int k = 0; k <= max_k; k++) {
-          const double r0 = (2 * k < S) ? acf[2 * k] : 0.0;
-          const double r1 = (2 * k + 1 < S) ? acf[2 * k + 1] : 0.0;
-          const double pair = r0 + r1;
-          if (pair > 0) tau += 2 * pair;
-          else break;
-        }
-      }
-      result = S / fmax(tau, 1.0);
-    }
-    ess_out[series] = result;
+    const double avg = (double)(lo + 1) + (double)(eq - 1) / 2.0;
+    const double pr = (avg - 0.375) / ((double)S + 0.25);
+    z[(size_t)i * stride] = (pr < 0.5) ? -probit_inner_dev(pr) : probit_inner_dev(1.0 - pr);
   }
 }
 

@@ -12,7 +12,7 @@ from exmc_amd import _lib, models, sampler
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("S,D,Cn", [(60, 3, 5), (101, 2, 300), (8, 1, 2), (250, 10, 64)])
+@pytest.mark.parametrize("S,D,Cn", [(60, 3, 5), (101, 2, 300), (8, 1, 2), (250, 10, 64), (5000, 2, 70)])
 def test_ess_and_rhat_kernels_bit_exact(hip, S, D, Cn):
     comp = sampler.compile(models.eight_schools())
     rng = np.random.default_rng(S + D)
@@ -38,4 +38,5 @@ def test_ess_and_rhat_kernels_bit_exact(hip, S, D, Cn):
         assert L.exo_rhat(O.dptr(chains), Cn, S) == rhat[dim], dim
         for c in range(min(Cn, 40)):
             assert L.exo_ess(O.dptr(np.ascontiguousarray(chains[c])), S) == ess[dim, c], (dim, c)
-    assert np.all(rhat > 0.9) and np.all(ess > 0)
+    if S >= 4:
+        assert np.all(rhat > 0.9) and np.all(ess > 0)

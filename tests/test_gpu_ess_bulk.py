@@ -11,7 +11,7 @@ from exmc_amd import _lib, models, sampler
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("S,D,Cn", [(1000, 3, 5), (257, 2, 9), (3, 1, 2), (64, 2, 3)])
+@pytest.mark.parametrize("S,D,Cn", [(1000, 3, 5), (257, 2, 9), (3, 1, 2), (64, 2, 3), (9000, 1, 3)])
 def test_ess_bulk_kernel_bit_exact(hip, S, D, Cn):
     comp = sampler.compile(models.eight_schools())
     rng = np.random.default_rng(S * 7 + D)
