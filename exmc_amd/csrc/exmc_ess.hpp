@@ -23,10 +23,12 @@
 
 namespace exmc {
 
+constexpr int kEssLoadBlock = 32;   // loads in flight per stream (a multiple of the ring size 8)
+
 EXMC_ESS_HD double ess_series(const double* x, size_t stride, int S) {
   if (S < 4) return S * 1.0;   // diagnostics.ex:46
   double sum = 0.0;
-#pragma unroll 16
+#pragma unroll 32
   for (int i = 0; i < S; i++) sum += x[(size_t)i * stride];
   const double mean = sum / S;
   const int max_k = (S - 1) / 2;
@@ -38,13 +40,26 @@ EXMC_ESS_HD double ess_series(const double* x, size_t stride, int S) {
     for (int k = 0; k < 8; k++) acc[k] = ring[k] = 0.0;
     // ring entries that are not filled yet stand for indices i < 0: they are zeros and add 0.0 to
     // their lag sum, which leaves it unchanged
-    for (int j0 = l0; j0 < S; j0 += 8) {
+    for (int j0 = l0; j0 < S; j0 += kEssLoadBlock) {
+      // all loads of a block first (clamped, so they need no guard and their latencies overlap:
+      // a lane walks its series with a stride of D * C doubles, every load is a cache miss), then
+      // the arithmetic
+      double xa[kEssLoadBlock], xb[kEssLoadBlock];
 #pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int j = j0 + u;
-        if (j < S) {
-          const double cj = x[(size_t)j * stride] - mean;
-          ring[u] = (l0 == 0) ? cj : (x[(size_t)(j - l0) * stride] - mean);
+      for (int u = 0; u < kEssLoadBlock; u++) {
+        const int j = (j0 + u < S) ? (j0 + u) : (S - 1);
+        xa[u] = x[(size_t)j * stride];
+      }
+#pragma unroll
+      for (int u = 0; u < kEssLoadBlock; u++) {
+        const int j = (j0 + u < S) ? (j0 + u) : (S - 1);
+        xb[u] = (l0 != 0) ? x[(size_t)(j - l0) * stride] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < kEssLoadBlock; u++) {
+        if (j0 + u < S) {
+          const double cj = xa[u] - mean;
+          ring[u & 7] = (l0 == 0) ? cj : (xb[u] - mean);
 #pragma unroll
           for (int k = 0; k < 8; k++) acc[k] = acc[k] + ring[(u - k) & 7] * cj;
         }

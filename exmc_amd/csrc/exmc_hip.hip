@@ -154,14 +154,17 @@ int dispatch(exmc_hip_model* m, int lanes, F&& f) {
 #ifndef EXMC_ONLY_CUSTOM      // plug-in builds carry the generated model only
     case EXMC_MODEL_EIGHT_SCHOOLS:
       switch (lanes) {
+#ifndef EXMC_DEV_ES16_ONLY    // development builds for kernel work: one model, one layout
         case 1: return f(Tag<EightSchools<1>, 1, 2>{}, m->es);
         case 2: return f(Tag<EightSchools<2>, 2, 3>{}, m->es);
         case 4: return f(Tag<EightSchools<4>, 4, 4>{}, m->es);
         case 8: return f(Tag<EightSchools<8>, 8, 5>{}, m->es);
+#endif
         case 16: return f(Tag<EightSchools<16>, 16, 6>{}, m->es);
         default: break;
       }
       break;
+#ifndef EXMC_DEV_ES16_ONLY
     case EXMC_MODEL_SIMPLE:
       if (lanes == 1) return f(Tag<Simple<1>, 1, 6>{}, m->sp);
       break;
@@ -187,6 +190,7 @@ int dispatch(exmc_hip_model* m, int lanes, F&& f) {
         default: break;
       }
       break;
+#endif
 #endif
     default: break;
   }
