@@ -1,0 +1,294 @@
+/* exmc_hip_nif.c -- NIF module `Elixir.Exmc.NUTS.HipNative`: the chain-batched entry points of
+ * libexmc_hip.so that have no counterpart in the Rust crate (the sampler seams B2 / B3 of
+ * SURVEY.md 8b). INTEGRATION.md shows where Exmc.NUTS.Sampler calls them.
+ *
+ *   model_create/2          Compiler.compile_for_sampling/2 for a built model kind (compiler.ex:46-58)
+ *   model_set_flat_order/2  PointMap.build's sorted-id layout (point_map.ex:30-60)
+ *   logp_grad/3             vag_fn, batched (compiler.ex:131-141)
+ *   multi_step/8            multi_step_fn, batched (batched_leapfrog.ex:21-48)
+ *   warmup/6                run_warmup of the shared chain (sampler.ex:537-762, 1068-1080)
+ *   sample_chains/10        sample_chains_vectorized_compiled's sampling loop (sampler.ex:1082-1130)
+ *   sample/7                sample/3 for one chain (sampler.ex:126-257)
+ *   stream_begin/6, stream_next/2   sample_stream/4 (sampler.ex:1186-1277)
+ *
+ * Binaries are native-endian f64 (int32 for the integer statistics), row-major
+ * [chain][draw][dim]; every call that waits on the GPU is a dirty IO-bound job; errors are
+ * {:error, message} from model_create and raised {:exmc_hip_error, code, message} elsewhere.
+ * Build as exmc_native_tree_nif.c (one shared object per NIF module, as OTP requires). */
+#include "exmc_nif_util.h"
+
+static ErlNifResourceType* MODEL_RT;
+static int g_device = 0;
+
+typedef struct { exmc_hip_model* m; } model_res;
+
+static void model_dtor(ErlNifEnv* env, void* obj) {
+  (void)env;
+  model_res* r = (model_res*)obj;
+  if (r->m) exmc_hip_model_destroy(r->m);
+  r->m = NULL;
+}
+static exmc_hip_model* get_model(ErlNifEnv* env, ERL_NIF_TERM t) {
+  void* obj;
+  if (!enif_get_resource(env, t, MODEL_RT, &obj)) return NULL;
+  return ((model_res*)obj)->m;
+}
+/* `nil` or an f64 binary of d values */
+static int get_init_q(ErlNifEnv* env, ERL_NIF_TERM t, int d, const double** q) {
+  char buf[8];
+  size_t n;
+  if (enif_get_atom(env, t, buf, sizeof buf, ERL_NIF_LATIN1)) {
+    *q = NULL;   /* init_values == %{}: 0.1 * normal_s per flat entry, sampler.ex:339-349 */
+    return strcmp(buf, "nil") == 0;
+  }
+  return get_f64_bin(env, t, q, &n) && n == (size_t)d;
+}
+
+/* model_create(kind, data_bin) -> {:ok, ref} | {:error, message} */
+static ERL_NIF_TERM model_create(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  int kind;
+  const double* data;
+  size_t n;
+  (void)argc;
+  if (!enif_get_int(env, argv[0], &kind) || !get_f64_bin(env, argv[1], &data, &n))
+    return enif_make_badarg(env);
+  exmc_hip_model* m = NULL;
+  int rc = exmc_hip_model_create(kind, 0, data, (int)n, g_device, &m);
+  if (rc != EXMC_OK)
+    return tuple2(env, enif_make_atom(env, "error"),
+                  enif_make_string(env, exmc_hip_last_error(), ERL_NIF_LATIN1));
+  model_res* r = (model_res*)enif_alloc_resource(MODEL_RT, sizeof(model_res));
+  r->m = m;
+  ERL_NIF_TERM ref = enif_make_resource(env, r);
+  enif_release_resource(r);
+  return tuple2(env, enif_make_atom(env, "ok"), ref);
+}
+
+/* model_set_flat_order(ref, perm :: [non_neg_integer]) -> :ok   (perm[r] = kernel dimension of
+ * the r-th id of Enum.sort_by(& &1.id), point_map.ex:37) */
+static ERL_NIF_TERM model_set_flat_order(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  exmc_hip_model* m = get_model(env, argv[0]);
+  unsigned len;
+  (void)argc;
+  if (!m || !enif_get_list_length(env, argv[1], &len) || (int)len != exmc_hip_model_dim(m))
+    return enif_make_badarg(env);
+  int32_t* perm = (int32_t*)enif_alloc((len ? len : 1) * sizeof(int32_t));
+  ERL_NIF_TERM head, tail = argv[1];
+  int ok = 1;
+  for (unsigned i = 0; i < len && ok; i++) {
+    int v;
+    ok = enif_get_list_cell(env, tail, &head, &tail) && enif_get_int(env, head, &v);
+    perm[i] = v;
+  }
+  int rc = ok ? exmc_hip_model_set_flat_order(m, perm, (int)len) : EXMC_ERR_BADARG;
+  enif_free(perm);
+  return rc == EXMC_OK ? enif_make_atom(env, "ok") : raise_hip(env, rc);
+}
+
+/* logp_grad(ref, q_bin [C][d], n_chains) -> {logp_bin [C], grad_bin [C][d]} */
+static ERL_NIF_TERM logp_grad(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  exmc_hip_model* m = get_model(env, argv[0]);
+  const double* q;
+  size_t n;
+  int c;
+  (void)argc;
+  if (!m || !get_f64_bin(env, argv[1], &q, &n) || !enif_get_int(env, argv[2], &c) || c < 1 ||
+      n != (size_t)c * (size_t)exmc_hip_model_dim(m))
+    return enif_make_badarg(env);
+  ERL_NIF_TERM tl, tg;
+  double* lp = new_f64_bin(env, (size_t)c, &tl);
+  double* g = new_f64_bin(env, n, &tg);
+  int rc = exmc_hip_logp_grad_host(m, q, c, 0, lp, g);
+  return rc == EXMC_OK ? tuple2(env, tl, tg) : raise_hip(env, rc);
+}
+
+/* multi_step(ref, q, p, grad :: binary [C][d], eps, inv_mass :: binary [d], n_steps, n_chains)
+ *   -> {all_q, all_p, all_logp, all_grad} binaries [C][n][d] / [C][n] */
+static ERL_NIF_TERM multi_step(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  exmc_hip_model* m = get_model(env, argv[0]);
+  const double *q, *p, *g, *im;
+  size_t nq, np, ng, nim;
+  double eps;
+  int n, c;
+  (void)argc;
+  if (!m || !get_f64_bin(env, argv[1], &q, &nq) || !get_f64_bin(env, argv[2], &p, &np) ||
+      !get_f64_bin(env, argv[3], &g, &ng) || !get_f64(env, argv[4], &eps) ||
+      !get_f64_bin(env, argv[5], &im, &nim) || !enif_get_int(env, argv[6], &n) ||
+      !enif_get_int(env, argv[7], &c) || n < 0 || c < 1)
+    return enif_make_badarg(env);
+  const size_t d = (size_t)exmc_hip_model_dim(m);
+  if (nq != (size_t)c * d || np != nq || ng != nq || nim != d) return enif_make_badarg(env);
+  ERL_NIF_TERM t[4];
+  double* aq = new_f64_bin(env, (size_t)c * n * d, &t[0]);
+  double* ap = new_f64_bin(env, (size_t)c * n * d, &t[1]);
+  double* al = new_f64_bin(env, (size_t)c * n, &t[2]);
+  double* ag = new_f64_bin(env, (size_t)c * n * d, &t[3]);
+  int rc = exmc_hip_multi_step_host(m, q, p, g, eps, im, n, c, 0, aq, ap, al, ag);
+  return rc == EXMC_OK ? enif_make_tuple_from_array(env, t, 4) : raise_hip(env, rc);
+}
+
+static ERL_NIF_TERM tuning_map(ErlNifEnv* env, const exmc_hip_tuning* tun, int d) {
+  ERL_NIF_TERM m = enif_make_new_map(env);
+  m = map_put(env, m, "epsilon", enif_make_double(env, tun->epsilon));
+  m = map_put(env, m, "inv_mass", make_f64_bin(env, tun->inv_mass, (size_t)d));
+  m = map_put(env, m, "warmup_divergences", enif_make_int(env, tun->warmup_divergences));
+  return m;
+}
+
+/* argv[0..3] = num_warmup, max_tree_depth, target_accept, seed */
+static int get_warm_opts(ErlNifEnv* env, const ERL_NIF_TERM argv[], exmc_hip_opts* o) {
+  ErlNifUInt64 seed;
+  memset(o, 0, sizeof *o);
+  if (!enif_get_int(env, argv[0], &o->num_warmup) || !enif_get_int(env, argv[1], &o->max_tree_depth) ||
+      !get_f64(env, argv[2], &o->target_accept) || !enif_get_uint64(env, argv[3], &seed))
+    return 0;
+  o->seed = seed;
+  return 1;
+}
+
+/* warmup(ref, init_q | nil, num_warmup, max_tree_depth, target_accept, seed)
+ *   -> %{epsilon, inv_mass, warmup_divergences}   (the `tuning` map of sampler.ex:62-71) */
+static ERL_NIF_TERM warmup(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  exmc_hip_model* m = get_model(env, argv[0]);
+  const double* iq;
+  exmc_hip_opts o;
+  exmc_hip_tuning tun;
+  (void)argc;
+  if (!m || !get_init_q(env, argv[1], exmc_hip_model_dim(m), &iq) || !get_warm_opts(env, argv + 2, &o))
+    return enif_make_badarg(env);
+  int rc = exmc_hip_warmup(m, iq, o, &tun);
+  return rc == EXMC_OK ? tuning_map(env, &tun, exmc_hip_model_dim(m)) : raise_hip(env, rc);
+}
+
+/* per-draw outputs as binaries: draws [C][S][d] f64; logp, accept_prob, energy [C][S] f64;
+ * tree_depth, n_steps, divergent [C][S] int32 (stats.sample_stats, sampler.ex:960-967) */
+typedef struct {
+  exmc_hip_trace tr;
+  ERL_NIF_TERM t[7];
+} trace_bins;
+static void new_trace(ErlNifEnv* env, size_t rows, size_t d, trace_bins* b) {
+  b->tr.draws = new_f64_bin(env, rows * d, &b->t[0]);
+  b->tr.logp = new_f64_bin(env, rows, &b->t[1]);
+  b->tr.accept_prob = new_f64_bin(env, rows, &b->t[2]);
+  b->tr.energy = new_f64_bin(env, rows, &b->t[3]);
+  b->tr.tree_depth = (int32_t*)enif_make_new_binary(env, rows * 4, &b->t[4]);
+  b->tr.n_steps = (int32_t*)enif_make_new_binary(env, rows * 4, &b->t[5]);
+  b->tr.divergent = (int32_t*)enif_make_new_binary(env, rows * 4, &b->t[6]);
+}
+static ERL_NIF_TERM trace_map(ErlNifEnv* env, const trace_bins* b) {
+  static const char* keys[7] = {"draws", "logp", "accept_prob", "energy", "tree_depth", "n_steps", "divergent"};
+  ERL_NIF_TERM m = enif_make_new_map(env);
+  for (int i = 0; i < 7; i++) m = map_put(env, m, keys[i], b->t[i]);
+  return m;
+}
+
+/* sample_chains(ref, epsilon, inv_mass_bin, init_q | nil, n_chains, chain_lo, chain_hi,
+ *               num_samples, max_tree_depth, seed) -> {trace_map, leapfrogs, divergences}
+ * chains chain_lo..chain_hi-1 of n_chains (chain i is seeded seed + 7919 i, sampler.ex:1083) */
+static ERL_NIF_TERM sample_chains(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  exmc_hip_model* m = get_model(env, argv[0]);
+  exmc_hip_tuning tun;
+  const double *im, *iq;
+  size_t nim;
+  int n_chains, lo, hi;
+  ErlNifUInt64 seed;
+  exmc_hip_opts o;
+  (void)argc;
+  memset(&o, 0, sizeof o);
+  memset(&tun, 0, sizeof tun);
+  if (!m) return enif_make_badarg(env);
+  const int d = exmc_hip_model_dim(m);
+  if (!get_f64(env, argv[1], &tun.epsilon) || !get_f64_bin(env, argv[2], &im, &nim) ||
+      nim != (size_t)d || !get_init_q(env, argv[3], d, &iq) || !enif_get_int(env, argv[4], &n_chains) ||
+      !enif_get_int(env, argv[5], &lo) || !enif_get_int(env, argv[6], &hi) ||
+      !enif_get_int(env, argv[7], &o.num_samples) || !enif_get_int(env, argv[8], &o.max_tree_depth) ||
+      !enif_get_uint64(env, argv[9], &seed) || lo < 0 || hi <= lo || hi > n_chains || o.num_samples < 0)
+    return enif_make_badarg(env);
+  memcpy(tun.inv_mass, im, (size_t)d * 8);
+  o.seed = seed;
+  o.target_accept = 0.8;
+  trace_bins b;
+  new_trace(env, (size_t)(hi - lo) * (size_t)o.num_samples, (size_t)d, &b);
+  int64_t lf = 0;
+  int32_t dv = 0;
+  int rc = exmc_hip_sample_chains_host(m, &tun, iq, n_chains, lo, hi, o, b.tr, &lf, &dv);
+  if (rc != EXMC_OK) return raise_hip(env, rc);
+  return tuple3(env, trace_map(env, &b), enif_make_uint64(env, (ErlNifUInt64)lf), enif_make_int(env, dv));
+}
+
+/* sample(ref, init_q | nil, num_warmup, num_samples, max_tree_depth, target_accept, seed)
+ *   -> {trace_map, tuning_map, divergences} */
+static ERL_NIF_TERM sample(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  exmc_hip_model* m = get_model(env, argv[0]);
+  const double* iq;
+  exmc_hip_opts o;
+  ErlNifUInt64 seed;
+  (void)argc;
+  memset(&o, 0, sizeof o);
+  if (!m) return enif_make_badarg(env);
+  const int d = exmc_hip_model_dim(m);
+  if (!get_init_q(env, argv[1], d, &iq) || !enif_get_int(env, argv[2], &o.num_warmup) ||
+      !enif_get_int(env, argv[3], &o.num_samples) || !enif_get_int(env, argv[4], &o.max_tree_depth) ||
+      !get_f64(env, argv[5], &o.target_accept) || !enif_get_uint64(env, argv[6], &seed) ||
+      o.num_samples < 1)
+    return enif_make_badarg(env);
+  o.seed = seed;
+  trace_bins b;
+  new_trace(env, (size_t)o.num_samples, (size_t)d, &b);
+  exmc_hip_tuning tun;
+  int32_t dv = 0;
+  int rc = exmc_hip_sample_host(m, iq, o, b.tr, &tun, &dv);
+  if (rc != EXMC_OK) return raise_hip(env, rc);
+  return tuple3(env, trace_map(env, &b), tuning_map(env, &tun, d), enif_make_int(env, dv));
+}
+
+/* stream_begin(ref, init_q | nil, num_warmup, max_tree_depth, target_accept, seed) -> tuning_map */
+static ERL_NIF_TERM stream_begin(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  exmc_hip_model* m = get_model(env, argv[0]);
+  const double* iq;
+  exmc_hip_opts o;
+  exmc_hip_tuning tun;
+  (void)argc;
+  if (!m || !get_init_q(env, argv[1], exmc_hip_model_dim(m), &iq) || !get_warm_opts(env, argv + 2, &o))
+    return enif_make_badarg(env);
+  int rc = exmc_hip_stream_begin(m, iq, o, &tun);
+  return rc == EXMC_OK ? tuning_map(env, &tun, exmc_hip_model_dim(m)) : raise_hip(env, rc);
+}
+
+/* stream_next(ref, n_draws) -> {trace_map, divergences}: the next n draws of the resident chain;
+ * the caller `send`s {:exmc_sample, i, point_map, step_stat} per row (sampler.ex:1270) */
+static ERL_NIF_TERM stream_next(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  exmc_hip_model* m = get_model(env, argv[0]);
+  int n;
+  (void)argc;
+  if (!m || !enif_get_int(env, argv[1], &n) || n < 1) return enif_make_badarg(env);
+  trace_bins b;
+  new_trace(env, (size_t)n, (size_t)exmc_hip_model_dim(m), &b);
+  int32_t dv = 0;
+  int rc = exmc_hip_stream_next_host(m, n, b.tr, &dv);
+  if (rc != EXMC_OK) return raise_hip(env, rc);
+  return tuple2(env, trace_map(env, &b), enif_make_int(env, dv));
+}
+
+static ErlNifFunc nif_funcs[] = {
+    {"model_create", 2, model_create, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"model_set_flat_order", 2, model_set_flat_order, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"logp_grad", 3, logp_grad, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"multi_step", 8, multi_step, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"warmup", 6, warmup, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"sample_chains", 10, sample_chains, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"sample", 7, sample, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"stream_begin", 6, stream_begin, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"stream_next", 2, stream_next, ERL_NIF_DIRTY_JOB_IO_BOUND},
+};
+
+static int on_load(ErlNifEnv* env, void** priv, ERL_NIF_TERM info) {
+  (void)priv;
+  (void)info;
+  const char* dev = getenv("EXMC_HIP_DEVICE");
+  g_device = dev ? atoi(dev) : 0;
+  MODEL_RT = enif_open_resource_type(env, NULL, "exmc_hip_model", model_dtor, ERL_NIF_RT_CREATE, NULL);
+  return MODEL_RT ? 0 : 1;
+}
+
+ERL_NIF_INIT(Elixir.Exmc.NUTS.HipNative, nif_funcs, on_load, NULL, NULL, NULL)

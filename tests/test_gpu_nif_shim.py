@@ -1,0 +1,167 @@
+"""The NIF shims of c_src/ CALLED on the GPU (through tests/host/fake_erl_nif.c, there being no
+BEAM here): `Elixir.Exmc.NUTS.NativeTree` runs the literal cases of the reference's own
+test/native_tree_test.exs (tests/golden/reference_known_answers.json cites each) with the
+reference's argument order and result shapes, and equals the Python mirror of the same C ABI bit
+for bit; `Elixir.Exmc.NUTS.HipNative` equals exmc_amd.sampler on the same seeds."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import nif_harness as H
+from exmc_amd import models, native_tree, sampler
+
+pytestmark = pytest.mark.gpu
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden",
+                                   "reference_known_answers.json")))["native_tree"]
+A = np.array
+
+
+@pytest.fixture(scope="module")
+def mods(tmp_path_factory):
+    return H.build(str(tmp_path_factory.mktemp("nif")))[1]
+
+
+def test_init_get_roundtrip(hip, mods):
+    """native_tree_test.exs:13-59: init_trajectory_bin + get_endpoint_bin round trip, the list twins,
+    is_terminated false on a fresh trajectory."""
+    nt, c = mods["NativeTree"], GOLD["init_get"]
+    ref = nt.call("init_trajectory_bin", A(c["q"]), A(c["p"]), A(c["grad"]), c["logp"])
+    for right in (True, False):
+        q, p, g = nt.call("get_endpoint_bin", ref, right)
+        assert (list(H.f64(q)), list(H.f64(p)), list(H.f64(g))) == (c["q"], c["p"], c["grad"])
+    assert nt.call("is_terminated", ref) is False
+    ref2 = nt.call("init_trajectory", c["q"], c["p"], c["grad"], c["logp"])
+    assert nt.call("get_endpoint", ref2, True) == (c["q"], c["p"], c["grad"])
+    r = nt.call("get_result", ref2)
+    assert set(r) == {"q", "logp", "grad", "n_steps", "divergent", "accept_sum", "depth"}
+    assert (r["q"], r["logp"], r["n_steps"], r["depth"], r["divergent"]) == (c["q"], c["logp"], 0, 0, False)
+
+
+@pytest.mark.parametrize("name", ["depth0", "depth1", "divergent"])
+def test_build_and_merge_cases(hip, mods, name):
+    """native_tree_test.exs:63-178 through build_and_merge_bin/11 and the list twin build_and_merge/11;
+    same bits as the batched Python mirror of the C ABI."""
+    nt, c = mods["NativeTree"], GOLD[name]
+    e = c["expect"]
+    out = []
+    for binary in (True, False):
+        if binary:
+            ref = nt.call("init_trajectory_bin", A(c["q"]), A(c["p"]), A(c["grad"]), c["logp"])
+            assert nt.call("build_and_merge_bin", ref, A(c["all_q"]), A(c["all_p"]), A(c["all_logp"]),
+                           A(c["all_grad"]), A(c["inv_mass"]), c["jlp0"], c["depth"], c["d"],
+                           c["go_right"], c["seed"]) == H.Atom("ok")
+            r = nt.call("get_result_bin", ref)
+            assert set(r) == {"q_bin", "logp", "grad_bin", "n_steps", "divergent", "accept_sum", "depth"}
+            r = dict(r, q=list(H.f64(r["q_bin"])), grad=list(H.f64(r["grad_bin"])))
+        else:
+            ref = nt.call("init_trajectory", c["q"], c["p"], c["grad"], c["logp"])
+            assert nt.call("build_and_merge", ref, c["all_q"], c["all_p"], c["all_logp"], c["all_grad"],
+                           c["inv_mass"], c["jlp0"], c["depth"], c["d"], c["go_right"],
+                           c["seed"]) == H.Atom("ok")
+            r = nt.call("get_result", ref)
+        for k in ("n_steps", "depth", "divergent"):
+            if k in e:
+                assert r[k] == e[k], (name, k)
+        if "terminated" in e:
+            assert nt.call("is_terminated", ref) is e["terminated"]
+        out.append((r["q"], r["grad"], r["logp"], r["n_steps"], r["depth"], r["divergent"], r["accept_sum"]))
+    assert out[0] == out[1]
+    # the same call through the Python mirror (one chain)
+    d, n = c["d"], len(c["all_logp"])
+    T = native_tree.Trajectories(A([c["q"]]), A([c["p"]]), A([c["grad"]]), [c["logp"]])
+    T.build_and_merge_bin(A(c["all_q"]).reshape(1, n, d), A(c["all_p"]).reshape(1, n, d),
+                          A([c["all_logp"]]), A(c["all_grad"]).reshape(1, n, d), c["inv_mass"],
+                          [c["jlp0"]], c["depth"], d, c["go_right"], [c["seed"]])
+    m = T.get_result_bin()
+    assert list(m["q_bin"][0]) == out[0][0] and m["logp"][0] == out[0][2]
+    assert (m["n_steps"][0], m["depth"][0], bool(m["divergent"][0])) == out[0][3:6]
+    assert m["accept_sum"][0] == out[0][6]
+
+
+def test_build_subtree_bin_record(hip, mods):
+    """build_subtree_bin/10 returns the sixteen keys of lib.rs:146-210; values equal the mirror's."""
+    nt, c = mods["NativeTree"], GOLD["depth1"]
+    r = nt.call("build_subtree_bin", A(c["all_q"]), A(c["all_p"]), A(c["all_logp"]), A(c["all_grad"]),
+                A(c["inv_mass"]), c["jlp0"], c["depth"], c["d"], c["go_right"], c["seed"])
+    assert set(r) == {"q_left_bin", "p_left_bin", "grad_left_bin", "q_right_bin", "p_right_bin",
+                      "grad_right_bin", "q_prop_bin", "logp_prop", "grad_prop_bin", "log_sum_weight",
+                      "n_steps", "divergent", "accept_sum", "turning", "depth", "rho_bin"}
+    d, n = c["d"], len(c["all_logp"])
+    m = native_tree.build_subtree_bin(A(c["all_q"]).reshape(1, n, d), A(c["all_p"]).reshape(1, n, d),
+                                      A([c["all_logp"]]), A(c["all_grad"]).reshape(1, n, d),
+                                      c["inv_mass"], [c["jlp0"]], c["depth"], d, c["go_right"], [c["seed"]])
+    for k in ("q_left_bin", "p_right_bin", "q_prop_bin", "rho_bin", "grad_prop_bin"):
+        assert np.array_equal(H.f64(r[k]), m[k][0]), k
+    for k in ("logp_prop", "log_sum_weight", "accept_sum"):
+        assert r[k] == m[k][0], k
+    assert (r["n_steps"], r["depth"], r["divergent"], r["turning"]) == \
+        (m["n_steps"][0], m["depth"][0], bool(m["divergent"][0]), bool(m["turning"][0]))
+    assert r["n_steps"] == 2 and r["depth"] == 1
+
+
+def test_build_full_tree_bin_cases(hip, mods):
+    """native_tree_test.exs:182-291 with the reference's seventeen arguments."""
+    nt = mods["NativeTree"]
+    c = GOLD["full_tree"]
+    args = [A(c["q0"]), A(c["p0"]), A(c["grad0"]), c["logp0"], A(c["fwd_q"]), A(c["fwd_p"]),
+            A(c["fwd_logp"]), A(c["fwd_grad"]), A(c["bwd_q"]), A(c["bwd_p"]), A(c["bwd_logp"]),
+            A(c["bwd_grad"]), A(c["inv_mass"]), c["jlp0"], c["max_depth"], c["d"], c["seed"]]
+    r = nt.call("build_full_tree_bin", *args)
+    assert set(r) == {"q_bin", "logp", "grad_bin", "n_steps", "divergent", "accept_sum", "depth"}
+    e = c["expect"]
+    assert r["n_steps"] > e["n_steps_gt"] and r["accept_sum"] > e["accept_sum_gt"]
+    assert e["depth_gt"] < r["depth"] <= e["depth_le"]
+    k = lambda name: A(c[name])[None, :, None]  # noqa: E731
+    m = native_tree.build_full_tree_bin(
+        A([c["q0"]]), A([c["p0"]]), A([c["grad0"]]), [c["logp0"]], k("fwd_q"), k("fwd_p"),
+        A([c["fwd_logp"]]), k("fwd_grad"), k("bwd_q"), k("bwd_p"), A([c["bwd_logp"]]), k("bwd_grad"),
+        c["inv_mass"], [c["jlp0"]], c["max_depth"], 1, [c["seed"]])
+    assert np.array_equal(H.f64(r["q_bin"]), m["q_bin"][0]) and r["logp"] == m["logp"][0]
+    assert (r["n_steps"], r["depth"], r["divergent"], r["accept_sum"]) == \
+        (m["n_steps"][0], m["depth"][0], bool(m["divergent"][0]), m["accept_sum"][0])
+    c = GOLD["full_tree_divergent"]
+    n = c["n"]
+    full = lambda v: np.full(n, float(v))  # noqa: E731
+    r = nt.call("build_full_tree_bin", A(c["q0"]), A(c["p0"]), A(c["grad0"]), c["logp0"],
+                full(c["fwd_q_value"]), full(c["p_value"]), full(c["logp_value"]), full(c["grad_value"]),
+                full(c["bwd_q_value"]), full(c["p_value"]), full(c["logp_value"]), full(c["grad_value"]),
+                A(c["inv_mass"]), c["jlp0"], c["max_depth"], c["d"], c["seed"])
+    assert r["divergent"] is True and r["n_steps"] <= c["expect"]["n_steps_le"]
+
+
+def test_hip_native_equals_the_python_mirror(hip, mods):
+    """model_create -> warmup -> sample_chains / sample / stream through the NIF functions."""
+    hn = mods["HipNative"]
+    spec = models.eight_schools()
+    ok, ref = hn.call("model_create", spec.kind, spec.data)
+    assert ok == H.Atom("ok")
+    assert hn.call("model_set_flat_order", ref, spec.flat_order()) == H.Atom("ok")
+    q0 = spec.to_unconstrained(spec.default_init)
+    tun = hn.call("warmup", ref, q0, 120, 10, 0.8, 42)
+    comp = sampler.compile(spec)
+    opts = dict(num_warmup=120, num_samples=30, seed=42)
+    t2 = sampler.warmup(comp, spec.default_init, opts)
+    assert tun["epsilon"] == t2["epsilon"] and np.array_equal(H.f64(tun["inv_mass"]), t2["inv_mass"])
+    tr, lf, dv = hn.call("sample_chains", ref, tun["epsilon"], H.f64(tun["inv_mass"]), q0, 6, 0, 6, 30, 10, 42)
+    _, _, extra = sampler.sample_compiled_tuned(comp, t2, spec.default_init, opts, num_chains=6)
+    raw = extra["raw"]
+    assert np.array_equal(H.f64(tr["draws"]).reshape(6, 30, spec.d), raw["draws"])
+    assert np.array_equal(H.i32(tr["tree_depth"]).reshape(6, 30), raw["tree_depth"])
+    assert np.array_equal(H.i32(tr["n_steps"]).reshape(6, 30), raw["n_steps"])
+    assert np.array_equal(H.f64(tr["energy"]).reshape(6, 30), raw["energy"])
+    assert lf == extra["total_leapfrogs"]
+    # logp_grad and multi_step keep the B2 shapes
+    lp, g = hn.call("logp_grad", ref, np.tile(q0, 3), 3)
+    assert H.f64(lp).shape == (3,) and H.f64(g).shape == (30,)
+    aq, ap, al, ag = hn.call("multi_step", ref, q0, np.ones(spec.d), H.f64(g)[:spec.d], 0.1,
+                             np.ones(spec.d), 4, 1)
+    assert H.f64(aq).shape == (4 * spec.d,) and H.f64(al).shape == (4,)
+    # random init (nil) and the streaming pair
+    tun3 = hn.call("stream_begin", ref, None, 50, 10, 0.8, 3)
+    rows, _ = hn.call("stream_next", ref, 5)
+    assert H.f64(rows["draws"]).shape == (5 * spec.d,) and tun3["epsilon"] > 0
+    with pytest.raises(H.BadArg):
+        hn.call("warmup", ref, np.zeros(3), 10, 10, 0.8, 1)
