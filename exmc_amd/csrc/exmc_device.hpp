@@ -158,6 +158,93 @@ __device__ __forceinline__ double group_allsum(double v) {
   return a[0];
 }
 
+// ---- sums over a 16-lane chain group in lane order (v_fmac_f64_dpp row_newbcast) ---------------
+// The f64 ALU of gfx950 takes one DPP control, row_newbcast:i (operand 0 is read from lane i of the
+// row), and v_fmac_f64 is the one f64 arithmetic instruction with a DPP form. So
+//     acc = fma(v[lane i], 1.0, acc)   for i = 0 .. NL-1
+// is ONE instruction per term, leaves the sum in every lane of the row, and adds the terms left
+// to right -- the reference's own order (Enum.sum / Nx.sum over the flat vector), where the xor
+// butterfly costs 3 instructions per stage (two 32-bit DPP moves and the add) plus the selects
+// that mask the lanes past D. It wins while NL <= 12: chain groups of 16 lanes that hold one
+// dimension per lane with D <= 12 (eight_schools, generated models) sum this way, seeded with the
+// caller's start value; every other layout keeps the butterfly. ("Reductions": for
+// such a group the lane order IS the left-to-right sum of the numeric contract.)
+// One asm block per batch of sums: a block is not padded with hazard nops per instruction, and the
+// leading s_nop covers a DPP read of a register the preceding VALU instruction wrote.
+template <int G, int D>
+inline constexpr bool kSeqSum = (G == 16 && D <= 12);
+
+#define EXMC_FMAC_B(A, V, I) \
+  "v_fmac_f64_dpp %[" #A "], %[" #V "], %[one] row_newbcast:" #I " row_mask:0xf bank_mask:0xf\n\t"
+#define EXMC_SEQ1(I) EXMC_FMAC_B(a0, v0, I)
+#define EXMC_SEQ2(I) EXMC_SEQ1(I) EXMC_FMAC_B(a1, v1, I)
+#define EXMC_SEQ3(I) EXMC_SEQ2(I) EXMC_FMAC_B(a2, v2, I)
+#define EXMC_SEQ6(I) EXMC_SEQ3(I) EXMC_FMAC_B(a3, v3, I) EXMC_FMAC_B(a4, v4, I) EXMC_FMAC_B(a5, v5, I)
+#define EXMC_LANES_1(S) S(0)
+#define EXMC_LANES_2(S) EXMC_LANES_1(S) S(1)
+#define EXMC_LANES_3(S) EXMC_LANES_2(S) S(2)
+#define EXMC_LANES_4(S) EXMC_LANES_3(S) S(3)
+#define EXMC_LANES_5(S) EXMC_LANES_4(S) S(4)
+#define EXMC_LANES_6(S) EXMC_LANES_5(S) S(5)
+#define EXMC_LANES_7(S) EXMC_LANES_6(S) S(6)
+#define EXMC_LANES_8(S) EXMC_LANES_7(S) S(7)
+#define EXMC_LANES_9(S) EXMC_LANES_8(S) S(8)
+#define EXMC_LANES_10(S) EXMC_LANES_9(S) S(9)
+#define EXMC_LANES_11(S) EXMC_LANES_10(S) S(10)
+#define EXMC_LANES_12(S) EXMC_LANES_11(S) S(11)
+// the asm statement for NL lanes, chosen at compile time
+#define EXMC_SEQSUM_ASM(SEQ, OUTS, INS)                                                        \
+  if constexpr (NL == 1) __asm__("s_nop 1\n\t" EXMC_LANES_1(SEQ) : OUTS : INS);                \
+  else if constexpr (NL == 2) __asm__("s_nop 1\n\t" EXMC_LANES_2(SEQ) : OUTS : INS);           \
+  else if constexpr (NL == 3) __asm__("s_nop 1\n\t" EXMC_LANES_3(SEQ) : OUTS : INS);           \
+  else if constexpr (NL == 4) __asm__("s_nop 1\n\t" EXMC_LANES_4(SEQ) : OUTS : INS);           \
+  else if constexpr (NL == 5) __asm__("s_nop 1\n\t" EXMC_LANES_5(SEQ) : OUTS : INS);           \
+  else if constexpr (NL == 6) __asm__("s_nop 1\n\t" EXMC_LANES_6(SEQ) : OUTS : INS);           \
+  else if constexpr (NL == 7) __asm__("s_nop 1\n\t" EXMC_LANES_7(SEQ) : OUTS : INS);           \
+  else if constexpr (NL == 8) __asm__("s_nop 1\n\t" EXMC_LANES_8(SEQ) : OUTS : INS);           \
+  else if constexpr (NL == 9) __asm__("s_nop 1\n\t" EXMC_LANES_9(SEQ) : OUTS : INS);           \
+  else if constexpr (NL == 10) __asm__("s_nop 1\n\t" EXMC_LANES_10(SEQ) : OUTS : INS);         \
+  else if constexpr (NL == 11) __asm__("s_nop 1\n\t" EXMC_LANES_11(SEQ) : OUTS : INS);         \
+  else __asm__("s_nop 1\n\t" EXMC_LANES_12(SEQ) : OUTS : INS);
+#define EXMC_COMMA ,
+
+__device__ __forceinline__ double seq_one() {   // 1.0 in a vector register, not folded into the asm
+  double one = 1.0;
+  __asm__("" : "+v"(one));
+  return one;
+}
+
+// a_j <- a_j + v_j[lane 0] + v_j[lane 1] + ... + v_j[lane NL-1] (left to right), in every lane
+template <int NL>
+__device__ __forceinline__ void row_seqsum(double& a0, double v0) {
+  static_assert(NL >= 1 && NL <= 12, "lanes of one DPP row, where the chain beats the butterfly");
+  const double one = seq_one();
+  EXMC_SEQSUM_ASM(EXMC_SEQ1, [a0] "+v"(a0), [v0] "v"(v0) EXMC_COMMA [one] "v"(one))
+}
+template <int NL>
+__device__ __forceinline__ void row_seqsum(double& a0, double& a1, double v0, double v1) {
+  const double one = seq_one();
+  EXMC_SEQSUM_ASM(EXMC_SEQ2, [a0] "+v"(a0) EXMC_COMMA [a1] "+v"(a1),
+                  [v0] "v"(v0) EXMC_COMMA [v1] "v"(v1) EXMC_COMMA [one] "v"(one))
+}
+template <int NL>
+__device__ __forceinline__ void row_seqsum(double& a0, double& a1, double& a2, double v0, double v1,
+                                           double v2) {
+  const double one = seq_one();
+  EXMC_SEQSUM_ASM(EXMC_SEQ3, [a0] "+v"(a0) EXMC_COMMA [a1] "+v"(a1) EXMC_COMMA [a2] "+v"(a2),
+                  [v0] "v"(v0) EXMC_COMMA [v1] "v"(v1) EXMC_COMMA [v2] "v"(v2) EXMC_COMMA [one] "v"(one))
+}
+template <int NL>
+__device__ __forceinline__ void row_seqsum6(double (&a)[6], const double (&v)[6]) {
+  const double one = seq_one();
+  EXMC_SEQSUM_ASM(EXMC_SEQ6,
+                  [a0] "+v"(a[0]) EXMC_COMMA [a1] "+v"(a[1]) EXMC_COMMA [a2] "+v"(a[2]) EXMC_COMMA
+                  [a3] "+v"(a[3]) EXMC_COMMA [a4] "+v"(a[4]) EXMC_COMMA [a5] "+v"(a[5]),
+                  [v0] "v"(v[0]) EXMC_COMMA [v1] "v"(v[1]) EXMC_COMMA [v2] "v"(v[2]) EXMC_COMMA
+                  [v3] "v"(v[3]) EXMC_COMMA [v4] "v"(v[4]) EXMC_COMMA [v5] "v"(v[5]) EXMC_COMMA
+                  [one] "v"(one))
+}
+
 // value held by lane `src` (0..G-1) of this lane's group
 template <int G>
 __device__ __forceinline__ double group_bcast(double v, int src) {
@@ -339,33 +426,66 @@ struct Math {
     if constexpr (kVreg) return exmc_log_v(x);
     else return exmc_log(x);
   }
+  // the same functions where the call site proves the argument's range (exmc_detmath.h): the main
+  // path without its special-case branches, v_ldexp_f64 scaling; same bits on the stated domain
+  __device__ static __forceinline__ double exp_pm200(double x) {   // |x| <= 200
+    if constexpr (kVreg) return exmc_exp_pm200_v(x);
+    else return exmc_exp_pm200(x);
+  }
+  __device__ static __forceinline__ double exp_le0(double x) {     // x <= 0 or NaN
+    if constexpr (kVreg) return exmc_exp_le0_v(x);
+    else return exmc_exp_le0(x);
+  }
+  __device__ static __forceinline__ double log_ge1(double x) {     // 1 <= x < inf or NaN
+    if constexpr (kVreg) return exmc_log_ge1_v(x);
+    else return exmc_log_ge1(x);
+  }
+  __device__ static __forceinline__ double log_unit(double x) {    // a uniform_s variate, [0, 1)
+    if constexpr (kVreg) return exmc_log_unit_v(x);
+    else return exmc_log_unit(x);
+  }
   // tree.ex:1597-1605. exp(0) = 1 exactly under exmc_exp, so the larger term is not evaluated.
+  // mn - mx <= 0 (or NaN), 1 + exp(.) in [1, 2] (or NaN): the range-restricted forms apply.
   __device__ static __forceinline__ double log_sum_exp(double a, double b) {
     const double mx = (a > b) ? a : b;
     if (mx == -exmc_from_bits(EXMC_INF_BITS) || mx == -1.0e300) return -1.0e300;
     const double mn = (a > b) ? b : a;
-    return mx + log(1.0 + exp(mn - mx));
+    return mx + log_ge1(1.0 + exp_le0(mn - mx));
   }
 };
 
-// lane-partial sum over this lane's valid slots, lane 0 seeded with init0, then butterfly
-template <int G, int DPL>
+// init0 + the sum over the chain's dimensions: lane-partial sum over this lane's valid slots, lane 0
+// seeded with init0, then the butterfly -- or, for a kSeqSum group, init0 + v[dim 0] + v[dim 1] + ...
+template <int G, int DPL, int D = G * DPL>
 __device__ __forceinline__ double group_sum_slots(const double (&v)[DPL], const bool (&valid)[DPL],
                                                   int l, double init0) {
-  double acc = (l == 0) ? init0 : 0.0;
+  if constexpr (kSeqSum<G, D>) {
+    static_assert(DPL == 1, "one dimension per lane");
+    double acc = init0;
+    row_seqsum<D>(acc, v[0]);
+    return acc;
+  } else {
+    double acc = (l == 0) ? init0 : 0.0;
 #pragma unroll
-  for (int k = 0; k < DPL; k++) acc = valid[k] ? (acc + v[k]) : acc;
-  return group_allsum<G>(acc);
+    for (int k = 0; k < DPL; k++) acc = valid[k] ? (acc + v[k]) : acc;
+    return group_allsum<G>(acc);
+  }
 }
 
 // leapfrog.ex:39-42: 0.5 * sum(p * (M^-1 * p))
-template <int G, int DPL>
+template <int G, int DPL, int D = G * DPL>
 __device__ __forceinline__ double kinetic_energy(const double (&p)[DPL], const double (&im)[DPL],
                                                  const bool (&valid)[DPL]) {
-  double acc = 0.0;
+  if constexpr (kSeqSum<G, D>) {
+    double acc = 0.0;
+    row_seqsum<D>(acc, p[0] * (im[0] * p[0]));
+    return 0.5 * acc;
+  } else {
+    double acc = 0.0;
 #pragma unroll
-  for (int k = 0; k < DPL; k++) acc = valid[k] ? (acc + p[k] * (im[k] * p[k])) : acc;
-  return 0.5 * group_allsum<G>(acc);
+    for (int k = 0; k < DPL; k++) acc = valid[k] ? (acc + p[k] * (im[k] * p[k])) : acc;
+    return 0.5 * group_allsum<G>(acc);
+  }
 }
 
 // lane partials of the two dot products of tree.ex:1578-1588 for one (rho, pa, pb) triple
@@ -384,13 +504,19 @@ __device__ __forceinline__ void uturn_partials(const double (&rho)[DPL], const d
 }
 
 // tree.ex:1578-1588: rho-based U-turn test against two endpoint momenta
-template <int G, int DPL>
+template <int G, int DPL, int D = G * DPL>
 __device__ __forceinline__ bool uturn(const double (&rho)[DPL], const double (&pa)[DPL],
                                       const double (&pb)[DPL], const double (&im)[DPL],
                                       const bool (&valid)[DPL]) {
   double s[2];
-  uturn_partials<DPL>(rho, pa, pb, im, valid, s[0], s[1]);
-  group_allsum_n<G, 2>(s);
+  if constexpr (kSeqSum<G, D>) {
+    const double v = rho[0] * im[0];
+    s[0] = s[1] = 0.0;
+    row_seqsum<D>(s[0], s[1], v * pa[0], v * pb[0]);
+  } else {
+    uturn_partials<DPL>(rho, pa, pb, im, valid, s[0], s[1]);
+    group_allsum_n<G, 2>(s);
+  }
   return (s[0] < 0.0) || (s[1] < 0.0);
 }
 
@@ -400,7 +526,7 @@ __device__ __forceinline__ bool uturn(const double (&rho)[DPL], const double (&p
 //   check 3: rho3         against (pa3, pb3)
 // The tests have no side effects, so evaluating all three (instead of short-circuiting) leaves
 // every output unchanged. Returns {c1, c2 || c3}.
-template <int G, int DPL>
+template <int G, int DPL, int D = G * DPL>
 __device__ __forceinline__ void uturn3(const double (&r1)[DPL], const double (&a1)[DPL],
                                        const double (&b1)[DPL], const double (&r2)[DPL],
                                        const double (&a2)[DPL], const double (&b2)[DPL],
@@ -408,10 +534,18 @@ __device__ __forceinline__ void uturn3(const double (&r1)[DPL], const double (&a
                                        const double (&b3)[DPL], const double (&im)[DPL],
                                        const bool (&valid)[DPL], bool& c1, bool& c23) {
   double s[6];
-  uturn_partials<DPL>(r1, a1, b1, im, valid, s[0], s[1]);
-  uturn_partials<DPL>(r2, a2, b2, im, valid, s[2], s[3]);
-  uturn_partials<DPL>(r3, a3, b3, im, valid, s[4], s[5]);
-  group_allsum_n<G, 6>(s);
+  if constexpr (kSeqSum<G, D>) {
+    const double v1 = r1[0] * im[0], v2 = r2[0] * im[0], v3 = r3[0] * im[0];
+    const double t[6] = {v1 * a1[0], v1 * b1[0], v2 * a2[0], v2 * b2[0], v3 * a3[0], v3 * b3[0]};
+#pragma unroll
+    for (int j = 0; j < 6; j++) s[j] = 0.0;
+    row_seqsum6<D>(s, t);
+  } else {
+    uturn_partials<DPL>(r1, a1, b1, im, valid, s[0], s[1]);
+    uturn_partials<DPL>(r2, a2, b2, im, valid, s[2], s[3]);
+    uturn_partials<DPL>(r3, a3, b3, im, valid, s[4], s[5]);
+    group_allsum_n<G, 6>(s);
+  }
   c1 = (s[0] < 0.0) || (s[1] < 0.0);
   c23 = (s[2] < 0.0) || (s[3] < 0.0) || (s[4] < 0.0) || (s[5] < 0.0);
 }

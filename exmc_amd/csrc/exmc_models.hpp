@@ -91,7 +91,7 @@ struct EightSchools : ModelDefaults {
     const double mu = group_bcast_c<G, 0 % G>(q[0 / G]);
     const double zraw = group_bcast_c<G, 1 % G>(q[1 / G]);
     const double zc = clamp200(zraw);
-    const double tau = MM::exp(zc);
+    const double tau = MM::exp_pm200(zc);   // zc = clamp200(.)
     dv.watch(mu);
     double L[DPL], A[DPL], B[DPL], T[DPL];
     bool valid[DPL];
@@ -113,21 +113,26 @@ struct EightSchools : ModelDefaults {
       T[k] = -0.5 * (th * th + c.c1);
       g[k] = (-th) + a * tau;
     }
-    // three independent group sums in one butterfly pass
+    // three independent group sums in one pass: in lane order for a kSeqSum group (0 + L[0] +
+    // L[1] + ..., the reference's left-to-right sum), else lane partials and one butterfly
     double s3[3] = {0.0, 0.0, 0.0};
+    if constexpr (kSeqSum<G, D>) {
+      row_seqsum<D>(s3[0], s3[1], s3[2], L[0], A[0], B[0]);
+    } else {
 #pragma unroll
-    for (int k = 0; k < DPL; k++) {
-      s3[0] = valid[k] ? (s3[0] + L[k]) : s3[0];
-      s3[1] = valid[k] ? (s3[1] + A[k]) : s3[1];
-      s3[2] = valid[k] ? (s3[2] + B[k]) : s3[2];
+      for (int k = 0; k < DPL; k++) {
+        s3[0] = valid[k] ? (s3[0] + L[k]) : s3[0];
+        s3[1] = valid[k] ? (s3[1] + A[k]) : s3[1];
+        s3[2] = valid[k] ? (s3[2] + B[k]) : s3[2];
+      }
+      group_allsum_n<G, 3>(s3);
     }
-    group_allsum_n<G, 3>(s3);
     const double lik = s3[0], sa = s3[1], sb = s3[2];
     const double zmu = dv(mu - 0.0, ln.five);
     const double t_mu = -0.5 * (zmu * zmu + c.c_mu);
     const double zt = dv(tau, ln.five);
     const double zt2 = zt * zt;
-    const double t_tau = (c.c_hc - MM::log(1.0 + zt2)) + zc;
+    const double t_tau = (c.c_hc - MM::log_ge1(1.0 + zt2)) + zc;   // zt2 in [0, e^400 / 25]
     const double g_mu = (-dv(zmu, ln.five)) + sa;
     const double dhc = -dv(dv(2.0 * zt, ln.five), 1.0 + zt2);
     const bool in = (zraw > -200.0) && (zraw < 200.0);
@@ -138,7 +143,7 @@ struct EightSchools : ModelDefaults {
       if (i == 0) { T[k] = t_mu; g[k] = g_mu; }
       if (i == 1) { T[k] = t_tau; g[k] = g_tau; }
     }
-    return group_sum_slots<G, DPL>(T, valid, l, lik);
+    return group_sum_slots<G, DPL, D>(T, valid, l, lik);
   }
 };
 

@@ -463,14 +463,14 @@ __device__ __forceinline__ bool pipe_integrate_transition(const typename M::Cons
     const double logp_new = M::logp_grad(mc, L.ln, L.l, q, g);
 #pragma unroll
     for (int k = 0; k < DPL; k++) p[k] = p[k] + h * g[k];
-    const double jlp = logp_new - kinetic_energy<G, DPL>(p, im, L.valid);
+    const double jlp = logp_new - kinetic_energy<G, DPL, M::D>(p, im, L.valid);
     bool c_div;
     double c_lsw, c_acc;
     if (exmc_isfinite(jlp)) {
       const double dl = jlp - jlp0;
       c_div = dl < -1000.0;
       c_lsw = dl;
-      c_acc = fmin(1.0, MM::exp(fmin(dl, 0.0)));
+      c_acc = fmin(1.0, MM::exp_le0(fmin(dl, 0.0)));
     } else {
       c_div = true;
       c_lsw = -1001.0;
@@ -563,7 +563,7 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
     bool alive = has;
     if (has) {
       draw_momentum<M, G>(L, st.rng, pL);
-      jlp0 = st.logp - kinetic_energy<G, DPL>(pL, im, valid);
+      jlp0 = st.logp - kinetic_energy<G, DPL, M::D>(pL, im, valid);
       trng = st.rng;  // the tree consumes a copy (sampler.ex:897 discards its draws)
 #pragma unroll
       for (int k = 0; k < DPL; k++) {
@@ -641,7 +641,7 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
 #endif
 #pragma unroll
           for (int k = 0; k < DPL; k++) p[k] = p[k] + h * g[k];
-          jlp = logp_new - kinetic_energy<G, DPL>(p, im, valid);
+          jlp = logp_new - kinetic_energy<G, DPL, M::D>(p, im, valid);
         }
         EXMC_PROF(2)
 
@@ -661,7 +661,7 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
 #if EXMC_ABLATE == 4
             c_acc = fmin(1.0, 1.0 + fmin(dl, 0.0));
 #else
-            c_acc = fmin(1.0, MM::exp(fmin(dl, 0.0)));
+            c_acc = fmin(1.0, MM::exp_le0(fmin(dl, 0.0)));
 #endif
           } else {
             c_div = true;
@@ -698,7 +698,7 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
 #else
                 const double lsw = MM::log_sum_exp(a_lsw, c_lsw);
                 const double u = rng_uniform(trng);
-                const bool use_b = u < MM::exp(c_lsw - lsw);
+                const bool use_b = u < MM::exp_le0(c_lsw - lsw);   // lsw >= c_lsw
 #endif
                 if (!use_b) {
                   c_logpP = a_logpP;
@@ -722,8 +722,8 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
 #else
                   // tree.ex:1428-1446: the two sub-span checks apply from depth 2 on; lvl is
                   // wave-uniform, so the level-0 merges (3 of 4 in a 7-leaf tree) reduce 2 sums, not 6
-                  if (lvl == 0) c1 = uturn<G, DPL>(rho, a_pin, p, im, valid);
-                  else uturn3<G, DPL>(rho, a_pin, p, r2, a_pin, c_pin, r3, a_pout, p, im, valid, c1, c23);
+                  if (lvl == 0) c1 = uturn<G, DPL, M::D>(rho, a_pin, p, im, valid);
+                  else uturn3<G, DPL, M::D>(rho, a_pin, p, r2, a_pin, c_pin, r3, a_pout, p, im, valid, c1, c23);
 #endif
                   turning = c1 || c23;
 #pragma unroll
@@ -768,7 +768,7 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
 #else
             const double lsw = MM::log_sum_exp(t_lsw, c_lsw);
             const double u = rng_uniform(trng);
-            const bool use_sub = MM::log(u) < (c_lsw - t_lsw);
+            const bool use_sub = MM::log_unit(u) < (c_lsw - t_lsw);
 #endif
             if (use_sub) {
               t_logpP = c_logpP;
@@ -793,7 +793,7 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
 #if EXMC_ABLATE == 1
               c1 = c23 = false;
 #else
-              uturn3<G, DPL>(rho, farp, p, r2, farp, c_pin, r3, nearp, p, im, valid, c1, c23);
+              uturn3<G, DPL, M::D>(rho, farp, p, r2, farp, c_pin, r3, nearp, p, im, valid, c1, c23);
 #endif
               turning = c1 || c23;
             }
@@ -1024,7 +1024,7 @@ __device__ __forceinline__ double find_eps_dev(const typename M::Consts& mc,
   for (int k = 0; k < DPL; k++) p0[k] = 0.0;
   // plain sequential normal_s draws (as sample_momentum_fast does); identical to draw_momentum
   draw_momentum<M, G>(L, st.rng, p0);
-  const double jlp0 = st.logp - kinetic_energy<G, DPL>(p0, L.im, L.valid);
+  const double jlp0 = st.logp - kinetic_energy<G, DPL, M::D>(p0, L.im, L.valid);
   auto try_eps = [&](double eps) -> double {
     double q[DPL], p[DPL], g[DPL];
     const double h = eps / 2.0;
@@ -1038,7 +1038,7 @@ __device__ __forceinline__ double find_eps_dev(const typename M::Consts& mc,
     const double lp = M::logp_grad(mc, L.ln, L.l, q, g);
 #pragma unroll
     for (int k = 0; k < DPL; k++) p[k] = p[k] + h * g[k];
-    const double jlp = lp - kinetic_energy<G, DPL>(p, L.im, L.valid);
+    const double jlp = lp - kinetic_energy<G, DPL, M::D>(p, L.im, L.valid);
     return (exmc_isfinite(jlp0) && exmc_isfinite(jlp)) ? (jlp - jlp0) : -1000.0;
   };
   double eps = 1.0;

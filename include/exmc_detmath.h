@@ -227,9 +227,89 @@ EXMC_HD double exmc_log1p(double x) {
   return exmc_log(u) + (x - (u - 1.0)) / u;
 }
 
+/* ---- the same functions for arguments whose range the call site proves ----
+ * exmc_exp / exmc_log guard every special case (NaN, overflow, underflow, zero, negative,
+ * subnormal, infinity) with a branch; on the GPU each guard is a compare, an exec-mask save, a
+ * branch and a restore -- a dozen issue slots per call that a lone wavefront pays in full. The
+ * variants below are the main path of the same algorithm (same operations, same order, same bits)
+ * plus the one or two fix-ups their stated domain still needs. Outside the domain they are
+ * undefined; tests/test_detmath_rng.py compares each with the general function over its domain on
+ * the host and tools/probe/detmath_probe.hip does the same for the device spellings.
+ *
+ *   exmc_exp_pm200   |x| <= 200                          (a clamp200'ed unconstrained scale)
+ *   exmc_exp_le0     x <= 0 (including -inf), or NaN     (weights: exp(min(d, 0)), exp(b - lse))
+ *   exmc_log_ge1     1 <= x < +inf, or NaN               (log(1 + y), y >= 0)
+ *   exmc_log_unit    0 <= x < 1, x zero or normal        (log of a uniform_s variate)
+ *
+ * Scaling by 2^k: the general form multiplies by 2^(k>>1) and 2^(k - (k>>1)); the first product is
+ * exact (its exponent stays normal), so only the second rounds -- the single rounding ldexp
+ * performs. EXMC_EXP_SCALE is that ldexp (v_ldexp_f64 on the device, one issue slot). */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define EXMC_EXP_SCALE(p, k) __builtin_amdgcn_ldexp(p, k)
+#else
+#define EXMC_EXP_SCALE(p, k) \
+  (((p) * exmc_from_bits((uint64_t)(((k) >> 1) + 1023) << 52)) * exmc_from_bits((uint64_t)((k) - ((k) >> 1) + 1023) << 52))
+#endif
+
+#define EXMC_EXP_MAIN(CORE, xc)                                                              \
+  double kf = __builtin_rint((xc) * 0x1.71547652b82fep+0);                                   \
+  double r, p;                                                                               \
+  CORE(kf, (xc), &r, &p);                                                                    \
+  p = __builtin_fma(p, r, 0.5);                                                              \
+  p = __builtin_fma(p, r, 1.0);                                                              \
+  p = __builtin_fma(p, r, 1.0);                                                              \
+  int k = (int)kf;                                                                           \
+  return EXMC_EXP_SCALE(p, k);
+
+/* the reduction, the series and the reconstruction of EXMC_LOG_BODY for a normal positive x */
+#define EXMC_LOG_MAIN(CORE, x, res)                                                          \
+  uint64_t ix_ = exmc_to_bits(x);                                                            \
+  uint64_t t_ = ix_ + (0x3FF0000000000000ULL - 0x3FE6A09E667F3BCDULL);                       \
+  int e_ = (int)(t_ >> 52) - 1023;                                                           \
+  ix_ = (t_ & 0x000FFFFFFFFFFFFFULL) + 0x3FE6A09E667F3BCDULL;                                \
+  double f_ = exmc_from_bits(ix_) - 1.0;                                                     \
+  double hfsq_ = 0.5 * f_ * f_;                                                              \
+  double dn_ = 2.0 + f_;                                                                     \
+  double s_ = EXMC_DIV_LOG(f_, dn_);                                                         \
+  double z_ = s_ * s_;                                                                       \
+  double w_ = z_ * z_;                                                                       \
+  double u1_, u2_;                                                                           \
+  CORE(w_, &u1_, &u2_);                                                                      \
+  double t1_ = w_ * u1_;                                                                     \
+  double t2_ = z_ * u2_;                                                                     \
+  double R_ = t2_ + t1_;                                                                     \
+  double dk_ = (double)e_;                                                                   \
+  double acc_ = __builtin_fma(dk_, 1.90821492927058770002e-10, s_ * (hfsq_ + R_));           \
+  acc_ = (acc_ - hfsq_) + f_;                                                                \
+  double res = __builtin_fma(dk_, 6.93147180369123816490e-01, acc_);
+
+#define EXMC_RANGE_FUNCS(SUFFIX, EXPCORE, LOGCORE)                                           \
+  EXMC_RHD double exmc_exp_pm200##SUFFIX(double x) { EXMC_EXP_MAIN(EXPCORE, x) }             \
+  EXMC_RHD double exmc_exp_le0##SUFFIX(double x) {                                           \
+    /* below -746 the result is 0 whatever x is; a NaN fails the comparison and flows through   \
+     * (rint, fma and ldexp keep it, (int)NaN = 0) */                                        \
+    const double xc = (x < -746.0) ? -746.0 : x;                                             \
+    EXMC_EXP_MAIN(EXPCORE, xc)                                                               \
+  }                                                                                          \
+  EXMC_RHD double exmc_log_ge1##SUFFIX(double x) {                                           \
+    EXMC_LOG_MAIN(LOGCORE, x, res)                                                           \
+    return res + (x - x);   /* + 0.0 for a finite x (res is never -0), NaN for a NaN */       \
+  }                                                                                          \
+  EXMC_RHD double exmc_log_unit##SUFFIX(double x) {                                          \
+    EXMC_LOG_MAIN(LOGCORE, x, res)                                                           \
+    return (x == 0.0) ? -exmc_from_bits(EXMC_INF_BITS) : res;                                \
+  }
+
+#define EXMC_RHD EXMC_HD
+EXMC_RANGE_FUNCS(, exmc_exp_core, exmc_log_core)
+#undef EXMC_RHD
+
 #if defined(__HIPCC__)
 static __device__ __forceinline__ double exmc_exp_v(double x) { EXMC_EXP_BODY(exmc_exp_core_v) }
 static __device__ __forceinline__ double exmc_log_v(double x) { EXMC_LOG_BODY(exmc_log_core_v) }
+#define EXMC_RHD static __device__ __forceinline__
+EXMC_RANGE_FUNCS(_v, exmc_exp_core_v, exmc_log_core_v)
+#undef EXMC_RHD
 #endif
 
 #endif /* EXMC_DETMATH_H */

@@ -127,6 +127,10 @@ double exo_xoshiro_f64(uint64_t s[4]) { return (double)(exo_xoshiro_next(s) >> 1
  * lane 0's partial (used so that G = 1 reproduces compiler.ex:396-397's term fold).
  * ==================================================================================== */
 static double lane_sum(const double* v, int n, int G, double init0) {
+  /* A 16-lane chain group that holds one dimension per lane and at most 12 of them sums in lane
+   * order on the GPU (v_fmac_f64_dpp row_newbcast chains, exmc_device.hpp kSeqSum): that is the
+   * left-to-right sum seeded with init0, i.e. the reference's own order. */
+  if (G == 16 && n <= 12) G = 1;
   if (G <= 1) {
     double acc = init0;
     for (int i = 0; i < n; i++) acc = acc + v[i];

@@ -18,6 +18,7 @@ head -8 $out/kernel_stats.csv
 for what in "$@"; do
   case $what in
     probe) ./tools/probe/exec_mask_rate_probe > $out/exec_mask_rate_probe.txt 2>&1; cat $out/exec_mask_rate_probe.txt ;;
+    fmac) ./tools/probe/fmac_dpp_probe > $out/fmac_dpp_probe.txt 2>&1; cat $out/fmac_dpp_probe.txt ;;
     sections) EXMC_HIP_LIB=$PWD/exmc_amd/lib/libexmc_hip_prof.so python bench.py --no-cpu > $out/bench_sections.json 2> $out/sections.txt; grep "exmc prof" $out/sections.txt | tail -12 ;;
   esac
 done

@@ -12,34 +12,42 @@
 #define REP256(x) REP4(REP64(x))
 #define REP1024(x) REP4(REP256(x))
 
+// s_memtime with its own wait, fenced: the compiler may otherwise move clock reads across the
+// volatile asm blocks (the first version of this probe reported 0 clocks for its first block)
+__device__ __forceinline__ long long now() {
+  long long t;
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+  return t;
+}
+
 __global__ void k(double* out, long long* cyc, double seed, int quarter) {
   double a = seed + threadIdx.x, b = seed * 0.5, c = 1.0 + 1e-9, d = 0.25;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   long long t[4] = {0, 0, 0, 0};
   __syncthreads();
   if (!quarter || lane < 16) {
-    long long t0 = clock64();
-    asm volatile(REP1024("v_fma_f64 %0, %1, %2, %3\n\t") : "+v"(a), "+v"(b) : "v"(c), "v"(d));
-    long long t1 = clock64();
+    long long t0 = now();
+    asm volatile(REP1024("v_fma_f64 %0, %1, %2, %3\n\t") : "+v"(a), "+v"(b) : "v"(c), "v"(d) : "memory");
+    long long t1 = now();
     t[0] = t1 - t0;
-    t0 = clock64();
-    asm volatile(REP1024("v_add_f64 %0, %1, %2\n\t") : "+v"(a), "+v"(b) : "v"(c), "v"(d));
-    t1 = clock64();
+    t0 = now();
+    asm volatile(REP1024("v_add_f64 %0, %1, %2\n\t") : "+v"(a), "+v"(b) : "v"(c), "v"(d) : "memory");
+    t1 = now();
     t[1] = t1 - t0;
-    t0 = clock64();
+    t0 = now();
     // 2 VALU : 1 SALU : (1 not-taken branch per 4) -- roughly the NUTS pass mix
     asm volatile(REP256("v_fma_f64 %0, %1, %2, %3\n\t s_mov_b32 s20, s21\n\t v_add_f64 %1, %0, %2\n\t"
                         "v_mul_f64 %0, %1, %2\n\t s_and_b32 s22, s20, s21\n\t v_fma_f64 %1, %0, %2, %3\n\t"
                         "s_cbranch_execz 1f\n\t1:\n\t")
-                 : "+v"(a), "+v"(b) : "v"(c), "v"(d) : "s20", "s21", "s22");
-    t1 = clock64();
+                 : "+v"(a), "+v"(b) : "v"(c), "v"(d) : "s20", "s21", "s22", "memory");
+    t1 = now();
     t[2] = t1 - t0;
-    t0 = clock64();
+    t0 = now();
     int xi = lane + 3, yi = 7;
     asm volatile(REP1024("v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t")
-                 : "+v"(xi), "+v"(yi));
+                 : "+v"(xi), "+v"(yi) :: "memory");
     a += xi + yi;
-    t1 = clock64();
+    t1 = now();
     t[3] = t1 - t0;
   }
   if (lane == 0)
