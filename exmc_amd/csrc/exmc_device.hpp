@@ -208,11 +208,9 @@ inline constexpr bool kSeqSum = (G == 16 && D <= 12);
   else __asm__("s_nop 1\n\t" EXMC_LANES_12(SEQ) : OUTS : INS);
 #define EXMC_COMMA ,
 
-__device__ __forceinline__ double seq_one() {   // 1.0 in a vector register, not folded into the asm
-  double one = 1.0;
-  __asm__("" : "+v"(one));
-  return one;
-}
+// 1.0 as a vector-register operand (the DPP form of v_fmac_f64 takes no literal): a plain constant,
+// so the compiler keeps ONE copy live across the sampling loop instead of a v_mov_b64 per sum
+__device__ __forceinline__ double seq_one() { return 1.0; }
 
 // a_j <- a_j + v_j[lane 0] + v_j[lane 1] + ... + v_j[lane NL-1] (left to right), in every lane
 template <int NL>

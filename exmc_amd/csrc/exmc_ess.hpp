@@ -2,13 +2,15 @@
 //
 // The reference computes every lag of the autocorrelation (O(S^2) per series) and then keeps only
 // the lags in front of Geyer's first non-positive pair (diagnostics.ex:147-167). Here the lags are
-// computed eight at a time, one sweep over the series per block of eight, and the sweeps stop at
+// computed sixteen at a time, one sweep over the series per block of sixteen, and the sweeps stop at
 // that pair. The values that are used are the same bits: each lag sum runs left to right over i as
 // `acc + c[i] * c[i + lag]` (diagnostics.ex:137-141), the centred values are `x - mean` with
 // mean = (left-to-right sum) / S, and lag 0 of the first block is the variance.
-// A sweep for lags [l0, l0 + 8) walks j = i + lag from l0 up, reading c[j] and c[j - l0]; the last
-// eight values of the second stream sit in a register ring (ring[(j - l0) & 7], static indices
-// after unrolling by eight), so lag l0 + k multiplies c[j] with ring[(u - k) & 7].
+// A sweep for lags [l0, l0 + 16) walks j = i + lag from l0 up, reading c[j] and c[j - l0]; the last
+// sixteen values of the second stream sit in a register ring (ring[(j - l0) & 15], static indices
+// after unrolling), so lag l0 + k multiplies c[j] with ring[(u - k) & 15]. Typical chains stop
+// inside the first block (Geyer's cut at a few lags), so a wavefront whose 64 series all do costs
+// two sweeps: the mean and one block.
 // Plain C++ (no HIP types): the device kernel calls it per lane, and tests/test_ess_series_host.py
 // compiles it for the host to check it against the CPU checker. Build with -ffp-contract=off.
 #pragma once
@@ -23,7 +25,8 @@
 
 namespace exmc {
 
-constexpr int kEssLoadBlock = 32;   // loads in flight per stream (a multiple of the ring size 8)
+constexpr int kEssLags = 16;        // lags per sweep (the register ring)
+constexpr int kEssLoadBlock = 32;   // loads in flight per stream (a multiple of kEssLags)
 
 EXMC_ESS_HD double ess_series(const double* x, size_t stride, int S) {
   if (S < 4) return S * 1.0;   // diagnostics.ex:46
@@ -34,10 +37,10 @@ EXMC_ESS_HD double ess_series(const double* x, size_t stride, int S) {
   const int max_k = (S - 1) / 2;
   double tau = -1.0, var = 0.0;
   bool done = false;
-  for (int l0 = 0; !done; l0 += 8) {
-    double acc[8], ring[8];
+  for (int l0 = 0; !done; l0 += kEssLags) {
+    double acc[kEssLags], ring[kEssLags];
 #pragma unroll
-    for (int k = 0; k < 8; k++) acc[k] = ring[k] = 0.0;
+    for (int k = 0; k < kEssLags; k++) acc[k] = ring[k] = 0.0;
     // ring entries that are not filled yet stand for indices i < 0: they are zeros and add 0.0 to
     // their lag sum, which leaves it unchanged
     for (int j0 = l0; j0 < S; j0 += kEssLoadBlock) {
@@ -59,9 +62,9 @@ EXMC_ESS_HD double ess_series(const double* x, size_t stride, int S) {
       for (int u = 0; u < kEssLoadBlock; u++) {
         if (j0 + u < S) {
           const double cj = xa[u] - mean;
-          ring[u & 7] = (l0 == 0) ? cj : (xb[u] - mean);
+          ring[u & (kEssLags - 1)] = (l0 == 0) ? cj : (xb[u] - mean);
 #pragma unroll
-          for (int k = 0; k < 8; k++) acc[k] = acc[k] + ring[(u - k) & 7] * cj;
+          for (int k = 0; k < kEssLags; k++) acc[k] = acc[k] + ring[(u - k) & (kEssLags - 1)] * cj;
         }
       }
     }
@@ -70,7 +73,7 @@ EXMC_ESS_HD double ess_series(const double* x, size_t stride, int S) {
       if (var == 0.0) break;   // diagnostics.ex:130-131: all-zero ACF, tau stays -1
     }
 #pragma unroll
-    for (int kk = 0; kk < 4; kk++) {
+    for (int kk = 0; kk < kEssLags / 2; kk++) {
       const int k = l0 / 2 + kk;
       if (!done) {
         if (k > max_k) {

@@ -62,6 +62,7 @@ struct EightSchools : ModelDefaults {
     double y[DPL], lsg[DPL];
     Recip sg[DPL];   // sigma_j as a reusable divisor
     Recip five;      // the prior scales Normal(0, 5), HalfCauchy(5)
+    double cc;       // row form: the Normal prior's constant of this lane's dimension (c_mu | c1)
   };
 
   __device__ static __forceinline__ void load(const Consts& c, int l, Lane& ln) {
@@ -74,6 +75,7 @@ struct EightSchools : ModelDefaults {
       ln.lsg[k] = c.lsg[j];
     }
     ln.five = make_recip_literal(5.0);
+    ln.cc = (l == 0) ? c.c_mu : c.c1;
   }
 
   __device__ static __forceinline__ double logp_grad(const Consts& c, const Lane& ln, int l,
@@ -88,6 +90,70 @@ struct EightSchools : ModelDefaults {
   template <class DV>
   __device__ static __forceinline__ double eval(const Consts& c, const Lane& ln, int l,
                                                 const double (&q)[DPL], double (&g)[DPL], DV& dv) {
+    if constexpr (kSeqSum<G, D>) return eval_row(c, ln, l, q, g, dv);
+    else return eval_slots(c, ln, l, q, g, dv);
+  }
+
+  // One dimension per lane of a 16-lane row (lane 0 mu, lane 1 log tau, lanes 2..9 theta_trans_j),
+  // straight-line: no lane of the row takes a branch of its own. The two hyper-parameter terms
+  // share their instruction stream -- x / 5, its square, the quotient by 5 again are (mu - 0) / 5,
+  // zmu^2, zmu / 5 on lane 0 and tau / 5, zt^2, zt / 5 on lane 1 ((2 zt) / 5 = 2 (zt / 5) exactly) --
+  // and each lane then selects the term and the gradient entry of its own dimension. Same
+  // operations on the same operands as the slot form below, so the same bits.
+  template <class DV>
+  __device__ static __forceinline__ double eval_row(const Consts& c, const Lane& ln, int l,
+                                                    const double (&q)[DPL], double (&g)[DPL], DV& dv) {
+    static_assert(DPL == 1, "one dimension per lane");
+    const double mu = group_bcast_c<G, 0>(q[0]);
+    const double zraw = group_bcast_c<G, 1>(q[0]);
+    const double zc = clamp200(zraw);
+    const double tau = MM::exp_pm200(zc);   // zc = clamp200(.)
+    const bool isth = (l >= 2) && (l < D);
+    const bool l0 = (l == 0), l1 = (l == 1);
+    // theta lanes
+    const double th = q[0];
+    const double theta = mu + tau * th;
+    const double resid = ln.y[0] - theta;
+    dv.watch_if(isth, resid);
+    dv.watch_if(isth, ln.sg[0].b);
+    const double z = dv(resid, ln.sg[0]);
+    const double a = dv(z, ln.sg[0]);
+    const double Lk = isth ? ((-0.5 * (z * z)) - ln.lsg[0]) : 0.0;
+    const double Ak = isth ? a : 0.0;
+    const double Bk = isth ? (a * th) : 0.0;
+    double lik = 0.0, sa = 0.0, sb = 0.0;
+    row_seqsum<D>(lik, sa, sb, Lk, Ak, Bk);
+    // hyper-parameter lanes
+    const double x = l0 ? (mu - 0.0) : tau;
+    dv.watch_if(l0, x);                      // tau = exp(clamp200(.)) is in range by construction
+    const double zh = dv(x, ln.five);        // zmu | zt
+    const double zh2 = zh * zh;
+    const double w = dv(zh, ln.five);        // zmu / 5 | zt / 5
+    const double den = 1.0 + zh2;
+    const double lg = MM::log_ge1(den);      // lane 1: zt2 in [0, e^400 / 25]; elsewhere unused
+    const double dhc = -dv(2.0 * w, den);
+    const bool in = (zraw > -200.0) && (zraw < 200.0);
+    double g_tau = in ? ((dhc + sb) * tau + 1.0) : 0.0;
+    // keep the lane-1 values in the straight line: left alone, the compiler sinks them into an
+    // exec-masked region of their own (five scalar instructions and a branch per leapfrog)
+    __asm__("" : "+v"(g_tau));
+    const double g_mu = (-w) + sa;
+    const double g_th = (-th) + a * tau;
+    // T = -0.5 (u^2 + cc): u = zmu with cc = c_mu on lane 0, u = theta_trans with cc = c1 on its lanes
+    const double u2 = l0 ? zh2 : (th * th);
+    double T = -0.5 * (u2 + ln.cc);
+    double t_tau = (c.c_hc - lg) + zc;
+    __asm__("" : "+v"(t_tau));
+    T = l1 ? t_tau : T;
+    g[0] = l0 ? g_mu : (l1 ? g_tau : g_th);
+    const double Tv[1] = {T};
+    const bool valid[1] = {l < D};
+    return group_sum_slots<G, DPL, D>(Tv, valid, l, lik);
+  }
+
+  template <class DV>
+  __device__ static __forceinline__ double eval_slots(const Consts& c, const Lane& ln, int l,
+                                                      const double (&q)[DPL], double (&g)[DPL], DV& dv) {
     const double mu = group_bcast_c<G, 0 % G>(q[0 / G]);
     const double zraw = group_bcast_c<G, 1 % G>(q[1 / G]);
     const double zc = clamp200(zraw);

@@ -464,19 +464,13 @@ __device__ __forceinline__ bool pipe_integrate_transition(const typename M::Cons
 #pragma unroll
     for (int k = 0; k < DPL; k++) p[k] = p[k] + h * g[k];
     const double jlp = logp_new - kinetic_energy<G, DPL, M::D>(p, im, L.valid);
-    bool c_div;
-    double c_lsw, c_acc;
-    if (exmc_isfinite(jlp)) {
-      const double dl = jlp - jlp0;
-      c_div = dl < -1000.0;
-      c_lsw = dl;
-      c_acc = fmin(1.0, MM::exp_le0(fmin(dl, 0.0)));
-    } else {
-      c_div = true;
-      c_lsw = -1001.0;
-      c_acc = 0.0;
-    }
-    c_acc = c_div ? 0.0 : c_acc;
+    // tree.ex:1042-1048 without a branch: a non-finite joint log-probability is a divergence with
+    // log-weight -1001 and no acceptance; fmin(dl, 0) is 0 for a NaN, so the exponential is defined
+    const bool fin = exmc_isfinite(jlp);
+    const double dl = jlp - jlp0;
+    const bool c_div = fin ? (dl < -1000.0) : true;
+    const double c_lsw = fin ? dl : -1001.0;
+    const double c_acc = c_div ? 0.0 : fmin(1.0, MM::exp_le0(fmin(dl, 0.0)));
     pb.put_leaf(q, p, g, logp_new, c_lsw, c_acc, c_div);
   };
   bool go_right = rng_uniform(prng) > 0.5;   // tree.ex:403
@@ -654,19 +648,17 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
             c_div = pc_div;
             c_lsw = pc_lsw;
             c_acc = pc_acc;
-          } else if (exmc_isfinite(jlp)) {
+          } else {
+            // tree.ex:1042-1048 without a branch (see pipe_integrate_transition)
+            const bool fin = exmc_isfinite(jlp);
             const double dl = jlp - jlp0;
-            c_div = dl < -1000.0;
-            c_lsw = dl;
+            c_div = fin ? (dl < -1000.0) : true;
+            c_lsw = fin ? dl : -1001.0;
 #if EXMC_ABLATE == 4
             c_acc = fmin(1.0, 1.0 + fmin(dl, 0.0));
 #else
             c_acc = fmin(1.0, MM::exp_le0(fmin(dl, 0.0)));
 #endif
-          } else {
-            c_div = true;
-            c_lsw = -1001.0;
-            c_acc = 0.0;
           }
           c_acc = c_div ? 0.0 : c_acc;
           c_logpP = c_div ? -1.0e30 : logp_new;
