@@ -7,6 +7,10 @@ finished traces (RCCL over xGMI on the GPUs; gloo in the CPU tests) for split R-
 all-reduce of per-parameter ESS sums. This replaces Exmc.NUTS.Distributed's :erpc fan-out
 (lib/exmc/nuts/distributed.ex:56-101).
 """
+import os
+import tempfile
+
+import numpy as np
 import torch
 
 
@@ -98,3 +102,86 @@ def split_rhat(draws):
     b = n / (m - 1) * ((means - gm) ** 2).sum(dim=1)
     w = var.mean(dim=1)
     return torch.sqrt(((n - 1) / n * w + b / n) / w)
+
+
+# ------------------------------------------------------------------------------------------
+# The fan-out as an API: Exmc.NUTS.Distributed.sample_chains/2 (lib/exmc/nuts/distributed.ex:56-101)
+# re-designed for one node of GPUs. The reference compiles and warms up on the coordinator, ships
+# the tuning to peer nodes over :erpc and retries failed chains locally; here every worker process
+# owns one GPU, repeats the (deterministic) shared warmup with the same seed instead of receiving
+# it, samples its contiguous block of chains and hands its finished traces back -- no exchange
+# while sampling. `sampler.sample_chains(ir, n, devices=[0, 1, ...])` routes here.
+# ------------------------------------------------------------------------------------------
+def run_shard(engine, spec, num_chains, opts, device, rank, world):
+    """What one rank does (also the body bench.py's ranks follow): compile on `device`, the
+    shared warmup (every rank with the same seed: identical tuning, no broadcast), then chains
+    [lo, hi) of num_chains with seeds seed + 7919 * i. Returns the rank's host traces."""
+    o = dict(opts or {})
+    o["device"] = device
+    lo, hi = shard_range(num_chains, rank, world)
+    compiled = engine.compile(spec, {"device": device})
+    init_values = o.get("init_values") or {}
+    tuning = engine.warmup(compiled, init_values, o)
+    if hi > lo:
+        _, stats, extra = engine.sample_compiled_tuned(compiled, tuning, init_values, o,
+                                                       num_chains=num_chains, chain_lo=lo, chain_hi=hi)
+        raw = extra["raw"]
+        leapfrogs = int(extra["total_leapfrogs"])
+    else:           # more ranks than chains: an empty shard
+        raw, leapfrogs = None, 0
+    return dict(rank=rank, lo=lo, hi=hi, raw=raw, leapfrogs=leapfrogs, epsilon=float(tuning["epsilon"]),
+                inv_mass=np.asarray(tuning["inv_mass"], dtype=np.float64))
+
+
+def _shard_worker(rank, world, engine_name, spec, num_chains, opts, devices, out_dir):
+    import importlib
+    engine = importlib.import_module(engine_name)
+    res = run_shard(engine, spec, num_chains, opts, devices[rank], rank, world)
+    arrays = dict(lo=res["lo"], hi=res["hi"], leapfrogs=res["leapfrogs"], epsilon=res["epsilon"],
+                  inv_mass=res["inv_mass"])
+    if res["raw"] is not None:
+        arrays.update({"raw_" + k: v for k, v in res["raw"].items()})
+    np.savez(os.path.join(out_dir, "shard%d.npz" % rank), **arrays)
+
+
+def sample_chains_sharded(spec, num_chains, opts=None, devices=None, engine="exmc_amd.sampler"):
+    """sample_chains over several GPUs of one node: one spawned process per entry of `devices`
+    (started before it touches a GPU; the parent needs none), chain blocks by shard_range, results
+    concatenated in chain order -- so the returned ({name: draws}[], stats[]) equal the
+    single-device sample_chains whatever the number of devices. `engine` names the module that
+    provides compile / warmup / sample_compiled_tuned (the tests substitute the CPU checker)."""
+    import importlib
+
+    import torch.multiprocessing as mp
+    if num_chains < 1:
+        raise ValueError("num_chains must be >= 1")
+    devices = list(devices) if devices is not None else [0]
+    world = len(devices)
+    if world < 1:
+        raise ValueError("devices must name at least one GPU")
+    eng = importlib.import_module(engine)
+    with tempfile.TemporaryDirectory(prefix="exmc_shards_") as out_dir:
+        if world == 1:
+            _shard_worker(0, 1, engine, spec, num_chains, opts, devices, out_dir)
+        else:
+            mp.spawn(_shard_worker, args=(world, engine, spec, num_chains, opts, devices, out_dir),
+                     nprocs=world, join=True)
+        shards = [dict(np.load(os.path.join(out_dir, "shard%d.npz" % r))) for r in range(world)]
+    eps = {float(z["epsilon"]) for z in shards}
+    if len(eps) != 1 or any(not np.array_equal(z["inv_mass"], shards[0]["inv_mass"]) for z in shards):
+        raise RuntimeError("ranks disagree on the shared tuning: the warmup is not deterministic")
+    keys = [k[4:] for k in shards[0] if k.startswith("raw_")]
+    filled = [z for z in shards if int(z["hi"]) > int(z["lo"])]
+    raw = {k: np.concatenate([z["raw_" + k] for z in filled], axis=0) for k in keys}
+    o = eng._merge_opts(opts)
+    traces, stats = [], []
+    for c in range(num_chains):
+        traces.append(eng._build_trace(spec, raw["draws"][c]))
+        stats.append(dict(step_size=float(shards[0]["epsilon"]), inv_mass_diag=shards[0]["inv_mass"].copy(),
+                          divergences=int(raw["divergent"][c].sum()), num_warmup=o["num_warmup"],
+                          num_samples=o["num_samples"], sample_stats=eng.SampleStats(raw, c)))
+    extra = dict(total_leapfrogs=int(sum(int(z["leapfrogs"]) for z in shards)), raw=raw,
+                 shards=[(int(z["lo"]), int(z["hi"])) for z in shards], devices=devices)
+    for s_ in stats:
+        s_["extra"] = extra
+    return traces, stats

@@ -228,8 +228,18 @@ def sample_chains_compiled(compiled, num_chains, opts=None):
 
 
 def sample_chains(ir, num_chains, opts=None):
-    """Exmc.NUTS.Sampler.sample_chains/3."""
+    """Exmc.NUTS.Sampler.sample_chains/3. With opts["devices"] = [0, 1, ...] the chains are sharded
+    over those GPUs, one process each (exmc_amd.distributed.sample_chains_sharded, the analogue of
+    Exmc.NUTS.Distributed.sample_chains/2); the result does not depend on the number of devices."""
     opts = opts or {}
+    devices = opts.get("devices")
+    if devices is not None and len(devices) > 1:
+        if isinstance(ir, Compiled):
+            ir = ir.spec
+        from . import distributed
+        return distributed.sample_chains_sharded(ir, num_chains, opts, devices)
+    if devices:
+        opts = dict(opts, device=devices[0])
     compiled = ir if isinstance(ir, Compiled) else Compiled(ir, device=opts.get("device", 0))
     return sample_chains_compiled(compiled, num_chains, opts)
 

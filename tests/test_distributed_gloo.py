@@ -93,3 +93,31 @@ def test_two_rank_gloo_sharding_matches_single_process(tmp_path):
         assert np.allclose(z["rhat"], xd.split_rhat(torch.from_numpy(ref)).numpy())
         assert np.allclose(z["rhat_stats"], z["rhat"], rtol=1e-12, atol=0.0)
         assert np.all(np.abs(z["rhat"] - 1.0) < 0.5)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_sample_chains_sharded_api_is_independent_of_the_number_of_ranks(world):
+    """exmc_amd.distributed.sample_chains_sharded -- what sampler.sample_chains(ir, n, devices=[...])
+    calls -- with the CPU checker as the engine: spawned rank processes, the shared warmup repeated
+    on every rank, contiguous chain blocks, results concatenated in chain order. The answer equals
+    the one-process answer bit for bit for 1, 2 and 3 ranks (5 chains: unequal and empty shards)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle as O
+    from exmc_amd import distributed as xd
+    from exmc_amd import models
+    spec = models.eight_schools()
+    opts = dict(num_warmup=60, num_samples=25, seed=9, init_values=spec.default_init)
+    n_chains = 5 if world < 3 else 2          # 2 chains on 3 ranks: one shard is empty
+    traces, stats = xd.sample_chains_sharded(spec, n_chains, opts, devices=list(range(world)),
+                                             engine="oracle_engine")
+    t, st = O.sample_chains(O.model_for(spec), n_chains, init_q=spec.to_unconstrained(spec.default_init),
+                            num_warmup=60, num_samples=25, seed=9, cfg=O.Cfg(1, 1))
+    raw = stats[0]["extra"]["raw"]
+    assert np.array_equal(raw["draws"], t["draws"]) and np.array_equal(raw["tree_depth"], t["tree_depth"])
+    assert stats[0]["step_size"] == st.step_size
+    assert stats[0]["extra"]["total_leapfrogs"] == st.total_leapfrogs
+    assert len(traces) == n_chains and set(traces[0]) == set(spec.var_names)
+    assert np.array_equal(traces[n_chains - 1]["tau"], np.exp(t["draws"][n_chains - 1, :, 1]))
+    shards = stats[0]["extra"]["shards"]
+    assert shards[0][0] == 0 and shards[-1][1] == n_chains and len(shards) == world

@@ -26,14 +26,17 @@ __global__ void k(double* out, long long* cyc, double seed, int quarter) {
   long long t[4] = {0, 0, 0, 0};
   __syncthreads();
   if (!quarter || lane < 16) {
+    __builtin_amdgcn_s_barrier();
     long long t0 = now();
     asm volatile(REP1024("v_fma_f64 %0, %1, %2, %3\n\t") : "+v"(a), "+v"(b) : "v"(c), "v"(d) : "memory");
     long long t1 = now();
     t[0] = t1 - t0;
+    __builtin_amdgcn_s_barrier();
     t0 = now();
     asm volatile(REP1024("v_add_f64 %0, %1, %2\n\t") : "+v"(a), "+v"(b) : "v"(c), "v"(d) : "memory");
     t1 = now();
     t[1] = t1 - t0;
+    __builtin_amdgcn_s_barrier();
     t0 = now();
     // 2 VALU : 1 SALU : (1 not-taken branch per 4) -- roughly the NUTS pass mix
     asm volatile(REP256("v_fma_f64 %0, %1, %2, %3\n\t s_mov_b32 s20, s21\n\t v_add_f64 %1, %0, %2\n\t"
@@ -42,6 +45,7 @@ __global__ void k(double* out, long long* cyc, double seed, int quarter) {
                  : "+v"(a), "+v"(b) : "v"(c), "v"(d) : "s20", "s21", "s22", "memory");
     t1 = now();
     t[2] = t1 - t0;
+    __builtin_amdgcn_s_barrier();
     t0 = now();
     int xi = lane + 3, yi = 7;
     asm volatile(REP1024("v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t")
