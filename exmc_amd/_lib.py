@@ -21,7 +21,7 @@ EXPORTS = [
     "exmc_hip_traj_build_and_merge_host", "exmc_hip_traj_is_terminated_host",
     "exmc_hip_traj_get_result_host", "exmc_hip_build_subtree_host",
     "exmc_hip_stream_begin", "exmc_hip_stream_next_host", "exmc_hip_rhat", "exmc_hip_ess_bulk",
-    "exmc_hip_model_set_flat_order",
+    "exmc_hip_model_set_flat_order", "exmc_hip_warmup_from", "exmc_hip_sample_warm_host",
 ]
 
 
@@ -92,6 +92,9 @@ def bind(path):
                                           C.POINTER(C.c_int32)]
     L.exmc_hip_sample_host.argtypes = [vp, dp, Opts, Trace, C.POINTER(Tuning),
                                        C.POINTER(C.c_int32)]
+    L.exmc_hip_warmup_from.argtypes = [vp, dp, Opts, C.POINTER(Tuning), C.POINTER(Tuning)]
+    L.exmc_hip_sample_warm_host.argtypes = [vp, dp, Opts, C.POINTER(Tuning), Trace, C.POINTER(Tuning),
+                                            C.POINTER(C.c_int32)]
     ip = C.POINTER(C.c_int32)
     L.exmc_hip_build_full_tree_host.argtypes = [
         C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, dp, dp, C.c_int, dp, dp, dp, dp,

@@ -593,13 +593,16 @@ int find_eps(exmc_hip_model* m, int lanes, double* eps) {
 }
 
 // run_warmup (sampler.ex:537-762) on the single-chain state already initialised in m->state
-int run_warmup(exmc_hip_model* m, int lanes, exmc_hip_opts o, exmc_hip_tuning* tun) {
+int run_warmup(exmc_hip_model* m, int lanes, exmc_hip_opts o, exmc_hip_tuning* tun,
+               const exmc_hip_tuning* start = nullptr) {
   const int d = m->d, W = o.num_warmup;
   std::vector<double> im(d, 1.0), qh(d);
+  if (start) im.assign(start->inv_mass, start->inv_mass + d);
   int rc = upload_tuning(m, im.data());
   if (rc) return rc;
   double eps = 1.0;
-  rc = find_eps(m, lanes, &eps);
+  if (start) eps = start->epsilon;   // warm start: no initial search (sampler.ex:180-194)
+  else rc = find_eps(m, lanes, &eps);
   if (rc) return rc;
   int divergences = 0;
   auto finish = [&](double e) {
@@ -652,7 +655,8 @@ int run_warmup(exmc_hip_model* m, int lanes, exmc_hip_opts o, exmc_hip_tuning* t
 
 // run_warmup (sampler.ex:537-762) in one launch: warmup_kernel keeps dual averaging, Welford and
 // the step-size searches on the device; the host only lays out the window schedule.
-int run_warmup_device(exmc_hip_model* m, int lanes, exmc_hip_opts o, exmc_hip_tuning* tun) {
+int run_warmup_device(exmc_hip_model* m, int lanes, exmc_hip_opts o, exmc_hip_tuning* tun,
+                      const exmc_hip_tuning* start = nullptr) {
   if (o.max_tree_depth < 1 || o.max_tree_depth > kMaxLevels)
     return fail(EXMC_ERR_BADARG, "max_tree_depth out of range");
   const int d = m->d, W = o.num_warmup;
@@ -674,6 +678,15 @@ int run_warmup_device(exmc_hip_model* m, int lanes, exmc_hip_opts o, exmc_hip_tu
   P.zig_ki = zig_ki(m); P.zig_wi = zig_wi(m); P.zig_fi = zig_fi(m);
   P.nor_r = EXMC_NOR_R;
   P.flat = flat_order(m);
+  P.eps0 = 0.0;
+  P.inv_mass0 = P.sqrt_inv_mass0 = nullptr;
+  if (start) {   // warm start: previous inverse mass and step size, no initial search
+    int rcs = upload_tuning(m, start->inv_mass);
+    if (rcs) return rcs;
+    P.eps0 = start->epsilon;
+    P.inv_mass0 = m->tuning.as<double>();
+    P.sqrt_inv_mass0 = m->tuning.as<double>() + d;
+  }
   int rc = m->io.ensure((size_t)(8 + d) * 8);
   if (rc) return rc;
   P.out = m->io.as<double>();
@@ -1138,21 +1151,45 @@ int exmc_hip_transitions_host(exmc_hip_model* m, double* q, double* logp, double
   return EXMC_OK;
 }
 
-int exmc_hip_warmup(exmc_hip_model* m, const double* init_q, exmc_hip_opts o,
-                    exmc_hip_tuning* tuning) {
+namespace {
+int warmup_impl(exmc_hip_model* m, const double* init_q, exmc_hip_opts o, const exmc_hip_tuning* start,
+                exmc_hip_tuning* tuning) {
   if (check_model(m)) return EXMC_ERR_BADARG;
   if (!tuning || o.num_warmup < 0) return fail(EXMC_ERR_BADARG, "bad arguments");
+  if (start) {
+    if (!(start->epsilon > 0.0)) return fail(EXMC_ERR_BADARG, "warm start needs a positive step size");
+    for (int i = 0; i < m->d; i++)
+      if (!(start->inv_mass[i] > 0.0)) return fail(EXMC_ERR_BADARG, "warm start needs a positive inverse mass");
+  }
   HIP_TRY(hipSetDevice(m->device));
   const int lanes = resolve_lanes(m, o.lanes_per_chain);
   int rc = ensure_state(m, 1);
   if (rc) return rc;
   rc = launch_init(m, lanes, 1, 0, o.seed, init_q);
   if (rc) return rc;
+  if (start && o.num_warmup == 0) {   // sampler.ex:195-196: nothing to tune
+    *tuning = *start;
+    tuning->warmup_divergences = 0;
+    return EXMC_OK;
+  }
   // EXMC_HIP_HOST_WARMUP=1 keeps the adaptation scalars on the host (one launch per
   // transition); the default runs the whole schedule in one kernel. Both give the same bits.
   const char* hw = std::getenv("EXMC_HIP_HOST_WARMUP");
-  if (hw && hw[0] == '1') return run_warmup(m, lanes, o, tuning);
-  return run_warmup_device(m, lanes, o, tuning);
+  if (hw && hw[0] == '1') return run_warmup(m, lanes, o, tuning, start);
+  return run_warmup_device(m, lanes, o, tuning, start);
+}
+}  // namespace
+
+int exmc_hip_warmup(exmc_hip_model* m, const double* init_q, exmc_hip_opts o,
+                    exmc_hip_tuning* tuning) {
+  return warmup_impl(m, init_q, o, nullptr, tuning);
+}
+
+int exmc_hip_warmup_from(exmc_hip_model* m, const double* init_q, exmc_hip_opts o,
+                         const exmc_hip_tuning* warm_start, exmc_hip_tuning* tuning) {
+  if (!warm_start) return fail(EXMC_ERR_BADARG, "warm_start is null");
+  o.num_warmup = o.num_warmup < 50 ? o.num_warmup : 50;   // short_warmup, sampler.ex:188
+  return warmup_impl(m, init_q, o, warm_start, tuning);
 }
 
 int exmc_hip_chains_init(exmc_hip_model* m, const exmc_hip_tuning* tuning, const double* init_q,
@@ -1235,10 +1272,18 @@ int exmc_hip_sample_chains_host(exmc_hip_model* m, const exmc_hip_tuning* tuning
 
 int exmc_hip_sample_host(exmc_hip_model* m, const double* init_q, exmc_hip_opts o,
                          exmc_hip_trace tr, exmc_hip_tuning* tuning_out, int32_t* divergences) {
+  return exmc_hip_sample_warm_host(m, init_q, o, nullptr, tr, tuning_out, divergences);
+}
+
+int exmc_hip_sample_warm_host(exmc_hip_model* m, const double* init_q, exmc_hip_opts o,
+                              const exmc_hip_tuning* warm_start, exmc_hip_trace tr,
+                              exmc_hip_tuning* tuning_out, int32_t* divergences) {
   if (check_model(m)) return EXMC_ERR_BADARG;
   if (o.num_samples < 1) return fail(EXMC_ERR_BADARG, "num_samples must be >= 1");
   exmc_hip_tuning tun;
-  int rc = exmc_hip_warmup(m, init_q, o, &tun);  // leaves chain 0's state in m->state
+  // leaves chain 0's state in m->state
+  int rc = warm_start ? exmc_hip_warmup_from(m, init_q, o, warm_start, &tun)
+                      : exmc_hip_warmup(m, init_q, o, &tun);
   if (rc) return rc;
   const int lanes = resolve_lanes(m, o.lanes_per_chain);
   rc = upload_tuning(m, tun.inv_mass);

@@ -1073,6 +1073,9 @@ struct WarmupParams {
   int* race;                // null, or a zeroed word: the workgroups are replicas of the same
                             // deterministic chain and the first to finish publishes the result
   int stage_model;          // 1: dynamic LDS includes M::kStageDoubles for the model's LDS image
+  double eps0;              // > 0: warm start (sampler.ex:167-197) -- start from this step size and
+  const double* inv_mass0;  // this inverse mass (dev [D], with sqrt_inv_mass0) instead of the
+  const double* sqrt_inv_mass0;   // identity mass and the initial step-size search
   double* out;              // [0] eps_final, [1] divergences, [2] leapfrogs, [3..3+D) inv_mass
   const uint64_t* zig_ki;
   const double* zig_wi;
@@ -1133,7 +1136,7 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock)
   if (!M::kCoop && !writer) return;
 
   NutsLane<M, G> L;
-  lane_setup<M, G, LDSL>(L, mc, lds, P.stack, nullptr, nullptr, zt, P.nor_r, P.flat);
+  lane_setup<M, G, LDSL>(L, mc, lds, P.stack, P.inv_mass0, P.sqrt_inv_mass0, zt, P.nor_r, P.flat);
   if constexpr (M::kStageDoubles > 0) L.ln.xs = stage_ptr;
   if constexpr (M::kLdsDataDoubles > 0) L.ln.xoff = xoff;
   using Pipe = std::conditional_t<kPipe, PipeBox<DPL>, NoPipe>;
@@ -1172,7 +1175,7 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock)
 
   const int W = P.num_warmup;
   bool lost = false;
-  double eps = find_eps_dev<M, G>(mc, L, st, P.log_half);
+  double eps = (P.eps0 > 0.0) ? P.eps0 : find_eps_dev<M, G>(mc, L, st, P.log_half);
   double eps_final = eps;
   if (W > 0) {
     const bool has_windows = P.adapt_end > P.init_buffer;

@@ -147,7 +147,9 @@ def _tuning_struct(tuning, d):
 
 
 def sample_compiled(compiled, init_values=None, opts=None):
-    """sample_from_compiled (sampler.ex:126-257), cold start, diagonal mass."""
+    """sample_from_compiled (sampler.ex:126-257), diagonal mass. opts["warm_start"] =
+    {"inv_mass_diag": ..., "step_size": ...} (the `stats` of a previous run carry both keys)
+    reuses that tuning and runs only min(num_warmup, 50) warmup iterations (sampler.ex:167-197)."""
     o = _merge_opts(opts)
     spec = compiled.spec
     L = compiled.L
@@ -155,8 +157,12 @@ def sample_compiled(compiled, init_values=None, opts=None):
     tun = _lib.Tuning()
     div = C.c_int32()
     iq = _init_q(spec, init_values)
-    compiled.check(L.exmc_hip_sample_host(compiled.h, None if iq is None else _dp(iq), _c_opts(o), tr,
-                                      C.byref(tun), C.byref(div)))
+    ws = o.get("warm_start")
+    start = None
+    if ws is not None:
+        start = C.byref(_tuning_struct(dict(epsilon=ws["step_size"], inv_mass=ws["inv_mass_diag"]), spec.d))
+    compiled.check(L.exmc_hip_sample_warm_host(compiled.h, None if iq is None else _dp(iq), _c_opts(o),
+                                               start, tr, C.byref(tun), C.byref(div)))
     trace = _build_trace(spec, t["draws"][0])
     stats = dict(step_size=tun.epsilon, inv_mass_diag=np.array(tun.inv_mass[:spec.d]),
                  divergences=int(div.value), recoveries=0, num_warmup=o["num_warmup"],

@@ -145,6 +145,11 @@ int exmc_hip_transitions_host(exmc_hip_model* m, double* q, double* logp, double
  * init_q NULL => 0.1*normal_s per dim (sampler.ex:339-349). */
 int exmc_hip_warmup(exmc_hip_model* m, const double* init_q, exmc_hip_opts opts,
                     exmc_hip_tuning* tuning);
+/* opts[:warm_start] of Sampler.sample (lib/exmc/nuts/sampler.ex:167-197): the previous run's
+ * inv_mass_diag and step_size instead of the identity mass and the initial step-size search, and
+ * a short warmup of min(num_warmup, 50) iterations on top of them. */
+int exmc_hip_warmup_from(exmc_hip_model* m, const double* init_q, exmc_hip_opts opts,
+                         const exmc_hip_tuning* warm_start, exmc_hip_tuning* tuning);
 
 /* Exmc.NUTS.Sampler.sample_chains vectorized, sampling phase (sampler.ex:1082-1130) for chains
  * [chain_lo, chain_hi) of n_chains: chain i is seeded seed + 7919*i whatever the shard.
@@ -173,6 +178,10 @@ int exmc_hip_sample_chains_host(exmc_hip_model* m, const exmc_hip_tuning* tuning
 int exmc_hip_sample_host(exmc_hip_model* m, const double* init_q, exmc_hip_opts opts,
                          exmc_hip_trace trace_host, exmc_hip_tuning* tuning_out,
                          int32_t* divergences);
+/* the same with opts[:warm_start] (NULL = cold start, i.e. exmc_hip_sample_host) */
+int exmc_hip_sample_warm_host(exmc_hip_model* m, const double* init_q, exmc_hip_opts opts,
+                              const exmc_hip_tuning* warm_start, exmc_hip_trace trace,
+                              exmc_hip_tuning* tuning_out, int32_t* divergences);
 
 /* Exmc.Diagnostics.rhat (lib/exmc/diagnostics.ex:80-115): split R-hat per dimension across the
  * n_chains chains of a device trace [draw][dim][chain] (n_draws >= 4): rhat_dev [dim]. */

@@ -1148,6 +1148,22 @@ int exo_sample(const exo_model* m, const double* init_q, exo_opts o, exo_trace t
   return 0;
 }
 
+int exo_sample_warm(const exo_model* m, const double* init_q, double prev_epsilon,
+                    const double* prev_inv_mass, exo_opts o, exo_trace tr, exo_stats* st, exo_cfg c) {
+  /* sampler.ex:167-197 (opts[:warm_start]): the previous run's inverse mass and step size, a short
+   * warmup of min(num_warmup, 50) iterations without the initial step-size search, then sampling */
+  cstate s;
+  init_chain(m, init_q, o.seed, &s, c);
+  vcp(st->inv_mass, prev_inv_mass, m->d);
+  exo_opts ow = o;
+  ow.num_warmup = o.num_warmup < 50 ? o.num_warmup : 50;
+  st->step_size = run_warmup(m, &s, prev_epsilon, st->inv_mass, ow, c);
+  st->total_leapfrogs = 0;
+  run_sampling(m, &s, st->step_size, st->inv_mass, o, tr, 0, &st->total_leapfrogs, c);
+  st->divergences = s.divergences;
+  return 0;
+}
+
 int exo_sample_tuned(const exo_model* m, const double* init_q, double epsilon, const double* im,
                      exo_opts o, exo_trace tr, exo_stats* st, exo_cfg c) {
   /* sampler.ex:260-335 */

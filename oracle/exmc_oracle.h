@@ -178,6 +178,10 @@ int exo_sample_chains(const exo_model* m, const double* init_q, int n_chains, in
                       exo_cfg cfg);
 /* warmup only: returns tuned step size + inv_mass (used to hand the same tuning to the GPU) */
 int exo_warmup(const exo_model* m, const double* init_q, exo_opts o, exo_stats* st, exo_cfg cfg);
+/* opts[:warm_start] (sampler.ex:167-197): previous inv_mass_diag + step_size, min(num_warmup, 50)
+ * warmup iterations with no initial step-size search, then num_samples draws */
+int exo_sample_warm(const exo_model* m, const double* init_q, double prev_epsilon,
+                    const double* prev_inv_mass, exo_opts o, exo_trace tr, exo_stats* st, exo_cfg cfg);
 /* sampling with given tuning (sample_compiled_tuned, sampler.ex:260-335) */
 int exo_sample_tuned(const exo_model* m, const double* init_q, double epsilon,
                      const double* inv_mass, exo_opts o, exo_trace tr, exo_stats* st, exo_cfg cfg);

@@ -148,6 +148,7 @@ def lib():
     L.exo_warmup.argtypes = [C.c_void_p, dp, Opts, C.POINTER(Stats), Cfg]
     L.exo_sample_tuned.argtypes = [C.c_void_p, dp, C.c_double, dp, Opts, Trace, C.POINTER(Stats),
                                    Cfg]
+    L.exo_sample_warm.argtypes = [C.c_void_p, dp, C.c_double, dp, Opts, Trace, C.POINTER(Stats), Cfg]
     L.exo_ess.argtypes = [dp, C.c_int]
     L.exo_ess.restype = C.c_double
     L.exo_ess_bulk.argtypes = [dp, C.c_int]
@@ -292,6 +293,20 @@ def sample_tuned(model, epsilon, inv_mass, init_q=None, num_samples=1000, max_tr
     im = arr(inv_mass)
     lib().exo_sample_tuned(model.h, iq, epsilon, dptr(im),
                            Opts(0, num_samples, max_tree_depth, 0.8, seed), tr, C.byref(st), cfg)
+    return t, st
+
+
+def sample_warm(model, prev_epsilon, prev_inv_mass, init_q=None, num_warmup=1000, num_samples=1000,
+                max_tree_depth=10, target_accept=0.8, seed=0, cfg=None):
+    """opts[:warm_start] of Sampler.sample (sampler.ex:167-197)."""
+    cfg = cfg or Cfg(0, 1)
+    t, tr = alloc_trace(num_samples, model.d)
+    st = Stats()
+    iq = None if init_q is None else dptr(arr(init_q))
+    im = arr(prev_inv_mass)
+    lib().exo_sample_warm(model.h, iq, prev_epsilon, dptr(im),
+                          Opts(num_warmup, num_samples, max_tree_depth, target_accept, seed), tr,
+                          C.byref(st), cfg)
     return t, st
 
 

@@ -274,6 +274,27 @@ def test_single_chain_sample_bit_exact(hip):
     assert abs(trace["mu"].mean() - 2.15) < 0.3
 
 
+@pytest.mark.parametrize("num_warmup", [0, 30, 50, 400])
+def test_warm_start_bit_exact(hip, num_warmup):
+    """opts[:warm_start] (sampler.ex:167-197): the previous run's inv_mass_diag and step_size, a short
+    warmup of min(num_warmup, 50) iterations without the initial step-size search, then sampling."""
+    spec = models.eight_schools()
+    first, st1 = sampler.sample(spec, spec.default_init, dict(num_warmup=300, num_samples=20, seed=1))
+    ws = dict(inv_mass_diag=st1["inv_mass_diag"], step_size=st1["step_size"])
+    _, st2 = sampler.sample(spec, spec.default_init,
+                            dict(num_warmup=num_warmup, num_samples=60, seed=5, warm_start=ws))
+    om = O.eight_schools()
+    t, st = O.sample_warm(om, ws["step_size"], ws["inv_mass_diag"], spec.to_unconstrained(spec.default_init),
+                          num_warmup=num_warmup, num_samples=60, seed=5, cfg=O.Cfg(1, 16))
+    assert st.step_size == st2["step_size"]
+    assert np.array_equal(np.array(st.inv_mass[:spec.d]), st2["inv_mass_diag"])
+    assert np.array_equal(t["draws"], st2["raw"]["draws"][0])
+    assert np.array_equal(t["n_steps"], st2["raw"]["n_steps"][0])
+    assert st.divergences == st2["divergences"]
+    if num_warmup == 0:
+        assert st2["step_size"] == ws["step_size"]
+
+
 def _bench_models():
     import bench
     return [("sv", lambda: bench.make_spec("sv")[0], 64, 6, 12),

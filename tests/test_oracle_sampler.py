@@ -219,3 +219,22 @@ def test_diagnostics_ess_and_rhat():
     assert L.exo_rhat(O.dptr(ch), 4, n) > 1.3
     const = np.ones(50)
     assert L.exo_ess(O.dptr(const), 50) == 50.0     # var == 0 => acf 0 => tau -1 => n/max(tau,1)
+
+
+def test_warm_start_semantics():
+    """opts[:warm_start] (sampler.ex:167-197): num_warmup 0 keeps the previous tuning untouched;
+    the short warmup is capped at 50 iterations (400 behaves as 50); the mass matrix is not
+    re-estimated inside 50 iterations (no Phase II window fits)."""
+    m = O.eight_schools()
+    q0 = np.zeros(10)
+    im = 0.5 + np.arange(10) / 10.0
+    t0, s0 = O.sample_warm(m, 0.3, im, q0, num_warmup=0, num_samples=20, seed=4)
+    assert s0.step_size == 0.3 and np.array_equal(np.array(s0.inv_mass[:10]), im)
+    t50, s50 = O.sample_warm(m, 0.3, im, q0, num_warmup=50, num_samples=20, seed=4)
+    t400, s400 = O.sample_warm(m, 0.3, im, q0, num_warmup=400, num_samples=20, seed=4)
+    assert s50.step_size == s400.step_size and np.array_equal(t50["draws"], t400["draws"])
+    assert np.array_equal(np.array(s50.inv_mass[:10]), im) and s50.step_size != 0.3
+    # no initial step-size search: the first warmup transition uses the given step size, so the
+    # RNG stream differs from a cold start's (which spends d normals on the search first)
+    tc, sc = O.sample(m, q0, num_warmup=50, num_samples=20, seed=4)
+    assert not np.array_equal(tc["draws"], t50["draws"])
