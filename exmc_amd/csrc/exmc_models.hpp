@@ -868,9 +868,15 @@ struct Radon : ModelDefaults {
 static __host__ __device__ __noinline__ double exmc_gen_exp_call(double x) { return exmc_exp(x); }
 static __host__ __device__ __noinline__ double exmc_gen_log_call(double x) { return exmc_log(x); }
 static __host__ __device__ __noinline__ double exmc_gen_log1p_call(double x) { return exmc_log1p(x); }
+#ifdef EXMC_GEN_INLINE_MATH   // tools/probe/gen_inline_repro.py: the inlined form under investigation
+#define EXMC_GEN_EXP exmc_exp
+#define EXMC_GEN_LOG exmc_log
+#define EXMC_GEN_LOG1P exmc_log1p
+#else
 #define EXMC_GEN_EXP exmc_gen_exp_call
 #define EXMC_GEN_LOG exmc_gen_log_call
 #define EXMC_GEN_LOG1P exmc_gen_log1p_call
+#endif
 #include EXMC_CUSTOM_HEADER
 
 namespace exmc {

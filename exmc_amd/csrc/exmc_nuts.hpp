@@ -1191,7 +1191,9 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock)
     for (int i = 0; i < n_iter; i++) {
       // another replica of this chain has already finished: leave (the integrator wave is told
       // through the mailbox, at the barrier it is waiting at)
-      if (P.race && __hip_atomic_load(P.race, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+      // (looked at every eighth transition: the load is an exposed L2 round trip of a lone wave)
+      if (P.race && (i & 7) == 0 &&
+          __hip_atomic_load(P.race, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
         lost = true;
         if constexpr (kPipe) pipe.quit();
         break;
