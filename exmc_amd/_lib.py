@@ -22,6 +22,8 @@ EXPORTS = [
     "exmc_hip_traj_get_result_host", "exmc_hip_build_subtree_host",
     "exmc_hip_stream_begin", "exmc_hip_stream_next_host", "exmc_hip_rhat", "exmc_hip_ess_bulk",
     "exmc_hip_model_set_flat_order", "exmc_hip_warmup_from", "exmc_hip_sample_warm_host",
+    "exmc_hip_warmup_dense", "exmc_hip_model_set_dense_mass", "exmc_hip_model_clear_dense_mass",
+    "exmc_hip_sample_dense_host",
 ]
 
 
@@ -92,6 +94,10 @@ def bind(path):
                                           C.POINTER(C.c_int32)]
     L.exmc_hip_sample_host.argtypes = [vp, dp, Opts, Trace, C.POINTER(Tuning),
                                        C.POINTER(C.c_int32)]
+    L.exmc_hip_warmup_dense.argtypes = [vp, dp, Opts, C.POINTER(Tuning), dp, dp]
+    L.exmc_hip_model_set_dense_mass.argtypes = [vp, dp, dp, C.c_int]
+    L.exmc_hip_sample_dense_host.argtypes = [vp, dp, Opts, Trace, C.POINTER(Tuning), dp, dp, C.POINTER(C.c_int32)]
+    L.exmc_hip_model_clear_dense_mass.argtypes = [vp]
     L.exmc_hip_warmup_from.argtypes = [vp, dp, Opts, C.POINTER(Tuning), C.POINTER(Tuning)]
     L.exmc_hip_sample_warm_host.argtypes = [vp, dp, Opts, C.POINTER(Tuning), Trace, C.POINTER(Tuning),
                                             C.POINTER(C.c_int32)]

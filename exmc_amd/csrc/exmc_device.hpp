@@ -548,4 +548,63 @@ __device__ __forceinline__ void uturn3(const double (&r1)[DPL], const double (&a
   c23 = (s[2] < 0.0) || (s[3] < 0.0) || (s[4] < 0.0) || (s[5] < 0.0);
 }
 
+// ---- dense inverse mass (opts[:dense_mass]; mass_matrix.ex:27-35,56-72,105-140) for the layouts
+// that hold a whole chain in one lane (G = 1: DPL = D). cov = the covariance M^-1 (row-major D x D),
+// chol = its lower Cholesky factor; both chain-invariant, so a wavefront reads them through the
+// scalar cache. Products accumulate with fma in ascending index (the numeric contract's order for
+// this mode). cov == nullptr means the diagonal mass.
+struct DenseMass {
+  const double* cov = nullptr;
+  const double* chol = nullptr;
+};
+
+template <int D>
+__device__ __forceinline__ void dense_times(const double* cov, const double (&x)[D], double (&out)[D]) {
+#pragma unroll
+  for (int i = 0; i < D; i++) {
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < D; j++) acc = __builtin_fma(x[j], cov[i * D + j], acc);
+    out[i] = acc;
+  }
+}
+
+// leapfrog.ex:39-61: 0.5 * sum(p * (M^-1 p))
+template <int D>
+__device__ __forceinline__ double kinetic_energy_dense(const double* cov, const double (&p)[D]) {
+  double mp[D];
+  dense_times<D>(cov, p, mp);
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < D; k++) acc = acc + p[k] * mp[k];
+  return 0.5 * acc;
+}
+
+// v = M^-1 rho, turn <=> v . pa < 0 or v . pb < 0 (the rule of tree.ex:1572-1588 with a dense M^-1)
+template <int D>
+__device__ __forceinline__ bool uturn_dense(const double* cov, const double (&rho)[D],
+                                            const double (&pa)[D], const double (&pb)[D]) {
+  double v[D];
+  dense_times<D>(cov, rho, v);
+  double sa = 0.0, sb = 0.0;
+#pragma unroll
+  for (int k = 0; k < D; k++) {
+    sa = sa + v[k] * pa[k];
+    sb = sb + v[k] * pb[k];
+  }
+  return (sa < 0.0) || (sb < 0.0);
+}
+
+// sampler.ex:412-427: solve L^T p = z by back substitution
+template <int D>
+__device__ __forceinline__ void dense_momentum(const double* chol, const double (&z)[D], double (&p)[D]) {
+#pragma unroll
+  for (int i = D - 1; i >= 0; i--) {
+    double acc = z[i];
+#pragma unroll
+    for (int j = D - 1; j > i; j--) acc = __builtin_fma(-chol[j * D + i], p[j], acc);
+    p[i] = acc / chol[i * D + i];
+  }
+}
+
 }  // namespace exmc

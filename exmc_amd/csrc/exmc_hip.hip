@@ -90,6 +90,8 @@ struct exmc_hip_model {
   DevBuf trace;     // staging for host-trace entry points
   DevBuf io;        // staging for host vectors
   DevBuf scores;    // ess_bulk: the rank-normalised copy of the caller's trace
+  DevBuf dense;     // opts[:dense_mass]: cov[D][D], chol[D][D] while a dense mass is in force
+  bool dense_on = false;
   int state_chains = 0;
   // resident chains (exmc_hip_chains_init / _advance)
   int res_C = 0, res_lanes = 0, res_max_depth = 10;
@@ -329,6 +331,11 @@ int launch_nuts(exmc_hip_model* m, int lanes, int C, int n_draws, int draw_offse
     P.zig_ki = zig_ki(m); P.zig_wi = zig_wi(m); P.zig_fi = zig_fi(m);
     P.nor_r = EXMC_NOR_R;
     P.flat = flat_order(m);
+    if (m->dense_on) {
+      if (T::G != 1) return fail(EXMC_ERR_UNSUPPORTED, "a dense mass matrix needs lanes_per_chain = 1");
+      P.dm.cov = m->dense.as<double>();
+      P.dm.chol = m->dense.as<double>() + (size_t)m->d * m->d;
+    }
     if constexpr (M::kPipeNutsLevels > 0) {
       // wave pairs (tree + integrator), fewer stack levels in LDS to make room for the mailbox.
       // Opt-in (EXMC_HIP_NUTS_PIPE=1): bit-identical, but with the chip already full the pair
@@ -656,7 +663,9 @@ int run_warmup(exmc_hip_model* m, int lanes, exmc_hip_opts o, exmc_hip_tuning* t
 // run_warmup (sampler.ex:537-762) in one launch: warmup_kernel keeps dual averaging, Welford and
 // the step-size searches on the device; the host only lays out the window schedule.
 int run_warmup_device(exmc_hip_model* m, int lanes, exmc_hip_opts o, exmc_hip_tuning* tun,
-                      const exmc_hip_tuning* start = nullptr) {
+                      const exmc_hip_tuning* start = nullptr, double* cov_out = nullptr,
+                      double* chol_out = nullptr) {
+  const bool dense = cov_out != nullptr;
   if (o.max_tree_depth < 1 || o.max_tree_depth > kMaxLevels)
     return fail(EXMC_ERR_BADARG, "max_tree_depth out of range");
   const int d = m->d, W = o.num_warmup;
@@ -668,8 +677,10 @@ int run_warmup_device(exmc_hip_model* m, int lanes, exmc_hip_opts o, exmc_hip_tu
   P.log_half = std::log(0.5);
   P.init_buffer = (75 < W / 3) ? 75 : W / 3;
   P.adapt_end = W - 50;
-  auto wins = build_windows(P.init_buffer, P.adapt_end, 25);
+  // dense windows are max(25, 10 d) long at the start (sampler.ex:682)
+  auto wins = build_windows(P.init_buffer, P.adapt_end, dense ? std::max(25, 10 * d) : 25);
   if (wins.size() > 32) return fail(EXMC_ERR_BADARG, "num_warmup needs more than 32 windows");
+  P.dense = dense ? 1 : 0;
   P.n_windows = (int)wins.size();
   for (int k = 0; k < 32; k++) {
     P.win_start[k] = k < P.n_windows ? wins[k].first : -1;
@@ -687,7 +698,8 @@ int run_warmup_device(exmc_hip_model* m, int lanes, exmc_hip_opts o, exmc_hip_tu
     P.inv_mass0 = m->tuning.as<double>();
     P.sqrt_inv_mass0 = m->tuning.as<double>() + d;
   }
-  int rc = m->io.ensure((size_t)(8 + d) * 8);
+  const size_t n_out = (size_t)(8 + d) + (dense ? 2 * (size_t)d * d : 0);
+  int rc = m->io.ensure(n_out * 8);
   if (rc) return rc;
   P.out = m->io.as<double>();
   rc = dispatch(m, lanes, [&](auto tag, const auto& mc) {
@@ -701,6 +713,7 @@ int run_warmup_device(exmc_hip_model* m, int lanes, exmc_hip_opts o, exmc_hip_tu
     const char* re = std::getenv("EXMC_HIP_WARMUP_REPLICAS");
     int reps = re ? std::atoi(re) : 32;
     reps = reps < 1 ? 1 : (reps > 256 ? 256 : reps);
+    if (dense && T::G != 1) return fail(EXMC_ERR_UNSUPPORTED, "a dense mass matrix needs lanes_per_chain = 1");
     P.stack_stride = (size_t)kSpill * nuts_nslot<M>() * kNutsBlock;
     int r2 = m->stack.ensure(P.stack_stride * 8 * (size_t)reps);
     if (r2) return r2;
@@ -720,8 +733,10 @@ int run_warmup_device(exmc_hip_model* m, int lanes, exmc_hip_opts o, exmc_hip_tu
     // two-wave form (tree wave + integrator wave, exmc_nuts.hpp PipeBox) where the model gains
     // from it; EXMC_HIP_WARMUP_PIPE=0 / 1 forces the one-wave / two-wave kernel
     const char* pe = std::getenv("EXMC_HIP_WARMUP_PIPE");
-    const bool pipe = ((pe && pe[0] == '1') || (M::kPipeWarmup && !(pe && pe[0] == '0'))) &&
+    const bool pipe = !dense && ((pe && pe[0] == '1') || (M::kPipeWarmup && !(pe && pe[0] == '0'))) &&
                       lds_bytes + pipe_lds_doubles<M::DPL>() * 8 <= 160 * 1024;
+    if (dense) lds_bytes += 3 * (size_t)d * d * 8;   // m2, cov, chol behind everything else
+    if (lds_bytes > 160 * 1024) return fail(EXMC_ERR_UNSUPPORTED, "dense warmup state does not fit in LDS");
     if (pipe) {
       lds_bytes += pipe_lds_doubles<M::DPL>() * 8;
       if (lds_bytes > 64 * 1024)
@@ -745,7 +760,7 @@ int run_warmup_device(exmc_hip_model* m, int lanes, exmc_hip_opts o, exmc_hip_tu
     return (int)EXMC_OK;
   });
   if (rc) return rc;
-  std::vector<double> h(8 + d);
+  std::vector<double> h(n_out);
   HIP_TRY(hipMemcpyAsync(h.data(), m->io.p, h.size() * 8, hipMemcpyDeviceToHost, m->stream));
   HIP_TRY(hipStreamSynchronize(m->stream));
   rc = finish_timing(m);
@@ -757,6 +772,11 @@ int run_warmup_device(exmc_hip_model* m, int lanes, exmc_hip_opts o, exmc_hip_tu
   tun->epsilon = h[0];
   tun->warmup_divergences = (int)h[1];
   for (int i = 0; i < d; i++) tun->inv_mass[i] = h[3 + i];
+  if (dense) {
+    if (!(h[0] > 0.0)) return fail(EXMC_ERR_BADARG, "dense warmup: a window covariance was not positive definite");
+    std::memcpy(cov_out, h.data() + 3 + d, (size_t)d * d * 8);
+    std::memcpy(chol_out, h.data() + 3 + d + (size_t)d * d, (size_t)d * d * 8);
+  }
   return EXMC_OK;
 }
 
@@ -980,7 +1000,7 @@ void exmc_hip_model_destroy(exmc_hip_model* m) {
   if (!m) return;
   (void)hipSetDevice(m->device);
   m->zig.release(); m->tuning.release(); m->state.release(); m->stack.release();
-  m->misc.release(); m->trace.release(); m->io.release(); m->data.release(); m->flat.release(); m->scores.release();
+  m->misc.release(); m->trace.release(); m->io.release(); m->data.release(); m->flat.release(); m->scores.release(); m->dense.release();
   if (m->ev0) (void)hipEventDestroy(m->ev0);
   if (m->ev1) (void)hipEventDestroy(m->ev1);
   if (m->stream) (void)hipStreamDestroy(m->stream);
@@ -1192,6 +1212,44 @@ int exmc_hip_warmup_from(exmc_hip_model* m, const double* init_q, exmc_hip_opts 
   return warmup_impl(m, init_q, o, warm_start, tuning);
 }
 
+int exmc_hip_model_set_dense_mass(exmc_hip_model* m, const double* cov, const double* chol, int d) {
+  if (check_model(m)) return EXMC_ERR_BADARG;
+  if (!cov || !chol || d != m->d) return fail(EXMC_ERR_BADARG, "dense mass needs cov and chol_cov, d x d each");
+  for (int i = 0; i < d; i++)
+    if (!(chol[(size_t)i * d + i] > 0.0)) return fail(EXMC_ERR_BADARG, "chol_cov needs a positive diagonal");
+  HIP_TRY(hipSetDevice(m->device));
+  int rc = m->dense.ensure(2 * (size_t)d * d * 8);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpy(m->dense.p, cov, (size_t)d * d * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(m->dense.as<double>() + (size_t)d * d, chol, (size_t)d * d * 8, hipMemcpyHostToDevice));
+  m->dense_on = true;
+  m->res_C = 0;
+  return EXMC_OK;
+}
+
+int exmc_hip_model_clear_dense_mass(exmc_hip_model* m) {
+  if (check_model(m)) return EXMC_ERR_BADARG;
+  m->dense_on = false;
+  return EXMC_OK;
+}
+
+int exmc_hip_warmup_dense(exmc_hip_model* m, const double* init_q, exmc_hip_opts o,
+                          exmc_hip_tuning* tuning, double* cov, double* chol) {
+  if (check_model(m)) return EXMC_ERR_BADARG;
+  if (!tuning || !cov || !chol || o.num_warmup < 0) return fail(EXMC_ERR_BADARG, "bad arguments");
+  HIP_TRY(hipSetDevice(m->device));
+  const int lanes = resolve_lanes(m, o.lanes_per_chain);
+  if (lanes != 1) return fail(EXMC_ERR_UNSUPPORTED, "a dense mass matrix needs lanes_per_chain = 1");
+  m->dense_on = false;   // Phase I runs on the identity diagonal (sampler.ex:560-575)
+  int rc = ensure_state(m, 1);
+  if (rc) return rc;
+  rc = launch_init(m, lanes, 1, 0, o.seed, init_q);
+  if (rc) return rc;
+  rc = run_warmup_device(m, lanes, o, tuning, nullptr, cov, chol);
+  if (rc) return rc;
+  return exmc_hip_model_set_dense_mass(m, cov, chol, m->d);   // in force for the sampling that follows
+}
+
 int exmc_hip_chains_init(exmc_hip_model* m, const exmc_hip_tuning* tuning, const double* init_q,
                          int n_chains, int chain_lo, int chain_hi, exmc_hip_opts o) {
   if (check_model(m)) return EXMC_ERR_BADARG;
@@ -1302,6 +1360,36 @@ int exmc_hip_sample_warm_host(exmc_hip_model* m, const double* init_q, exmc_hip_
   rc = read_counters(m, nullptr, &div);
   if (rc) return rc;
   if (divergences) *divergences = div + tun.warmup_divergences;  // stats.divergences, sampler.ex:245
+  if (tuning_out) *tuning_out = tun;
+  return download_trace(m, L, o.num_samples, 1, tr);
+}
+
+int exmc_hip_sample_dense_host(exmc_hip_model* m, const double* init_q, exmc_hip_opts o,
+                               exmc_hip_trace tr, exmc_hip_tuning* tuning_out, double* cov, double* chol,
+                               int32_t* divergences) {
+  // Sampler.sample/3 with dense_mass: true (sampler.ex:156, 170-176): the dense warmup, then the
+  // warmup chain goes on sampling under the dense mass
+  if (check_model(m)) return EXMC_ERR_BADARG;
+  if (o.num_samples < 1) return fail(EXMC_ERR_BADARG, "num_samples must be >= 1");
+  exmc_hip_tuning tun;
+  o.lanes_per_chain = 1;
+  int rc = exmc_hip_warmup_dense(m, init_q, o, &tun, cov, chol);   // leaves chain 0's state in m->state
+  if (rc) return rc;
+  rc = upload_tuning(m, tun.inv_mass);
+  if (rc) return rc;
+  TraceLayout L = trace_layout(o.num_samples, m->d, 1);
+  rc = m->trace.ensure(L.total);
+  if (rc) return rc;
+  rc = reset_counters(m);
+  if (rc) return rc;
+  rc = launch_nuts(m, 1, 1, o.num_samples, 0, tun.epsilon, o.max_tree_depth, trace_view(m->trace.p, L), true);
+  if (rc) return rc;
+  rc = finish_timing(m);
+  if (rc) return rc;
+  int32_t div = 0;
+  rc = read_counters(m, nullptr, &div);
+  if (rc) return rc;
+  if (divergences) *divergences = div + tun.warmup_divergences;
   if (tuning_out) *tuning_out = tun;
   return download_trace(m, L, o.num_samples, 1, tr);
 }

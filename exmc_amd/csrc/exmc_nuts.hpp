@@ -119,6 +119,7 @@ struct NutsParams {
   const double* zig_fi;
   double nor_r;
   FlatOrder flat;
+  DenseMass dm;   // opts[:dense_mass] in force (lanes_per_chain = 1 only)
 };
 
 constexpr int kMaxLevels = 12;
@@ -175,6 +176,7 @@ struct NutsLane {
   bool valid[DPL];
   int rank[DPL];     // flat (draw) position of this lane's dimensions; M::D for slots past D
   const int32_t* perm;   // flat position -> kernel dimension, null = identity
+  DenseMass dm;          // opts[:dense_mass] (one-lane-per-chain layouts only); cov == null: diagonal
   int l;
   double* lstk;      // this lane's column of the LDS stack
   double* gstk;      // this lane's column of the global spill stack
@@ -183,6 +185,58 @@ struct NutsLane {
   double nor_r;
   bool alive;        // false: a lane group kept only so that wave-cooperative models see all lanes
 };
+
+// the mass-dependent operations of a transition: diagonal everywhere; dense (L.dm.cov set, a
+// wave-uniform choice) for the layouts that keep a whole chain in one lane
+template <class M, int G>
+__device__ __forceinline__ double mass_ke(const NutsLane<M, G>& L, const double (&p)[M::DPL]) {
+  if constexpr (G == 1) {
+    if (L.dm.cov) return kinetic_energy_dense<M::D>(L.dm.cov, p);
+  }
+  return kinetic_energy<G, M::DPL, M::D>(p, L.im, L.valid);
+}
+// q += eps * (M^-1 p_half)
+template <class M, int G>
+__device__ __forceinline__ void mass_drift(const NutsLane<M, G>& L, double eps, const double (&ph)[M::DPL],
+                                           double (&q)[M::DPL]) {
+  if constexpr (G == 1) {
+    if (L.dm.cov) {
+      double mp[M::DPL];
+      dense_times<M::D>(L.dm.cov, ph, mp);
+#pragma unroll
+      for (int k = 0; k < M::DPL; k++) q[k] = q[k] + eps * mp[k];
+      return;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < M::DPL; k++) q[k] = q[k] + eps * (L.im[k] * ph[k]);
+}
+template <class M, int G>
+__device__ __forceinline__ bool mass_uturn(const NutsLane<M, G>& L, const double (&rho)[M::DPL],
+                                           const double (&pa)[M::DPL], const double (&pb)[M::DPL]) {
+  if constexpr (G == 1) {
+    if (L.dm.cov) return uturn_dense<M::D>(L.dm.cov, rho, pa, pb);
+  }
+  return uturn<G, M::DPL, M::D>(rho, pa, pb, L.im, L.valid);
+}
+template <class M, int G>
+__device__ __forceinline__ void mass_uturn3(const NutsLane<M, G>& L, const double (&r1)[M::DPL],
+                                            const double (&a1)[M::DPL], const double (&b1)[M::DPL],
+                                            const double (&r2)[M::DPL], const double (&a2)[M::DPL],
+                                            const double (&b2)[M::DPL], const double (&r3)[M::DPL],
+                                            const double (&a3)[M::DPL], const double (&b3)[M::DPL],
+                                            bool& c1, bool& c23) {
+  if constexpr (G == 1) {
+    if (L.dm.cov) {
+      c1 = uturn_dense<M::D>(L.dm.cov, r1, a1, b1);
+      const bool c2 = uturn_dense<M::D>(L.dm.cov, r2, a2, b2);
+      const bool c3 = uturn_dense<M::D>(L.dm.cov, r3, a3, b3);
+      c23 = c2 || c3;
+      return;
+    }
+  }
+  uturn3<G, M::DPL, M::D>(r1, a1, b1, r2, a2, b2, r3, a3, b3, L.im, L.valid, c1, c23);
+}
 
 // a chain's state between transitions
 template <int DPL>
@@ -328,6 +382,12 @@ __device__ __forceinline__ void draw_momentum(const NutsLane<M, G>& L, Rng& rng,
     } else {
       rng = r2;
       pos = D;
+    }
+  }
+  if constexpr (G == 1) {
+    if (L.dm.chol) {
+      dense_momentum<M::D>(L.dm.chol, z, p);
+      return;
     }
   }
 #pragma unroll
@@ -528,7 +588,6 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
   using MM = Math<M::kVregMath>;
   const int l = L.l;
   const auto& im = L.im;
-  const auto& valid = L.valid;
   double* lstk = L.lstk;
   double* gstk = L.gstk;
   const size_t nthreads = L.nthreads;
@@ -557,7 +616,7 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
     bool alive = has;
     if (has) {
       draw_momentum<M, G>(L, st.rng, pL);
-      jlp0 = st.logp - kinetic_energy<G, DPL, M::D>(pL, im, valid);
+      jlp0 = st.logp - mass_ke<M, G>(L, pL);
       trng = st.rng;  // the tree consumes a copy (sampler.ex:897 discards its draws)
 #pragma unroll
       for (int k = 0; k < DPL; k++) {
@@ -621,10 +680,9 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
           for (int k = 0; k < DPL; k++) {
             qold[k] = q[k];
             gold[k] = g[k];
-            const double ph = p[k] + h * g[k];
-            p[k] = ph;
-            q[k] = q[k] + eps_dir * (im[k] * ph);
+            p[k] = p[k] + h * g[k];
           }
+          mass_drift<M, G>(L, eps_dir, p, q);
 #if EXMC_ABLATE == 3
           logp_new = 0.0;
 #pragma unroll
@@ -635,7 +693,7 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
 #endif
 #pragma unroll
           for (int k = 0; k < DPL; k++) p[k] = p[k] + h * g[k];
-          jlp = logp_new - kinetic_energy<G, DPL, M::D>(p, im, valid);
+          jlp = logp_new - mass_ke<M, G>(L, p);
         }
         EXMC_PROF(2)
 
@@ -714,8 +772,8 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
 #else
                   // tree.ex:1428-1446: the two sub-span checks apply from depth 2 on; lvl is
                   // wave-uniform, so the level-0 merges (3 of 4 in a 7-leaf tree) reduce 2 sums, not 6
-                  if (lvl == 0) c1 = uturn<G, DPL, M::D>(rho, a_pin, p, im, valid);
-                  else uturn3<G, DPL, M::D>(rho, a_pin, p, r2, a_pin, c_pin, r3, a_pout, p, im, valid, c1, c23);
+                  if (lvl == 0) c1 = mass_uturn<M, G>(L, rho, a_pin, p);
+                  else mass_uturn3<M, G>(L, rho, a_pin, p, r2, a_pin, c_pin, r3, a_pout, p, c1, c23);
 #endif
                   turning = c1 || c23;
 #pragma unroll
@@ -785,7 +843,7 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
 #if EXMC_ABLATE == 1
               c1 = c23 = false;
 #else
-              uturn3<G, DPL, M::D>(rho, farp, p, r2, farp, c_pin, r3, nearp, p, im, valid, c1, c23);
+              mass_uturn3<M, G>(L, rho, farp, p, r2, farp, c_pin, r3, nearp, p, c1, c23);
 #endif
               turning = c1 || c23;
             }
@@ -828,7 +886,8 @@ template <class M, int G, int LDSL>
 __device__ __forceinline__ void lane_setup(NutsLane<M, G>& L, const typename M::Consts& mc,
                                            double* lds, double* stack, const double* inv_mass,
                                            const double* sqrt_inv_mass, const ZigTables& zt,
-                                           double nor_r, const FlatOrder& flat = FlatOrder{}) {
+                                           double nor_r, const FlatOrder& flat = FlatOrder{},
+                                           const DenseMass& dm = DenseMass{}) {
   constexpr int D = M::D, DPL = M::DPL;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   L.l = threadIdx.x & (G - 1);
@@ -850,6 +909,7 @@ __device__ __forceinline__ void lane_setup(NutsLane<M, G>& L, const typename M::
     L.rank[k] = L.valid[k] ? (flat.rank ? flat.rank[i] : i) : D;
   }
   L.perm = flat.perm;
+  L.dm = dm;
 }
 
 template <class M, int G>
@@ -906,7 +966,7 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock)
   if (!M::kCoop && !has_chain) return;
 
   NutsLane<M, G> L;
-  lane_setup<M, G, LDSL>(L, mc, lds, P.stack, P.inv_mass, P.sqrt_inv_mass, zt, P.nor_r, P.flat);
+  lane_setup<M, G, LDSL>(L, mc, lds, P.stack, P.inv_mass, P.sqrt_inv_mass, zt, P.nor_r, P.flat, P.dm);
   if constexpr (M::kLdsDataDoubles > 0) L.ln.xoff = xoff;
   L.alive = has_chain;
   using Pipe = std::conditional_t<kPipe, PipeBox<DPL>, NoPipe>;
@@ -1016,21 +1076,21 @@ __device__ __forceinline__ double find_eps_dev(const typename M::Consts& mc,
   for (int k = 0; k < DPL; k++) p0[k] = 0.0;
   // plain sequential normal_s draws (as sample_momentum_fast does); identical to draw_momentum
   draw_momentum<M, G>(L, st.rng, p0);
-  const double jlp0 = st.logp - kinetic_energy<G, DPL, M::D>(p0, L.im, L.valid);
+  const double jlp0 = st.logp - mass_ke<M, G>(L, p0);
   auto try_eps = [&](double eps) -> double {
     double q[DPL], p[DPL], g[DPL];
     const double h = eps / 2.0;
 #pragma unroll
     for (int k = 0; k < DPL; k++) {
-      const double ph = p0[k] + h * st.g[k];
-      p[k] = ph;
-      q[k] = st.q[k] + eps * (L.im[k] * ph);
+      p[k] = p0[k] + h * st.g[k];
+      q[k] = st.q[k];
       g[k] = 0.0;
     }
+    mass_drift<M, G>(L, eps, p, q);
     const double lp = M::logp_grad(mc, L.ln, L.l, q, g);
 #pragma unroll
     for (int k = 0; k < DPL; k++) p[k] = p[k] + h * g[k];
-    const double jlp = lp - kinetic_energy<G, DPL, M::D>(p, L.im, L.valid);
+    const double jlp = lp - mass_ke<M, G>(L, p);
     return (exmc_isfinite(jlp0) && exmc_isfinite(jlp)) ? (jlp - jlp0) : -1000.0;
   };
   double eps = 1.0;
@@ -1076,7 +1136,10 @@ struct WarmupParams {
   double eps0;              // > 0: warm start (sampler.ex:167-197) -- start from this step size and
   const double* inv_mass0;  // this inverse mass (dev [D], with sqrt_inv_mass0) instead of the
   const double* sqrt_inv_mass0;   // identity mass and the initial step-size search
-  double* out;              // [0] eps_final, [1] divergences, [2] leapfrogs, [3..3+D) inv_mass
+  int dense;                // opts[:dense_mass]: dense Welford windows (lanes_per_chain = 1, one-wave form);
+                            // the dynamic LDS then ends with 3 D^2 doubles (m2, cov, chol)
+  double* out;              // [0] eps_final (< 0: a window covariance was not positive definite),
+                            // [1] divergences, [2] leapfrogs, [3..3+D) inv_mass, dense: cov, chol [D][D] each
   const uint64_t* zig_ki;
   const double* zig_wi;
   const double* zig_fi;
@@ -1158,6 +1221,23 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock)
   }
   ChainRegs<DPL> st;
   chain_load<M, G>(P.st, 1, 0, L.l, st);
+  // dense mode: the window's co-moment matrix, its covariance and factor live behind everything
+  // else in LDS; the one lane that carries the chain is their only user
+  double* dn_m2 = nullptr;
+  double* dn_cov = nullptr;
+  double* dn_chol = nullptr;
+  bool dense_ok = true;
+  if constexpr (G == 1 && !kPipe) {
+    if (P.dense) {
+      dn_m2 = lds + lds_used;
+      dn_cov = dn_m2 + D * D;
+      dn_chol = dn_cov + D * D;
+      for (int i = 0; i < D * D; i++) {
+        dn_m2[i] = 0.0;
+        dn_cov[i] = dn_chol[i] = ((i / D) == (i % D)) ? 1.0 : 0.0;
+      }
+    }
+  }
 #ifdef EXMC_XCC_PROBE
   const long long probe_c0 = clock64(), probe_w0 = wall_clock64();
 #endif
@@ -1204,6 +1284,8 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock)
           wn = 0;
 #pragma unroll
           for (int k = 0; k < DPL; k++) wmean[k] = wm2[k] = 0.0;
+          if (dn_m2)
+            for (int e = 0; e < D * D; e++) dn_m2[e] = 0.0;
           da.init(eps, P.target_accept);
           in_window = true;
         }
@@ -1217,8 +1299,9 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock)
       da.update(accept);
       if (in_window) {
         if (!diverged) {
-          // mass_matrix.ex:40-54
+          // mass_matrix.ex:40-54 (diagonal), :56-72 (dense: m2 += outer(delta, delta2))
           const int nn = wn + 1;
+          double dl[DPL], dl2[DPL];
 #pragma unroll
           for (int k = 0; k < DPL; k++) {
             const double delta = st.q[k] - wmean[k];
@@ -1226,12 +1309,59 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock)
             const double d2 = st.q[k] - nm;
             wm2[k] = wm2[k] + delta * d2;
             wmean[k] = nm;
+            dl[k] = delta;
+            dl2[k] = d2;
+          }
+          if constexpr (G == 1 && !kPipe) {
+            if (dn_m2) {
+#pragma unroll
+              for (int a = 0; a < D; a++)
+#pragma unroll
+                for (int b = 0; b < D; b++) dn_m2[a * D + b] = __builtin_fma(dl[a], dl2[b], dn_m2[a * D + b]);
+            }
           }
           wn = nn;
         }
         if (i + 1 == P.win_end[win]) {
           // mass_matrix.ex:77-97, then re-search the step size (sampler.ex:747-756)
-          if (wn < 3) {
+          bool dense_done = false;
+          if constexpr (G == 1 && !kPipe) {
+            if (dn_m2) {
+              // finalize_dense (mass_matrix.ex:105-140): cov = m2 / (n - 1), shrunk toward its floored
+              // diagonal; lower Cholesky factor row by row, sums with fma in ascending k
+              L.dm = DenseMass{};
+              if (wn < 3) {
+                for (int e = 0; e < D * D; e++) dn_cov[e] = dn_chol[e] = ((e / D) == (e % D)) ? 1.0 : 0.0;
+              } else {
+                const double alpha = 5.0 / (wn + 5.0);
+                for (int e = 0; e < D * D; e++) dn_cov[e] = dn_m2[e] / ((double)(wn - 1) * 1.0);
+                for (int a = 0; a < D; a++)
+                  for (int b = 0; b < D; b++) {
+                    const double dg = (a == b) ? fmax(dn_cov[a * D + a], 1.0e-6) : 0.0;
+                    dn_cov[a * D + b] = (1.0 - alpha) * dn_cov[a * D + b] + alpha * dg;
+                  }
+                for (int e = 0; e < D * D; e++) dn_chol[e] = 0.0;
+                for (int a = 0; a < D; a++)
+                  for (int b = 0; b <= a; b++) {
+                    double acc = dn_cov[a * D + b];
+                    for (int k = 0; k < b; k++) acc = __builtin_fma(-dn_chol[a * D + k], dn_chol[b * D + k], acc);
+                    if (a == b) {
+                      dense_ok = dense_ok && (acc > 0.0);
+                      dn_chol[a * D + a] = __dsqrt_rn(acc);
+                    } else {
+                      dn_chol[a * D + b] = acc / dn_chol[b * D + b];
+                    }
+                  }
+              }
+#pragma unroll
+              for (int k = 0; k < DPL; k++) L.im[k] = dn_cov[k * D + k];   // inv_mass_diag_out
+              L.dm.cov = dn_cov;
+              L.dm.chol = dn_chol;
+              dense_done = true;
+            }
+          }
+          if (dense_done) {
+          } else if (wn < 3) {
 #pragma unroll
             for (int k = 0; k < DPL; k++) L.im[k] = 1.0;
           } else {
@@ -1282,6 +1412,15 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock)
   for (int k = 0; k < DPL; k++) {
     const int i = L.l + k * G;
     if (i < D) P.out[3 + i] = L.im[k];
+  }
+  if constexpr (G == 1 && !kPipe) {
+    if (dn_m2) {
+      for (int e = 0; e < D * D; e++) {
+        P.out[3 + D + e] = dn_cov[e];
+        P.out[3 + D + D * D + e] = dn_chol[e];
+      }
+      if (!dense_ok) P.out[0] = -1.0;
+    }
   }
 }
 

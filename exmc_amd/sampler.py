@@ -139,8 +139,10 @@ def _tuning_struct(tuning, d):
     t = _lib.Tuning()
     t.epsilon = float(tuning["epsilon"])
     im = np.asarray(tuning["inv_mass"], dtype=np.float64)
+    if im.ndim == 2 and im.shape == (d, d):
+        im = np.diag(im).copy()   # a dense tuning carries cov; the struct takes its diagonal (sampler.ex:236-240)
     if im.ndim != 1 or im.shape[0] != d:
-        raise ValueError("inv_mass must be a rank-1 tensor of length d (dense mass is not built)")
+        raise ValueError("inv_mass must be a rank-1 tensor of length d, or d x d with chol_cov for a dense mass")
     for i in range(d):
         t.inv_mass[i] = im[i]
     return t
@@ -157,6 +159,17 @@ def sample_compiled(compiled, init_values=None, opts=None):
     tun = _lib.Tuning()
     div = C.c_int32()
     iq = _init_q(spec, init_values)
+    if o.get("dense_mass"):
+        d = spec.d
+        cov, chol = np.zeros((d, d)), np.zeros((d, d))
+        compiled.check(L.exmc_hip_sample_dense_host(compiled.h, None if iq is None else _dp(iq), _c_opts(o, lanes=1),
+                                                    tr, C.byref(tun), _dp(cov), _dp(chol), C.byref(div)))
+        trace = _build_trace(spec, t["draws"][0])
+        stats = dict(step_size=tun.epsilon, inv_mass_diag=np.array(tun.inv_mass[:d]), chol_cov=chol, cov=cov,
+                     divergences=int(div.value), recoveries=0, num_warmup=o["num_warmup"],
+                     num_samples=o["num_samples"], sample_stats=SampleStats(t, 0), raw=t)
+        return trace, stats
+    compiled.check(L.exmc_hip_model_clear_dense_mass(compiled.h))
     ws = o.get("warm_start")
     start = None
     if ws is not None:
@@ -177,12 +190,38 @@ def sample(ir, init_values=None, opts=None):
     return sample_compiled(compiled, init_values, opts)
 
 
+def _apply_mass(compiled, tuning):
+    """Install the mass matrix a tuning map names: dense when it carries :chol_cov (sampler.ex:274,
+    292), diagonal otherwise."""
+    L, d = compiled.L, compiled.d
+    chol = tuning.get("chol_cov")
+    if chol is None:
+        compiled.check(L.exmc_hip_model_clear_dense_mass(compiled.h))
+        return
+    cov = np.ascontiguousarray(tuning.get("cov", tuning["inv_mass"]), dtype=np.float64)
+    chol = np.ascontiguousarray(chol, dtype=np.float64)
+    if cov.shape != (d, d) or chol.shape != (d, d):
+        raise ValueError("a dense tuning needs cov and chol_cov of shape (d, d)")
+    compiled.check(L.exmc_hip_model_set_dense_mass(compiled.h, _dp(cov), _dp(chol), d))
+
+
 def warmup(compiled, init_values=None, opts=None):
-    """Shared warmup on chain 0 (sampler.ex:1053-1080); returns the tuning map."""
+    """Shared warmup on chain 0 (sampler.ex:1053-1080); returns the tuning map. With
+    opts["dense_mass"] the map carries the covariance under "cov" (and as "inv_mass", the d x d
+    M^-1 the reference's tuning holds) and its Cholesky factor under "chol_cov" (sampler.ex:65)."""
     o = _merge_opts(opts)
     L = compiled.L
     tun = _lib.Tuning()
     iq = _init_q(compiled.spec, init_values)
+    if o.get("dense_mass"):
+        d = compiled.d
+        cov, chol = np.zeros((d, d)), np.zeros((d, d))
+        compiled.check(L.exmc_hip_warmup_dense(compiled.h, None if iq is None else _dp(iq),
+                                               _c_opts(o, lanes=o.get("lanes_per_chain", 1) or 1),
+                                               C.byref(tun), _dp(cov), _dp(chol)))
+        return dict(epsilon=tun.epsilon, inv_mass=cov, cov=cov, chol_cov=chol,
+                    inv_mass_diag=np.array(tun.inv_mass[:d]), warmup_divergences=tun.warmup_divergences)
+    compiled.check(L.exmc_hip_model_clear_dense_mass(compiled.h))
     compiled.check(L.exmc_hip_warmup(compiled.h, None if iq is None else _dp(iq), _c_opts(o),
                                  C.byref(tun)))
     return dict(epsilon=tun.epsilon, inv_mass=np.array(tun.inv_mass[:compiled.d]), chol_cov=None,
@@ -200,6 +239,9 @@ def sample_compiled_tuned(compiled, tuning, init_values=None, opts=None, num_cha
     nc = chain_hi - chain_lo
     t, tr = _host_trace(nc, o["num_samples"], spec.d)
     tun = _tuning_struct(tuning, spec.d)
+    _apply_mass(compiled, tuning)
+    if tuning.get("chol_cov") is not None and not o.get("lanes_per_chain"):
+        o["lanes_per_chain"] = 1          # the dense path exists for the one-lane-per-chain layouts
     lf = C.c_int64()
     dv = C.c_int32()
     iq = _init_q(spec, init_values)

@@ -145,6 +145,25 @@ int exmc_hip_transitions_host(exmc_hip_model* m, double* q, double* logp, double
  * init_q NULL => 0.1*normal_s per dim (sampler.ex:339-349). */
 int exmc_hip_warmup(exmc_hip_model* m, const double* init_q, exmc_hip_opts opts,
                     exmc_hip_tuning* tuning);
+/* opts[:dense_mass] (lib/exmc/nuts/mass_matrix.ex:27-35,56-72,105-140; sampler.ex:412-427,682;
+ * leapfrog.ex:39-61). Warmup with dense Welford windows of base max(25, 10 d): tuning gets epsilon and
+ * inv_mass = diag(cov) (stats.inv_mass_diag, sampler.ex:236-240), cov / chol (caller-owned, row-major
+ * d x d) the covariance M^-1 and its lower Cholesky factor (the tuning map's :chol_cov). The dense
+ * mass then stays in force on the handle -- momentum p = L^-T z, M^-1 p by the dense product, the
+ * U-turn rule through v = M^-1 rho -- for sample_chains / chains_advance / sample_host / stream until
+ * exmc_hip_model_clear_dense_mass. exmc_hip_model_set_dense_mass installs a (cov, chol) pair from an
+ * earlier run (sample_compiled_tuned with tuning.chol_cov). Layouts with lanes_per_chain = 1 only:
+ * EXMC_ERR_UNSUPPORTED otherwise. (The reference raises inside its first dense transition for d >= 2,
+ * DESIGN.md "Dense mass"; this is the documented intent of the mode.) */
+int exmc_hip_warmup_dense(exmc_hip_model* m, const double* init_q, exmc_hip_opts opts,
+                          exmc_hip_tuning* tuning, double* cov, double* chol);
+int exmc_hip_model_set_dense_mass(exmc_hip_model* m, const double* cov, const double* chol, int d);
+/* Sampler.sample/3 with dense_mass: true: exmc_hip_warmup_dense, then num_samples draws of the same
+ * chain under the dense mass (host trace as exmc_hip_sample_host) */
+int exmc_hip_sample_dense_host(exmc_hip_model* m, const double* init_q, exmc_hip_opts opts,
+                               exmc_hip_trace trace, exmc_hip_tuning* tuning_out, double* cov,
+                               double* chol, int32_t* divergences);
+int exmc_hip_model_clear_dense_mass(exmc_hip_model* m);
 /* opts[:warm_start] of Sampler.sample (lib/exmc/nuts/sampler.ex:167-197): the previous run's
  * inv_mass_diag and step_size instead of the identity mass and the initial step-size search, and
  * a short warmup of min(num_warmup, 50) iterations on top of them. */

@@ -7,6 +7,7 @@
 
 #include <math.h>
 #include <pthread.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -649,9 +650,38 @@ void exo_constrain(const exo_model* m, const double* q, double* x) {
 /* ======================================================================================
  * Leapfrog (leapfrog.ex:14-51; batched_leapfrog.ex:79-85; compiler.ex:143-170)
  * ==================================================================================== */
+/* ---- dense inverse mass (opts[:dense_mass], mass_matrix.ex:27-35,56-72,105-140) ----
+ * tl_cov: the row-major d x d covariance (= M^-1, leapfrog.ex:57-61 `Nx.dot(inv_mass, p)`) in
+ * force on this thread, or NULL for the diagonal mass the `im` arguments carry. Thread-local, so
+ * the chain workers of exo_sample_chains each set their own.
+ *
+ * NOTE on the reference: with dense_mass: true its tree hands check_uturn_rho the FLATTENED d x d
+ * matrix as the per-dimension list (tree.ex:1425,1517 `Nx.to_flat_list(inv_mass_diag)`; the zip in
+ * tree.ex:1583-1588 then has no clause for lists of unequal length) and find_reasonable_epsilon
+ * draws d*d momenta (sampler.ex:452 `sample_momentum_fast(rng, inv_mass_diag)`), so for d >= 2 the
+ * reference raises before the first dense transition completes and no reference test covers the
+ * mode. What is restated here is the documented intent (DECISIONS.md 37; Betancourt's criterion
+ * rho . (M^-1 p+-) < 0 as the comment at tree.ex:1572-1577 states it): v = M^-1 rho by the dense
+ * product, momentum p = L^-T z (sampler.ex:412-427), kinetic energy and position update through
+ * M^-1 p (leapfrog.ex:39-61). Products accumulate with fma in ascending index, as the device does. */
+static __thread const double* tl_cov = NULL;
+
+static void mass_times(const double* im, const double* x, int d, double* out) {
+  if (!tl_cov) {
+    for (int i = 0; i < d; i++) out[i] = im[i] * x[i];
+    return;
+  }
+  for (int i = 0; i < d; i++) {
+    double acc = 0.0;
+    for (int j = 0; j < d; j++) acc = fma(x[j], tl_cov[(size_t)i * d + j], acc);
+    out[i] = acc;
+  }
+}
+
 double exo_kinetic_energy(const double* p, const double* im, int d, exo_cfg c) {
-  double v[EXO_MAX_D];
-  for (int i = 0; i < d; i++) v[i] = p[i] * (im[i] * p[i]);
+  double v[EXO_MAX_D], mp[EXO_MAX_D];
+  mass_times(im, p, d, mp);
+  for (int i = 0; i < d; i++) v[i] = p[i] * mp[i];
   return 0.5 * lane_sum(v, d, c.lanes, 0.0);
 }
 
@@ -659,11 +689,10 @@ double exo_leapfrog(const exo_model* m, double* q, double* p, double* g, double 
                     const double* im, double* jlp, exo_cfg c) {
   int d = m->d;
   double h = eps / 2.0;
-  for (int i = 0; i < d; i++) {
-    double ph = p[i] + h * g[i];
-    p[i] = ph;
-    q[i] = q[i] + eps * (im[i] * ph);
-  }
+  double mp[EXO_MAX_D];
+  for (int i = 0; i < d; i++) p[i] = p[i] + h * g[i];
+  mass_times(im, p, d, mp);
+  for (int i = 0; i < d; i++) q[i] = q[i] + eps * mp[i];
   double logp = exo_logp_grad(m, q, g, c);
   for (int i = 0; i < d; i++) p[i] = p[i] + h * g[i];
   if (jlp) *jlp = logp - exo_kinetic_energy(p, im, d, c);
@@ -733,11 +762,12 @@ double exo_log_sum_exp(double a, double b, int mm) {
 int exo_check_uturn(const double* rho, const double* pl, const double* pr, const double* im, int d,
                     exo_cfg c) {
   /* tree.ex:1578-1588 */
-  double vr[EXO_MAX_D], vl[EXO_MAX_D];
+  double vr[EXO_MAX_D], vl[EXO_MAX_D], v[EXO_MAX_D];
+  if (tl_cov) mass_times(im, rho, d, v);                 /* v = M^-1 rho */
+  else for (int i = 0; i < d; i++) v[i] = rho[i] * im[i];
   for (int i = 0; i < d; i++) {
-    double v = rho[i] * im[i];
-    vr[i] = v * pr[i];
-    vl[i] = v * pl[i];
+    vr[i] = v[i] * pr[i];
+    vl[i] = v[i] * pl[i];
   }
   double dr = lane_sum(vr, d, c.lanes, 0.0);
   double dl = lane_sum(vl, d, c.lanes, 0.0);
@@ -986,12 +1016,28 @@ typedef struct {
   int divergences;
 } cstate;
 
+static __thread const double* tl_chol = NULL;   /* lower Cholesky factor of tl_cov, row-major */
+
 static void sample_momentum(const exo_model* m, exo_rng* rng, const double* im, double* p, int mm) {
   /* sampler.ex:393-403: one normal_s per entry of the flat vector, in flat (sorted-id) order */
-  for (int r = 0; r < m->d; r++) {
-    int i = m->flat[r];
-    double z = exo_rng_normal(rng, mm);
-    p[i] = z / sqrt(im[i]);
+  int d = m->d;
+  if (!tl_chol) {
+    for (int r = 0; r < d; r++) {
+      int i = m->flat[r];
+      double z = exo_rng_normal(rng, mm);
+      p[i] = z / sqrt(im[i]);
+    }
+    return;
+  }
+  /* sampler.ex:412-427: z_1..z_d, then solve L^T p = z (L^T upper triangular) by back substitution;
+   * z_r belongs to flat entry r, the factor is that of the covariance in kernel order (the kinds
+   * with a dense path on the device have kernel order = flat order) */
+  double z[EXO_MAX_D];
+  for (int r = 0; r < d; r++) z[m->flat[r]] = exo_rng_normal(rng, mm);
+  for (int i = d - 1; i >= 0; i--) {
+    double acc = z[i];
+    for (int j = d - 1; j > i; j--) acc = fma(-tl_chol[(size_t)j * d + i], p[j], acc);
+    p[i] = acc / tl_chol[(size_t)i * d + i];
   }
 }
 
@@ -1065,6 +1111,112 @@ static void run_phase(const exo_model* m, cstate* s, const double* im, int max_d
     nuts_step(m, s, da_current(da), im, max_depth, &info, c);
     exo_da_update(da, info.accept);
   }
+}
+
+/* ---- dense Welford / finalize (mass_matrix.ex:27-35, 56-72, 105-140) ---- */
+typedef struct {
+  int n, d;
+  double mean[EXO_MAX_D];
+  double* m2;   /* d x d */
+} welford_dense;
+
+static void wd_init(welford_dense* w, int d, double* m2_store) {
+  w->n = 0; w->d = d; w->m2 = m2_store;
+  for (int i = 0; i < d; i++) w->mean[i] = 0.0;
+  for (int i = 0; i < d * d; i++) m2_store[i] = 0.0;
+}
+static void wd_update(welford_dense* w, const double* q) {
+  /* mass_matrix.ex:56-72: m2 += outer(delta, delta2), accumulated with fma */
+  int d = w->d, nn = w->n + 1;
+  double delta[EXO_MAX_D], delta2[EXO_MAX_D];
+  for (int i = 0; i < d; i++) {
+    delta[i] = q[i] - w->mean[i];
+    double nm = w->mean[i] + delta[i] / ((double)nn * 1.0);
+    delta2[i] = q[i] - nm;
+    w->mean[i] = nm;
+  }
+  for (int i = 0; i < d; i++)
+    for (int j = 0; j < d; j++) w->m2[(size_t)i * d + j] = fma(delta[i], delta2[j], w->m2[(size_t)i * d + j]);
+  w->n = nn;
+}
+int exo_cholesky_lower(const double* a, int d, double* l) {
+  /* Nx.LinAlg.cholesky (mass_matrix.ex:138): lower factor, row by row (Cholesky-Banachiewicz),
+   * sums accumulated with fma in ascending k. Returns -1 if a pivot is not positive. */
+  for (int i = 0; i < d * d; i++) l[i] = 0.0;
+  for (int i = 0; i < d; i++)
+    for (int j = 0; j <= i; j++) {
+      double acc = a[(size_t)i * d + j];
+      for (int k = 0; k < j; k++) acc = fma(-l[(size_t)i * d + k], l[(size_t)j * d + k], acc);
+      if (i == j) {
+        if (!(acc > 0.0)) return -1;
+        l[(size_t)i * d + i] = sqrt(acc);
+      } else {
+        l[(size_t)i * d + j] = acc / l[(size_t)j * d + j];
+      }
+    }
+  return 0;
+}
+static int wd_finalize(const welford_dense* w, double* cov, double* chol) {
+  /* mass_matrix.ex:105-140 */
+  int d = w->d, n = w->n;
+  if (n < 3) {
+    for (int i = 0; i < d * d; i++) cov[i] = chol[i] = 0.0;
+    for (int i = 0; i < d; i++) cov[(size_t)i * d + i] = chol[(size_t)i * d + i] = 1.0;
+    return 0;
+  }
+  double alpha = 5.0 / (n + 5.0);
+  for (int i = 0; i < d * d; i++) cov[i] = w->m2[i] / ((double)(n - 1) * 1.0);
+  for (int i = 0; i < d; i++)
+    for (int j = 0; j < d; j++) {
+      /* shrink toward the floored sample diagonal: (1 - alpha) cov + alpha max(diag(cov), 1e-6 I) */
+      double dg = (i == j) ? fmax(cov[(size_t)i * d + i], 1.0e-6) : 0.0;
+      cov[(size_t)i * d + j] = (1.0 - alpha) * cov[(size_t)i * d + j] + alpha * dg;
+    }
+  return exo_cholesky_lower(cov, d, chol);
+}
+
+static double run_warmup_dense(const exo_model* m, cstate* s, double eps, double* im, double* cov,
+                               double* chol, int* dense_on, exo_opts o, exo_cfg c) {
+  /* sampler.ex:537-762 with use_dense: Phase I on the identity diagonal, windows of base
+   * max(25, 10 d) (sampler.ex:682), after each window the dense covariance and its factor, then
+   * the step-size search and the remaining phases under the dense mass */
+  int d = m->d, W = o.num_warmup;
+  *dense_on = 0;
+  if (W == 0) return eps;
+  int init_buffer = (75 < W / 3) ? 75 : W / 3;
+  int adapt_end = W - 50;
+  exo_da da;
+  exo_da_init_mode(&da, eps, o.target_accept, c.math_mode);
+  run_phase(m, s, im, o.max_tree_depth, &da, 0, init_buffer, c);
+  eps = da_current(&da);
+  if (adapt_end <= init_buffer) return exo_da_finalize(&da);
+  int ws[32], we[32];
+  int base = 10 * d > 25 ? 10 * d : 25;
+  int nw = exo_build_windows(init_buffer, adapt_end, base, ws, we, 32);
+  double* m2 = (double*)malloc(sizeof(double) * d * d);
+  for (int k = 0; k < nw; k++) {
+    welford_dense wf;
+    wd_init(&wf, d, m2);
+    exo_da_init_mode(&da, eps, o.target_accept, c.math_mode);
+    for (int i = ws[k]; i < we[k]; i++) {
+      int cap = (i < 200) ? (o.max_tree_depth < 8 ? o.max_tree_depth : 8) : o.max_tree_depth;
+      int div_before = s->divergences;
+      step_info info;
+      nuts_step(m, s, da_current(&da), im, cap, &info, c);
+      exo_da_update(&da, info.accept);
+      if (s->divergences == div_before) wd_update(&wf, s->q);
+    }
+    tl_cov = NULL; tl_chol = NULL;
+    if (wd_finalize(&wf, cov, chol) != 0) { free(m2); return -1.0; }   /* not positive definite */
+    for (int i = 0; i < d; i++) im[i] = cov[(size_t)i * d + i];
+    tl_cov = cov; tl_chol = chol;
+    *dense_on = 1;
+    eps = find_reasonable_epsilon(m, s, im, c);
+  }
+  free(m2);
+  exo_da_init_mode(&da, eps, o.target_accept, c.math_mode);
+  run_phase(m, s, im, o.max_tree_depth, &da, adapt_end, W, c);
+  return exo_da_finalize(&da);
 }
 
 static double run_warmup(const exo_model* m, cstate* s, double eps, double* im, exo_opts o,
@@ -1175,6 +1327,71 @@ int exo_sample_tuned(const exo_model* m, const double* init_q, double epsilon, c
   run_sampling(m, &s, epsilon, im, o, tr, 0, &st->total_leapfrogs, c);
   st->divergences = s.divergences;
   return 0;
+}
+
+/* ---- opts[:dense_mass] entry points (cov, chol: row-major d x d, caller-owned) ---- */
+int exo_warmup_dense(const exo_model* m, const double* init_q, exo_opts o, exo_stats* st, double* cov,
+                     double* chol, exo_cfg c) {
+  cstate s;
+  int d = m->d, on = 0;
+  tl_cov = NULL; tl_chol = NULL;
+  init_chain(m, init_q, o.seed, &s, c);
+  for (int i = 0; i < d; i++) st->inv_mass[i] = 1.0;
+  double eps = find_reasonable_epsilon(m, &s, st->inv_mass, c);
+  st->step_size = run_warmup_dense(m, &s, eps, st->inv_mass, cov, chol, &on, o, c);
+  tl_cov = NULL; tl_chol = NULL;
+  if (!on) {   /* no window ran: identity covariance, as finalize of an empty Welford would give */
+    for (int i = 0; i < d * d; i++) cov[i] = chol[i] = 0.0;
+    for (int i = 0; i < d; i++) cov[(size_t)i * d + i] = chol[(size_t)i * d + i] = 1.0;
+  }
+  st->divergences = s.divergences;
+  st->total_leapfrogs = 0;
+  return st->step_size < 0.0 ? -1 : 0;
+}
+
+int exo_sample_tuned_dense(const exo_model* m, const double* init_q, double epsilon, const double* cov,
+                           const double* chol, exo_opts o, exo_trace tr, exo_stats* st, exo_cfg c) {
+  /* sample_compiled_tuned with tuning.chol_cov (sampler.ex:260-335) for one chain */
+  cstate s;
+  int d = m->d;
+  tl_cov = NULL; tl_chol = NULL;
+  init_chain(m, init_q, o.seed, &s, c);
+  for (int i = 0; i < d; i++) st->inv_mass[i] = cov[(size_t)i * d + i];
+  st->step_size = epsilon;
+  st->total_leapfrogs = 0;
+  tl_cov = cov; tl_chol = chol;
+  run_sampling(m, &s, epsilon, st->inv_mass, o, tr, 0, &st->total_leapfrogs, c);
+  tl_cov = NULL; tl_chol = NULL;
+  st->divergences = s.divergences;
+  return 0;
+}
+
+/* one product / solve each, for the unit tests */
+void exo_dense_mass_times(const double* cov, const double* x, int d, double* out) {
+  tl_cov = cov;
+  mass_times(NULL, x, d, out);
+  tl_cov = NULL;
+}
+int exo_dense_check_uturn(const double* cov, const double* rho, const double* pl, const double* pr, int d,
+                          exo_cfg c) {
+  tl_cov = cov;
+  int r = exo_check_uturn(rho, pl, pr, NULL, d, c);
+  tl_cov = NULL;
+  return r;
+}
+void exo_dense_momentum(const exo_model* m, const double* chol, exo_rng* rng, double* p, int math_mode) {
+  tl_chol = chol;
+  sample_momentum(m, rng, NULL, p, math_mode);
+  tl_chol = NULL;
+}
+void exo_welford_dense_finalize(const double* draws, int n, int d, double* cov, double* chol) {
+  /* n draws [n][d] through the dense Welford, then finalize_dense */
+  double* m2 = (double*)malloc(sizeof(double) * d * d);
+  welford_dense w;
+  wd_init(&w, d, m2);
+  for (int i = 0; i < n; i++) wd_update(&w, draws + (size_t)i * d);
+  wd_finalize(&w, cov, chol);
+  free(m2);
 }
 
 typedef struct {

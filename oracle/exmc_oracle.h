@@ -186,6 +186,19 @@ int exo_sample_warm(const exo_model* m, const double* init_q, double prev_epsilo
 int exo_sample_tuned(const exo_model* m, const double* init_q, double epsilon,
                      const double* inv_mass, exo_opts o, exo_trace tr, exo_stats* st, exo_cfg cfg);
 
+/* ---- opts[:dense_mass] (mass_matrix.ex:27-35,56-72,105-140; sampler.ex:412-427,682): see the note
+ * in exmc_oracle.c on what the reference itself does in this mode. cov / chol: row-major d x d. */
+int exo_warmup_dense(const exo_model* m, const double* init_q, exo_opts o, exo_stats* st, double* cov,
+                     double* chol, exo_cfg cfg);
+int exo_sample_tuned_dense(const exo_model* m, const double* init_q, double epsilon, const double* cov,
+                           const double* chol, exo_opts o, exo_trace tr, exo_stats* st, exo_cfg cfg);
+int exo_cholesky_lower(const double* a, int d, double* l);
+void exo_dense_mass_times(const double* cov, const double* x, int d, double* out);
+int exo_dense_check_uturn(const double* cov, const double* rho, const double* pl, const double* pr, int d,
+                          exo_cfg cfg);
+void exo_dense_momentum(const exo_model* m, const double* chol, exo_rng* rng, double* p, int math_mode);
+void exo_welford_dense_finalize(const double* draws, int n, int d, double* cov, double* chol);
+
 /* ---- diagnostics (diagnostics.ex:42-167) */
 double exo_ess(const double* x, int n);
 double exo_ess_bulk(const double* x, int n);

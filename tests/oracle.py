@@ -149,6 +149,16 @@ def lib():
     L.exo_sample_tuned.argtypes = [C.c_void_p, dp, C.c_double, dp, Opts, Trace, C.POINTER(Stats),
                                    Cfg]
     L.exo_sample_warm.argtypes = [C.c_void_p, dp, C.c_double, dp, Opts, Trace, C.POINTER(Stats), Cfg]
+    L.exo_warmup_dense.argtypes = [C.c_void_p, dp, Opts, C.POINTER(Stats), dp, dp, Cfg]
+    L.exo_sample_tuned_dense.argtypes = [C.c_void_p, dp, C.c_double, dp, dp, Opts, Trace, C.POINTER(Stats), Cfg]
+    L.exo_cholesky_lower.argtypes = [dp, C.c_int, dp]
+    L.exo_dense_mass_times.argtypes = [dp, dp, C.c_int, dp]
+    L.exo_dense_mass_times.restype = None
+    L.exo_dense_check_uturn.argtypes = [dp, dp, dp, dp, C.c_int, Cfg]
+    L.exo_dense_momentum.argtypes = [C.c_void_p, dp, C.POINTER(Rng), dp, C.c_int]
+    L.exo_dense_momentum.restype = None
+    L.exo_welford_dense_finalize.argtypes = [dp, C.c_int, C.c_int, dp, dp]
+    L.exo_welford_dense_finalize.restype = None
     L.exo_ess.argtypes = [dp, C.c_int]
     L.exo_ess.restype = C.c_double
     L.exo_ess_bulk.argtypes = [dp, C.c_int]
@@ -307,6 +317,33 @@ def sample_warm(model, prev_epsilon, prev_inv_mass, init_q=None, num_warmup=1000
     lib().exo_sample_warm(model.h, iq, prev_epsilon, dptr(im),
                           Opts(num_warmup, num_samples, max_tree_depth, target_accept, seed), tr,
                           C.byref(st), cfg)
+    return t, st
+
+
+def warmup_dense(model, init_q=None, num_warmup=1000, max_tree_depth=10, target_accept=0.8, seed=0,
+                 cfg=None):
+    """opts[:dense_mass] warmup: returns (stats, cov [d][d], chol_cov [d][d])."""
+    cfg = cfg or Cfg(0, 1)
+    st = Stats()
+    d = model.d
+    cov, chol = np.zeros((d, d)), np.zeros((d, d))
+    iq = None if init_q is None else dptr(arr(init_q))
+    rc = lib().exo_warmup_dense(model.h, iq, Opts(num_warmup, 0, max_tree_depth, target_accept, seed),
+                                C.byref(st), dptr(cov), dptr(chol), cfg)
+    if rc != 0:
+        raise ArithmeticError("the window covariance is not positive definite")
+    return st, cov, chol
+
+
+def sample_tuned_dense(model, epsilon, cov, chol, init_q=None, num_samples=1000, max_tree_depth=10,
+                       seed=0, cfg=None):
+    cfg = cfg or Cfg(0, 1)
+    t, tr = alloc_trace(num_samples, model.d)
+    st = Stats()
+    iq = None if init_q is None else dptr(arr(init_q))
+    cov, chol = arr(cov), arr(chol)
+    lib().exo_sample_tuned_dense(model.h, iq, epsilon, dptr(cov), dptr(chol),
+                                 Opts(0, num_samples, max_tree_depth, 0.8, seed), tr, C.byref(st), cfg)
     return t, st
 
 

@@ -125,4 +125,7 @@ def test_sampler_option_defaults_match_reference():
     c = sampler._c_opts(o)
     assert (c.num_warmup, c.num_samples, c.max_tree_depth, c.seed, c.lanes_per_chain) == (1000, 1000, 10, 7, 0)
     with pytest.raises(ValueError):
-        sampler._tuning_struct({"epsilon": 0.1, "inv_mass": np.ones((3, 3))}, 3)
+        sampler._tuning_struct({"epsilon": 0.1, "inv_mass": np.ones((2, 3))}, 3)
+    # a dense tuning (d x d covariance) contributes its diagonal to the struct (sampler.ex:236-240)
+    t = sampler._tuning_struct({"epsilon": 0.1, "inv_mass": np.diag([1.0, 2.0, 3.0]) + 0.1}, 3)
+    assert [t.inv_mass[i] for i in range(3)] == [1.1, 2.1, 3.1]

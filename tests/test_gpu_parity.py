@@ -427,3 +427,40 @@ def test_warmup_replicas_race_to_the_same_result(es, hip, monkeypatch, pipe):
     for o in out[1:]:
         assert o[0] == out[0][0] and np.array_equal(o[1], out[0][1])
         assert np.array_equal(o[2], out[0][2]) and o[3] == out[0][3]
+
+
+@pytest.mark.parametrize("name", ["eight_schools", "simple"])
+def test_dense_mass_bit_exact(hip, name):
+    """opts[:dense_mass] on the one-lane-per-chain layouts: dense Welford windows of base
+    max(25, 10 d), covariance shrinkage and Cholesky on the device, momentum p = L^-T z, M^-1 p by
+    the dense product, U-turn through v = M^-1 rho -- tuning (step size, covariance, factor) and
+    every per-draw output identical to the checker's restatement (tests/test_dense_mass_oracle.py
+    pins that restatement; the reference raises in this mode for d >= 2)."""
+    spec = models.eight_schools() if name == "eight_schools" else models.simple()
+    om = O.eight_schools() if name == "eight_schools" else O.simple()
+    comp = sampler.compile(spec)
+    opts = dict(num_warmup=600, num_samples=40, seed=13, lanes_per_chain=1, dense_mass=True)
+    tuning = sampler.warmup(comp, spec.default_init, opts)
+    q0 = spec.to_unconstrained(spec.default_init)
+    st, cov, chol = O.warmup_dense(om, q0, num_warmup=600, seed=13, cfg=O.Cfg(1, 1))
+    assert st.step_size == tuning["epsilon"]
+    assert np.array_equal(cov, tuning["cov"]) and np.array_equal(chol, tuning["chol_cov"])
+    assert np.array_equal(np.diag(cov), tuning["inv_mass_diag"])
+    assert np.abs(cov - np.diag(np.diag(cov))).max() > 0          # it is a dense matrix
+    _, _, extra = sampler.sample_compiled_tuned(comp, tuning, spec.default_init, opts, num_chains=5)
+    raw = extra["raw"]
+    for c in range(5):
+        t, _ = O.sample_tuned_dense(om, st.step_size, cov, chol, q0, num_samples=40, seed=13 + 7919 * c,
+                                    cfg=O.Cfg(1, 1))
+        for k in ("draws", "tree_depth", "n_steps", "divergent", "energy", "accept_prob"):
+            assert np.array_equal(t[k], raw[k][c]), (c, k)
+    # back to a diagonal tuning on the same handle: the dense mass is no longer in force
+    diag = sampler.warmup(comp, spec.default_init, dict(num_warmup=100, seed=13, lanes_per_chain=1))
+    _, _, e2 = sampler.sample_compiled_tuned(comp, diag, spec.default_init,
+                                             dict(num_samples=10, seed=13, lanes_per_chain=1), num_chains=2)
+    t2, _ = O.sample_tuned(om, diag["epsilon"], diag["inv_mass"], q0, num_samples=10, seed=13, cfg=O.Cfg(1, 1))
+    assert np.array_equal(t2["draws"], e2["raw"]["draws"][0])
+    # the multi-lane layouts refuse the mode
+    if name == "eight_schools":
+        with pytest.raises(Exception):
+            sampler.warmup(comp, spec.default_init, dict(opts, lanes_per_chain=16))
