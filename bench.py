@@ -78,6 +78,39 @@ def measured_traffic(model, chains, steps, lanes):
     return table.get("%s:%d:%d:%d" % (model, chains, steps, lanes), {}).get("hbm_bytes")
 
 
+SIMDS = 1024               # 256 CUs x 4 SIMDs
+CLOCK_HZ = 2.4e9           # MI355X_MICROARCH.md: max clock
+
+
+def issue_roofline(model, chains, steps, lanes, kernel_ms, leapfrogs):
+    """The bound that binds nuts_kernel: one wavefront per SIMD, so a SIMD retires at
+    most one vector instruction per 4 clocks (the f64 pipe: 16 lanes per clock) and a lone wave
+    issues one instruction of any kind per ~5.2 clocks (tools/probe/exec_mask_rate_probe.hip).
+    Instruction counts of the timed launch come from the committed SQ counter pass of this exact
+    workload (same seeds => same instruction stream); the time is the one measured in this run."""
+    try:
+        table = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    except (OSError, ValueError):
+        return None
+    e = table.get("%s:%d:%d:%d" % (model, chains, steps, lanes), {})
+    sq = e.get("sq")
+    if not sq or e.get("leapfrogs") != leapfrogs:
+        return None           # another workload (or another instruction stream) than the one profiled
+    t = kernel_ms * 1e-3
+    valu = sq["SQ_INSTS_VALU"]
+    f64 = sq["SQ_INSTS_VALU_ADD_F64"] + sq["SQ_INSTS_VALU_MUL_F64"] + sq["SQ_INSTS_VALU_FMA_F64"]
+    every = valu + sq["SQ_INSTS_SALU"] + sq["SQ_INSTS_BRANCH"] + sq["SQ_INSTS_LDS"]
+    peak = SIMDS * CLOCK_HZ / 4.0 / 1e9
+    lone = SIMDS * CLOCK_HZ / 5.2 / 1e9
+    return {"bound": "valu_issue", "achieved": valu / t / 1e9, "peak": peak, "unit": "G wave-instr/s",
+            "frac": valu / t / 1e9 / peak, "kernel": "nuts_kernel",
+            "valu_per_leapfrog": valu / leapfrogs, "f64_arith_share_of_valu": f64 / valu,
+            "instructions_per_leapfrog": every / leapfrogs,
+            "lone_wave_issue": {"achieved": every / t / 1e9, "peak": lone, "frac": every / t / 1e9 / lone,
+                                "note": "all instructions against one issue per 5.2 clocks per SIMD"},
+            "source": e.get("source")}
+
+
 def multi_step_roofline(comp, spec, dev, n_chains=262144, n_steps=32, lanes=1, reps=3):
     """The B2 `multi_step_fn` contract at scale (batched_leapfrog.ex:50-101): every chain takes
     n_steps leapfrogs and every intermediate (q, p, grad, logp) is written to HBM, [step][dim][chain].
@@ -367,6 +400,9 @@ def main():
                          "algorithmic_bytes_per_leapfrog": bytes_per_leapfrog,
                          "leapfrogs_per_launch": local_lf},
         }
+        ri = issue_roofline(args.model, Cper, S, lanes, kernel_ms, local_lf) if world == 1 else None
+        if ri:
+            out["roofline_issue"] = ri
         if world == 1 and args.model == "eight_schools":
             # the B2 batched-leapfrog contract at a batch that fills the chip (not the timed path)
             out["roofline_multi_step"] = multi_step_roofline(comp, spec, dev)
