@@ -9,7 +9,7 @@ plug-in library with the same C ABI as libexmc_hip.so (include/exmc_hip.h, kind
 EXMC_MODEL_CUSTOM).
 
 What is covered (everything else raises CodegenError -- there is no interpreter fallback):
-  * scalar free RVs (a vector free RV with an elementwise distribution does not compile in the
+  * scalar free RVs (a vector free RV with an ELEMENTWISE distribution does not compile in the
     reference either: sum_logps reshapes every term to {});
   * Normal, HalfNormal, HalfCauchy, Exponential, Cauchy, Laplace, Lognormal, StudentT and
     (as an observation) Bernoulli, each restated operation by operation from lib/exmc/dist/;
@@ -17,7 +17,18 @@ What is covered (everything else raises CodegenError -- there is no interpreter 
   * params that are numbers, vectors (observation targets only) or string refs to free RVs
     (resolve_params_constrained, compiler.ex:436-463), the non-centred rewrite of
     Normal(ref, ref) RVs included (rewrite/non_centered_parameterization.ex:50-55);
-  * obs nodes with scalar or vector values and reduce :sum (builder.ex:97-102).
+  * obs nodes with scalar or vector values and reduce :sum (builder.ex:97-102);
+  * (round 2) vector free RVs whose distribution returns a scalar: GaussianRandomWalk
+    (dist/gaussian_random_walk.ex:21-57) and MvNormal with constant mu / cov
+    (dist/mv_normal.ex:20-47: precision and log-determinant prepared eagerly on the host); they
+    occupy `length` consecutive flat entries (point_map.ex:30-60) and may be referenced as vector
+    params (e.g. as the mean of a vector obs);
+  * (round 2) Custom distributions (dist/custom.ex): the closure is a Python callable over a
+    declarative op set (`Ops`: add sub mul div neg exp log log1p abs max min lit sum), called with
+    the value and the resolved params -- validate_posteriordb.exs:279-295 writes eight schools'
+    likelihood that way;
+  * (round 2) meas_obs nodes with {:affine, a, b} and {:matmul, A} (compiler.ex:258-266, 342-369):
+    eager, i.e. constants of the data -- they shift the log-density and leave the gradient alone.
 
 Numeric contract of the generated code:
   * forward value: the reference's Nx operation sequence with its f32-rounded literals
@@ -100,6 +111,24 @@ class IR:
         if v.ndim == 1 and reduce_ != "sum":
             raise CodegenError("vector obs needs reduce :sum")
         return self._add(id_, dict(op="obs", target=rv_id, value=v))
+
+    def meas_obs(self, id_, rv_id, value, op_info):
+        """Builder.meas_obs (builder.ex:69-82): an observation of a measurable function of an rv;
+        op_info = ("affine", a, b) for y = a x + b or ("matmul", A) for y = A x."""
+        v = np.asarray(value, dtype=np.float64)
+        if v.ndim > 1:
+            raise CodegenError("meas_obs values are scalars or vectors")
+        kind = op_info[0]
+        if kind == "affine" and len(op_info) == 3:
+            info = ("affine", float(op_info[1]), float(op_info[2]))
+        elif kind == "matmul" and len(op_info) == 2:
+            a = np.asarray(op_info[1], dtype=np.float64)
+            if a.ndim != 2 or a.shape[0] != a.shape[1] or v.ndim != 1 or a.shape[0] != v.shape[0]:
+                raise CodegenError("matmul meas_obs needs a square matrix matching the value")
+            info = ("matmul", a)
+        else:
+            raise CodegenError("meas_obs op %r is not covered" % (kind,))
+        return self._add(id_, dict(op="meas_obs", target=rv_id, value=v, info=info))
 
 
 def simple_ir(y=None):
@@ -377,6 +406,90 @@ def _logpdf(g, dist, x, p):
     raise CodegenError("distribution %r is not covered" % (dist,))
 
 
+VECTOR_DISTS = ("gaussian_random_walk", "mv_normal")
+LOG_2PI_OF_F64_F32 = _f32(math.log(2.0 * math.pi))   # Nx.tensor(:math.log(2 pi)), mv_normal.ex:27
+
+
+def _vector_length(id_, n):
+    p = n["params"]
+    if n["dist"] == "gaussian_random_walk":
+        if "steps" not in p or int(p["steps"]) < 1:
+            raise CodegenError("gaussian_random_walk %r needs steps >= 1" % id_)
+        return int(p["steps"])
+    mu = np.asarray(p.get("mu"), dtype=np.float64)
+    if mu.ndim != 1:
+        raise CodegenError("mv_normal %r needs a vector mu" % id_)
+    return int(mu.shape[0])
+
+
+def _sum_left(g, xs):
+    acc = xs[0]                                   # Nx.sum on the BinaryBackend: left to right
+    for e in xs[1:]:
+        acc = g.add(acc, e)
+    return acc
+
+
+def _logpdf_vector(g, dist, xs, p, resolve_value):
+    if dist == "gaussian_random_walk":            # gaussian_random_walk.ex:21-57
+        sigma = resolve_value(p["sigma"])
+        if isinstance(sigma, list):
+            raise CodegenError("gaussian_random_walk takes a scalar sigma")
+        ss = g.max(sigma, g.lit(TINY_F32))
+        log_sigma = g.log(ss)
+        norm = g.add(g.lit(LOG_2PI_F32), g.mul(g.lit(2.0), log_sigma))
+
+        def step(d):
+            z = g.div(d, ss)
+            return g.mul(g.lit(-0.5), g.add(g.mul(z, z), norm))
+        logp_init = step(xs[0])
+        if len(xs) == 1:
+            return logp_init
+        steps = [step(g.sub(xs[t], xs[t - 1])) for t in range(1, len(xs))]
+        return g.add(logp_init, _sum_left(g, steps))
+    if dist == "mv_normal":                       # mv_normal.ex:20-47
+        mu = np.asarray(p["mu"], dtype=np.float64)
+        cov = np.asarray(p["cov"], dtype=np.float64)
+        d = mu.shape[0]
+        if cov.shape != (d, d) or len(xs) != d:
+            raise CodegenError("mv_normal needs mu {d} and cov {d, d}")
+        # prepare_params (eager, host): Nx.LinAlg.cholesky / invert are third-party LinAlg, taken
+        # from numpy here (a rounding-level difference in constants of the data)
+        chol = np.linalg.cholesky(cov)
+        log_det = 2.0 * float(np.sum(np.log(np.diag(chol))))
+        prec = np.linalg.inv(cov)
+        diff = [g.sub(xs[i], g.datum(mu[i])) for i in range(d)]
+        inner = [_sum_left(g, [g.mul(g.datum(prec[i, j]), diff[j]) for j in range(d)]) for i in range(d)]
+        mahal = _sum_left(g, [g.mul(diff[i], inner[i]) for i in range(d)])
+        base = g.add(g.mul(g.lit(_f32(d * 1.0)), g.lit(LOG_2PI_OF_F64_F32)), g.datum(log_det))
+        return g.mul(g.lit(-0.5), g.add(base, mahal))
+    raise CodegenError("vector distribution %r is not covered" % (dist,))
+
+
+class Ops:
+    """The declarative op set a Custom distribution's closure may use (dist/custom.ex: the
+    reference's closure composes Nx ops; here the same composition builds expression-graph nodes,
+    so value and gradient are generated like any other term). Scalars are opaque handles; vectors
+    are python lists of them."""
+
+    def __init__(self, g):
+        self._g = g
+
+    def lit(self, x): return self._g.lit(float(x))
+    def f32(self, x): return self._g.lit(_f32(x))          # Nx.tensor(<float>) defaults to f32
+    def add(self, a, b): return self._g.add(a, b)
+    def sub(self, a, b): return self._g.sub(a, b)
+    def mul(self, a, b): return self._g.mul(a, b)
+    def div(self, a, b): return self._g.div(a, b)
+    def neg(self, a): return self._g.neg(a)
+    def exp(self, a): return self._g.exp(a)
+    def log(self, a): return self._g.log(a)
+    def log1p(self, a): return self._g.log1p(a)
+    def abs(self, a): return self._g.abs(a)
+    def max(self, a, b): return self._g.max(a, b)
+    def min(self, a, b): return self._g.min(a, b)
+    def sum(self, xs): return _sum_left(self._g, list(xs))   # Nx.sum: left to right
+
+
 # ---------------------------------------------------------------------------------------------
 # the term walk
 # ---------------------------------------------------------------------------------------------
@@ -386,7 +499,7 @@ class Generated:
 
 
 def _observed_targets(ir):
-    return {n["target"] for n in ir.nodes.values() if n["op"] == "obs"}
+    return {n["target"] for n in ir.nodes.values() if n["op"] in ("obs", "meas_obs")}
 
 
 def _apply_ncp(ir, ncp):
@@ -417,10 +530,22 @@ def generate(ir, ncp=True, vectorize=True):
     free = sorted(i for i, n in nodes.items() if n["op"] == "rv" and i not in observed)
     if not free:
         raise CodegenError("no free random variables")
-    if len(free) > MAX_D:
-        raise CodegenError("%d free variables; the one-lane-per-chain kernels take at most %d"
-                           % (len(free), MAX_D))
-    offset = {id_: k for k, id_ in enumerate(free)}
+    # PointMap.build (point_map.ex:30-60): entries sorted by id, each `length` flat slots
+    offset, length, flat_names, vector_entries = {}, {}, [], {}
+    for id_ in free:
+        n = nodes[id_]
+        ln = _vector_length(id_, n) if n["dist"] in VECTOR_DISTS else 1
+        if n["dist"] in VECTOR_DISTS and n["transform"] is not None:
+            raise CodegenError("a transformed vector rv is not covered")
+        offset[id_], length[id_] = len(flat_names), ln
+        if n["dist"] in VECTOR_DISTS:
+            vector_entries[id_] = (len(flat_names), ln)
+            flat_names.extend("%s[%d]" % (id_, i) for i in range(ln))
+        else:
+            flat_names.append(id_)
+    if len(flat_names) > MAX_D:
+        raise CodegenError("%d free dimensions; the one-lane-per-chain kernels take at most %d"
+                           % (len(flat_names), MAX_D))
     g = _Graph()
 
     def resolve_ref(id_, stack=()):
@@ -429,6 +554,8 @@ def generate(ir, ncp=True, vectorize=True):
             raise CodegenError("param ref %r is not a free random variable" % id_)
         if id_ in stack:
             raise CodegenError("cyclic non-centred reference through %r" % id_)
+        if id_ in vector_entries:
+            return [g.q(offset[id_] + i) for i in range(length[id_])]
         z = g.q(offset[id_])
         if id_ in ncp_info:
             mu = resolve_value(ncp_info[id_]["mu"], stack + (id_,))
@@ -457,20 +584,66 @@ def generate(ir, ncp=True, vectorize=True):
         return [_logpdf(g, dist, pick(x, i), {k: pick(v, i) for k, v in params.items()})
                 for i in range(n)], True
 
+    ops = Ops(g)
+
+    def custom_logpdf(params, x):
+        fn = params.get("logpdf")
+        if not callable(fn):
+            raise CodegenError("a custom distribution needs a callable 'logpdf'")
+        rest = {k: resolve_value(v) for k, v in params.items() if k != "logpdf"}
+        t = fn(ops, x, rest)
+        if isinstance(t, list):
+            raise CodegenError("a custom logpdf must return a scalar (reduce inside the closure)")
+        return t
+
     terms = []
     for id_ in sorted(nodes):                     # Map.values order, compiler.ex:176-180
         n = nodes[id_]
         if n["op"] == "rv":
             if id_ not in offset:
                 continue
-            params = {k: resolve_value(v) for k, v in n["params"].items()}
-            if any(isinstance(v, list) for v in params.values()):
-                raise CodegenError("free RV %r has a vector param" % id_)
+            if n["dist"] in VECTOR_DISTS:
+                xs = [g.q(offset[id_] + i) for i in range(length[id_])]
+                terms.append(_logpdf_vector(g, n["dist"], xs, n["params"], resolve_value))
+                continue
             z = g.q(offset[id_])
             x = _apply_transform(g, n["transform"], z)
-            t = _logpdf(g, n["dist"], x, params)
+            if n["dist"] == "custom":
+                t = custom_logpdf(n["params"], x)
+            else:
+                params = {k: resolve_value(v) for k, v in n["params"].items()}
+                if any(isinstance(v, list) for v in params.values()):
+                    raise CodegenError("free RV %r has a vector param" % id_)
+                t = _logpdf(g, n["dist"], x, params)
             if n["transform"] is not None:
                 t = g.add(t, _log_abs_det_jacobian(g, n["transform"], z))   # compiler.ex:222-229
+            terms.append(t)
+        elif n["op"] == "meas_obs":
+            # compiler.ex:258-266, 342-369: eager -- the target's params are used as written (no
+            # refs), so the whole term is a constant of the data
+            tgt = nodes[n["target"]]
+            if tgt["op"] != "rv" or tgt["transform"] is not None or tgt["dist"] in VECTOR_DISTS + ("custom",):
+                raise CodegenError("meas_obs %r: target not covered" % id_)
+            if any(isinstance(v, str) for v in tgt["params"].values()):
+                raise CodegenError("meas_obs %r: the reference evaluates it eagerly, params must be constants" % id_)
+            params = {k: resolve_value(v) for k, v in tgt["params"].items()}
+            val, info = n["value"], n["info"]
+            if info[0] == "affine":
+                a, b = g.datum(info[1]), g.datum(info[2])
+                conv = lambda v: g.div(g.sub(g.datum(float(v)), b), a)   # noqa: E731
+                x = conv(val) if val.ndim == 0 else [conv(v) for v in val]
+                jac = g.neg(g.log(g.abs(a)))
+            else:
+                sol = np.linalg.solve(info[1], val)                  # jit_solve: third-party LinAlg
+                x = [g.datum(float(v)) for v in sol]
+                jac = g.datum(-math.log(abs(float(np.linalg.det(info[1])))))
+            t, vec = elementwise(tgt["dist"], x, params)
+            if vec:
+                # logpdf of a vector value is a vector; combined = logp + jac broadcasts, then the
+                # term is reduced by sum_logps' Nx.sum (compiler.ex:396-397)
+                t = _sum_left(g, [g.add(e, jac) for e in t])
+            else:
+                t = g.add(t, jac)
             terms.append(t)
         else:
             tgt = nodes[n["target"]]
@@ -478,17 +651,22 @@ def generate(ir, ncp=True, vectorize=True):
                 raise CodegenError("obs %r does not target an rv" % id_)
             if tgt["transform"] is not None:
                 raise CodegenError("obs of a transformed rv is not covered")
-            params = {k: resolve_value(v) for k, v in tgt["params"].items()}
             val = n["value"]
             x = g.datum(float(val)) if val.ndim == 0 else [g.datum(float(v)) for v in val]
+            if tgt["dist"] == "custom":
+                terms.append(custom_logpdf(tgt["params"], x))
+                continue
+            if tgt["dist"] in VECTOR_DISTS:
+                if val.ndim != 1:
+                    raise CodegenError("obs %r of a vector distribution needs a vector value" % id_)
+                terms.append(_logpdf_vector(g, tgt["dist"], x, tgt["params"], resolve_value))
+                continue
+            params = {k: resolve_value(v) for k, v in tgt["params"].items()}
             t, vec = elementwise(tgt["dist"], x, params)
             if vec:
                 if val.ndim == 0:
                     raise CodegenError("scalar obs %r of a vector-valued target" % id_)
-                acc = t[0]                        # Nx.sum on the BinaryBackend: left to right
-                for e in t[1:]:
-                    acc = g.add(acc, e)
-                t = acc
+                t = _sum_left(g, t)               # Nx.sum on the BinaryBackend: left to right
             terms.append(t)
     total = terms[0]                              # sum_logps, compiler.ex:394-395
     for t in terms[1:]:
@@ -499,11 +677,12 @@ def generate(ir, ncp=True, vectorize=True):
     n_fwd = len(g.ops)
     ad = _Grad(g, total)
     ad.run(n_fwd)
-    grads = [ad.adj.get(g.key.get(("q", k))) for k in range(len(free))]
+    grads = [ad.adj.get(g.key.get(("q", k))) for k in range(len(flat_names))]
 
     out = Generated()
-    out.d = len(free)
-    out.var_names = free
+    out.d = len(flat_names)
+    out.var_names = flat_names
+    out.vector_entries = vector_entries
     out.transforms = {i: nodes[i]["transform"] for i in free if nodes[i]["transform"]}
     out.ncp_info = ncp_info
     out.data = np.asarray(g.data, dtype=np.float64)
@@ -511,7 +690,9 @@ def generate(ir, ncp=True, vectorize=True):
     # the 16-lane layout, when the model has plates to spread over lanes (codegen_vec.py): the
     # plug-in then carries Custom<16> next to Custom<1> and defaults to it
     from . import codegen_vec
-    out.vec = codegen_vec.generate(ir, ncp=ncp) if vectorize else None
+    plain = all(n["op"] in ("rv", "obs") and (n["op"] != "rv" or n["dist"] not in VECTOR_DISTS + ("custom",))
+                for n in nodes.values())
+    out.vec = codegen_vec.generate(ir, ncp=ncp) if (vectorize and plain) else None
     out.lanes = 1
     if out.vec is not None:
         out.header += "\n" + out.vec["text"]
@@ -681,10 +862,24 @@ class GeneratedSpec(ModelSpec):
         super().__init__(CUSTOM, name, gen.data, gen.var_names, gen.transforms, default_init)
         self.gen = gen
         self.lib_path = lib_path
+        self.vector_entries = dict(getattr(gen, "vector_entries", {}))   # id -> (offset, length)
+
+    def flat_order(self):
+        # the generator lays the entries out in PointMap order already (ids sorted, a vector entry's
+        # elements consecutive: point_map.ex:30-60); sorting the per-element names would not be it
+        return list(range(self.d))
 
     def to_unconstrained(self, init_values):
         # invert_ncp_init + PointMap.to_unconstrained (sampler.ex:351-392)
-        vals = {k: float(v) for k, v in init_values.items()}
+        vals = {}
+        for k, v in init_values.items():
+            if k in self.vector_entries:          # a vector rv's init is a sequence of its elements
+                a = np.asarray(v, dtype=np.float64)
+                if a.shape != (self.vector_entries[k][1],):
+                    raise ValueError("init value of %r must have %d elements" % (k, self.vector_entries[k][1]))
+                vals.update({"%s[%d]" % (k, i): float(x) for i, x in enumerate(a)})
+            else:
+                vals[k] = float(v)
         raw = {}
         for id_, src in self.gen.ncp_info.items():
             if id_ in vals:

@@ -132,7 +132,11 @@ class SampleStats:
 def _build_trace(spec, draws):
     """build_trace (sampler.ex:1281-1298): slice per entry + forward transform."""
     x = spec.constrain(draws)
-    return {name: x[:, i] for i, name in enumerate(spec.var_names)}
+    trace = {name: x[:, i] for i, name in enumerate(spec.var_names)}
+    # a vector rv is one PointMap entry: its draws also come back as one {S, length} array under its id
+    for id_, (off, n) in getattr(spec, "vector_entries", {}).items():
+        trace[id_] = x[:, off:off + n]
+    return trace
 
 
 def _tuning_struct(tuning, d):

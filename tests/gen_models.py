@@ -34,3 +34,38 @@ def zoo_ir(seed=5):
 
 ZOO_INIT = dict(a_loc=0.3, b_scale=1.2, c_df=5.0, d_p=0.4, e_lap=-0.2, f_ln=0.9, g_t=0.1, h_hc=1.5,
                 i_centered=0.0)
+
+
+def walk_ir(seed=3):
+    """Round-2 generator coverage in one model (d = 12): a GaussianRandomWalk latent path driven by a
+    log-scale rv, an MvNormal block with a constant covariance, a Custom-distribution likelihood
+    written as a closure over the declarative op set (the shape of validate_posteriordb.exs:279-295),
+    a vector obs whose mean is the random walk, and two meas_obs terms (affine, matmul)."""
+    rng = np.random.default_rng(seed)
+    ir = cg.IR()
+    ir.rv("sigma", "exponential", {"lambda": 2.0}, transform="log")
+    ir.rv("w", "gaussian_random_walk", dict(sigma="sigma", steps=6))
+    cov = np.array([[1.0, 0.3, 0.1], [0.3, 2.0, 0.2], [0.1, 0.2, 1.5]])
+    ir.rv("m", "mv_normal", dict(mu=[0.1, -0.2, 0.3], cov=cov))
+    ir.rv("tau", "half_cauchy", dict(scale=2.0), transform="log")
+    ir.rv("c", "normal", dict(mu=0.0, sigma=3.0))
+    ir.rv("y_rv", "normal", dict(mu="w", sigma=0.5))
+    ir.obs("y", "y_rv", rng.normal(size=6) * 0.4)
+
+    def lik(o, x, p):
+        # sum_j Normal(x_j; c + tau * m_j, s_j) up to the constant the posteriordb script drops
+        terms = []
+        for xj, mj, sj in zip(x, p["m"], p["s"]):
+            z = o.div(o.sub(xj, o.add(p["c"], o.mul(p["tau"], mj))), sj)
+            terms.append(o.sub(o.mul(o.lit(-0.5), o.mul(z, z)), o.log(sj)))
+        return o.sum(terms)
+    ir.rv("z_rv", "custom", dict(logpdf=lik, m="m", c="c", tau="tau", s=[1.0, 2.0, 0.7]))
+    ir.obs("z", "z_rv", [0.4, -1.1, 2.0])
+    ir.rv("k_rv", "normal", dict(mu=1.0, sigma=2.0))
+    ir.meas_obs("k", "k_rv", 3.0, ("affine", 2.0, 1.0))
+    ir.rv("v_rv", "normal", dict(mu=0.0, sigma=1.0))
+    ir.meas_obs("v", "v_rv", [0.5, -0.25], ("matmul", [[2.0, 1.0], [0.0, 3.0]]))
+    return ir
+
+
+WALK_INIT = dict(sigma=0.5, w=[0.0, 0.1, 0.0, -0.1, 0.05, 0.0], m=[0.0, 0.0, 0.0], tau=1.0, c=0.2)
