@@ -23,6 +23,30 @@ using namespace exmc;
 
 namespace {
 
+#if EXMC_PROFILE_SECTIONS
+hipError_t print_sections(const char* what, double ms) {
+  unsigned long long h[16], z[16] = {0};
+  hipError_t e = hipMemcpyFromSymbol(h, HIP_SYMBOL(g_prof), sizeof(h));
+  if (e != hipSuccess) return e;
+  e = hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z));
+  if (e != hipSuccess) return e;
+  static const char* nm[9] = {"transition_start", "doubling_start", "leapfrog+model", "leaf",
+                              "ascend", "outer_merge", "transition_done", "", "loop"};
+  unsigned long long tot = 0;
+  for (int i = 0; i < 9; i++) tot += h[i];
+  fprintf(stderr, "[exmc prof] %s %.3f ms, passes (sum over waves) %llu, cycles %llu\n", what, ms, h[9], tot);
+  for (int i = 0; i < 9; i++)
+    if (i != 7 && h[9])
+      fprintf(stderr, "[exmc prof]   %-18s %6.1f%%  %8.1f cycles/pass\n", nm[i],
+              100.0 * (double)h[i] / (double)tot, (double)h[i] / (double)h[9]);
+  if (h[10])
+    fprintf(stderr, "[exmc prof]   integrator wave: %llu units, %.1f cycles/unit compute, %.1f barrier wait, %.1f other\n",
+            h[10], (double)h[11] / (double)h[10], (double)h[12] / (double)h[10], (double)h[13] / (double)h[10]);
+  return hipSuccess;
+}
+#endif
+
+
 thread_local std::string g_last_error;
 
 int fail(int code, const std::string& msg) {
@@ -397,20 +421,7 @@ int finish_timing(exmc_hip_model* m) {
   }
 #endif
 #if EXMC_PROFILE_SECTIONS
-  {
-    unsigned long long h[16], z[16] = {0};
-    HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_prof), sizeof(h)));
-    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)));
-    static const char* nm[9] = {"transition_start", "doubling_start", "leapfrog+model", "leaf",
-                                "ascend", "outer_merge", "transition_done", "", "loop"};
-    unsigned long long tot = 0;
-    for (int i = 0; i < 9; i++) tot += h[i];
-    fprintf(stderr, "[exmc prof] %.3f ms, passes (sum over waves) %llu\n", ms, h[9]);
-    for (int i = 0; i < 9; i++)
-      if (i != 7 && h[9])
-        fprintf(stderr, "[exmc prof]   %-18s %6.1f%%  %8.1f cycles/pass\n", nm[i],
-                100.0 * (double)h[i] / (double)tot, (double)h[i] / (double)h[9]);
-  }
+  HIP_TRY(print_sections("nuts", ms));
 #endif
   return EXMC_OK;
 }
@@ -765,6 +776,10 @@ int run_warmup_device(exmc_hip_model* m, int lanes, exmc_hip_opts o, exmc_hip_tu
   HIP_TRY(hipStreamSynchronize(m->stream));
   rc = finish_timing(m);
   if (rc) return rc;
+#if EXMC_PROFILE_SECTIONS
+  HIP_TRY(print_sections("warmup", m->last_ms));
+  fprintf(stderr, "[exmc prof]   warmup leapfrogs %.0f\n", h[2]);
+#endif
 #ifdef EXMC_XCC_PROBE
   fprintf(stderr, "[xcc probe] warmup ran on xcc/cu/se %d, %.3f ms  shader clocks %.0f  wall ticks %.0f\n",
           (int)h[2], m->last_ms, h[3 + d], h[4 + d]);

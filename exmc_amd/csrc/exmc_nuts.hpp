@@ -67,7 +67,19 @@ __device__ unsigned long long g_prof[16];
   if ((threadIdx.x & 63) == 0) {                                               \
     for (int i_ = 0; i_ < 10; i_++) atomicAdd(&g_prof[i_], (unsigned long long)prof_[i_]); \
   }
+// integrator wave of the two-wave pipeline: [10] units, [11] unit compute, [12] barrier waits, [13] rest
+#define EXMC_IPROF_DECL long long iprof_[4] = {0, 0, 0, 0}; long long iprof_t_ = clock64();
+#define EXMC_IPROF(i) { const long long n_ = clock64(); iprof_[i] += n_ - iprof_t_; iprof_t_ = n_; }
+#define EXMC_IPROF_COUNT { iprof_[0] += 1; }
+#define EXMC_IPROF_FLUSH                                                       \
+  if ((threadIdx.x & 63) == 0) {                                               \
+    for (int i_ = 0; i_ < 4; i_++) atomicAdd(&g_prof[10 + i_], (unsigned long long)iprof_[i_]); \
+  }
 #else
+#define EXMC_IPROF_DECL
+#define EXMC_IPROF(i)
+#define EXMC_IPROF_COUNT
+#define EXMC_IPROF_FLUSH
 #define EXMC_PROF_DECL
 #define EXMC_PROF(i)
 #define EXMC_PROF_COUNT(i)
@@ -395,26 +407,44 @@ __device__ __forceinline__ void draw_momentum(const NutsLane<M, G>& L, Rng& rng,
 }
 
 // ------------------------------------------------------------------------------------------
-// Two-wave pipeline for a single chain (the serial warmup): wave 0 keeps the tree (nuts_run with
-// a PipeBox), wave 1 integrates. Both walk the same skeleton -- transition, doubling, leaf -- and
-// meet at one workgroup barrier per leaf; between two barriers the tree wave merges leaf k while
-// the integrator computes leaf k+1 (leapfrog, model gradient, the leaf's weight and accept
-// statistic) into the other of two LDS slots. The integrator does not wait for the end of a
-// doubling either: a complete doubling j consumes exactly 2^j uniforms after its direction draw
-// (2^j - 1 inner merges, one outer merge; tree.ex:403, 1397, 1489), so it advances a copy of the
-// tree's generator, knows the next direction, and has the first leaf of the next doubling ready
-// while the tree wave is still in the outer merge (wasted when the tree stops there).
+// Two-wave pipeline (the serial warmup; the paired sampling kernel): wave 0 keeps the tree
+// (nuts_run with a PipeBox), wave 1 integrates. Both walk the same skeleton -- transition,
+// doubling, unit -- and meet at one workgroup barrier per unit. A unit is what the integrator hands
+// over: in doubling 0 the single leaf; in every later doubling a pair of leaves (2k, 2k+1) already
+// merged at level 0 (tree.ex:1390-1476 with depth 1: log-sum-exp of the two weights, the proposal
+// draw, the rho-based U-turn test) -- or leaf 2k alone when it diverged (tree.ex:1175-1177, the
+// node goes upward unmerged and the tree ends). Between two barriers the tree wave ascends unit k
+// through levels >= 1 while the integrator computes unit k+1 into the other of two LDS slots:
+// half the barriers of a leaf-per-barrier hand-over, and the level-0 merge (half of all merges)
+// runs on the wave that would otherwise wait.
+// The integrator keeps a copy of the tree's generator. Leaf pair k of a doubling draws its level-0
+// uniform at the position the tree's own order gives it: after it, the tree wave draws one uniform
+// for every further level that closes at leaf 2k+1 (the trailing ones of k), which the copy skips.
+// A complete doubling j therefore consumes 2^j uniforms after its direction draw on both sides
+// (2^j - 1 inner merges, one outer merge; tree.ex:403, 1397, 1489), the integrator knows the next
+// direction, and has the first unit of the next doubling ready while the tree wave is still in
+// the outer merge (wasted when the tree stops there).
 // What either side decides (alive) is published in LDS before the barrier that precedes its use,
 // double-buffered by the parity of the barrier count, so both waves always take the same number
-// of barriers. The arithmetic of a leaf is the one nuts_run performs itself: results are
-// bit-identical to the one-wave kernel.
+// of barriers. The arithmetic of a leaf and of a level-0 merge is the one nuts_run performs
+// itself: results are bit-identical to the one-wave kernel.
 // Mailbox rows (each row = 64 doubles, one column per lane of the wave):
 //   start  q0[DPL] p0[DPL] g0[DPL] im[DPL] eps jlp0 rng.a rng.b
 //   ctrl   [parity][alive, go_right]
-//   slot   [parity][q[DPL] p[DPL] g[DPL] logp lsw acc div]
+//   slot   [parity][q p g rho p_in q_prop g_prop (DPL each) logp_prop lsw acc n div turn]
 // ------------------------------------------------------------------------------------------
 struct NoPipe {
   static constexpr bool kOn = false;
+};
+
+// a finished subtree as the tree wave continues with it (nuts_run's c_* variables)
+template <int DPL>
+struct PipeUnit {
+  double q[DPL], p[DPL], g[DPL];   // the outward endpoint
+  double rho[DPL], pin[DPL], qp[DPL], gp[DPL];
+  double logpP, lsw, acc;
+  int n;
+  bool div, turn;
 };
 
 template <int DPL>
@@ -423,7 +453,7 @@ struct PipeBox {
   static constexpr int kQuit = 4 * DPL + 4;   // start row: the tree wave abandons the kernel
   static constexpr int kCtrl = 4 * DPL + 5;
   static constexpr int kSlot = kCtrl + 4;
-  static constexpr int kSlotRows = 3 * DPL + 4;
+  static constexpr int kSlotRows = 7 * DPL + 6;
   static constexpr int kRows = kSlot + 2 * kSlotRows;
   double* box;   // this lane's column
   int seq;       // barriers passed (identical on both waves)
@@ -460,28 +490,37 @@ struct PipeBox {
   __device__ __forceinline__ void put_alive(bool alive) const {
     row(kCtrl + 2 * ((seq + 1) & 1)) = alive ? 1.0 : 0.0;
   }
-  __device__ __forceinline__ void get_leaf(double (&q)[DPL], double (&p)[DPL], double (&g)[DPL],
-                                           double& logp, double& lsw, double& acc, bool& div) const {
+  __device__ __forceinline__ void get_unit(PipeUnit<DPL>& u) const {
     const int b = kSlot + kSlotRows * (seq & 1);
 #pragma unroll
-    for (int k = 0; k < DPL; k++) { q[k] = row(b + k); p[k] = row(b + DPL + k); g[k] = row(b + 2 * DPL + k); }
-    logp = row(b + 3 * DPL);
-    lsw = row(b + 3 * DPL + 1);
-    acc = row(b + 3 * DPL + 2);
-    div = row(b + 3 * DPL + 3) != 0.0;
+    for (int k = 0; k < DPL; k++) {
+      u.q[k] = row(b + k); u.p[k] = row(b + DPL + k); u.g[k] = row(b + 2 * DPL + k);
+      u.rho[k] = row(b + 3 * DPL + k); u.pin[k] = row(b + 4 * DPL + k);
+      u.qp[k] = row(b + 5 * DPL + k); u.gp[k] = row(b + 6 * DPL + k);
+    }
+    u.logpP = row(b + 7 * DPL);
+    u.lsw = row(b + 7 * DPL + 1);
+    u.acc = row(b + 7 * DPL + 2);
+    u.n = (row(b + 7 * DPL + 3) != 1.0) ? 2 : 1;
+    u.div = row(b + 7 * DPL + 4) != 0.0;
+    u.turn = row(b + 7 * DPL + 5) != 0.0;
   }
   // ---- integrator wave ----
   __device__ __forceinline__ bool get_alive() const { return row(kCtrl + 2 * (seq & 1)) != 0.0; }
-  __device__ __forceinline__ void put_leaf(const double (&q)[DPL], const double (&p)[DPL],
-                                           const double (&g)[DPL], double logp, double lsw,
-                                           double acc, bool div) const {
+  __device__ __forceinline__ void put_unit(const PipeUnit<DPL>& u) const {
     const int b = kSlot + kSlotRows * ((seq + 1) & 1);
 #pragma unroll
-    for (int k = 0; k < DPL; k++) { row(b + k) = q[k]; row(b + DPL + k) = p[k]; row(b + 2 * DPL + k) = g[k]; }
-    row(b + 3 * DPL) = logp;
-    row(b + 3 * DPL + 1) = lsw;
-    row(b + 3 * DPL + 2) = acc;
-    row(b + 3 * DPL + 3) = div ? 1.0 : 0.0;
+    for (int k = 0; k < DPL; k++) {
+      row(b + k) = u.q[k]; row(b + DPL + k) = u.p[k]; row(b + 2 * DPL + k) = u.g[k];
+      row(b + 3 * DPL + k) = u.rho[k]; row(b + 4 * DPL + k) = u.pin[k];
+      row(b + 5 * DPL + k) = u.qp[k]; row(b + 6 * DPL + k) = u.gp[k];
+    }
+    row(b + 7 * DPL) = u.logpP;
+    row(b + 7 * DPL + 1) = u.lsw;
+    row(b + 7 * DPL + 2) = u.acc;
+    row(b + 7 * DPL + 3) = (u.n == 2) ? 2.0 : 1.0;
+    row(b + 7 * DPL + 4) = u.div ? 1.0 : 0.0;
+    row(b + 7 * DPL + 5) = u.turn ? 1.0 : 0.0;
   }
 };
 
@@ -496,7 +535,9 @@ __device__ __forceinline__ bool pipe_integrate_transition(const typename M::Cons
   constexpr int DPL = M::DPL;
   using MM = Math<M::kVregMath>;
   double q[DPL], p[DPL], g[DPL], qL[DPL], pL[DPL], gL[DPL], qR[DPL], pR[DPL], gR[DPL], im[DPL];
+  EXMC_IPROF_DECL
   pb.sync();   // the tree wave has published the start of the transition
+  EXMC_IPROF(2)
   if (__any(pb.row(PipeBox<DPL>::kQuit) != 0.0 ? 1 : 0) != 0) return false;
 #pragma unroll
   for (int k = 0; k < DPL; k++) {
@@ -507,12 +548,12 @@ __device__ __forceinline__ bool pipe_integrate_transition(const typename M::Cons
   }
   const double eps = pb.row(4 * DPL);
   const double jlp0 = pb.row(4 * DPL + 1);
-  Rng prng;   // copy of the tree's generator, used for the direction draws only
+  Rng prng;   // copy of the tree's generator: direction draws and level-0 proposal draws
   prng.a = (uint64_t)__double_as_longlong(pb.row(4 * DPL + 2));
   prng.b = (uint64_t)__double_as_longlong(pb.row(4 * DPL + 3));
-  auto leap = [&](double eps_dir) {
-    // batched_leapfrog.ex:79-85 and the leaf's scalars (tree.ex:1042-1109): the same operations
-    // in the same order as nuts_run's own leaf pass
+  // one leapfrog from (q, p, g) in place and the leaf's scalars: batched_leapfrog.ex:79-85,
+  // tree.ex:1042-1109, the same operations in the same order as nuts_run's own leaf pass
+  auto leap = [&](double eps_dir, double& logp_new, double& c_lsw, double& c_acc, bool& c_div) {
     const double h = eps_dir / 2.0;
 #pragma unroll
     for (int k = 0; k < DPL; k++) {
@@ -520,7 +561,7 @@ __device__ __forceinline__ bool pipe_integrate_transition(const typename M::Cons
       p[k] = ph;
       q[k] = q[k] + eps_dir * (im[k] * ph);
     }
-    const double logp_new = M::logp_grad(mc, L.ln, L.l, q, g);
+    logp_new = M::logp_grad(mc, L.ln, L.l, q, g);
 #pragma unroll
     for (int k = 0; k < DPL; k++) p[k] = p[k] + h * g[k];
     const double jlp = logp_new - kinetic_energy<G, DPL, M::D>(p, im, L.valid);
@@ -528,33 +569,100 @@ __device__ __forceinline__ bool pipe_integrate_transition(const typename M::Cons
     // log-weight -1001 and no acceptance; fmin(dl, 0) is 0 for a NaN, so the exponential is defined
     const bool fin = exmc_isfinite(jlp);
     const double dl = jlp - jlp0;
-    const bool c_div = fin ? (dl < -1000.0) : true;
-    const double c_lsw = fin ? dl : -1001.0;
-    const double c_acc = c_div ? 0.0 : fmin(1.0, MM::exp_le0(fmin(dl, 0.0)));
-    pb.put_leaf(q, p, g, logp_new, c_lsw, c_acc, c_div);
+    c_div = fin ? (dl < -1000.0) : true;
+    c_lsw = fin ? dl : -1001.0;
+    c_acc = c_div ? 0.0 : fmin(1.0, MM::exp_le0(fmin(dl, 0.0)));
+  };
+  // unit `idx` of a doubling of `pair ? 2 : 1` leaves per unit, published for the next barrier
+  auto unit = [&](double eps_dir, bool pair, int idx) {
+    PipeUnit<DPL> u;
+    double q0[DPL], g0[DPL];
+#pragma unroll
+    for (int k = 0; k < DPL; k++) { q0[k] = q[k]; g0[k] = g[k]; }
+    double a_logp, a_lsw, a_acc;
+    bool a_div;
+    leap(eps_dir, a_logp, a_lsw, a_acc, a_div);
+#pragma unroll
+    for (int k = 0; k < DPL; k++) {
+      u.q[k] = q[k]; u.p[k] = p[k]; u.g[k] = g[k];
+      u.rho[k] = p[k]; u.pin[k] = p[k];
+      u.qp[k] = a_div ? q0[k] : q[k];
+      u.gp[k] = a_div ? g0[k] : g[k];
+    }
+    u.logpP = a_div ? -1.0e30 : a_logp;
+    u.lsw = a_lsw;
+    u.acc = a_acc;
+    u.n = 1;
+    u.div = a_div;
+    u.turn = false;
+    if (pair) {   // wave-uniform
+      double b_logp, b_lsw, b_acc;
+      bool b_div;
+      leap(eps_dir, b_logp, b_lsw, b_acc, b_div);   // every lane: the model may be wave-cooperative
+      // level-0 merge of (a, b), nuts_run's ascent at lvl 0 (tree.ex:1390-1476)
+      const double lsw = MM::log_sum_exp(a_lsw, b_lsw);
+      Rng r = prng;
+      const double uu = rng_uniform(r);
+      const bool use_b = uu < MM::exp_le0(b_lsw - lsw);   // lsw >= b_lsw
+      bool turning = b_div;
+      double rho[DPL];
+#pragma unroll
+      for (int k = 0; k < DPL; k++) rho[k] = u.pin[k] + p[k];
+      const bool c1 = uturn<G, DPL, M::D>(rho, u.pin, p, im, L.valid);
+      turning = turning ? true : c1;
+      if (!a_div) {   // a diverged first leaf stays alone: its group's tree ends with it
+        prng = r;
+#pragma unroll
+        for (int k = 0; k < DPL; k++) {
+          // proposal: b's own (its start when it diverged) or a's
+          const double bq = b_div ? u.q[k] : q[k];
+          const double bg = b_div ? u.g[k] : g[k];
+          u.qp[k] = use_b ? bq : u.qp[k];
+          u.gp[k] = use_b ? bg : u.gp[k];
+          u.rho[k] = b_div ? p[k] : rho[k];
+          u.pin[k] = b_div ? p[k] : u.pin[k];
+          u.q[k] = q[k]; u.p[k] = p[k]; u.g[k] = g[k];
+        }
+        u.logpP = use_b ? (b_div ? -1.0e30 : b_logp) : u.logpP;
+        u.lsw = lsw;
+        u.acc = a_acc + b_acc;
+        u.n = 2;
+        u.div = b_div;
+        u.turn = turning;
+      }
+      // the uniforms of the levels >= 1 that close at leaf 2 idx + 1 belong to the tree wave
+      for (int t = idx; t & 1; t >>= 1) rng_advance(prng);
+    }
+    pb.put_unit(u);
+    EXMC_IPROF_COUNT
   };
   bool go_right = rng_uniform(prng) > 0.5;   // tree.ex:403
-  leap(go_right ? eps : -eps);               // first leaf of doubling 0
+  EXMC_IPROF(3)
+  unit(go_right ? eps : -eps, false, 0);     // the leaf of doubling 0
+  EXMC_IPROF(1)
   for (int depth = 0;; depth++) {
-    pb.sync();   // the tree wave says whether this doubling happens; its first leaf is in the slot
+    pb.sync();   // the tree wave says whether this doubling happens; its first unit is in the slot
+    EXMC_IPROF(2)
     if (__any(pb.get_alive() ? 1 : 0) == 0) break;
     const double eps_dir = go_right ? eps : -eps;
-    const int nleaf = 1 << depth;
+    const int nunit = (depth == 0) ? 1 : (1 << (depth - 1));
     bool stopped = false;
-    for (int leaf = 1; leaf < nleaf; leaf++) {
-      leap(eps_dir);
-      pb.sync();   // leaf `leaf` is in its slot; the tree wave is done with leaf - 1
+    for (int i = 1; i < nunit; i++) {
+      unit(eps_dir, true, i);
+      EXMC_IPROF(1)
+      pb.sync();   // unit i is in its slot; the tree wave is done with unit i - 1
+      EXMC_IPROF(2)
       if (__any(pb.get_alive() ? 1 : 0) == 0) { stopped = true; break; }
     }
     if (stopped) continue;   // the next barrier carries alive = false
-    // this doubling is complete on this side: the new endpoint, the next direction (2^depth
-    // uniforms later in the tree's stream) and, ahead of the tree wave, the next first leaf
+    // this doubling is complete on this side: the new endpoint, the outer merge's uniform, the
+    // next direction and, ahead of the tree wave, the next first unit
 #pragma unroll
     for (int k = 0; k < DPL; k++) {
       if (go_right) { qR[k] = q[k]; pR[k] = p[k]; gR[k] = g[k]; }
       else { qL[k] = q[k]; pL[k] = p[k]; gL[k] = g[k]; }
     }
-    for (int i = 0; i < nleaf; i++) rng_advance(prng);
+    rng_advance(prng);
     go_right = rng_uniform(prng) > 0.5;
 #pragma unroll
     for (int k = 0; k < DPL; k++) {
@@ -562,8 +670,11 @@ __device__ __forceinline__ bool pipe_integrate_transition(const typename M::Cons
       p[k] = go_right ? pR[k] : pL[k];
       g[k] = go_right ? gR[k] : gL[k];
     }
-    leap(go_right ? eps : -eps);
+    EXMC_IPROF(3)
+    unit(go_right ? eps : -eps, true, 0);
+    EXMC_IPROF(1)
   }
+  EXMC_IPROF_FLUSH
   return true;
 }
 
@@ -657,22 +768,20 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
       }
       EXMC_PROF(1)
 
-      const int nleaf = 1 << depth;
+      // one-wave form: a pass per leaf, ascent from level 0. Pipelined form: a pass per unit of the
+      // integrator wave (a leaf in doubling 0, afterwards a leaf pair merged at level 0), so loop
+      // level lvl is tree level lvl + kLvl0
+      constexpr int kLvl0 = Pipe::kOn ? 1 : 0;
+      const int nlev = (Pipe::kOn && depth > 0) ? depth - 1 : depth;
+      const int nleaf = 1 << nlev;
       for (int leaf = 0; leaf < nleaf; leaf++) {
         if constexpr (Pipe::kOn) {
-          if (leaf > 0) pipe->sync();   // leaf 0 arrived with the doubling's barrier
+          if (leaf > 0) pipe->sync();   // unit 0 arrived with the doubling's barrier
         }
         if (leaf > 0 && __any(alive ? 1 : 0) == 0) break;
         EXMC_PROF_COUNT(9)
-        double logp_new, jlp = 0.0;
-        bool pc_div = false;
-        double pc_lsw = 0.0, pc_acc = 0.0;
-        if constexpr (Pipe::kOn) {
-          // the integrator wave computed this leaf while the previous one was merged here
-#pragma unroll
-          for (int k = 0; k < DPL; k++) { qold[k] = q[k]; gold[k] = g[k]; }
-          pipe->get_leaf(q, p, g, logp_new, pc_lsw, pc_acc, pc_div);
-        } else {
+        double logp_new = 0.0, jlp = 0.0;
+        if constexpr (!Pipe::kOn) {
           // ---- one leapfrog on every lane (batched_leapfrog.ex:79-85); idle groups integrate
           // scratch registers so that wave-cooperative models see all 64 lanes ----
           const double h = eps_dir / 2.0;
@@ -703,9 +812,21 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
           double c_lsw, c_acc, c_logpP;
           int c_n = 1;
           if constexpr (Pipe::kOn) {
-            c_div = pc_div;
-            c_lsw = pc_lsw;
-            c_acc = pc_acc;
+            // the integrator wave computed this unit while the previous one was merged here
+            PipeUnit<DPL> pu;
+            pipe->get_unit(pu);
+#pragma unroll
+            for (int k = 0; k < DPL; k++) {
+              q[k] = pu.q[k]; p[k] = pu.p[k]; g[k] = pu.g[k];
+              c_rho[k] = pu.rho[k]; c_pin[k] = pu.pin[k]; c_qp[k] = pu.qp[k]; c_gp[k] = pu.gp[k];
+            }
+            c_div = pu.div;
+            c_turn = pu.turn;
+            c_lsw = pu.lsw;
+            c_acc = pu.acc;
+            c_logpP = pu.logpP;
+            c_n = pu.n;
+            if (c_n == 2) rng_advance(trng);   // the level-0 proposal draw happened over there
           } else {
             // tree.ex:1042-1048 without a branch (see pipe_integrate_transition)
             const bool fin = exmc_isfinite(jlp);
@@ -717,22 +838,22 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
 #else
             c_acc = fmin(1.0, MM::exp_le0(fmin(dl, 0.0)));
 #endif
-          }
-          c_acc = c_div ? 0.0 : c_acc;
-          c_logpP = c_div ? -1.0e30 : logp_new;
+            c_acc = c_div ? 0.0 : c_acc;
+            c_logpP = c_div ? -1.0e30 : logp_new;
 #pragma unroll
-          for (int k = 0; k < DPL; k++) {
-            c_qp[k] = c_div ? qold[k] : q[k];
-            c_gp[k] = c_div ? gold[k] : g[k];
-            c_rho[k] = p[k];
-            c_pin[k] = p[k];
+            for (int k = 0; k < DPL; k++) {
+              c_qp[k] = c_div ? qold[k] : q[k];
+              c_gp[k] = c_div ? gold[k] : g[k];
+              c_rho[k] = p[k];
+              c_pin[k] = p[k];
+            }
           }
           EXMC_PROF(3)
 
           // ---- ascend (tree.ex:1144-1203, 1390-1476): level lvl holds a pending first half iff
           // bit lvl of `leaf` is set; the first clear bit is where an unfinished node parks ----
           bool parked = false;
-          for (int lvl = 0; lvl < depth; lvl++) {
+          for (int lvl = 0; lvl < nlev; lvl++) {
             if ((leaf >> lvl) & 1) {
               if (!parked) {
                 double nd[NSLOT];
@@ -772,7 +893,7 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
 #else
                   // tree.ex:1428-1446: the two sub-span checks apply from depth 2 on; lvl is
                   // wave-uniform, so the level-0 merges (3 of 4 in a 7-leaf tree) reduce 2 sums, not 6
-                  if (lvl == 0) c1 = mass_uturn<M, G>(L, rho, a_pin, p);
+                  if (lvl + kLvl0 == 0) c1 = mass_uturn<M, G>(L, rho, a_pin, p);
                   else mass_uturn3<M, G>(L, rho, a_pin, p, r2, a_pin, c_pin, r3, a_pout, p, c1, c23);
 #endif
                   turning = c1 || c23;
@@ -781,7 +902,7 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
                 }
                 c_lsw = lsw;
                 c_acc = a_acc + c_acc;
-                c_n = (1 << lvl) + c_n;
+                c_n = (1 << (lvl + kLvl0)) + c_n;
                 c_turn = turning;
               }
             } else {
