@@ -229,6 +229,8 @@ def main():
     ap.add_argument("--lanes", type=int, default=0)
     ap.add_argument("--adapt", type=int, default=1000, help="NUTS adaptation iterations")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-multi-step", action="store_true",
+                    help="skip the batched-leapfrog roofline leg (development builds without that layout)")
     ap.add_argument("--gather-traces", action="store_true",
                     help="all-gather the full [S][d][C] traces for split R-hat instead of the "
                          "per-chain half-chain statistics")
@@ -403,7 +405,7 @@ def main():
         ri = issue_roofline(args.model, Cper, S, lanes, kernel_ms, local_lf) if world == 1 else None
         if ri:
             out["roofline_issue"] = ri
-        if world == 1 and args.model == "eight_schools":
+        if world == 1 and args.model == "eight_schools" and not args.no_multi_step:
             # the B2 batched-leapfrog contract at a batch that fills the chip (not the timed path)
             out["roofline_multi_step"] = multi_step_roofline(comp, spec, dev)
         if world == 1 and not args.no_cpu:

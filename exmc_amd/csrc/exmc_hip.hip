@@ -178,19 +178,40 @@ int dispatch(exmc_hip_model* m, int lanes, F&& f) {
       break;
 #endif
 #ifndef EXMC_ONLY_CUSTOM      // plug-in builds carry the generated model only
+// development builds for kernel work carry one model in one layout: -DEXMC_DEV_ES16_ONLY,
+// -DEXMC_DEV_ONLY=EXMC_DEV_SV64 (or _RADON64, _LOGISTIC16)
+#define EXMC_DEV_SV64 1
+#define EXMC_DEV_RADON64 2
+#define EXMC_DEV_LOGISTIC16 3
+#if defined(EXMC_DEV_ES16_ONLY)
+    case EXMC_MODEL_EIGHT_SCHOOLS:
+      if (lanes == 16) return f(Tag<EightSchools<16>, 16, 6>{}, m->es);
+      break;
+#elif defined(EXMC_DEV_ONLY)
+#if EXMC_DEV_ONLY == EXMC_DEV_SV64
+    case EXMC_MODEL_SV:
+      if (lanes == 64) return f(Tag<SV<64>, 64, 2>{}, m->sv);
+      break;
+#elif EXMC_DEV_ONLY == EXMC_DEV_RADON64
+    case EXMC_MODEL_RADON:
+      if (lanes == 64) return f(Tag<Radon<64>, 64, 2>{}, m->rd);
+      break;
+#elif EXMC_DEV_ONLY == EXMC_DEV_LOGISTIC16
+    case EXMC_MODEL_LOGISTIC:
+      if (lanes == 16) return f(Tag<Logistic<16>, 16, 2>{}, m->lg);
+      break;
+#endif
+#else
     case EXMC_MODEL_EIGHT_SCHOOLS:
       switch (lanes) {
-#ifndef EXMC_DEV_ES16_ONLY    // development builds for kernel work: one model, one layout
         case 1: return f(Tag<EightSchools<1>, 1, 2>{}, m->es);
         case 2: return f(Tag<EightSchools<2>, 2, 3>{}, m->es);
         case 4: return f(Tag<EightSchools<4>, 4, 4>{}, m->es);
         case 8: return f(Tag<EightSchools<8>, 8, 5>{}, m->es);
-#endif
         case 16: return f(Tag<EightSchools<16>, 16, 6>{}, m->es);
         default: break;
       }
       break;
-#ifndef EXMC_DEV_ES16_ONLY
     case EXMC_MODEL_SIMPLE:
       if (lanes == 1) return f(Tag<Simple<1>, 1, 6>{}, m->sp);
       break;

@@ -32,6 +32,11 @@ struct ModelDefaults {
   // tree bookkeeping is a real share of a leaf pass: sv 900 -> 695 ms, radon 194 -> 169 ms,
   // eight_schools ~20 -> ~17 ms; not for logistic, whose pass is nearly all model (158 -> 162 ms)
   static constexpr bool kPipeWarmup = true;
+  // Resident waves per SIMD the sampling kernel's register allocation must allow (the second
+  // launch bound). 2 caps the kernel at 256 vector registers: what the allocator would have kept
+  // in accumulator registers goes to scratch instead. Worth it when the configuration launches
+  // more waves than SIMDs and the spilled values are per-transition state, not leaf-pass state.
+  static constexpr int kNutsWavesPerSimd = 1;
   // > 0: the sampling kernel runs as wave pairs too, with this many tree-stack levels in LDS
   static constexpr int kPipeNutsLevels = 0;
 };
@@ -322,6 +327,11 @@ struct SV : ModelDefaults {
   static constexpr int D = T + 2;
   static constexpr int DPL = (D + G - 1) / G;
   static_assert(G >= 16, "sv spreads a chain over >= 16 lanes (lane-batched lgamma series)");
+  // G = 64: 2048 chains are 2048 waves on 1024 SIMDs. At 304 registers one wave is resident per
+  // SIMD and issues every ~5 clocks; capped at 256 (49 dwords of per-transition state in scratch,
+  // one scratch access inside the leaf loop) two are, and the pair issues every ~3.5
+  // (4096 chains x 200 draws: 1307 -> 950 ms)
+  static constexpr int kNutsWavesPerSimd = (G == 64) ? 2 : 1;
   using Consts = SVConsts;
   struct Lane {
     double r[DPL];
@@ -457,6 +467,9 @@ struct LogisticConsts {
 template <int G>
 struct Logistic : ModelDefaults {
   static constexpr bool kPipeWarmup = false;
+  // G = 16: 8192 chains are 2048 waves; two resident waves per SIMD at 256 registers + scratch
+  // beat one at 364 (8192 x 200 draws: 63.5 -> 53.8 ms)
+  static constexpr int kNutsWavesPerSimd = (G == 16) ? 2 : 1;
   static constexpr int K = 20;
   static constexpr int D = K + 1;
   static constexpr int DPL = (D + G - 1) / G;

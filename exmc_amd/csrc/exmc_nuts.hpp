@@ -1072,7 +1072,7 @@ __device__ __forceinline__ void chain_store(const ChainState& s, int C, int chai
 // the bubbles of one wave (taken branches, > 4-clock issues, LDS round trips) are the other's
 // issue slots.
 template <class M, int G, int LDSL, bool kPipe = false>
-__global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock)
+__global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock, M::kNutsWavesPerSimd)
     nuts_kernel(NutsParams P, typename M::Consts mc) {
   constexpr int D = M::D, DPL = M::DPL;
   constexpr int NSLOT = 5 * DPL + 3;
