@@ -704,6 +704,14 @@ struct Logistic<4> : ModelDefaults {
 // hierarchical radon, J = 85 counties (notebooks/09_radon_bhm.livemd "The Radon Model").
 // dims: 0..J-1 alpha_raw_j, J mu_alpha, J+1 gamma_u, J+2 log sigma_alpha, J+3 log sigma_y,
 // J+4 beta. The lane that owns alpha_raw_j walks county j's observations (sorted by county).
+// G = 64: a county's observations are cut into chunks of B = ceil(N / 64). The owner lane walks
+// the first chunk; the chunks after it (only the largest counties have any, at most floor(N / B)
+// <= 64 in total) are numbered county by county and chunk e is walked by lane e as a third work
+// item -- a wave walks at most 3 B observations per leapfrog instead of the largest county
+// (116 of 919 in the bench data). Sums: a chunk from 0.0 in observation
+// order; a county = its chunks in order; the likelihood / floor / z^2 totals = each lane's three
+// work items in order, then the lanes. The CPU checker restates the same rule from the county
+// offsets.
 // ------------------------------------------------------------------------------------------
 struct RadonConsts {
   const double* u;      // dev [J]
@@ -725,9 +733,13 @@ struct Radon : ModelDefaults {
   using Consts = RadonConsts;
   static constexpr int kObsCap = 1024;                 // observations an LDS image can hold
   static constexpr int kLdsDataDoubles = 2 * kObsCap;  // [floor | y]
+  static constexpr bool kChunks = (G == 64);
   struct Lane {
     double u[DPL];
-    int i0[DPL], i1[DPL];
+    int i0[DPL], i1[DPL];   // own counties: the observations this lane walks (kChunks: first chunk)
+    int xi0, xi1, xsrc;     // kChunks: this lane's later chunk [xi0, xi1) and the county it belongs to
+    int xe0[DPL], nx[DPL];  // kChunks: an own county's later chunks sit on lanes xe0 .. xe0 + nx - 1
+    int maxx;               // kChunks: most later chunks of any county
     Recip ten, five, c25;   // prior scales Normal(0, 10), Normal(0, 5), HalfCauchy(2.5)
     int xoff;               // LDS image of floor / y (offset in doubles), or -1: read from global
   };
@@ -743,13 +755,39 @@ struct Radon : ModelDefaults {
   }
   __device__ static __forceinline__ void load(const Consts& c, int l, Lane& ln) {
     ln.xoff = -1;
+    ln.xi0 = ln.xi1 = ln.xsrc = ln.maxx = 0;
 #pragma unroll
     for (int k = 0; k < DPL; k++) {
       const int j = l + k * G;
       const bool cty = j < J;
+      ln.xe0[k] = ln.nx[k] = 0;
       ln.u[k] = cty ? c.u[j] : 0.0;
       ln.i0[k] = cty ? (int)c.cs[j] : 0;
       ln.i1[k] = cty ? (int)c.cs[j + 1] : 0;
+    }
+    if constexpr (kChunks) {
+      const int N = (int)c.cs[J];
+      const int B = (N + G - 1) / G;
+      int later = 0;   // later chunks of the counties before j
+      for (int j = 0; j < J; j++) {
+        const int a = (int)c.cs[j], b = (int)c.cs[j + 1];
+        const int nch = (b - a + B - 1) / B;
+        const int nxj = nch > 1 ? nch - 1 : 0;
+#pragma unroll
+        for (int k = 0; k < DPL; k++)
+          if (j == l + k * G) { ln.xe0[k] = later; ln.nx[k] = nxj; }
+        if (l >= later && l < later + nxj) {   // at most floor(N / B) <= 64 later chunks in all
+          const int tt = l - later + 1;
+          ln.xi0 = a + tt * B;
+          ln.xi1 = (a + (tt + 1) * B < b) ? a + (tt + 1) * B : b;
+          ln.xsrc = j;
+        }
+        ln.maxx = nxj > ln.maxx ? nxj : ln.maxx;
+        later += nxj;
+      }
+#pragma unroll
+      for (int k = 0; k < DPL; k++)
+        ln.i1[k] = (ln.i0[k] + B < ln.i1[k]) ? ln.i0[k] + B : ln.i1[k];
     }
     ln.ten = make_recip_literal(10.0);
     ln.five = make_recip_literal(5.0);
@@ -798,13 +836,9 @@ struct Radon : ModelDefaults {
     double s[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // lik, S, S*u, S*alpha_raw, F, Z2 partials
     double T[DPL];
     bool valid[DPL];
-#pragma unroll
-    for (int k = 0; k < DPL; k++) {
-      const int j = l + k * G;
-      valid[k] = j < D;
-      const double ar = q[k];
-      const double alpha = (mu + gam * ln.u[k]) + sa * ar;
-      double lik = 0.0, sj = 0.0, f = 0.0, z2s = 0.0;
+    // observations [i0, i1) against the county intercept alpha, sums from 0.0 in order
+    auto walk = [&](int i0, int i1, double alpha, double& lik, double& sj, double& f, double& z2s) {
+      lik = 0.0; sj = 0.0; f = 0.0; z2s = 0.0;
       auto obs = [&](double fi, double yi) {
         const double mean = alpha + beta * fi;
         const double resid = yi - mean;
@@ -819,26 +853,63 @@ struct Radon : ModelDefaults {
       if (ln.xoff >= 0) {
         // LDS image, the next observation fetched while this one is used
         const double* im = exmc_dyn_lds + ln.xoff;
-        int i = ln.i0[k];
-        const int iend = ln.i1[k];
+        int i = i0;
         double fn = 0.0, yn = 0.0;
-        if (i < iend) { fn = im[i]; yn = im[kObsCap + i]; }
-        for (; i < iend; i++) {
+        if (i < i1) { fn = im[i]; yn = im[kObsCap + i]; }
+        for (; i < i1; i++) {
           const double fi = fn, yi = yn;
           fn = im[i + 1];            // one past the lane's last observation is still inside the
           yn = im[kObsCap + i + 1];  // image (N < kObsCap) and never used
           obs(fi, yi);
         }
       } else {
-        for (int i = ln.i0[k]; i < ln.i1[k]; i++) obs(c.fl[i], c.y[i]);
+        for (int i = i0; i < i1; i++) obs(c.fl[i], c.y[i]);
       }
-      if (valid[k]) {
+    };
+    double alpha_own[DPL], sj_own[DPL];
+#pragma unroll
+    for (int k = 0; k < DPL; k++) {
+      const int j = l + k * G;
+      valid[k] = j < D;
+      alpha_own[k] = (mu + gam * ln.u[k]) + sa * q[k];
+      double lik, f, z2s;
+      walk(ln.i0[k], ln.i1[k], alpha_own[k], lik, sj_own[k], f, z2s);
+      if (kChunks || valid[k]) {
         s[0] = s[0] + lik;
+        s[4] = s[4] + f;
+        s[5] = s[5] + z2s;
+      }
+    }
+    if constexpr (kChunks) {
+      // this lane's later chunk, then the county sums of the counties that have later chunks
+      double alpha_x = 0.0;
+#pragma unroll
+      for (int k = 0; k < DPL; k++) {
+        const double v = __shfl(alpha_own[k], ln.xsrc & 63, 64);
+        alpha_x = ((ln.xsrc >> 6) == k) ? v : alpha_x;
+      }
+      double likx, sjx, fx, z2x;
+      walk(ln.xi0, ln.xi1, alpha_x, likx, sjx, fx, z2x);
+      s[0] = s[0] + likx;
+      s[4] = s[4] + fx;
+      s[5] = s[5] + z2x;
+      const int maxx = __builtin_amdgcn_readfirstlane(ln.maxx);   // the same number on every lane
+      for (int tt = 0; tt < maxx; tt++) {
+#pragma unroll
+        for (int k = 0; k < DPL; k++) {
+          const double v = __shfl(sjx, (ln.xe0[k] + tt) & 63, 64);
+          sj_own[k] = (tt < ln.nx[k]) ? (sj_own[k] + v) : sj_own[k];
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < DPL; k++) {
+      const double ar = q[k];
+      const double sj = sj_own[k];
+      if (valid[k]) {
         s[1] = s[1] + sj;
         s[2] = s[2] + sj * ln.u[k];
         s[3] = s[3] + sj * ar;
-        s[4] = s[4] + f;
-        s[5] = s[5] + z2s;
       }
       T[k] = -0.5 * (ar * ar + c.c1);
       g[k] = (-ar) + sj * sa;
