@@ -316,11 +316,10 @@ __device__ __forceinline__ int group_min_i32(int v) {
 // dimension), and the pass repeats from j + 1. Expected passes: 1 + 0.015 d, against d sequential
 // draws.
 template <class M, int G>
-__device__ __forceinline__ void draw_momentum(const NutsLane<M, G>& L, Rng& rng,
-                                              double (&p)[M::DPL]) {
+__device__ __forceinline__ void draw_momentum_variates(const NutsLane<M, G>& L, Rng& rng,
+                                                       double (&z)[M::DPL]) {
   constexpr int D = M::D, DPL = M::DPL;
   const int base = (threadIdx.x & 63) & ~(G - 1);
-  double z[DPL];
 #pragma unroll
   for (int k = 0; k < DPL; k++) z[k] = 0.0;
   int pos = 0;   // draws [0, pos) are final and rng stands in front of draw pos
@@ -396,6 +395,12 @@ __device__ __forceinline__ void draw_momentum(const NutsLane<M, G>& L, Rng& rng,
       pos = D;
     }
   }
+}
+
+// p = z / sqrt(M^-1) (sampler.ex:400), or the dense form p = L^-T z (sampler.ex:412-427)
+template <class M, int G>
+__device__ __forceinline__ void momentum_from_variates(const NutsLane<M, G>& L, const double (&z)[M::DPL],
+                                                       double (&p)[M::DPL]) {
   if constexpr (G == 1) {
     if (L.dm.chol) {
       dense_momentum<M::D>(L.dm.chol, z, p);
@@ -403,35 +408,45 @@ __device__ __forceinline__ void draw_momentum(const NutsLane<M, G>& L, Rng& rng,
     }
   }
 #pragma unroll
-  for (int k = 0; k < DPL; k++) p[k] = z[k] / L.sim[k];
+  for (int k = 0; k < M::DPL; k++) p[k] = z[k] / L.sim[k];
+}
+
+template <class M, int G>
+__device__ __forceinline__ void draw_momentum(const NutsLane<M, G>& L, Rng& rng,
+                                              double (&p)[M::DPL]) {
+  double z[M::DPL];
+  draw_momentum_variates<M, G>(L, rng, z);
+  momentum_from_variates<M, G>(L, z, p);
 }
 
 // ------------------------------------------------------------------------------------------
 // Two-wave pipeline (the serial warmup; the paired sampling kernel): wave 0 keeps the tree
 // (nuts_run with a PipeBox), wave 1 integrates. Both walk the same skeleton -- transition,
 // doubling, unit -- and meet at one workgroup barrier per unit. A unit is what the integrator hands
-// over: in doubling 0 the single leaf; in every later doubling a pair of leaves (2k, 2k+1) already
-// merged at level 0 (tree.ex:1390-1476 with depth 1: log-sum-exp of the two weights, the proposal
-// draw, the rho-based U-turn test) -- or leaf 2k alone when it diverged (tree.ex:1175-1177, the
-// node goes upward unmerged and the tree ends). Between two barriers the tree wave ascends unit k
-// through levels >= 1 while the integrator computes unit k+1 into the other of two LDS slots:
-// half the barriers of a leaf-per-barrier hand-over, and the level-0 merge (half of all merges)
-// runs on the wave that would otherwise wait.
-// The integrator keeps a copy of the tree's generator. Leaf pair k of a doubling draws its level-0
-// uniform at the position the tree's own order gives it: after it, the tree wave draws one uniform
-// for every further level that closes at leaf 2k+1 (the trailing ones of k), which the copy skips.
-// A complete doubling j therefore consumes 2^j uniforms after its direction draw on both sides
-// (2^j - 1 inner merges, one outer merge; tree.ex:403, 1397, 1489), the integrator knows the next
+// over: in doubling 0 the single leaf, in every later doubling a pair of leaves (2k, 2k+1). The
+// tree wave merges the pair at level 0 in registers (pipe_pair_unit: tree.ex:1390-1476 with
+// depth 1 -- or keeps leaf 2k alone when it diverged, tree.ex:1175-1177) and ascends the result
+// through levels >= 1, while the integrator computes the next pair into the other of two LDS
+// slots: half the barriers of a leaf-per-barrier hand-over and no level-0 traffic on the stack.
+// The integrator does not wait for the end of a doubling either: a complete doubling j consumes
+// exactly 2^j uniforms after its direction draw (2^j - 1 inner merges, one outer merge;
+// tree.ex:403, 1397, 1489), so it advances a copy of the tree's generator, knows the next
 // direction, and has the first unit of the next doubling ready while the tree wave is still in
-// the outer merge (wasted when the tree stops there).
+// the outer merge (wasted when the tree stops there). When the tree has stopped it draws the
+// standard normals of the NEXT transition's momentum (sampler.ex:393-403; the generator state
+// they start from is known: the post-momentum state of this transition advanced by the one
+// uniform of sampler.ex:897) while the tree wave runs the adaptation update; the tree wave takes
+// them if its generator stands where the draw started (not after a step-size search, which
+// consumes draws in between).
 // What either side decides (alive) is published in LDS before the barrier that precedes its use,
 // double-buffered by the parity of the barrier count, so both waves always take the same number
-// of barriers. The arithmetic of a leaf and of a level-0 merge is the one nuts_run performs
-// itself: results are bit-identical to the one-wave kernel.
+// of barriers. The arithmetic of a leaf and of a merge is the one nuts_run performs itself:
+// results are bit-identical to the one-wave kernel.
 // Mailbox rows (each row = 64 doubles, one column per lane of the wave):
-//   start  q0[DPL] p0[DPL] g0[DPL] im[DPL] eps jlp0 rng.a rng.b
+//   start  q0[DPL] p0[DPL] g0[DPL] im[DPL] eps jlp0 rng.a rng.b quit
 //   ctrl   [parity][alive, go_right]
-//   slot   [parity][q p g rho p_in q_prop g_prop (DPL each) logp_prop lsw acc n div turn]
+//   slot   [parity][2 leaves][q[DPL] p[DPL] g[DPL] logp lsw acc div]
+//   next   z[DPL] rng_before.a .b rng_after.a .b   (the pre-drawn momentum variates)
 // ------------------------------------------------------------------------------------------
 struct NoPipe {
   static constexpr bool kOn = false;
@@ -448,15 +463,25 @@ struct PipeUnit {
 };
 
 template <int DPL>
+struct PipeLeaf {
+  double q[DPL], p[DPL], g[DPL];
+  double logp, lsw, acc;
+  bool div;
+};
+
+template <int DPL>
 struct PipeBox {
   static constexpr bool kOn = true;
   static constexpr int kQuit = 4 * DPL + 4;   // start row: the tree wave abandons the kernel
   static constexpr int kCtrl = 4 * DPL + 5;
   static constexpr int kSlot = kCtrl + 4;
-  static constexpr int kSlotRows = 7 * DPL + 6;
-  static constexpr int kRows = kSlot + 2 * kSlotRows;
-  double* box;   // this lane's column
-  int seq;       // barriers passed (identical on both waves)
+  static constexpr int kLeafRows = 3 * DPL + 4;
+  static constexpr int kSlotRows = 2 * kLeafRows;
+  static constexpr int kNext = kSlot + 2 * kSlotRows;
+  static constexpr int kRows = kNext + DPL + 4;
+  double* box;    // this lane's column
+  int seq;        // barriers passed (identical on both waves)
+  bool pending;   // tree wave: the barrier behind the integrator's momentum variates is still to come
 
   __device__ __forceinline__ double& row(int r) const { return box[(size_t)r * 64]; }
   __device__ __forceinline__ void sync() {
@@ -479,6 +504,10 @@ struct PipeBox {
   }
   // instead of a transition: tell the integrator wave to leave (it waits at the start barrier)
   __device__ __forceinline__ void quit() {
+    if (pending) {
+      sync();
+      pending = false;
+    }
     row(kQuit) = 1.0;
     sync();
   }
@@ -490,42 +519,113 @@ struct PipeBox {
   __device__ __forceinline__ void put_alive(bool alive) const {
     row(kCtrl + 2 * ((seq + 1) & 1)) = alive ? 1.0 : 0.0;
   }
-  __device__ __forceinline__ void get_unit(PipeUnit<DPL>& u) const {
-    const int b = kSlot + kSlotRows * (seq & 1);
+  __device__ __forceinline__ void get_leaf(int which, PipeLeaf<DPL>& f) const {
+    const int b = kSlot + kSlotRows * (seq & 1) + kLeafRows * which;
 #pragma unroll
-    for (int k = 0; k < DPL; k++) {
-      u.q[k] = row(b + k); u.p[k] = row(b + DPL + k); u.g[k] = row(b + 2 * DPL + k);
-      u.rho[k] = row(b + 3 * DPL + k); u.pin[k] = row(b + 4 * DPL + k);
-      u.qp[k] = row(b + 5 * DPL + k); u.gp[k] = row(b + 6 * DPL + k);
-    }
-    u.logpP = row(b + 7 * DPL);
-    u.lsw = row(b + 7 * DPL + 1);
-    u.acc = row(b + 7 * DPL + 2);
-    u.n = (row(b + 7 * DPL + 3) != 1.0) ? 2 : 1;
-    u.div = row(b + 7 * DPL + 4) != 0.0;
-    u.turn = row(b + 7 * DPL + 5) != 0.0;
+    for (int k = 0; k < DPL; k++) { f.q[k] = row(b + k); f.p[k] = row(b + DPL + k); f.g[k] = row(b + 2 * DPL + k); }
+    f.logp = row(b + 3 * DPL);
+    f.lsw = row(b + 3 * DPL + 1);
+    f.acc = row(b + 3 * DPL + 2);
+    f.div = row(b + 3 * DPL + 3) != 0.0;
+  }
+  // the pre-drawn variates of this transition's momentum, if the generator stands where the
+  // integrator wave assumed it would; rng moves behind the draws
+  __device__ __forceinline__ bool take_momentum(Rng& rng, double (&z)[DPL]) const {
+    const uint64_t a = (uint64_t)__double_as_longlong(row(kNext + DPL));
+    const uint64_t b = (uint64_t)__double_as_longlong(row(kNext + DPL + 1));
+    const bool ok = (a == rng.a) && (b == rng.b);
+    if (__any(ok ? 0 : 1) != 0) return false;
+#pragma unroll
+    for (int k = 0; k < DPL; k++) z[k] = row(kNext + k);
+    rng.a = (uint64_t)__double_as_longlong(row(kNext + DPL + 2));
+    rng.b = (uint64_t)__double_as_longlong(row(kNext + DPL + 3));
+    return true;
+  }
+  __device__ __forceinline__ void clear_momentum() const {
+    row(kNext + DPL) = __longlong_as_double(-1LL);   // no 58-bit state word looks like this
+    row(kNext + DPL + 1) = __longlong_as_double(-1LL);
   }
   // ---- integrator wave ----
   __device__ __forceinline__ bool get_alive() const { return row(kCtrl + 2 * (seq & 1)) != 0.0; }
-  __device__ __forceinline__ void put_unit(const PipeUnit<DPL>& u) const {
-    const int b = kSlot + kSlotRows * ((seq + 1) & 1);
+  __device__ __forceinline__ void put_leaf(int which, const PipeLeaf<DPL>& f) const {
+    const int b = kSlot + kSlotRows * ((seq + 1) & 1) + kLeafRows * which;
 #pragma unroll
-    for (int k = 0; k < DPL; k++) {
-      row(b + k) = u.q[k]; row(b + DPL + k) = u.p[k]; row(b + 2 * DPL + k) = u.g[k];
-      row(b + 3 * DPL + k) = u.rho[k]; row(b + 4 * DPL + k) = u.pin[k];
-      row(b + 5 * DPL + k) = u.qp[k]; row(b + 6 * DPL + k) = u.gp[k];
-    }
-    row(b + 7 * DPL) = u.logpP;
-    row(b + 7 * DPL + 1) = u.lsw;
-    row(b + 7 * DPL + 2) = u.acc;
-    row(b + 7 * DPL + 3) = (u.n == 2) ? 2.0 : 1.0;
-    row(b + 7 * DPL + 4) = u.div ? 1.0 : 0.0;
-    row(b + 7 * DPL + 5) = u.turn ? 1.0 : 0.0;
+    for (int k = 0; k < DPL; k++) { row(b + k) = f.q[k]; row(b + DPL + k) = f.p[k]; row(b + 2 * DPL + k) = f.g[k]; }
+    row(b + 3 * DPL) = f.logp;
+    row(b + 3 * DPL + 1) = f.lsw;
+    row(b + 3 * DPL + 2) = f.acc;
+    row(b + 3 * DPL + 3) = f.div ? 1.0 : 0.0;
+  }
+  __device__ __forceinline__ void put_momentum(const double (&z)[DPL], const Rng& before, const Rng& after) const {
+#pragma unroll
+    for (int k = 0; k < DPL; k++) row(kNext + k) = z[k];
+    row(kNext + DPL) = __longlong_as_double((long long)before.a);
+    row(kNext + DPL + 1) = __longlong_as_double((long long)before.b);
+    row(kNext + DPL + 2) = __longlong_as_double((long long)after.a);
+    row(kNext + DPL + 3) = __longlong_as_double((long long)after.b);
   }
 };
 
 template <int DPL>
 __host__ __device__ constexpr size_t pipe_lds_doubles() { return (size_t)PipeBox<DPL>::kRows * 64; }
+
+// The unit the tree wave ascends with, from the integrator's leaves: leaf a alone (doubling 0, or
+// a diverged first leaf of a pair), or (a, b) merged at level 0 exactly as nuts_run's own ascent
+// does at lvl 0 (tree.ex:1390-1476). q0 / g0: the state leaf a started from (a diverged leaf's
+// proposal, tree.ex:1042-1048). The proposal draw comes from trng only when the pair is merged.
+template <class M, int G>
+__device__ __forceinline__ void pipe_pair_unit(const NutsLane<M, G>& L, const PipeLeaf<M::DPL>& a,
+                                               const PipeLeaf<M::DPL>& b, bool pair,
+                                               const double (&q0)[M::DPL], const double (&g0)[M::DPL],
+                                               Rng& trng, PipeUnit<M::DPL>& u) {
+  constexpr int DPL = M::DPL;
+  using MM = Math<M::kVregMath>;
+#pragma unroll
+  for (int k = 0; k < DPL; k++) {
+    u.q[k] = a.q[k]; u.p[k] = a.p[k]; u.g[k] = a.g[k];
+    u.rho[k] = a.p[k]; u.pin[k] = a.p[k];
+    u.qp[k] = a.div ? q0[k] : a.q[k];
+    u.gp[k] = a.div ? g0[k] : a.g[k];
+  }
+  u.logpP = a.div ? -1.0e30 : a.logp;
+  u.lsw = a.lsw;
+  u.acc = a.acc;
+  u.n = 1;
+  u.div = a.div;
+  u.turn = false;
+  if (pair && !a.div) {
+    const double lsw = MM::log_sum_exp(a.lsw, b.lsw);
+    const double uu = rng_uniform(trng);
+    const bool use_b = uu < MM::exp_le0(b.lsw - lsw);   // lsw >= b.lsw
+    bool turning = b.div;
+    if (!turning) {
+      double rho[DPL];
+#pragma unroll
+      for (int k = 0; k < DPL; k++) rho[k] = a.p[k] + b.p[k];
+      turning = mass_uturn<M, G>(L, rho, a.p, b.p);
+#pragma unroll
+      for (int k = 0; k < DPL; k++) { u.rho[k] = rho[k]; u.pin[k] = a.p[k]; }
+    } else {
+#pragma unroll
+      for (int k = 0; k < DPL; k++) { u.rho[k] = b.p[k]; u.pin[k] = b.p[k]; }
+    }
+#pragma unroll
+    for (int k = 0; k < DPL; k++) {
+      // proposal: b's own (its start, leaf a, when it diverged) or a's
+      const double bq = b.div ? a.q[k] : b.q[k];
+      const double bg = b.div ? a.g[k] : b.g[k];
+      u.qp[k] = use_b ? bq : u.qp[k];
+      u.gp[k] = use_b ? bg : u.gp[k];
+      u.q[k] = b.q[k]; u.p[k] = b.p[k]; u.g[k] = b.g[k];
+    }
+    u.logpP = use_b ? (b.div ? -1.0e30 : b.logp) : u.logpP;
+    u.lsw = lsw;
+    u.acc = a.acc + b.acc;
+    u.n = 2;
+    u.div = b.div;
+    u.turn = turning;
+  }
+}
 
 // the integrator wave's side of one transition (mirror of nuts_run's skeleton)
 template <class M, int G>
@@ -548,12 +648,15 @@ __device__ __forceinline__ bool pipe_integrate_transition(const typename M::Cons
   }
   const double eps = pb.row(4 * DPL);
   const double jlp0 = pb.row(4 * DPL + 1);
-  Rng prng;   // copy of the tree's generator: direction draws and level-0 proposal draws
+  Rng prng;   // copy of the tree's generator, used for the direction draws only
   prng.a = (uint64_t)__double_as_longlong(pb.row(4 * DPL + 2));
   prng.b = (uint64_t)__double_as_longlong(pb.row(4 * DPL + 3));
+  Rng next_rng = prng;          // where the next transition's momentum draw starts: the
+  rng_advance(next_rng);        // post-momentum state advanced by one uniform (sampler.ex:897)
   // one leapfrog from (q, p, g) in place and the leaf's scalars: batched_leapfrog.ex:79-85,
   // tree.ex:1042-1109, the same operations in the same order as nuts_run's own leaf pass
-  auto leap = [&](double eps_dir, double& logp_new, double& c_lsw, double& c_acc, bool& c_div) {
+  auto leap = [&](double eps_dir, int which) {
+    PipeLeaf<DPL> f;
     const double h = eps_dir / 2.0;
 #pragma unroll
     for (int k = 0; k < DPL; k++) {
@@ -561,84 +664,30 @@ __device__ __forceinline__ bool pipe_integrate_transition(const typename M::Cons
       p[k] = ph;
       q[k] = q[k] + eps_dir * (im[k] * ph);
     }
-    logp_new = M::logp_grad(mc, L.ln, L.l, q, g);
+    f.logp = M::logp_grad(mc, L.ln, L.l, q, g);
 #pragma unroll
     for (int k = 0; k < DPL; k++) p[k] = p[k] + h * g[k];
-    const double jlp = logp_new - kinetic_energy<G, DPL, M::D>(p, im, L.valid);
+    const double jlp = f.logp - kinetic_energy<G, DPL, M::D>(p, im, L.valid);
     // tree.ex:1042-1048 without a branch: a non-finite joint log-probability is a divergence with
     // log-weight -1001 and no acceptance; fmin(dl, 0) is 0 for a NaN, so the exponential is defined
     const bool fin = exmc_isfinite(jlp);
     const double dl = jlp - jlp0;
-    c_div = fin ? (dl < -1000.0) : true;
-    c_lsw = fin ? dl : -1001.0;
-    c_acc = c_div ? 0.0 : fmin(1.0, MM::exp_le0(fmin(dl, 0.0)));
+    f.div = fin ? (dl < -1000.0) : true;
+    f.lsw = fin ? dl : -1001.0;
+    f.acc = f.div ? 0.0 : fmin(1.0, MM::exp_le0(fmin(dl, 0.0)));
+#pragma unroll
+    for (int k = 0; k < DPL; k++) { f.q[k] = q[k]; f.p[k] = p[k]; f.g[k] = g[k]; }
+    pb.put_leaf(which, f);
   };
-  // unit `idx` of a doubling of `pair ? 2 : 1` leaves per unit, published for the next barrier
-  auto unit = [&](double eps_dir, bool pair, int idx) {
-    PipeUnit<DPL> u;
-    double q0[DPL], g0[DPL];
-#pragma unroll
-    for (int k = 0; k < DPL; k++) { q0[k] = q[k]; g0[k] = g[k]; }
-    double a_logp, a_lsw, a_acc;
-    bool a_div;
-    leap(eps_dir, a_logp, a_lsw, a_acc, a_div);
-#pragma unroll
-    for (int k = 0; k < DPL; k++) {
-      u.q[k] = q[k]; u.p[k] = p[k]; u.g[k] = g[k];
-      u.rho[k] = p[k]; u.pin[k] = p[k];
-      u.qp[k] = a_div ? q0[k] : q[k];
-      u.gp[k] = a_div ? g0[k] : g[k];
-    }
-    u.logpP = a_div ? -1.0e30 : a_logp;
-    u.lsw = a_lsw;
-    u.acc = a_acc;
-    u.n = 1;
-    u.div = a_div;
-    u.turn = false;
-    if (pair) {   // wave-uniform
-      double b_logp, b_lsw, b_acc;
-      bool b_div;
-      leap(eps_dir, b_logp, b_lsw, b_acc, b_div);   // every lane: the model may be wave-cooperative
-      // level-0 merge of (a, b), nuts_run's ascent at lvl 0 (tree.ex:1390-1476)
-      const double lsw = MM::log_sum_exp(a_lsw, b_lsw);
-      Rng r = prng;
-      const double uu = rng_uniform(r);
-      const bool use_b = uu < MM::exp_le0(b_lsw - lsw);   // lsw >= b_lsw
-      bool turning = b_div;
-      double rho[DPL];
-#pragma unroll
-      for (int k = 0; k < DPL; k++) rho[k] = u.pin[k] + p[k];
-      const bool c1 = uturn<G, DPL, M::D>(rho, u.pin, p, im, L.valid);
-      turning = turning ? true : c1;
-      if (!a_div) {   // a diverged first leaf stays alone: its group's tree ends with it
-        prng = r;
-#pragma unroll
-        for (int k = 0; k < DPL; k++) {
-          // proposal: b's own (its start when it diverged) or a's
-          const double bq = b_div ? u.q[k] : q[k];
-          const double bg = b_div ? u.g[k] : g[k];
-          u.qp[k] = use_b ? bq : u.qp[k];
-          u.gp[k] = use_b ? bg : u.gp[k];
-          u.rho[k] = b_div ? p[k] : rho[k];
-          u.pin[k] = b_div ? p[k] : u.pin[k];
-          u.q[k] = q[k]; u.p[k] = p[k]; u.g[k] = g[k];
-        }
-        u.logpP = use_b ? (b_div ? -1.0e30 : b_logp) : u.logpP;
-        u.lsw = lsw;
-        u.acc = a_acc + b_acc;
-        u.n = 2;
-        u.div = b_div;
-        u.turn = turning;
-      }
-      // the uniforms of the levels >= 1 that close at leaf 2 idx + 1 belong to the tree wave
-      for (int t = idx; t & 1; t >>= 1) rng_advance(prng);
-    }
-    pb.put_unit(u);
+  // the next unit into the slot: one leaf in doubling 0, afterwards two
+  auto unit = [&](double eps_dir, bool pair) {
+    leap(eps_dir, 0);
+    if (pair) leap(eps_dir, 1);   // wave-uniform
     EXMC_IPROF_COUNT
   };
   bool go_right = rng_uniform(prng) > 0.5;   // tree.ex:403
   EXMC_IPROF(3)
-  unit(go_right ? eps : -eps, false, 0);     // the leaf of doubling 0
+  unit(go_right ? eps : -eps, false);        // the leaf of doubling 0
   EXMC_IPROF(1)
   for (int depth = 0;; depth++) {
     pb.sync();   // the tree wave says whether this doubling happens; its first unit is in the slot
@@ -648,21 +697,22 @@ __device__ __forceinline__ bool pipe_integrate_transition(const typename M::Cons
     const int nunit = (depth == 0) ? 1 : (1 << (depth - 1));
     bool stopped = false;
     for (int i = 1; i < nunit; i++) {
-      unit(eps_dir, true, i);
+      unit(eps_dir, true);
       EXMC_IPROF(1)
       pb.sync();   // unit i is in its slot; the tree wave is done with unit i - 1
       EXMC_IPROF(2)
       if (__any(pb.get_alive() ? 1 : 0) == 0) { stopped = true; break; }
     }
     if (stopped) continue;   // the next barrier carries alive = false
-    // this doubling is complete on this side: the new endpoint, the outer merge's uniform, the
-    // next direction and, ahead of the tree wave, the next first unit
+    // this doubling is complete on this side: the new endpoint, the next direction (2^depth
+    // uniforms later in the tree's stream) and, ahead of the tree wave, the next first unit
 #pragma unroll
     for (int k = 0; k < DPL; k++) {
       if (go_right) { qR[k] = q[k]; pR[k] = p[k]; gR[k] = g[k]; }
       else { qL[k] = q[k]; pL[k] = p[k]; gL[k] = g[k]; }
     }
-    rng_advance(prng);
+    const int nleaf = 1 << depth;
+    for (int i = 0; i < nleaf; i++) rng_advance(prng);
     go_right = rng_uniform(prng) > 0.5;
 #pragma unroll
     for (int k = 0; k < DPL; k++) {
@@ -671,9 +721,21 @@ __device__ __forceinline__ bool pipe_integrate_transition(const typename M::Cons
       g[k] = go_right ? gR[k] : gL[k];
     }
     EXMC_IPROF(3)
-    unit(go_right ? eps : -eps, true, 0);
+    unit(go_right ? eps : -eps, true);
     EXMC_IPROF(1)
   }
+  // the tree has stopped: while the tree wave finishes the transition (adaptation update), draw
+  // the variates of the next momentum; it reads them after the barrier that starts the next
+  // transition's hand-shake (PipeBox::take_momentum)
+  {
+    double z[DPL];
+    const Rng before = next_rng;
+    draw_momentum_variates<M, G>(L, next_rng, z);
+    pb.put_momentum(z, before, next_rng);
+  }
+  EXMC_IPROF(3)
+  pb.sync();   // the variates are in the box
+  EXMC_IPROF(2)
   EXMC_IPROF_FLUSH
   return true;
 }
@@ -725,8 +787,22 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
     EXMC_PROF(8)
     // ---- transition start (sampler.ex:393-403, 890-899) ----
     bool alive = has;
+    bool have_z = false;
+    double z_pre[DPL];
+#pragma unroll
+    for (int k = 0; k < DPL; k++) z_pre[k] = 0.0;
+    if constexpr (Pipe::kOn) {
+      // the integrator wave drew the variates of this momentum while the previous transition was
+      // being finished here (valid if the generator has not moved since, see PipeBox)
+      if (pipe->pending) {
+        pipe->sync();
+        pipe->pending = false;
+        have_z = pipe->take_momentum(st.rng, z_pre);
+      }
+    }
     if (has) {
-      draw_momentum<M, G>(L, st.rng, pL);
+      if (have_z) momentum_from_variates<M, G>(L, z_pre, pL);
+      else draw_momentum<M, G>(L, st.rng, pL);
       jlp0 = st.logp - mass_ke<M, G>(L, pL);
       trng = st.rng;  // the tree consumes a copy (sampler.ex:897 discards its draws)
 #pragma unroll
@@ -814,7 +890,13 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
           if constexpr (Pipe::kOn) {
             // the integrator wave computed this unit while the previous one was merged here
             PipeUnit<DPL> pu;
-            pipe->get_unit(pu);
+            {
+              PipeLeaf<DPL> la, lb;
+              pipe->get_leaf(0, la);
+              if (depth > 0) pipe->get_leaf(1, lb);
+              else lb = la;
+              pipe_pair_unit<M, G>(L, la, lb, depth > 0, q, g, trng, pu);
+            }
 #pragma unroll
             for (int k = 0; k < DPL; k++) {
               q[k] = pu.q[k]; p[k] = pu.p[k]; g[k] = pu.g[k];
@@ -826,7 +908,6 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
             c_acc = pu.acc;
             c_logpP = pu.logpP;
             c_n = pu.n;
-            if (c_n == 2) rng_advance(trng);   // the level-0 proposal draw happened over there
           } else {
             // tree.ex:1042-1048 without a branch (see pipe_integrate_transition)
             const bool fin = exmc_isfinite(jlp);
@@ -990,6 +1071,7 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
     }
 
     // ---- transition done for every group of the wavefront (sampler.ex:890-925) ----
+    if constexpr (Pipe::kOn) pipe->pending = true;   // the integrator wave is drawing the next momentum
     if (has) {
       (void)rng_uniform(st.rng);
       st.logp = t_logpP;
@@ -1098,6 +1180,7 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock, M::kNutsW
     L.nthreads = (size_t)gridDim.x * kNutsBlock;
     pipe.box = lds + nuts_lds_bytes<M, LDSL>() / 8 + lane;
     pipe.seq = 0;
+    pipe.pending = false;
     if (threadIdx.x >= kNutsBlock) {
       for (int i = 0; i < P.n_draws; i++)
         if (!pipe_integrate_transition<M, G>(mc, L, pipe)) break;
@@ -1163,8 +1246,12 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock, M::kNutsW
 #ifdef EXMC_XCC_PROBE
   const long long wave_c0 = clock64();
 #endif
-  if constexpr (kPipe) nuts_run<M, G, LDSL>(mc, L, st, P.n_draws, P.eps, P.max_depth, sink, &pipe);
-  else nuts_run<M, G, LDSL>(mc, L, st, P.n_draws, P.eps, P.max_depth, sink);
+  if constexpr (kPipe) {
+    nuts_run<M, G, LDSL>(mc, L, st, P.n_draws, P.eps, P.max_depth, sink, &pipe);
+    if (pipe.pending) pipe.sync();   // the integrator wave's last barrier (momentum variates nobody takes)
+  } else {
+    nuts_run<M, G, LDSL>(mc, L, st, P.n_draws, P.eps, P.max_depth, sink);
+  }
 #ifdef EXMC_XCC_PROBE   // development: per-wave clocks and placement of the sampling kernel
   if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096) {
     unsigned xcc, hw;
@@ -1332,6 +1419,7 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock)
     L.nthreads = kNutsBlock;
     pipe.box = lds + lds_used + lane;
     pipe.seq = 0;
+    pipe.pending = false;
     if (threadIdx.x >= kNutsBlock) {
       const bool windows = P.adapt_end > P.init_buffer;
       const int n = (P.num_warmup > 0) ? (windows ? P.num_warmup : P.init_buffer) : 0;
@@ -1503,6 +1591,11 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock)
       }
     }
     eps_final = exmc_exp(da.log_epsilon_bar);
+    if constexpr (kPipe) {
+      // the integrator wave has served its n_iter transitions and waits at its last barrier
+      // (a lost race has been through quit(), which clears `pending`)
+      if (pipe.pending) pipe.sync();
+    }
   }
 
   if (!writer) return;

@@ -109,19 +109,20 @@ def radon_data(seed=42, n_counties=85, n_obs=919):
     return u, start, floor, y
 
 
-def radon(data=None):
+def radon(data=None, sort_counties=True):
     """Hierarchical radon, d = J+5 = 90. Kernel order: the county intercepts alpha_raw_j by
     DESCENDING observation count, then mu_alpha, gamma_u, sigma_alpha, sigma_y, beta (the
     reference's flat order is the string sort; names carry the original county index). A lane of
-    the 64-lane chain group walks the observations of counties l and l + 64: with the 21 smallest
-    counties in the second slot a leapfrog costs max(slot 0) + max(slot 1) = 39 + 5 observation
-    steps instead of 28 + 39 in file order."""
+    the 64-lane chain group walks the observations of counties l and l + 64 (with the 21 smallest
+    counties in the second slot), a county larger than ceil(N / 64) observations in chunks spread
+    over the lanes (exmc_models.hpp Radon). sort_counties=False keeps the file order (any order
+    is valid input for the library; the sorted one is the fastest)."""
     u, start, floor, y = data if data is not None else radon_data()
     J = len(u)
     u, start, floor, y = (np.asarray(u, float), np.asarray(start).astype(int),
                           np.asarray(floor, float), np.asarray(y, float))
     sizes = np.diff(start)
-    order = np.argsort(-sizes, kind="stable")
+    order = np.argsort(-sizes, kind="stable") if sort_counties else np.arange(J)
     obs = np.concatenate([np.arange(start[j], start[j + 1]) for j in order])
     u, floor, y = u[order], floor[obs], y[obs]
     start = np.concatenate([[0], np.cumsum(sizes[order])])

@@ -79,6 +79,56 @@ def test_model_logp_grad_bit_exact(hip, name, factory, lane_list):
             assert np.array_equal(og, g[c]), (name, lanes, c)
 
 
+def _skewed_radon():
+    """County sizes like the real radon survey (one county with 116 observations, one with 105,
+    many with 1-3), the large ones LAST in file order: their later chunks and their owner lanes
+    sit in the second dimension slot of the 64-lane layout."""
+    rng = np.random.default_rng(17)
+    J, N = 85, 919
+    sizes = np.concatenate([rng.integers(1, 6, size=J - 6), [14, 25, 46, 52, 105, 116]])
+    sizes[:J - 6] += 1
+    while sizes.sum() > N:
+        sizes[int(np.argmax(sizes[:J - 6]))] -= 1
+    while sizes.sum() < N:
+        sizes[int(rng.integers(0, J - 6))] += 1
+    start = np.concatenate([[0], np.cumsum(sizes)])
+    u = rng.normal(0.0, 0.5, size=J)
+    county = np.repeat(np.arange(J), sizes)
+    floor = (rng.uniform(size=N) < 0.2).astype(float)
+    y = 1.4 + 0.7 * u[county] - 0.7 * floor + 0.7 * rng.normal(size=N)
+    return u, start, floor, y
+
+
+@pytest.mark.parametrize("sort_counties", [False, True])
+def test_radon_chunked_counties_bit_exact(hip, sort_counties):
+    """Radon with 64 lanes per chain on survey-like county sizes: counties larger than
+    ceil(N / 64) observations are summed in chunks spread over the lanes; in file order the large
+    counties are owned by the second dimension slot. logp / gradient and whole transitions."""
+    spec = models.radon(_skewed_radon(), sort_counties=sort_counties)
+    comp = sampler.compile(spec)
+    om = O.model_for(spec)
+    rng = np.random.default_rng(5)
+    C_ = 21
+    q = _rand_q(rng, C_, spec.d, 0.4)
+    lp = np.zeros(C_)
+    g = np.zeros((C_, spec.d))
+    _lib.check(hip.exmc_hip_logp_grad_host(comp.h, _dp(q), C_, 64, _dp(lp), _dp(g)))
+    cfg = O.Cfg(1, 64)
+    for c in range(C_):
+        olp, og = om.logp_grad(q[c], cfg)
+        assert olp == lp[c], (c, olp, lp[c])
+        assert np.array_equal(og, g[c]), c
+    # 32 lanes per chain keep whole counties: a different (documented) sum order, same value to rounding
+    lp32 = np.zeros(C_)
+    _lib.check(hip.exmc_hip_logp_grad_host(comp.h, _dp(q), C_, 32, _dp(lp32), _dp(g)))
+    assert np.allclose(lp32, lp, rtol=1e-12, atol=0)
+    opts = dict(num_warmup=40, num_samples=30, seed=3, lanes_per_chain=64)
+    tuning = sampler.warmup(comp, spec.default_init, opts)
+    st = O.warmup(om, spec.to_unconstrained(spec.default_init), num_warmup=40, seed=3, cfg=O.Cfg(1, 64))
+    assert tuning["epsilon"] == st.step_size
+    assert np.array_equal(tuning["inv_mass"], np.array(st.inv_mass[:spec.d]))
+
+
 @pytest.mark.parametrize("lanes", [1, 8, 16])
 @pytest.mark.parametrize("eps", [0.3, -0.3])
 def test_multi_step_bit_exact(es, hip, lanes, eps):
