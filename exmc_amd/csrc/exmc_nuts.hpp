@@ -752,10 +752,17 @@ __device__ __forceinline__ bool pipe_integrate_transition(const typename M::Cons
 // tree.ex:1175-1177 path, handled by the same level loop) idles until the deepest tree of the
 // wavefront is finished: for eight_schools E[max of 4 trees] / E[tree] = 1.18 extra passes buy a
 // pass that costs ~0.6x of the asynchronous one (no union of divergent paths, no exec juggling).
-template <class M, int G, int LDSL, class Sink, class Pipe = NoPipe>
+// idle(): work of the caller that does not depend on this transition's outcome; called once per
+// transition where the pipelined tree wave would otherwise wait for the first leaf.
+struct NoIdle {
+  __device__ __forceinline__ void operator()() const {}
+};
+
+template <class M, int G, int LDSL, class Sink, class Pipe = NoPipe, class Idle = NoIdle>
 __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const NutsLane<M, G>& L,
                                          ChainRegs<M::DPL>& st, int n_draws, double eps,
-                                         int max_depth, Sink&& sink, Pipe* pipe = nullptr) {
+                                         int max_depth, Sink&& sink, Pipe* pipe = nullptr,
+                                         Idle&& idle = Idle{}) {
   constexpr int DPL = M::DPL;
   constexpr int NSLOT = 5 * DPL + 3;
   using MM = Math<M::kVregMath>;
@@ -822,6 +829,7 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
       pipe->put_start(st.q, pL, st.g, im, eps, jlp0, trng);
       pipe->sync();
     }
+    idle();
     EXMC_PROF(0)
 
     for (int depth = 0; Pipe::kOn || __any(alive ? 1 : 0) != 0; depth++) {   // depth is wave-uniform
@@ -1366,14 +1374,23 @@ struct DualAvgDev {
     m = 0;
     target = target_accept;
   }
-  __device__ __forceinline__ void update(double accept_stat) {
+  // The factors of update() that depend on the iteration count alone (step_size.ex:28-40):
+  // computed while the transition runs, so that only the accept-statistic part is left between
+  // the end of one tree and the step size of the next. Same operations, same values.
+  double eta_, one_m_eta_, sq_, mk_, one_m_mk_;
+  __device__ __forceinline__ void prepare() {
     const int mm = m + 1;
-    const double eta = 1.0 / (mm + 10.0);
-    const double hb = (1.0 - eta) * h_bar + eta * (target - accept_stat);
-    const double le = mu - __dsqrt_rn((double)mm) / 0.05 * hb;
-    const double mk = exmc_exp(-0.75 * exmc_log((double)mm));
-    const double leb = mk * le + (1.0 - mk) * log_epsilon_bar;
-    m = mm;
+    eta_ = 1.0 / (mm + 10.0);
+    one_m_eta_ = 1.0 - eta_;
+    sq_ = __dsqrt_rn((double)mm) / 0.05;
+    mk_ = exmc_exp(-0.75 * exmc_log((double)mm));
+    one_m_mk_ = 1.0 - mk_;
+  }
+  __device__ __forceinline__ void update(double accept_stat) {   // after prepare()
+    const double hb = one_m_eta_ * h_bar + eta_ * (target - accept_stat);
+    const double le = mu - sq_ * hb;
+    const double leb = mk_ * le + one_m_mk_ * log_epsilon_bar;
+    m = m + 1;
     h_bar = hb;
     log_epsilon = le;
     log_epsilon_bar = leb;
@@ -1477,16 +1494,18 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock)
     double wmean[DPL], wm2[DPL];
 #pragma unroll
     for (int k = 0; k < DPL; k++) wmean[k] = wm2[k] = 0.0;
+    int race_seen = 0;
     for (int i = 0; i < n_iter; i++) {
       // another replica of this chain has already finished: leave (the integrator wave is told
       // through the mailbox, at the barrier it is waiting at)
-      // (looked at every eighth transition: the load is an exposed L2 round trip of a lone wave)
-      if (P.race && (i & 7) == 0 &&
-          __hip_atomic_load(P.race, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+      if (race_seen != 0) {
         lost = true;
         if constexpr (kPipe) pipe.quit();
         break;
       }
+      // the flag is loaded here and looked at one transition later: the L2 round trip, which a
+      // lone wave would otherwise sit out, returns while the tree is built
+      if (P.race) race_seen = __hip_atomic_load(P.race, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (has_windows) {
         if (win < P.n_windows && i == P.win_start[win]) {
           if (win == 0) eps = exmc_exp(da.log_epsilon);   // sampler.ex:578
@@ -1502,8 +1521,9 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock)
       }
       // sampler.ex:709: depth cap 8 for absolute warmup index < 200, Phase II only
       const int cap = (in_window && i < 200) ? (P.max_depth < 8 ? P.max_depth : 8) : P.max_depth;
-      if constexpr (kPipe) nuts_run<M, G, LDSL>(mc, L, st, 1, exmc_exp(da.log_epsilon), cap, sink, &pipe);
-      else nuts_run<M, G, LDSL>(mc, L, st, 1, exmc_exp(da.log_epsilon), cap, sink);
+      auto idle = [&]() { da.prepare(); };
+      if constexpr (kPipe) nuts_run<M, G, LDSL>(mc, L, st, 1, exmc_exp(da.log_epsilon), cap, sink, &pipe, idle);
+      else nuts_run<M, G, LDSL>(mc, L, st, 1, exmc_exp(da.log_epsilon), cap, sink, (NoPipe*)nullptr, idle);
       divergences += diverged ? 1 : 0;
       da.update(accept);
       if (in_window) {
