@@ -11,6 +11,10 @@
 // after unrolling), so lag l0 + k multiplies c[j] with ring[(u - k) & 15]. Typical chains stop
 // inside the first block (Geyer's cut at a few lags), so a wavefront whose 64 series all do costs
 // two sweeps: the mean and one block.
+// On the device the series that are not finished after the first block (a percent or so: pairs of
+// pure noise stay positive with probability 1/2 each, so the longest run over 40 000 series is
+// ~15 pairs) are handed to a second kernel instead of holding their wavefront: ess_series(...,
+// max_blocks = 1, &partial) returns with `finished = false` and the state after lag 15.
 // Plain C++ (no HIP types): the device kernel calls it per lane, and tests/test_ess_series_host.py
 // compiles it for the host to check it against the CPU checker. Build with -ffp-contract=off.
 #pragma once
@@ -28,7 +32,16 @@ namespace exmc {
 constexpr int kEssLags = 16;        // lags per sweep (the register ring)
 constexpr int kEssLoadBlock = 32;   // loads in flight per stream (a multiple of kEssLags)
 
-EXMC_ESS_HD double ess_series(const double* x, size_t stride, int S) {
+// where a series stands after max_blocks blocks of lags without having met Geyer's cut
+struct EssPartial {
+  double mean, var, tau;
+  int next_lag;     // first lag not yet summed
+  bool finished;    // the returned value is the ESS
+};
+
+EXMC_ESS_HD double ess_series(const double* x, size_t stride, int S, int max_blocks = 1 << 30,
+                              EssPartial* part = nullptr) {
+  if (part) part->finished = true;
   if (S < 4) return S * 1.0;   // diagnostics.ex:46
   double sum = 0.0;
 #pragma unroll 32
@@ -38,6 +51,14 @@ EXMC_ESS_HD double ess_series(const double* x, size_t stride, int S) {
   double tau = -1.0, var = 0.0;
   bool done = false;
   for (int l0 = 0; !done; l0 += kEssLags) {
+    if (l0 / kEssLags >= max_blocks) {   // the caller continues from here (ess_tail_kernel)
+      part->mean = mean;
+      part->var = var;
+      part->tau = tau;
+      part->next_lag = l0;
+      part->finished = false;
+      return 0.0;
+    }
     double acc[kEssLags], ring[kEssLags];
 #pragma unroll
     for (int k = 0; k < kEssLags; k++) acc[k] = ring[k] = 0.0;

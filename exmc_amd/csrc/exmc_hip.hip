@@ -115,6 +115,7 @@ struct exmc_hip_model {
   DevBuf io;        // staging for host vectors
   DevBuf scores;    // ess_bulk: the rank-normalised copy of the caller's trace
   DevBuf dense;     // opts[:dense_mass]: cov[D][D], chol[D][D] while a dense mass is in force
+  DevBuf esswork;   // ESS: [count | EssTailItem...] of the series that go on to ess_tail_kernel
   bool dense_on = false;
   int state_chains = 0;
   // resident chains (exmc_hip_chains_init / _advance)
@@ -1036,7 +1037,7 @@ void exmc_hip_model_destroy(exmc_hip_model* m) {
   if (!m) return;
   (void)hipSetDevice(m->device);
   m->zig.release(); m->tuning.release(); m->state.release(); m->stack.release();
-  m->misc.release(); m->trace.release(); m->io.release(); m->data.release(); m->flat.release(); m->scores.release(); m->dense.release();
+  m->misc.release(); m->trace.release(); m->io.release(); m->data.release(); m->flat.release(); m->scores.release(); m->dense.release(); m->esswork.release();
   if (m->ev0) (void)hipEventDestroy(m->ev0);
   if (m->ev1) (void)hipEventDestroy(m->ev1);
   if (m->stream) (void)hipStreamDestroy(m->stream);
@@ -1549,6 +1550,39 @@ int exmc_hip_build_full_tree_host(int device, int C, int d, const double* q0, co
   return EXMC_OK;
 }
 
+namespace {
+// Diagnostics.ess of every series of a [S][D][C] device array: one lane per series up to lag 15,
+// then a wavefront per unfinished series (ess_tail_kernel needs the series in LDS; longer ones
+// stay with their lane to the end)
+int launch_ess(exmc_hip_model* m, const double* src, int n_draws, int d, int n_chains, double* ess_dev) {
+  const size_t series = (size_t)d * n_chains;
+  const dim3 grid((unsigned)((series + kEssBlock - 1) / kEssBlock));
+  const size_t lds = (size_t)n_draws * 8;
+  if (lds > 160 * 1024) {
+    hipLaunchKernelGGL(ess_series_kernel, grid, dim3(kEssBlock), 0, m->stream, src, n_draws, d, n_chains,
+                       ess_dev, (int*)nullptr, (EssTailItem*)nullptr);
+    HIP_TRY(hipGetLastError());
+    return EXMC_OK;
+  }
+  int rc = m->esswork.ensure(16 + series * sizeof(EssTailItem));
+  if (rc) return rc;
+  int* count = (int*)m->esswork.p;
+  EssTailItem* items = (EssTailItem*)((char*)m->esswork.p + 16);
+  HIP_TRY(hipMemsetAsync(count, 0, 16, m->stream));
+  hipLaunchKernelGGL(ess_series_kernel, grid, dim3(kEssBlock), 0, m->stream, src, n_draws, d, n_chains,
+                     ess_dev, count, items);
+  HIP_TRY(hipGetLastError());
+  if (lds > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute((const void*)ess_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds));
+  const unsigned tail_blocks = (unsigned)(series < 2048 ? series : 2048);
+  hipLaunchKernelGGL(ess_tail_kernel, dim3(tail_blocks), dim3(64), lds, m->stream, src, n_draws, d,
+                     n_chains, ess_dev, (const int*)count, (const EssTailItem*)items);
+  HIP_TRY(hipGetLastError());
+  return EXMC_OK;
+}
+}  // namespace
+
 int exmc_hip_ess(exmc_hip_model* m, const double* draws_dev, int n_draws, int d, int n_chains,
                  double* ess_dev) {
   if (check_model(m)) return EXMC_ERR_BADARG;
@@ -1556,10 +1590,8 @@ int exmc_hip_ess(exmc_hip_model* m, const double* draws_dev, int n_draws, int d,
     return fail(EXMC_ERR_BADARG, "bad arguments");
   HIP_TRY(hipSetDevice(m->device));
   HIP_TRY(hipEventRecord(m->ev0, m->stream));
-  const size_t series = (size_t)d * n_chains;
-  hipLaunchKernelGGL(ess_series_kernel, dim3((unsigned)((series + kEssBlock - 1) / kEssBlock)),
-                     dim3(kEssBlock), 0, m->stream, draws_dev, n_draws, d, n_chains, ess_dev);
-  HIP_TRY(hipGetLastError());
+  int rc = launch_ess(m, draws_dev, n_draws, d, n_chains, ess_dev);
+  if (rc) return rc;
   HIP_TRY(hipEventRecord(m->ev1, m->stream));
   return finish_timing(m);
 }
@@ -1582,10 +1614,9 @@ int exmc_hip_ess_bulk(exmc_hip_model* m, const double* draws_dev, int n_draws, i
   HIP_TRY(hipEventRecord(m->ev0, m->stream));
   hipLaunchKernelGGL(rank_scores_kernel, dim3((unsigned)series), dim3(256), lds, m->stream,
                      draws_dev, n_draws, d, n_chains, m->scores.as<double>());
-  hipLaunchKernelGGL(ess_series_kernel, dim3((unsigned)((series + kEssBlock - 1) / kEssBlock)),
-                     dim3(kEssBlock), 0, m->stream, (const double*)m->scores.as<double>(), n_draws, d,
-                     n_chains, ess_dev);
   HIP_TRY(hipGetLastError());
+  rc = launch_ess(m, (const double*)m->scores.as<double>(), n_draws, d, n_chains, ess_dev);
+  if (rc) return rc;
   HIP_TRY(hipEventRecord(m->ev1, m->stream));
   return finish_timing(m);
 }

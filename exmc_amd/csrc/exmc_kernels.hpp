@@ -241,12 +241,82 @@ __global__ void __launch_bounds__(kNutsBlock) find_eps_kernel(FindEpsParams P,
 // the per-series routine is exmc_ess.hpp.
 constexpr int kEssBlock = 64;
 
+// One lane per series for the mean and the first sixteen lags. A series that has not met Geyer's
+// cut by then goes on a worklist for ess_tail_kernel; `work` = [count | items...], null = finish
+// every series here.
+struct EssTailItem {
+  double mean, var, tau;
+  int series, next_lag;
+};
+
 __global__ void __launch_bounds__(kEssBlock)
-ess_series_kernel(const double* draws, int S, int D, int C, double* ess_out) {
+ess_series_kernel(const double* draws, int S, int D, int C, double* ess_out, int* work_count,
+                  EssTailItem* work) {
   const size_t series = (size_t)blockIdx.x * kEssBlock + threadIdx.x;   // dim * C + chain
   const size_t stride = (size_t)D * C;
   if (series >= stride) return;
-  ess_out[series] = ess_series(draws + series, stride, S);
+  if (work == nullptr) {
+    ess_out[series] = ess_series(draws + series, stride, S);
+    return;
+  }
+  EssPartial part;
+  const double e = ess_series(draws + series, stride, S, 1, &part);
+  if (part.finished) {
+    ess_out[series] = e;
+  } else {
+    const int slot = atomicAdd(work_count, 1);
+    work[slot] = EssTailItem{part.mean, part.var, part.tau, (int)series, part.next_lag};
+  }
+}
+
+// The rest of a series' lags, a wavefront per series: the centred series in LDS, lane k sums lag
+// l0 + k left to right over i exactly as ess_series does (`acc + c[i] * c[i + lag]`,
+// diagnostics.ex:137-141), 64 lags per sweep; then Geyer's pairs in order (diagnostics.ex:147-167).
+__global__ void __launch_bounds__(64)
+ess_tail_kernel(const double* draws, int S, int D, int C, double* ess_out, const int* work_count,
+                const EssTailItem* work) {
+  extern __shared__ double cen[];   // S centred values
+  const int lane = threadIdx.x;
+  const size_t stride = (size_t)D * C;
+  const int count = *work_count;
+  const int max_k = (S - 1) / 2;
+  for (int item = blockIdx.x; item < count; item += gridDim.x) {
+    const EssTailItem it = work[item];
+    const double* x = draws + it.series;
+    __syncthreads();   // the previous item's readers are done with cen[]
+    for (int i = lane; i < S; i += 64) cen[i] = x[(size_t)i * stride] - it.mean;
+    __syncthreads();
+    double tau = it.tau;
+    bool done = false;
+    for (int l0 = it.next_lag; !done; l0 += 64) {
+      const int lag = l0 + lane;
+      const int n = S - lag;   // terms of this lane's sum; <= 0: the empty sum 0.0
+      double acc = 0.0;
+      for (int i = 0; i < S - l0; i++) {   // the longest sum of the sweep (lane 0)
+        const double prod = cen[i] * cen[(i + lag < S) ? (i + lag) : (S - 1)];
+        acc = (i < n) ? (acc + prod) : acc;
+      }
+      // pair kk of this sweep: lags l0 + 2 kk and l0 + 2 kk + 1, on lanes 2 kk and 2 kk + 1
+      const double r = acc / it.var;
+      const double rn = __shfl_down(r, 1, 64);
+      const double pair = r + rn;   // meaningful on even lanes
+#pragma unroll 1
+      for (int kk = 0; kk < 32 && !done; kk++) {
+        const int k = l0 / 2 + kk;
+        if (k > max_k) {
+          done = true;
+        } else {
+          const double pk = __shfl(pair, 2 * kk, 64);
+          if (pk > 0) tau += 2 * pk;
+          else done = true;
+        }
+      }
+    }
+    if (lane == 0) {
+      const double t = tau > 1.0 ? tau : 1.0;   // max(tau, 1.0), diagnostics.ex:165
+      ess_out[it.series] = S / t;
+    }
+  }
 }
 
 // Diagnostics.ess_bulk (diagnostics.ex:60-72, 186-219), first half: every series is replaced by
