@@ -229,6 +229,9 @@ def main():
     ap.add_argument("--lanes", type=int, default=0)
     ap.add_argument("--adapt", type=int, default=1000, help="NUTS adaptation iterations")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--dense-mass", action="store_true",
+                    help="opts[:dense_mass]: dense adaptation windows and a dense mass matrix while sampling "
+                         "(layouts that carry it; not the default protocol, the CPU leg is skipped)")
     ap.add_argument("--no-multi-step", action="store_true",
                     help="skip the batched-leapfrog roofline leg (development builds without that layout)")
     ap.add_argument("--gather-traces", action="store_true",
@@ -271,6 +274,9 @@ def main():
     lanes = args.lanes or comp.default_lanes
     opts = sampler._merge_opts(dict(num_warmup=args.adapt, num_samples=S, seed=42,
                                     lanes_per_chain=lanes))
+    if args.dense_mass:
+        opts["dense_mass"] = True
+        args.no_cpu = True
     init = spec.default_init
     L = comp.L
 
@@ -382,8 +388,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%s d=%d, %d chains/GPU (%d total), %d draws/chain (%d steps of %d "
                                    "draws) after one shared %d-iteration warmup, max_tree_depth 10, "
-                                   "target_accept 0.8"
-                                   % (args.model, d, Cper, Ctot, S, K, B, args.adapt),
+                                   "target_accept 0.8%s"
+                                   % (args.model, d, Cper, Ctot, S, K, B, args.adapt,
+                                      ", dense mass matrix" if args.dense_mass else ""),
                        "draws_per_step": B, "draws_per_chain": S,
                        "lanes_per_chain": lanes, "seed": 42},
             "ess_per_s": ess_min / total_s,

@@ -232,6 +232,54 @@ __device__ __forceinline__ void row_seqsum(double& a0, double& a1, double& a2, d
   EXMC_SEQSUM_ASM(EXMC_SEQ3, [a0] "+v"(a0) EXMC_COMMA [a1] "+v"(a1) EXMC_COMMA [a2] "+v"(a2),
                   [v0] "v"(v0) EXMC_COMMA [v1] "v"(v1) EXMC_COMMA [v2] "v"(v2) EXMC_COMMA [one] "v"(one))
 }
+// ---- a dense D x D matrix against a vector held one entry per lane (row layout of a 16-lane
+// chain group): lane i keeps row i of the matrix in registers and
+//     acc = fma(x[lane j], c[j], acc)   for j = 0 .. NL-1, from 0.0
+// is the i-th entry of the product with the fma chain in ascending j (dense_times' order) ----
+#define EXMC_MV1(I) \
+  "v_fmac_f64_dpp %[acc], %[x], %[c" #I "] row_newbcast:" #I " row_mask:0xf bank_mask:0xf\n\t"
+template <int NL>
+__device__ __forceinline__ double row_matvec(double x, const double (&c)[NL]) {
+  static_assert(NL >= 1 && NL <= 12, "lanes of one DPP row");
+  double acc = 0.0;
+#define EXMC_MV_C(I) [c##I] "v"(c[(I) < NL ? (I) : 0])
+  EXMC_SEQSUM_ASM(EXMC_MV1, [acc] "+v"(acc),
+                  [x] "v"(x) EXMC_COMMA EXMC_MV_C(0) EXMC_COMMA EXMC_MV_C(1) EXMC_COMMA EXMC_MV_C(2) EXMC_COMMA
+                  EXMC_MV_C(3) EXMC_COMMA EXMC_MV_C(4) EXMC_COMMA EXMC_MV_C(5) EXMC_COMMA EXMC_MV_C(6) EXMC_COMMA
+                  EXMC_MV_C(7) EXMC_COMMA EXMC_MV_C(8) EXMC_COMMA EXMC_MV_C(9) EXMC_COMMA EXMC_MV_C(10) EXMC_COMMA
+                  EXMC_MV_C(11))
+#undef EXMC_MV_C
+  return acc;
+}
+// m[j] = fma(x[lane j], c, m[j]) for j = 0 .. NL-1: lane i's row of the rank-one update c x^T
+#define EXMC_OUTER1(I) \
+  "v_fmac_f64_dpp %[m" #I "], %[x], %[c] row_newbcast:" #I " row_mask:0xf bank_mask:0xf\n\t"
+template <int NL>
+__device__ __forceinline__ void row_outer_acc(double (&m)[NL], double x, double c) {
+  static_assert(NL >= 1 && NL <= 12, "lanes of one DPP row");
+  double pad[12];
+#pragma unroll
+  for (int j = 0; j < 12; j++) pad[j] = (j < NL) ? m[j < NL ? j : 0] : 0.0;
+#define EXMC_OUTER_M(I) [m##I] "+v"(pad[I])
+  EXMC_SEQSUM_ASM(EXMC_OUTER1,
+                  EXMC_OUTER_M(0) EXMC_COMMA EXMC_OUTER_M(1) EXMC_COMMA EXMC_OUTER_M(2) EXMC_COMMA EXMC_OUTER_M(3) EXMC_COMMA
+                  EXMC_OUTER_M(4) EXMC_COMMA EXMC_OUTER_M(5) EXMC_COMMA EXMC_OUTER_M(6) EXMC_COMMA EXMC_OUTER_M(7) EXMC_COMMA
+                  EXMC_OUTER_M(8) EXMC_COMMA EXMC_OUTER_M(9) EXMC_COMMA EXMC_OUTER_M(10) EXMC_COMMA EXMC_OUTER_M(11),
+                  [x] "v"(x) EXMC_COMMA [c] "v"(c))
+#undef EXMC_OUTER_M
+#pragma unroll
+  for (int j = 0; j < NL; j++) m[j] = pad[j];
+}
+// x[lane J] in every lane of the row (one fmac from 0.0: fma(x_J, 1, 0) = x_J)
+template <int J>
+__device__ __forceinline__ double row_bcast_f64(double x) {
+  double acc = 0.0;
+  const double one = seq_one();
+  __asm__("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+          : "+v"(acc) : "v"(x), "v"(one), "n"(J));
+  return acc;
+}
+
 template <int NL>
 __device__ __forceinline__ void row_seqsum6(double (&a)[6], const double (&v)[6]) {
   const double one = seq_one();
@@ -605,6 +653,49 @@ __device__ __forceinline__ void dense_momentum(const double* chol, const double 
     for (int j = D - 1; j > i; j--) acc = __builtin_fma(-chol[j * D + i], p[j], acc);
     p[i] = acc / chol[i * D + i];
   }
+}
+
+// ---- the same four operations for the row layout (16 lanes, one dimension per lane, D <= 12):
+// lane i holds row i of M^-1 (cr), the negated column i of its Cholesky factor below the diagonal
+// (ncc[j] = -L[j][i]) and L[i][i]. Same fma chains and sums as above, in the same order. ----
+template <int D>
+struct RowDense {
+  double cr[D], ncc[D], diag;
+};
+
+template <int D>
+__device__ __forceinline__ double kinetic_energy_rowdense(const RowDense<D>& m, double p) {
+  const double mp = row_matvec<D>(p, m.cr);
+  double acc = 0.0;
+  row_seqsum<D>(acc, p * mp);
+  return 0.5 * acc;
+}
+
+template <int D>
+__device__ __forceinline__ bool uturn_rowdense(const RowDense<D>& m, double rho, double pa, double pb) {
+  const double v = row_matvec<D>(rho, m.cr);
+  double sa = 0.0, sb = 0.0;
+  row_seqsum<D>(sa, sb, v * pa, v * pb);
+  return (sa < 0.0) || (sb < 0.0);
+}
+
+// solve L^T p = z by back substitution: at step j lane j's accumulator is final, its quotient by
+// L[j][j] is p_j, and every lane takes fma(-L[j][i], p_j, acc) (only the lanes i < j still count)
+template <int D, int J = D - 1>
+__device__ __forceinline__ void rowdense_backsub(const RowDense<D>& m, int l, double& acc, double& p) {
+  const double pj = acc / m.diag;
+  p = (l == J) ? pj : p;
+  if constexpr (J > 0) {
+    const double pb = row_bcast_f64<J>(pj);
+    acc = __builtin_fma(m.ncc[J], pb, acc);
+    rowdense_backsub<D, J - 1>(m, l, acc, p);
+  }
+}
+template <int D>
+__device__ __forceinline__ double momentum_rowdense(const RowDense<D>& m, int l, double z) {
+  double acc = z, p = 0.0;
+  rowdense_backsub<D>(m, l, acc, p);
+  return p;
 }
 
 }  // namespace exmc

@@ -245,6 +245,22 @@ int dispatch(exmc_hip_model* m, int lanes, F&& f) {
   return fail(EXMC_ERR_UNSUPPORTED, "model kind / lanes_per_chain combination not compiled in");
 }
 
+// the layouts that carry a dense mass matrix: a whole chain in one lane, or eight_schools' row
+// layout (16 lanes, one dimension per lane) through RowDenseModel
+bool dense_layout_ok(const exmc_hip_model* m, int lanes) {
+  return lanes == 1 || (m->kind == EXMC_MODEL_EIGHT_SCHOOLS && lanes == 16);
+}
+
+// dispatch for the launches whose mass-dependent operations depend on the dense mode
+template <class F>
+int dispatch_mass(exmc_hip_model* m, int lanes, bool dense, F&& f) {
+#if !defined(EXMC_ONLY_CUSTOM) && !defined(EXMC_DEV_ONLY)
+  if (dense && m->kind == EXMC_MODEL_EIGHT_SCHOOLS && lanes == 16)
+    return f(Tag<RowDenseModel<EightSchools<16>>, 16, 6>{}, m->es);
+#endif
+  return dispatch(m, lanes, f);
+}
+
 int default_lanes(int kind) {
   switch (kind) {
     case EXMC_MODEL_EIGHT_SCHOOLS: return 16;
@@ -353,7 +369,7 @@ int launch_init(exmc_hip_model* m, int lanes, int C, int chain_lo, uint64_t seed
 int launch_nuts(exmc_hip_model* m, int lanes, int C, int n_draws, int draw_offset, double eps,
                 int max_depth, TraceDev tr, bool timed) {
   if (max_depth < 1 || max_depth > kMaxLevels) return fail(EXMC_ERR_BADARG, "max_tree_depth out of range");
-  return dispatch(m, lanes, [&](auto tag, const auto& mc) {
+  return dispatch_mass(m, lanes, m->dense_on, [&](auto tag, const auto& mc) {
     using T = decltype(tag);
     using M = typename T::M;
     dim3 grid = grid_for(C, T::G, kNutsBlock);
@@ -378,7 +394,8 @@ int launch_nuts(exmc_hip_model* m, int lanes, int C, int n_draws, int draw_offse
     P.nor_r = EXMC_NOR_R;
     P.flat = flat_order(m);
     if (m->dense_on) {
-      if (T::G != 1) return fail(EXMC_ERR_UNSUPPORTED, "a dense mass matrix needs lanes_per_chain = 1");
+      if (T::G != 1 && !M::kRowDense)
+        return fail(EXMC_ERR_UNSUPPORTED, "a dense mass matrix needs lanes_per_chain = 1 (eight_schools: 1 or 16)");
       P.dm.cov = m->dense.as<double>();
       P.dm.chol = m->dense.as<double>() + (size_t)m->d * m->d;
     }
@@ -735,7 +752,7 @@ int run_warmup_device(exmc_hip_model* m, int lanes, exmc_hip_opts o, exmc_hip_tu
   int rc = m->io.ensure(n_out * 8);
   if (rc) return rc;
   P.out = m->io.as<double>();
-  rc = dispatch(m, lanes, [&](auto tag, const auto& mc) {
+  rc = dispatch_mass(m, lanes, dense, [&](auto tag, const auto& mc) {
     using T = decltype(tag);
     using M = typename T::M;
     constexpr int kSpill = (kMaxLevels > T::LDSL) ? (kMaxLevels - T::LDSL) : 1;
@@ -746,7 +763,8 @@ int run_warmup_device(exmc_hip_model* m, int lanes, exmc_hip_opts o, exmc_hip_tu
     const char* re = std::getenv("EXMC_HIP_WARMUP_REPLICAS");
     int reps = re ? std::atoi(re) : 32;
     reps = reps < 1 ? 1 : (reps > 256 ? 256 : reps);
-    if (dense && T::G != 1) return fail(EXMC_ERR_UNSUPPORTED, "a dense mass matrix needs lanes_per_chain = 1");
+    if (dense && T::G != 1 && !M::kRowDense)
+      return fail(EXMC_ERR_UNSUPPORTED, "a dense mass matrix needs lanes_per_chain = 1 (eight_schools: 1 or 16)");
     P.stack_stride = (size_t)kSpill * nuts_nslot<M>() * kNutsBlock;
     int r2 = m->stack.ensure(P.stack_stride * 8 * (size_t)reps);
     if (r2) return r2;
@@ -1276,7 +1294,8 @@ int exmc_hip_warmup_dense(exmc_hip_model* m, const double* init_q, exmc_hip_opts
   if (!tuning || !cov || !chol || o.num_warmup < 0) return fail(EXMC_ERR_BADARG, "bad arguments");
   HIP_TRY(hipSetDevice(m->device));
   const int lanes = resolve_lanes(m, o.lanes_per_chain);
-  if (lanes != 1) return fail(EXMC_ERR_UNSUPPORTED, "a dense mass matrix needs lanes_per_chain = 1");
+  if (!dense_layout_ok(m, lanes))
+    return fail(EXMC_ERR_UNSUPPORTED, "a dense mass matrix needs lanes_per_chain = 1 (eight_schools: 1 or 16)");
   m->dense_on = false;   // Phase I runs on the identity diagonal (sampler.ex:560-575)
   int rc = ensure_state(m, 1);
   if (rc) return rc;
@@ -1409,7 +1428,8 @@ int exmc_hip_sample_dense_host(exmc_hip_model* m, const double* init_q, exmc_hip
   if (check_model(m)) return EXMC_ERR_BADARG;
   if (o.num_samples < 1) return fail(EXMC_ERR_BADARG, "num_samples must be >= 1");
   exmc_hip_tuning tun;
-  o.lanes_per_chain = 1;
+  const int lanes = dense_layout_ok(m, resolve_lanes(m, o.lanes_per_chain)) ? resolve_lanes(m, o.lanes_per_chain) : 1;
+  o.lanes_per_chain = lanes;
   int rc = exmc_hip_warmup_dense(m, init_q, o, &tun, cov, chol);   // leaves chain 0's state in m->state
   if (rc) return rc;
   rc = upload_tuning(m, tun.inv_mass);
@@ -1419,7 +1439,7 @@ int exmc_hip_sample_dense_host(exmc_hip_model* m, const double* init_q, exmc_hip
   if (rc) return rc;
   rc = reset_counters(m);
   if (rc) return rc;
-  rc = launch_nuts(m, 1, 1, o.num_samples, 0, tun.epsilon, o.max_tree_depth, trace_view(m->trace.p, L), true);
+  rc = launch_nuts(m, lanes, 1, o.num_samples, 0, tun.epsilon, o.max_tree_depth, trace_view(m->trace.p, L), true);
   if (rc) return rc;
   rc = finish_timing(m);
   if (rc) return rc;

@@ -32,6 +32,8 @@ struct ModelDefaults {
   // tree bookkeeping is a real share of a leaf pass: sv 900 -> 695 ms, radon 194 -> 169 ms,
   // eight_schools ~20 -> ~17 ms; not for logistic, whose pass is nearly all model (158 -> 162 ms)
   static constexpr bool kPipeWarmup = true;
+  // opts[:dense_mass] in the row layout (16 lanes, one dimension per lane): see RowDenseModel
+  static constexpr bool kRowDense = false;
   // Resident waves per SIMD the sampling kernel's register allocation must allow (the second
   // launch bound). 2 caps the kernel at 256 vector registers: what the allocator would have kept
   // in accumulator registers goes to scratch instead. Worth it when the configuration launches
@@ -930,6 +932,16 @@ struct Radon : ModelDefaults {
     }
     return group_sum_slots<G, DPL>(T, valid, l, s[0]);
   }
+};
+
+// The same model with a dense mass matrix in the row layout: a compile-time switch of the
+// mass-dependent operations of nuts_run (exmc_nuts.hpp mass_*), so the diagonal kernels carry no
+// trace of the mode. Valid for 16-lane groups that hold one dimension per lane with D <= 12.
+template <class M>
+struct RowDenseModel : M {
+  static constexpr bool kRowDense = true;
+  static constexpr bool kPipeWarmup = false;   // the dense warmup is the one-wave form
+  static_assert(M::DPL == 1 && M::D <= 12, "row layout: one dimension per lane, D <= 12");
 };
 
 }  // namespace exmc

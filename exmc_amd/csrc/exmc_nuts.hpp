@@ -188,7 +188,9 @@ struct NutsLane {
   bool valid[DPL];
   int rank[DPL];     // flat (draw) position of this lane's dimensions; M::D for slots past D
   const int32_t* perm;   // flat position -> kernel dimension, null = identity
-  DenseMass dm;          // opts[:dense_mass] (one-lane-per-chain layouts only); cov == null: diagonal
+  DenseMass dm;          // opts[:dense_mass], one-lane-per-chain layouts; cov == null: diagonal
+  RowDense<M::kRowDense ? M::D : 1> rd;   // opts[:dense_mass], row layout (M::kRowDense): this lane's
+                                          // row of M^-1 and column of its Cholesky factor
   int l;
   double* lstk;      // this lane's column of the LDS stack
   double* gstk;      // this lane's column of the global spill stack
@@ -202,6 +204,7 @@ struct NutsLane {
 // wave-uniform choice) for the layouts that keep a whole chain in one lane
 template <class M, int G>
 __device__ __forceinline__ double mass_ke(const NutsLane<M, G>& L, const double (&p)[M::DPL]) {
+  if constexpr (M::kRowDense) return kinetic_energy_rowdense<M::D>(L.rd, p[0]);
   if constexpr (G == 1) {
     if (L.dm.cov) return kinetic_energy_dense<M::D>(L.dm.cov, p);
   }
@@ -211,6 +214,10 @@ __device__ __forceinline__ double mass_ke(const NutsLane<M, G>& L, const double 
 template <class M, int G>
 __device__ __forceinline__ void mass_drift(const NutsLane<M, G>& L, double eps, const double (&ph)[M::DPL],
                                            double (&q)[M::DPL]) {
+  if constexpr (M::kRowDense) {
+    q[0] = q[0] + eps * row_matvec<M::D>(ph[0], L.rd.cr);
+    return;
+  }
   if constexpr (G == 1) {
     if (L.dm.cov) {
       double mp[M::DPL];
@@ -226,6 +233,7 @@ __device__ __forceinline__ void mass_drift(const NutsLane<M, G>& L, double eps, 
 template <class M, int G>
 __device__ __forceinline__ bool mass_uturn(const NutsLane<M, G>& L, const double (&rho)[M::DPL],
                                            const double (&pa)[M::DPL], const double (&pb)[M::DPL]) {
+  if constexpr (M::kRowDense) return uturn_rowdense<M::D>(L.rd, rho[0], pa[0], pb[0]);
   if constexpr (G == 1) {
     if (L.dm.cov) return uturn_dense<M::D>(L.dm.cov, rho, pa, pb);
   }
@@ -238,6 +246,13 @@ __device__ __forceinline__ void mass_uturn3(const NutsLane<M, G>& L, const doubl
                                             const double (&b2)[M::DPL], const double (&r3)[M::DPL],
                                             const double (&a3)[M::DPL], const double (&b3)[M::DPL],
                                             bool& c1, bool& c23) {
+  if constexpr (M::kRowDense) {
+    c1 = uturn_rowdense<M::D>(L.rd, r1[0], a1[0], b1[0]);
+    const bool c2 = uturn_rowdense<M::D>(L.rd, r2[0], a2[0], b2[0]);
+    const bool c3 = uturn_rowdense<M::D>(L.rd, r3[0], a3[0], b3[0]);
+    c23 = c2 || c3;
+    return;
+  }
   if constexpr (G == 1) {
     if (L.dm.cov) {
       c1 = uturn_dense<M::D>(L.dm.cov, r1, a1, b1);
@@ -401,6 +416,10 @@ __device__ __forceinline__ void draw_momentum_variates(const NutsLane<M, G>& L, 
 template <class M, int G>
 __device__ __forceinline__ void momentum_from_variates(const NutsLane<M, G>& L, const double (&z)[M::DPL],
                                                        double (&p)[M::DPL]) {
+  if constexpr (M::kRowDense) {
+    p[0] = momentum_rowdense<M::D>(L.rd, L.l, z[0]);
+    return;
+  }
   if constexpr (G == 1) {
     if (L.dm.chol) {
       dense_momentum<M::D>(L.dm.chol, z, p);
@@ -1092,6 +1111,21 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
   EXMC_PROF_FLUSH
 }
 
+// this lane's row of cov and (negated, below the diagonal) column of chol, both row-major [D][D]
+// with `stride` doubles between consecutive entries (1: global arrays); null = identity
+template <class M, int G>
+__device__ __forceinline__ void rowdense_load(NutsLane<M, G>& L, const double* cov, const double* chol,
+                                              int stride) {
+  constexpr int D = M::D;
+  const int i = L.l < D ? L.l : 0;   // lanes past D carry no dimension; any row keeps them finite
+#pragma unroll
+  for (int j = 0; j < (M::kRowDense ? D : 1); j++) {
+    L.rd.cr[j] = cov ? cov[(size_t)(i * D + j) * stride] : ((i == j) ? 1.0 : 0.0);
+    L.rd.ncc[j] = (chol && j > i) ? -chol[(size_t)(j * D + i) * stride] : 0.0;
+  }
+  L.rd.diag = chol ? chol[(size_t)(i * D + i) * stride] : 1.0;
+}
+
 // fill the per-lane constants; inv_mass / sqrt_inv_mass may be null (identity mass)
 template <class M, int G, int LDSL>
 __device__ __forceinline__ void lane_setup(NutsLane<M, G>& L, const typename M::Consts& mc,
@@ -1121,6 +1155,7 @@ __device__ __forceinline__ void lane_setup(NutsLane<M, G>& L, const typename M::
   }
   L.perm = flat.perm;
   L.dm = dm;
+  if constexpr (M::kRowDense) rowdense_load<M, G>(L, dm.cov, dm.chol, 1);
 }
 
 template <class M, int G>
@@ -1397,6 +1432,38 @@ struct DualAvgDev {
   }
 };
 
+// finalize_dense (mass_matrix.ex:105-140) by one lane on [D][D] arrays: cov = m2 / (n - 1), shrunk
+// toward its floored diagonal; lower Cholesky factor row by row, sums with fma in ascending k.
+// Fewer than 3 samples: identity. Returns false if a pivot is not positive.
+template <int D>
+__device__ __forceinline__ bool dense_finalize_serial(const double* m2, double* cov, double* chol, int wn) {
+  bool ok = true;
+  if (wn < 3) {
+    for (int e = 0; e < D * D; e++) cov[e] = chol[e] = ((e / D) == (e % D)) ? 1.0 : 0.0;
+    return ok;
+  }
+  const double alpha = 5.0 / (wn + 5.0);
+  for (int e = 0; e < D * D; e++) cov[e] = m2[e] / ((double)(wn - 1) * 1.0);
+  for (int a = 0; a < D; a++)
+    for (int b = 0; b < D; b++) {
+      const double dg = (a == b) ? fmax(cov[a * D + a], 1.0e-6) : 0.0;
+      cov[a * D + b] = (1.0 - alpha) * cov[a * D + b] + alpha * dg;
+    }
+  for (int e = 0; e < D * D; e++) chol[e] = 0.0;
+  for (int a = 0; a < D; a++)
+    for (int b = 0; b <= a; b++) {
+      double acc = cov[a * D + b];
+      for (int k = 0; k < b; k++) acc = __builtin_fma(-chol[a * D + k], chol[b * D + k], acc);
+      if (a == b) {
+        ok = ok && (acc > 0.0);
+        chol[a * D + a] = __dsqrt_rn(acc);
+      } else {
+        chol[a * D + b] = acc / chol[b * D + b];
+      }
+    }
+  return ok;
+}
+
 // kPipe: two waves, the second one integrating one leaf ahead of the tree (see PipeBox above).
 template <class M, int G, int LDSL, bool kPipe = false>
 __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock)
@@ -1453,12 +1520,19 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock)
   double* dn_cov = nullptr;
   double* dn_chol = nullptr;
   bool dense_ok = true;
-  if constexpr (G == 1 && !kPipe) {
+  // where the dense mode is built: a whole chain in one lane, or the row layout (M::kRowDense: the
+  // window's co-moment rows in registers m2r, one row per lane; LDS holds what finalize exchanges)
+  constexpr bool kDenseHere = (G == 1 || M::kRowDense) && !kPipe;
+  constexpr int kRowN = M::kRowDense ? D : 1;
+  double m2r[kRowN];
+#pragma unroll
+  for (int j = 0; j < kRowN; j++) m2r[j] = 0.0;
+  if constexpr (kDenseHere) {
     if (P.dense) {
       dn_m2 = lds + lds_used;
       dn_cov = dn_m2 + D * D;
       dn_chol = dn_cov + D * D;
-      for (int i = 0; i < D * D; i++) {
+      for (int i = 0; i < D * D; i++) {   // every active lane writes the same values
         dn_m2[i] = 0.0;
         dn_cov[i] = dn_chol[i] = ((i / D) == (i % D)) ? 1.0 : 0.0;
       }
@@ -1512,8 +1586,14 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock)
           wn = 0;
 #pragma unroll
           for (int k = 0; k < DPL; k++) wmean[k] = wm2[k] = 0.0;
-          if (dn_m2)
-            for (int e = 0; e < D * D; e++) dn_m2[e] = 0.0;
+          if (dn_m2) {
+            if constexpr (M::kRowDense) {
+#pragma unroll
+              for (int j = 0; j < kRowN; j++) m2r[j] = 0.0;
+            } else {
+              for (int e = 0; e < D * D; e++) dn_m2[e] = 0.0;
+            }
+          }
           da.init(eps, P.target_accept);
           in_window = true;
         }
@@ -1541,12 +1621,17 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock)
             dl[k] = delta;
             dl2[k] = d2;
           }
-          if constexpr (G == 1 && !kPipe) {
+          if constexpr (kDenseHere) {
             if (dn_m2) {
+              if constexpr (M::kRowDense) {
+                // lane a's row: m2[a][b] = fma(delta_a, delta2_b, m2[a][b]), delta2_b from lane b
+                row_outer_acc<kRowN>(m2r, dl2[0], dl[0]);
+              } else {
 #pragma unroll
-              for (int a = 0; a < D; a++)
+                for (int a = 0; a < D; a++)
 #pragma unroll
-                for (int b = 0; b < D; b++) dn_m2[a * D + b] = __builtin_fma(dl[a], dl2[b], dn_m2[a * D + b]);
+                  for (int b = 0; b < D; b++) dn_m2[a * D + b] = __builtin_fma(dl[a], dl2[b], dn_m2[a * D + b]);
+              }
             }
           }
           wn = nn;
@@ -1554,38 +1639,33 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock)
         if (i + 1 == P.win_end[win]) {
           // mass_matrix.ex:77-97, then re-search the step size (sampler.ex:747-756)
           bool dense_done = false;
-          if constexpr (G == 1 && !kPipe) {
+          if constexpr (kDenseHere) {
             if (dn_m2) {
-              // finalize_dense (mass_matrix.ex:105-140): cov = m2 / (n - 1), shrunk toward its floored
-              // diagonal; lower Cholesky factor row by row, sums with fma in ascending k
-              L.dm = DenseMass{};
-              if (wn < 3) {
-                for (int e = 0; e < D * D; e++) dn_cov[e] = dn_chol[e] = ((e / D) == (e % D)) ? 1.0 : 0.0;
-              } else {
-                const double alpha = 5.0 / (wn + 5.0);
-                for (int e = 0; e < D * D; e++) dn_cov[e] = dn_m2[e] / ((double)(wn - 1) * 1.0);
-                for (int a = 0; a < D; a++)
-                  for (int b = 0; b < D; b++) {
-                    const double dg = (a == b) ? fmax(dn_cov[a * D + a], 1.0e-6) : 0.0;
-                    dn_cov[a * D + b] = (1.0 - alpha) * dn_cov[a * D + b] + alpha * dg;
-                  }
-                for (int e = 0; e < D * D; e++) dn_chol[e] = 0.0;
-                for (int a = 0; a < D; a++)
-                  for (int b = 0; b <= a; b++) {
-                    double acc = dn_cov[a * D + b];
-                    for (int k = 0; k < b; k++) acc = __builtin_fma(-dn_chol[a * D + k], dn_chol[b * D + k], acc);
-                    if (a == b) {
-                      dense_ok = dense_ok && (acc > 0.0);
-                      dn_chol[a * D + a] = __dsqrt_rn(acc);
-                    } else {
-                      dn_chol[a * D + b] = acc / dn_chol[b * D + b];
-                    }
-                  }
-              }
+              if constexpr (M::kRowDense) {
+                // the rows go to LDS, lane 0 of the group finalizes, every lane takes back its row
+                // of the covariance and its column of the factor
+                if (L.l < D) {
 #pragma unroll
-              for (int k = 0; k < DPL; k++) L.im[k] = dn_cov[k * D + k];   // inv_mass_diag_out
-              L.dm.cov = dn_cov;
-              L.dm.chol = dn_chol;
+                  for (int j = 0; j < kRowN; j++) dn_m2[L.l * D + j] = m2r[j];
+                }
+                __syncthreads();
+                if (L.l == 0) {
+                  const bool ok = dense_finalize_serial<D>(dn_m2, dn_cov, dn_chol, wn);
+                  dn_m2[0] = ok ? 1.0 : 0.0;
+                }
+                __syncthreads();
+                dense_ok = dense_ok && (dn_m2[0] != 0.0);
+                rowdense_load<M, G>(L, dn_cov, dn_chol, 1);
+                L.im[0] = (L.l < D) ? dn_cov[L.l * D + L.l] : 1.0;   // inv_mass_diag_out
+                __syncthreads();   // dn_m2[0] is read before the next window's rows overwrite it
+              } else {
+                L.dm = DenseMass{};
+                dense_ok = dense_finalize_serial<D>(dn_m2, dn_cov, dn_chol, wn) && dense_ok;
+#pragma unroll
+                for (int k = 0; k < DPL; k++) L.im[k] = dn_cov[k * D + k];   // inv_mass_diag_out
+                L.dm.cov = dn_cov;
+                L.dm.chol = dn_chol;
+              }
               dense_done = true;
             }
           }
@@ -1647,8 +1727,8 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock)
     const int i = L.l + k * G;
     if (i < D) P.out[3 + i] = L.im[k];
   }
-  if constexpr (G == 1 && !kPipe) {
-    if (dn_m2) {
+  if constexpr (kDenseHere) {
+    if (dn_m2 && L.l == 0) {
       for (int e = 0; e < D * D; e++) {
         P.out[3 + D + e] = dn_cov[e];
         P.out[3 + D + D * D + e] = dn_chol[e];

@@ -166,7 +166,8 @@ def sample_compiled(compiled, init_values=None, opts=None):
     if o.get("dense_mass"):
         d = spec.d
         cov, chol = np.zeros((d, d)), np.zeros((d, d))
-        compiled.check(L.exmc_hip_sample_dense_host(compiled.h, None if iq is None else _dp(iq), _c_opts(o, lanes=1),
+        compiled.check(L.exmc_hip_sample_dense_host(compiled.h, None if iq is None else _dp(iq),
+                                                    _c_opts(o, lanes=o.get("lanes_per_chain") or 1),
                                                     tr, C.byref(tun), _dp(cov), _dp(chol), C.byref(div)))
         trace = _build_trace(spec, t["draws"][0])
         stats = dict(step_size=tun.epsilon, inv_mass_diag=np.array(tun.inv_mass[:d]), chol_cov=chol, cov=cov,
@@ -245,7 +246,7 @@ def sample_compiled_tuned(compiled, tuning, init_values=None, opts=None, num_cha
     tun = _tuning_struct(tuning, spec.d)
     _apply_mass(compiled, tuning)
     if tuning.get("chol_cov") is not None and not o.get("lanes_per_chain"):
-        o["lanes_per_chain"] = 1          # the dense path exists for the one-lane-per-chain layouts
+        o["lanes_per_chain"] = 1          # the layout every model kind carries a dense mass in
     lf = C.c_int64()
     dv = C.c_int32()
     iq = _init_q(spec, init_values)

@@ -479,9 +479,11 @@ def test_warmup_replicas_race_to_the_same_result(es, hip, monkeypatch, pipe):
         assert np.array_equal(o[2], out[0][2]) and o[3] == out[0][3]
 
 
-@pytest.mark.parametrize("name", ["eight_schools", "simple"])
-def test_dense_mass_bit_exact(hip, name):
-    """opts[:dense_mass] on the one-lane-per-chain layouts: dense Welford windows of base
+@pytest.mark.parametrize("name,lanes", [("eight_schools", 1), ("eight_schools", 16), ("simple", 1)])
+def test_dense_mass_bit_exact(hip, name, lanes):
+    """opts[:dense_mass] on the one-lane-per-chain layouts and on eight_schools' row layout (16
+    lanes, one dimension per lane: matrix rows in registers, products by v_fmac_f64_dpp, the same
+    fma chains in the same order): dense Welford windows of base
     max(25, 10 d), covariance shrinkage and Cholesky on the device, momentum p = L^-T z, M^-1 p by
     the dense product, U-turn through v = M^-1 rho -- tuning (step size, covariance, factor) and
     every per-draw output identical to the checker's restatement (tests/test_dense_mass_oracle.py
@@ -489,10 +491,10 @@ def test_dense_mass_bit_exact(hip, name):
     spec = models.eight_schools() if name == "eight_schools" else models.simple()
     om = O.eight_schools() if name == "eight_schools" else O.simple()
     comp = sampler.compile(spec)
-    opts = dict(num_warmup=600, num_samples=40, seed=13, lanes_per_chain=1, dense_mass=True)
+    opts = dict(num_warmup=600, num_samples=40, seed=13, lanes_per_chain=lanes, dense_mass=True)
     tuning = sampler.warmup(comp, spec.default_init, opts)
     q0 = spec.to_unconstrained(spec.default_init)
-    st, cov, chol = O.warmup_dense(om, q0, num_warmup=600, seed=13, cfg=O.Cfg(1, 1))
+    st, cov, chol = O.warmup_dense(om, q0, num_warmup=600, seed=13, cfg=O.Cfg(1, lanes))
     assert st.step_size == tuning["epsilon"]
     assert np.array_equal(cov, tuning["cov"]) and np.array_equal(chol, tuning["chol_cov"])
     assert np.array_equal(np.diag(cov), tuning["inv_mass_diag"])
@@ -501,16 +503,21 @@ def test_dense_mass_bit_exact(hip, name):
     raw = extra["raw"]
     for c in range(5):
         t, _ = O.sample_tuned_dense(om, st.step_size, cov, chol, q0, num_samples=40, seed=13 + 7919 * c,
-                                    cfg=O.Cfg(1, 1))
+                                    cfg=O.Cfg(1, lanes))
         for k in ("draws", "tree_depth", "n_steps", "divergent", "energy", "accept_prob"):
             assert np.array_equal(t[k], raw[k][c]), (c, k)
+    # Sampler.sample/3 with dense_mass: the warmup chain goes on sampling under the dense mass
+    tr1, st1 = sampler.sample(spec, spec.default_init, dict(opts, num_warmup=300, num_samples=25))
+    o_st, o_cov, o_chol = O.warmup_dense(om, q0, num_warmup=300, seed=13, cfg=O.Cfg(1, lanes))
+    assert st1["step_size"] == o_st.step_size and np.array_equal(st1["cov"], o_cov)
+    assert np.array_equal(st1["chol_cov"], o_chol)
     # back to a diagonal tuning on the same handle: the dense mass is no longer in force
-    diag = sampler.warmup(comp, spec.default_init, dict(num_warmup=100, seed=13, lanes_per_chain=1))
+    diag = sampler.warmup(comp, spec.default_init, dict(num_warmup=100, seed=13, lanes_per_chain=lanes))
     _, _, e2 = sampler.sample_compiled_tuned(comp, diag, spec.default_init,
-                                             dict(num_samples=10, seed=13, lanes_per_chain=1), num_chains=2)
-    t2, _ = O.sample_tuned(om, diag["epsilon"], diag["inv_mass"], q0, num_samples=10, seed=13, cfg=O.Cfg(1, 1))
+                                             dict(num_samples=10, seed=13, lanes_per_chain=lanes), num_chains=2)
+    t2, _ = O.sample_tuned(om, diag["epsilon"], diag["inv_mass"], q0, num_samples=10, seed=13, cfg=O.Cfg(1, lanes))
     assert np.array_equal(t2["draws"], e2["raw"]["draws"][0])
-    # the multi-lane layouts refuse the mode
+    # the other multi-lane layouts refuse the mode
     if name == "eight_schools":
         with pytest.raises(Exception):
-            sampler.warmup(comp, spec.default_init, dict(opts, lanes_per_chain=16))
+            sampler.warmup(comp, spec.default_init, dict(opts, lanes_per_chain=8))
