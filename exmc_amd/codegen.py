@@ -403,10 +403,58 @@ def _logpdf(g, dist, x, p):
         pc = g.min(g.max(pp, g.lit(BERN_LO)), g.lit(BERN_HI))
         return g.add(g.mul(x, g.log(pc)),
                      g.mul(g.sub(g.lit(1.0), x), g.log(g.sub(g.lit(1.0), pc))))
+    if dist == "gamma":           # gamma.ex:15-27 (shape alpha, rate beta)
+        alpha, beta = _need(p, dist, "alpha", "beta")
+        a = g.add(g.mul(g.sub(alpha, g.lit(1.0)), g.log(x)), g.mul(alpha, g.log(beta)))
+        return g.sub(a, g.add(g.mul(beta, x), _lgamma(g, alpha)))
+    if dist == "beta":            # beta.ex:15-24, math.ex:57-61
+        alpha, beta = _need(p, dist, "alpha", "beta")
+        a = g.add(g.mul(g.sub(alpha, g.lit(1.0)), g.log(x)),
+                  g.mul(g.sub(beta, g.lit(1.0)), g.log(g.sub(g.lit(1.0), x))))
+        lbeta = g.sub(g.add(_lgamma(g, alpha), _lgamma(g, beta)), _lgamma(g, g.add(alpha, beta)))
+        return g.add(a, g.neg(lbeta))
+    if dist == "weibull":         # weibull.ex:17-27 (shape k, scale lambda)
+        k, lam = _need(p, dist, "k", "lambda")
+        log_lam, log_k = g.log(lam), g.log(k)
+        z = g.sub(g.log(x), log_lam)
+        a = g.add(g.sub(log_k, log_lam), g.mul(g.sub(k, g.lit(1.0)), z))
+        return g.sub(a, g.exp(g.mul(k, z)))
+    if dist == "poisson":         # poisson.ex:16-20
+        (mu,) = _need(p, dist, "mu")
+        return g.sub(g.sub(g.mul(x, g.log(mu)), mu), _lgamma(g, g.add(x, g.lit(1.0))))
+    if dist == "uniform01":       # uniform01.ex:14-16
+        _need(p, dist)
+        return g.lit(0.0)
     raise CodegenError("distribution %r is not covered" % (dist,))
 
 
-VECTOR_DISTS = ("gaussian_random_walk", "mv_normal")
+VECTOR_DISTS = ("gaussian_random_walk", "mv_normal", "dirichlet")
+
+
+def _sigmoid(g, z):
+    # transform.ex:274-276
+    return g.exp(g.neg(_softplus(g, g.neg(z))))
+
+
+def _stick_breaking_forward(g, zs):
+    # transform.ex:125-143: y_i = sigmoid(z_i), x_i = y_i * remaining, remaining *= 1 - y_i
+    xs, rem = [], g.lit(1.0)
+    for z in zs:
+        y = _sigmoid(g, z)
+        xs.append(g.mul(y, rem))
+        rem = g.mul(rem, g.sub(g.lit(1.0), y))
+    return xs + [rem]
+
+
+def _stick_breaking_ladj(g, zs):
+    # transform.ex:186-203
+    lj, rem = g.lit(0.0), g.lit(1.0)
+    for z in zs:
+        y = _sigmoid(g, z)
+        log_dy = g.add(g.neg(_softplus(g, g.neg(z))), g.neg(_softplus(g, z)))
+        lj = g.add(lj, g.add(g.log(rem), log_dy))
+        rem = g.mul(rem, g.sub(g.lit(1.0), y))
+    return lj
 LOG_2PI_OF_F64_F32 = _f32(math.log(2.0 * math.pi))   # Nx.tensor(:math.log(2 pi)), mv_normal.ex:27
 
 
@@ -416,6 +464,14 @@ def _vector_length(id_, n):
         if "steps" not in p or int(p["steps"]) < 1:
             raise CodegenError("gaussian_random_walk %r needs steps >= 1" % id_)
         return int(p["steps"])
+    if n["dist"] == "dirichlet":
+        # Transform.unconstrained_length(:stick_breaking, {K}) = K - 1 (transform.ex:80-83)
+        alpha = np.asarray(p.get("alpha"), dtype=np.float64)
+        if alpha.ndim != 1 or alpha.shape[0] < 2:
+            raise CodegenError("dirichlet %r needs a constant concentration vector of length >= 2" % id_)
+        if n["transform"] != "stick_breaking":
+            raise CodegenError("a free dirichlet %r lives on the simplex: transform must be 'stick_breaking'" % id_)
+        return int(alpha.shape[0]) - 1
     mu = np.asarray(p.get("mu"), dtype=np.float64)
     if mu.ndim != 1:
         raise CodegenError("mv_normal %r needs a vector mu" % id_)
@@ -462,6 +518,14 @@ def _logpdf_vector(g, dist, xs, p, resolve_value):
         mahal = _sum_left(g, [g.mul(diff[i], inner[i]) for i in range(d)])
         base = g.add(g.mul(g.lit(_f32(d * 1.0)), g.lit(LOG_2PI_OF_F64_F32)), g.datum(log_det))
         return g.mul(g.lit(-0.5), g.add(base, mahal))
+    if dist == "dirichlet":                       # dirichlet.ex:19-27; xs on the simplex
+        alpha = np.asarray(p["alpha"], dtype=np.float64)
+        if alpha.ndim != 1 or len(xs) != alpha.shape[0]:
+            raise CodegenError("dirichlet needs alpha {K} and a value of K elements")
+        al = [g.datum(float(a)) for a in alpha]
+        kernel = _sum_left(g, [g.mul(g.sub(al[i], g.lit(1.0)), g.log(xs[i])) for i in range(len(xs))])
+        log_norm = g.sub(_lgamma(g, _sum_left(g, al)), _sum_left(g, [_lgamma(g, a) for a in al]))
+        return g.add(kernel, log_norm)
     raise CodegenError("vector distribution %r is not covered" % (dist,))
 
 
@@ -535,7 +599,7 @@ def generate(ir, ncp=True, vectorize=True):
     for id_ in free:
         n = nodes[id_]
         ln = _vector_length(id_, n) if n["dist"] in VECTOR_DISTS else 1
-        if n["dist"] in VECTOR_DISTS and n["transform"] is not None:
+        if n["dist"] in VECTOR_DISTS and n["transform"] is not None and n["dist"] != "dirichlet":
             raise CodegenError("a transformed vector rv is not covered")
         offset[id_], length[id_] = len(flat_names), ln
         if n["dist"] in VECTOR_DISTS:
@@ -555,7 +619,8 @@ def generate(ir, ncp=True, vectorize=True):
         if id_ in stack:
             raise CodegenError("cyclic non-centred reference through %r" % id_)
         if id_ in vector_entries:
-            return [g.q(offset[id_] + i) for i in range(length[id_])]
+            zs = [g.q(offset[id_] + i) for i in range(length[id_])]
+            return _stick_breaking_forward(g, zs) if nodes[id_]["dist"] == "dirichlet" else zs
         z = g.q(offset[id_])
         if id_ in ncp_info:
             mu = resolve_value(ncp_info[id_]["mu"], stack + (id_,))
@@ -604,6 +669,10 @@ def generate(ir, ncp=True, vectorize=True):
                 continue
             if n["dist"] in VECTOR_DISTS:
                 xs = [g.q(offset[id_] + i) for i in range(length[id_])]
+                if n["dist"] == "dirichlet":      # logpdf on the simplex + log|J| (compiler.ex:222-229)
+                    t = _logpdf_vector(g, "dirichlet", _stick_breaking_forward(g, xs), n["params"], resolve_value)
+                    terms.append(g.add(t, _stick_breaking_ladj(g, xs)))
+                    continue
                 terms.append(_logpdf_vector(g, n["dist"], xs, n["params"], resolve_value))
                 continue
             z = g.q(offset[id_])
@@ -683,6 +752,8 @@ def generate(ir, ncp=True, vectorize=True):
     out.d = len(flat_names)
     out.var_names = flat_names
     out.vector_entries = vector_entries
+    # simplex entries: K - 1 flat slots each, a K-vector in the trace
+    out.simplex_entries = {i: vector_entries[i] for i in vector_entries if nodes[i]["dist"] == "dirichlet"}
     out.transforms = {i: nodes[i]["transform"] for i in free if nodes[i]["transform"]}
     out.ncp_info = ncp_info
     out.data = np.asarray(g.data, dtype=np.float64)
@@ -854,6 +925,32 @@ def build_plugin(gen, force=False, verbose=False):
     return so
 
 
+def inverse_stick_breaking(x):
+    """Transform.inverse_stick_breaking (transform.ex:234-249): a point of the K-simplex to its
+    K - 1 unconstrained coordinates (host side: initial values only)."""
+    x = np.asarray(x, dtype=np.float64)
+    z, rem = [], 1.0
+    for i in range(x.shape[0] - 1):
+        y = min(max(x[i] / rem, 1.0e-10), 1.0 - 1.0e-10)
+        z.append(math.log(y) - math.log(1.0 - y))
+        rem = rem - x[i]
+    return np.array(z)
+
+
+def stick_breaking(z):
+    """Transform.apply(:stick_breaking, z) on the last axis (transform.ex:125-165): {.., K-1} -> {.., K}."""
+    z = np.asarray(z, dtype=np.float64)
+    sp = lambda v: np.maximum(v, 0.0) + np.log1p(np.exp(-np.abs(v)))   # noqa: E731
+    y = np.exp(-sp(-z))
+    rem = np.ones(z.shape[:-1])
+    cols = []
+    for i in range(z.shape[-1]):
+        cols.append(y[..., i] * rem)
+        rem = rem * (1.0 - y[..., i])
+    cols.append(rem)
+    return np.stack(cols, axis=-1)
+
+
 class GeneratedSpec(ModelSpec):
     """ModelSpec of a generated model; `lib_path` names the plug-in library sampler.Compiled
     loads instead of libexmc_hip.so."""
@@ -863,6 +960,7 @@ class GeneratedSpec(ModelSpec):
         self.gen = gen
         self.lib_path = lib_path
         self.vector_entries = dict(getattr(gen, "vector_entries", {}))   # id -> (offset, length)
+        self.simplex_entries = dict(getattr(gen, "simplex_entries", {}))  # id -> (offset, K - 1)
 
     def flat_order(self):
         # the generator lays the entries out in PointMap order already (ids sorted, a vector entry's
@@ -873,7 +971,12 @@ class GeneratedSpec(ModelSpec):
         # invert_ncp_init + PointMap.to_unconstrained (sampler.ex:351-392)
         vals = {}
         for k, v in init_values.items():
-            if k in self.vector_entries:          # a vector rv's init is a sequence of its elements
+            if k in self.simplex_entries:         # a point of the K-simplex -> K - 1 unconstrained slots
+                z = inverse_stick_breaking(v)
+                if z.shape != (self.simplex_entries[k][1],):
+                    raise ValueError("init value of %r must have %d elements" % (k, self.simplex_entries[k][1] + 1))
+                vals.update({"%s[%d]" % (k, i): float(x) for i, x in enumerate(z)})
+            elif k in self.vector_entries:        # a vector rv's init is a sequence of its elements
                 a = np.asarray(v, dtype=np.float64)
                 if a.shape != (self.vector_entries[k][1],):
                     raise ValueError("init value of %r must have %d elements" % (k, self.vector_entries[k][1]))

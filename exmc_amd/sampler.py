@@ -132,10 +132,16 @@ class SampleStats:
 def _build_trace(spec, draws):
     """build_trace (sampler.ex:1281-1298): slice per entry + forward transform."""
     x = spec.constrain(draws)
-    trace = {name: x[:, i] for i, name in enumerate(spec.var_names)}
+    simplex = getattr(spec, "simplex_entries", {})
+    inside = {off + i for off, n in simplex.values() for i in range(n)}
+    trace = {name: x[:, i] for i, name in enumerate(spec.var_names) if i not in inside}
     # a vector rv is one PointMap entry: its draws also come back as one {S, length} array under its id
     for id_, (off, n) in getattr(spec, "vector_entries", {}).items():
-        trace[id_] = x[:, off:off + n]
+        if id_ in simplex:    # K - 1 unconstrained slots -> the K-simplex (Transform.apply(:stick_breaking))
+            from .codegen import stick_breaking
+            trace[id_] = stick_breaking(x[:, off:off + n])
+        else:
+            trace[id_] = x[:, off:off + n]
     return trace
 
 

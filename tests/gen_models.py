@@ -69,3 +69,33 @@ def walk_ir(seed=3):
 
 
 WALK_INIT = dict(sigma=0.5, w=[0.0, 0.1, 0.0, -0.1, 0.05, 0.0], m=[0.0, 0.0, 0.0], tau=1.0, c=0.2)
+
+
+def simplex_ir(seed=7):
+    """The distributions added at the end of round 2 (d = 8): a Dirichlet rv on the 4-simplex behind
+    the stick-breaking transform, Gamma / Beta / Weibull / Uniform01 free rvs with their default
+    transforms, a Poisson likelihood whose rate is the Gamma rv, Gamma- and Weibull-distributed
+    observations, and a Dirichlet-distributed observation."""
+    rng = np.random.default_rng(seed)
+    ir = cg.IR()
+    ir.rv("theta", "dirichlet", dict(alpha=[2.0, 1.5, 1.0, 3.0]), transform="stick_breaking")
+    ir.rv("rate", "gamma", dict(alpha=3.0, beta=2.0), transform="log")
+    ir.rv("p", "beta", dict(alpha=2.0, beta=5.0), transform="logit")
+    ir.rv("k", "weibull", {"k": 1.5, "lambda": 2.0}, transform="log")
+    ir.rv("u", "uniform01", {}, transform="logit")
+    ir.rv("cnt_rv", "poisson", dict(mu="rate"))
+    ir.obs("cnt", "cnt_rv", rng.poisson(1.5, size=6).astype(float))
+    ir.rv("wait_rv", "weibull", {"k": "k", "lambda": 1.3})
+    ir.obs("wait", "wait_rv", rng.weibull(1.5, size=5) * 1.3 + 0.05)
+    ir.rv("g_rv", "gamma", dict(alpha=2.5, beta="rate"))
+    ir.obs("g", "g_rv", rng.gamma(2.5, 0.6, size=4) + 0.05)
+    ir.rv("b_rv", "bernoulli", dict(p="p"))
+    ir.obs("b", "b_rv", (rng.uniform(size=7) < 0.3).astype(float))
+    ir.rv("mix_rv", "dirichlet", dict(alpha=[4.0, 2.0, 1.0, 1.0]))
+    ir.obs("mix", "mix_rv", [0.4, 0.3, 0.2, 0.1])
+    ir.rv("n_rv", "normal", dict(mu="u", sigma=0.5))
+    ir.obs("n", "n_rv", 0.6)
+    return ir
+
+
+SIMPLEX_INIT = dict(theta=[0.25, 0.25, 0.25, 0.25], rate=1.0, p=0.3, k=1.2, u=0.5)

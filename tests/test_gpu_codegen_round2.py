@@ -61,3 +61,38 @@ def test_sample_and_chains_bit_exact(walk):
                             cfg=O.Cfg(1, 1))
     assert np.array_equal(tc["draws"], extra["raw"]["draws"])
     assert np.array_equal(tc["n_steps"], extra["raw"]["n_steps"])
+
+
+@pytest.fixture(scope="module")
+def simplex(hip):
+    spec = cg.compile_ir(GM.simplex_ir(), name="gen_simplex", default_init=GM.SIMPLEX_INIT)
+    assert spec.gen.lanes == 1 and spec.d == 7
+    return spec, sampler.compile(spec), GC.model(spec.gen, 1)
+
+
+def test_simplex_model_bit_exact(simplex):
+    """Dirichlet behind :stick_breaking, Gamma / Beta / Weibull / Uniform01 free rvs, Poisson /
+    Weibull / Gamma / Dirichlet observations (tests/gen_models.py::simplex_ir)."""
+    spec, comp, om = simplex
+    rng = np.random.default_rng(8)
+    n = 200
+    q = np.ascontiguousarray(rng.normal(size=(n, spec.d)) * 1.2)
+    q[0] = spec.to_unconstrained(spec.default_init)
+    q[1, :] = 40.0
+    q[2, :] = -40.0
+    q[3, :] = 0.0
+    lp, g = np.zeros(n), np.zeros((n, spec.d))
+    comp.check(comp.L.exmc_hip_logp_grad_host(comp.h, _dp(q), n, 1, _dp(lp), _dp(g)))
+    for i in range(n):
+        lpo, go = om.logp_grad(q[i], O.Cfg(1, 1))
+        assert (lp[i] == lpo) or (np.isnan(lp[i]) and np.isnan(lpo)), i
+        assert np.array_equal(g[i], go, equal_nan=True), i
+    q0 = spec.to_unconstrained(spec.default_init)
+    trace, stats = sampler.sample(spec, spec.default_init, dict(num_warmup=150, num_samples=80, seed=6))
+    t, st = O.sample(om, q0, num_warmup=150, num_samples=80, seed=6, cfg=O.Cfg(1, 1))
+    assert st.step_size == stats["step_size"]
+    assert np.array_equal(t["draws"], stats["raw"]["draws"][0])
+    assert np.array_equal(t["n_steps"], stats["raw"]["n_steps"][0])
+    th = trace["theta"]
+    assert th.shape == (80, 4) and np.allclose(th.sum(axis=1), 1.0) and np.all(th > 0)
+    assert np.all(trace["rate"] > 0) and np.all((trace["p"] > 0) & (trace["p"] < 1))
