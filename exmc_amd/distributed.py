@@ -30,13 +30,14 @@ def gather_traces(draws_local, dist=None):
     world = dist.get_world_size()
     S, D, Cl = draws_local.shape
     src = draws_local.contiguous()
-    gathered = torch.empty((world, S, D, Cl), dtype=src.dtype, device=src.device)
-    try:
-        dist.all_gather_into_tensor(gathered, src)
-    except (RuntimeError, NotImplementedError):
+    if dist.get_backend() == "gloo":
+        # gloo has no all_gather_into_tensor; the list form is the same exchange
         parts = [torch.empty_like(src) for _ in range(world)]
         dist.all_gather(parts, src)
         gathered = torch.stack(parts, dim=0)
+    else:
+        gathered = torch.empty((world, S, D, Cl), dtype=src.dtype, device=src.device)
+        dist.all_gather_into_tensor(gathered, src)   # RCCL: one collective over xGMI; errors propagate
     return gathered.permute(1, 2, 0, 3).reshape(S, D, world * Cl)
 
 

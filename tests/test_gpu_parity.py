@@ -4,7 +4,7 @@ The checker runs in deterministic-math mode with the same lane layout G as the k
 (oracle/exmc_oracle.h). Integer outputs (tree depth, n_steps, divergence flags) AND floating
 outputs (positions, log-prob, accept stat, energy) are required to be identical bits; the
 tolerance against libm mode (the reference's own arithmetic) is asserted separately in
-tests/test_oracle_modes.py.
+tests/test_oracle_sampler.py.
 """
 import ctypes as C
 
