@@ -160,6 +160,75 @@ static ERL_NIF_TERM warmup(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) 
   return rc == EXMC_OK ? tuning_map(env, &tun, exmc_hip_model_dim(m)) : raise_hip(env, rc);
 }
 
+/* warmup_from(ref, init_q | nil, num_warmup, max_tree_depth, target_accept, seed, prev_epsilon,
+ *             prev_inv_mass_bin) -> tuning map: opts[:warm_start] of Sampler.sample
+ * (sampler.ex:167-197): the previous run's step size and inverse mass, min(num_warmup, 50) iterations */
+static ERL_NIF_TERM warmup_from(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  exmc_hip_model* m = get_model(env, argv[0]);
+  const double *iq, *im;
+  size_t nim;
+  exmc_hip_opts o;
+  exmc_hip_tuning prev, tun;
+  (void)argc;
+  memset(&prev, 0, sizeof prev);
+  if (!m) return enif_make_badarg(env);
+  const int d = exmc_hip_model_dim(m);
+  if (!get_init_q(env, argv[1], d, &iq) || !get_warm_opts(env, argv + 2, &o) ||
+      !get_f64(env, argv[6], &prev.epsilon) || !get_f64_bin(env, argv[7], &im, &nim) || nim != (size_t)d)
+    return enif_make_badarg(env);
+  memcpy(prev.inv_mass, im, (size_t)d * 8);
+  int rc = exmc_hip_warmup_from(m, iq, o, &prev, &tun);
+  return rc == EXMC_OK ? tuning_map(env, &tun, d) : raise_hip(env, rc);
+}
+
+/* warmup_dense(ref, init_q | nil, num_warmup, max_tree_depth, target_accept, seed, lanes_per_chain)
+ *   -> %{epsilon, inv_mass (diagonal), cov, chol_cov (d x d row-major binaries), warmup_divergences}:
+ * opts[:dense_mass] (sampler.ex:156, 412-431); the dense mass stays in force on the handle for
+ * sample_chains / stream_next until clear_dense_mass */
+static ERL_NIF_TERM warmup_dense(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  exmc_hip_model* m = get_model(env, argv[0]);
+  const double* iq;
+  exmc_hip_opts o;
+  exmc_hip_tuning tun;
+  (void)argc;
+  if (!m) return enif_make_badarg(env);
+  const int d = exmc_hip_model_dim(m);
+  if (!get_init_q(env, argv[1], d, &iq) || !get_warm_opts(env, argv + 2, &o) ||
+      !enif_get_int(env, argv[6], &o.lanes_per_chain) || o.lanes_per_chain < 0)
+    return enif_make_badarg(env);
+  ERL_NIF_TERM tc, tl;
+  double* cov = new_f64_bin(env, (size_t)d * d, &tc);
+  double* chol = new_f64_bin(env, (size_t)d * d, &tl);
+  int rc = exmc_hip_warmup_dense(m, iq, o, &tun, cov, chol);
+  if (rc != EXMC_OK) return raise_hip(env, rc);
+  ERL_NIF_TERM map = tuning_map(env, &tun, d);
+  map = map_put(env, map, "cov", tc);
+  map = map_put(env, map, "chol_cov", tl);
+  return map;
+}
+
+/* set_dense_mass(ref, cov_bin, chol_cov_bin) -> :ok; clear_dense_mass(ref) -> :ok
+ * (sample_compiled_tuned with a tuning that carries :chol_cov, sampler.ex:274, 292) */
+static ERL_NIF_TERM set_dense_mass(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  exmc_hip_model* m = get_model(env, argv[0]);
+  const double *cov, *chol;
+  size_t nc, nl;
+  (void)argc;
+  if (!m) return enif_make_badarg(env);
+  const size_t d = (size_t)exmc_hip_model_dim(m);
+  if (!get_f64_bin(env, argv[1], &cov, &nc) || !get_f64_bin(env, argv[2], &chol, &nl) || nc != d * d || nl != d * d)
+    return enif_make_badarg(env);
+  int rc = exmc_hip_model_set_dense_mass(m, cov, chol, (int)d);
+  return rc == EXMC_OK ? enif_make_atom(env, "ok") : raise_hip(env, rc);
+}
+static ERL_NIF_TERM clear_dense_mass(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  exmc_hip_model* m = get_model(env, argv[0]);
+  (void)argc;
+  if (!m) return enif_make_badarg(env);
+  int rc = exmc_hip_model_clear_dense_mass(m);
+  return rc == EXMC_OK ? enif_make_atom(env, "ok") : raise_hip(env, rc);
+}
+
 /* per-draw outputs as binaries: draws [C][S][d] f64; logp, accept_prob, energy [C][S] f64;
  * tree_depth, n_steps, divergent [C][S] int32 (stats.sample_stats, sampler.ex:960-967) */
 typedef struct {
@@ -276,6 +345,10 @@ static ErlNifFunc nif_funcs[] = {
     {"logp_grad", 3, logp_grad, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"multi_step", 8, multi_step, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"warmup", 6, warmup, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"warmup_from", 8, warmup_from, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"warmup_dense", 7, warmup_dense, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"set_dense_mass", 3, set_dense_mass, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"clear_dense_mass", 1, clear_dense_mass, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"sample_chains", 10, sample_chains, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"sample", 7, sample, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"stream_begin", 6, stream_begin, ERL_NIF_DIRTY_JOB_IO_BOUND},

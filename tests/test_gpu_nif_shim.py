@@ -165,3 +165,19 @@ def test_hip_native_equals_the_python_mirror(hip, mods):
     assert H.f64(rows["draws"]).shape == (5 * spec.d,) and tun3["epsilon"] > 0
     with pytest.raises(H.BadArg):
         hn.call("warmup", ref, np.zeros(3), 10, 10, 0.8, 1)
+    # warm start and the dense mass through the shim = the Python mirror of the same C ABI
+    ws = hn.call("warmup_from", ref, q0, 200, 10, 0.8, 7, tun["epsilon"], H.f64(tun["inv_mass"]))
+    _, st = sampler.sample(spec, spec.default_init, dict(num_warmup=200, num_samples=5, seed=7, lanes_per_chain=16,
+                                                          warm_start=dict(step_size=tun["epsilon"],
+                                                                          inv_mass_diag=H.f64(tun["inv_mass"]))))
+    assert ws["epsilon"] == st["step_size"] and np.array_equal(H.f64(ws["inv_mass"]), st["inv_mass_diag"])
+    dn = hn.call("warmup_dense", ref, q0, 300, 10, 0.8, 13, 16)
+    d2 = sampler.warmup(comp, spec.default_init, dict(num_warmup=300, seed=13, lanes_per_chain=16, dense_mass=True))
+    assert dn["epsilon"] == d2["epsilon"]
+    assert np.array_equal(H.f64(dn["cov"]).reshape(spec.d, spec.d), d2["cov"])
+    assert np.array_equal(H.f64(dn["chol_cov"]).reshape(spec.d, spec.d), d2["chol_cov"])
+    assert hn.call("clear_dense_mass", ref) == H.Atom("ok")
+    assert hn.call("set_dense_mass", ref, H.f64(dn["cov"]), H.f64(dn["chol_cov"])) == H.Atom("ok")
+    assert hn.call("clear_dense_mass", ref) == H.Atom("ok")
+    with pytest.raises(H.BadArg):
+        hn.call("set_dense_mass", ref, np.zeros(5), np.zeros(5))
