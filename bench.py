@@ -227,6 +227,9 @@ def main():
     ap.add_argument("--model", default="eight_schools")
     ap.add_argument("--chains-per-gpu", type=int, default=0)
     ap.add_argument("--lanes", type=int, default=0)
+    ap.add_argument("--warmup-lanes", type=int, default=0,
+                    help="lanes per chain of the shared one-chain warmup (default: --lanes if given, else the "
+                         "library's choice for the model)")
     ap.add_argument("--adapt", type=int, default=1000, help="NUTS adaptation iterations")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--dense-mass", action="store_true",
@@ -284,10 +287,11 @@ def main():
     # broadcast is needed) ---
     # (a 2-iteration throwaway call first, untimed like the W warmup steps of the sampling region:
     # it pays for loading the code object and the first-launch setup, not for adaptation)
-    sampler.warmup(comp, init, dict(opts, num_warmup=2))
+    warm_lanes = args.warmup_lanes or args.lanes or comp.default_warmup_lanes
+    sampler.warmup(comp, init, dict(opts, num_warmup=2, warmup_lanes=warm_lanes))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    tuning = sampler.warmup(comp, init, opts)
+    tuning = sampler.warmup(comp, init, dict(opts, warmup_lanes=warm_lanes))
     adapt_s = time.perf_counter() - t0
     tun = sampler._tuning_struct(tuning, d)
     if rank == 0:
@@ -392,7 +396,7 @@ def main():
                                    % (args.model, d, Cper, Ctot, S, K, B, args.adapt,
                                       ", dense mass matrix" if args.dense_mass else ""),
                        "draws_per_step": B, "draws_per_chain": S,
-                       "lanes_per_chain": lanes, "seed": 42},
+                       "lanes_per_chain": lanes, "warmup_lanes_per_chain": warm_lanes, "seed": 42},
             "ess_per_s": ess_min / total_s,
             "ess_min_total": ess_min,
             "ess_wall_s": {"adaptation": adapt_s, "sampling": elapsed, "ess_kernel": ess_s,

@@ -200,6 +200,7 @@ int dispatch(exmc_hip_model* m, int lanes, F&& f) {
 #elif EXMC_DEV_ONLY == EXMC_DEV_LOGISTIC16
     case EXMC_MODEL_LOGISTIC:
       if (lanes == 16) return f(Tag<Logistic<16>, 16, 2>{}, m->lg);
+      if (lanes == 64) return f(Tag<Logistic<64>, 64, 2>{}, m->lg);
       break;
 #endif
 #else
@@ -228,6 +229,7 @@ int dispatch(exmc_hip_model* m, int lanes, F&& f) {
         case 4: return f(Tag<Logistic<4>, 4, 2>{}, m->lg);   // matrix-core path
         case 8: return f(Tag<Logistic<8>, 8, 2>{}, m->lg);
         case 16: return f(Tag<Logistic<16>, 16, 2>{}, m->lg);
+        case 64: return f(Tag<Logistic<64>, 64, 2>{}, m->lg);   // one chain per wave: the warmup's layout
         default: break;
       }
       break;
@@ -1064,6 +1066,14 @@ void exmc_hip_model_destroy(exmc_hip_model* m) {
 
 int exmc_hip_model_dim(const exmc_hip_model* m) { return m ? m->d : -1; }
 int exmc_hip_model_default_lanes(const exmc_hip_model* m) { return m ? default_lanes(m->kind) : -1; }
+
+int exmc_hip_model_default_warmup_lanes(const exmc_hip_model* m) {
+  if (!m) return -1;
+  // logistic: the shared warmup is ONE chain, so its 500 observations are best spread over a whole
+  // wavefront (8 per lane instead of 32: 158 -> 62 ms); sampling keeps 16 lanes per chain
+  if (m->kind == EXMC_MODEL_LOGISTIC) return 64;
+  return default_lanes(m->kind);
+}
 void* exmc_hip_model_stream(const exmc_hip_model* m) { return m ? (void*)m->stream : nullptr; }
 double exmc_hip_last_kernel_ms(const exmc_hip_model* m) { return m ? m->last_ms : 0.0; }
 

@@ -64,6 +64,10 @@ class Compiled:
         return self.L.exmc_hip_model_default_lanes(self.h)
 
     @property
+    def default_warmup_lanes(self):
+        return self.L.exmc_hip_model_default_warmup_lanes(self.h)
+
+    @property
     def last_kernel_ms(self):
         return self.L.exmc_hip_last_kernel_ms(self.h)
 
@@ -233,7 +237,10 @@ def warmup(compiled, init_values=None, opts=None):
         return dict(epsilon=tun.epsilon, inv_mass=cov, cov=cov, chol_cov=chol,
                     inv_mass_diag=np.array(tun.inv_mass[:d]), warmup_divergences=tun.warmup_divergences)
     compiled.check(L.exmc_hip_model_clear_dense_mass(compiled.h))
-    compiled.check(L.exmc_hip_warmup(compiled.h, None if iq is None else _dp(iq), _c_opts(o),
+    # the layout of the one-chain warmup: opts["warmup_lanes"], else the sampling layout when the
+    # caller named one, else the library's choice for this model (its tuning is layout-independent)
+    lanes = o.get("warmup_lanes") or o.get("lanes_per_chain") or compiled.default_warmup_lanes
+    compiled.check(L.exmc_hip_warmup(compiled.h, None if iq is None else _dp(iq), _c_opts(o, lanes=lanes),
                                  C.byref(tun)))
     return dict(epsilon=tun.epsilon, inv_mass=np.array(tun.inv_mass[:compiled.d]), chol_cov=None,
                 warmup_divergences=tun.warmup_divergences)

@@ -111,6 +111,10 @@ void exmc_hip_model_destroy(exmc_hip_model* m);
 int exmc_hip_model_set_flat_order(exmc_hip_model* m, const int32_t* perm, int d);
 int exmc_hip_model_dim(const exmc_hip_model* m);
 int exmc_hip_model_default_lanes(const exmc_hip_model* m);
+/* lanes_per_chain that suits the shared one-chain warmup (sampler.ex:1053-1080) when it differs
+ * from the sampling layout (logistic: 64). The tuning it returns is layout-independent; chains
+ * that continue the warmup chain itself (sample_host, stream) keep one layout for both phases. */
+int exmc_hip_model_default_warmup_lanes(const exmc_hip_model* m);
 /* the model handle's HIP stream (hipStream_t as void*) */
 void* exmc_hip_model_stream(const exmc_hip_model* m);
 

@@ -380,6 +380,34 @@ def test_bench_protocol_other_models_bit_exact(hip, name, factory, lanes, n_chai
         assert t["tree_depth"].max() >= 7   # the global spill levels were exercised
 
 
+def test_logistic_warmup_layout_differs_from_sampling_layout(hip):
+    """logistic: the shared one-chain warmup runs with the chain spread over a whole wavefront
+    (exmc_hip_model_default_warmup_lanes = 64: 8 observations per lane instead of 32), sampling
+    with 16 lanes per chain. The tuning is layout-independent data; each phase equals the checker
+    in its own layout, bit for bit."""
+    spec = models.logistic()
+    comp = sampler.compile(spec)
+    assert comp.default_lanes == 16 and comp.default_warmup_lanes == 64
+    om = O.model_for(spec)
+    q0 = spec.to_unconstrained(spec.default_init)
+    opts = dict(num_warmup=300, num_samples=30, seed=42)
+    tuning = sampler.warmup(comp, spec.default_init, opts)                  # library defaults: 64 lanes
+    st = O.warmup(om, q0, num_warmup=300, seed=42, cfg=O.Cfg(1, 64))
+    assert st.step_size == tuning["epsilon"]
+    assert np.array_equal(np.array(st.inv_mass[:spec.d]), tuning["inv_mass"])
+    t16 = sampler.warmup(comp, spec.default_init, dict(opts, lanes_per_chain=16))   # a named layout is kept
+    st16 = O.warmup(om, q0, num_warmup=300, seed=42, cfg=O.Cfg(1, 16))
+    assert st16.step_size == t16["epsilon"]
+    assert abs(st16.step_size - st.step_size) < 0.5 * st.step_size          # same sampler, other roundings
+    _, _, extra = sampler.sample_compiled_tuned(comp, tuning, spec.default_init, opts, num_chains=20)
+    raw = extra["raw"]
+    for c in (0, 7, 19):
+        t, _ = O.sample_tuned(om, tuning["epsilon"], tuning["inv_mass"], q0, num_samples=30,
+                              seed=42 + 7919 * c, cfg=O.Cfg(1, 16))
+        for k in ("draws", "tree_depth", "n_steps", "divergent", "energy", "accept_prob"):
+            assert np.array_equal(t[k], raw[k][c]), (c, k)
+
+
 @pytest.mark.parametrize("chunk", [1, 7, 64])
 def test_sample_stream_equals_sample(hip, chunk):
     """sample_stream/4 (sampler.ex:1186-1277): the messages ("exmc_sample", i, point, stat) for
