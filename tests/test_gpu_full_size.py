@@ -136,3 +136,51 @@ def test_every_chain_of_a_batch_bit_exact(hip, name, lanes, n_chains, n_draws):
     if name == "eight_schools":
         ns = extra["raw"]["n_steps"]
         assert (ns != (1 << extra["raw"]["tree_depth"]) - 1).sum() > 50   # early-ended subtrees occurred
+
+
+def _bench_models():
+    import bench
+    return [("sv", lambda: bench.make_spec("sv")[0], 2048, 64, 64),
+            ("logistic", lambda: bench.make_spec("logistic")[0], 8192, 16, 64),
+            ("radon", lambda: bench.make_spec("radon")[0], 1024, 64, 64)]
+
+
+@pytest.mark.parametrize("name,factory,n_chains,lanes,warm_lanes", _bench_models(),
+                         ids=lambda x: x if isinstance(x, str) else "")
+def test_other_baseline_configs_at_full_size(hip, name, factory, n_chains, lanes, warm_lanes):
+    """The other BASELINE.json configurations at the sizes and layouts `bench.py --model <name>`
+    runs (sv 2048 x 1000 at 64 lanes, logistic 8192 x 1000 at 16 lanes after its 64-lane warmup,
+    radon 1024 x 1000 at 64 lanes): chains from the first, a middle and the last wavefront against
+    the checker bit for bit, shard independence, the counters, run-to-run determinism."""
+    spec = factory()
+    comp = sampler.compile(spec)
+    om = O.model_for(spec)
+    n_draws = 1000
+    opts = dict(num_warmup=1000, num_samples=n_draws, seed=42, lanes_per_chain=lanes)
+    tuning = sampler.warmup(comp, spec.default_init, dict(opts, warmup_lanes=warm_lanes))
+    q0 = spec.to_unconstrained(spec.default_init)
+    st = O.warmup(om, q0, num_warmup=1000, seed=42, cfg=O.Cfg(1, warm_lanes))
+    assert st.step_size == tuning["epsilon"]
+    assert np.array_equal(np.array(st.inv_mass[:spec.d]), tuning["inv_mass"])
+    _, _, extra = sampler.sample_compiled_tuned(comp, tuning, spec.default_init, opts, num_chains=n_chains)
+    raw = extra["raw"]
+    assert raw["draws"].shape == (n_chains, n_draws, spec.d)
+    for c in (0, n_chains // 2 + 1, n_chains - 1):
+        t, _ = O.sample_tuned(om, tuning["epsilon"], tuning["inv_mass"], q0, num_samples=n_draws,
+                              seed=42 + 7919 * c, cfg=O.Cfg(1, lanes))
+        for k in ("tree_depth", "n_steps", "divergent", "draws", "accept_prob", "energy"):
+            assert np.array_equal(t[k], raw[k][c]), (name, c, k)
+    lo = n_chains // 3
+    _, _, ex2 = sampler.sample_compiled_tuned(comp, tuning, spec.default_init, opts,
+                                              num_chains=n_chains, chain_lo=lo, chain_hi=lo + 5)
+    for k in KEYS:
+        assert np.array_equal(ex2["raw"][k], raw[k][lo:lo + 5]), (name, k)
+    assert extra["total_leapfrogs"] == int(raw["n_steps"].astype(np.int64).sum())
+    assert extra["total_divergences"] == int(raw["divergent"].astype(np.int64).sum())
+    d1 = _digest(raw)
+    del raw, extra
+    _, _, ex3 = sampler.sample_compiled_tuned(comp, tuning, spec.default_init, opts, num_chains=n_chains)
+    assert _digest(ex3["raw"]) == d1
+    r = ex3["raw"]
+    assert int(r["tree_depth"].max()) <= 10 and np.all(r["n_steps"] <= (1 << r["tree_depth"]) - 1)
+    assert np.isfinite(r["draws"]).all() and float(r["divergent"].mean()) < 0.05
