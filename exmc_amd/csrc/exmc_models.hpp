@@ -294,7 +294,7 @@ __device__ __forceinline__ void lanczos_sums(double term, double tdd, double c0,
 }
 
 template <class MM, int G, class DV>
-__device__ __forceinline__ void lanczos_pair_d(const SVConsts& c, int l, double lzc, double lzj,
+__device__ __forceinline__ void lanczos_pair_d(double lz0, double half_log_2pi, int l, double lzc, double lzj,
                                                double x1, double x0, double (&extra)[2],
                                                double& lg1, double& d1, double& lg0, double& d0,
                                                DV& dv) {
@@ -304,7 +304,7 @@ __device__ __forceinline__ void lanczos_pair_d(const SVConsts& c, int l, double 
   const double term = dv(lzc, den);
   const double tdd = dv(term, den);
   double ag1, dag1, ag0, dag0;
-  lanczos_sums<MM, G>(term, tdd, c.lanczos[0], ag1, dag1, ag0, dag0,
+  lanczos_sums<MM, G>(term, tdd, lz0, ag1, dag1, ag0, dag0,
                       std::make_integer_sequence<int, 8>{});
   const double t1 = x1 + 6.5, t0 = x0 + 6.5;
   double la[4] = {t1, t0, extra[0], extra[1]};
@@ -319,8 +319,8 @@ __device__ __forceinline__ void lanczos_pair_d(const SVConsts& c, int l, double 
   dv.watch(dag1); dv.watch(dag0);
   d1 = ((la[0] + dv(xm1, t1)) - 1.0) + dv(dag1, ag1);
   d0 = ((la[1] + dv(xm0, t0)) - 1.0) + dv(dag0, ag0);
-  lg1 = ((c.half_log_2pi32 + xm1 * la[0]) - t1) + lb[0];
-  lg0 = ((c.half_log_2pi32 + xm0 * la[1]) - t0) + lb[1];
+  lg1 = ((half_log_2pi + xm1 * la[0]) - t1) + lb[0];
+  lg0 = ((half_log_2pi + xm0 * la[1]) - t0) + lb[1];
 }
 
 template <int G>
@@ -338,7 +338,16 @@ struct SV : ModelDefaults {
   struct Lane {
     double r[DPL];
     double lzc, lzj;   // this lane's Lanczos coefficient and offset (lanczos_pair_d)
+    // the model's scalar constants as vector registers (the same value in every lane): as scalar
+    // registers they are spilled in 16-dword tuples around the leaf loop and every use pays a
+    // v_readlane per dword (400 of the kernel's 1400 vector instructions per leapfrog)
+    double k[9];
   };
+  enum { kTiny = 0, kLogLamS, kLamS, kLogLamN, kLamN, kPi, kLog2Pi, kLz0, kHalfLog2Pi };
+  __device__ static __forceinline__ double pin(double x) {
+    asm volatile("" : "+v"(x));
+    return x;
+  }
   __device__ static __forceinline__ void load(const Consts& c, int l, Lane& ln) {
 #pragma unroll
     for (int k = 0; k < DPL; k++) {
@@ -347,6 +356,9 @@ struct SV : ModelDefaults {
     }
     ln.lzc = c.lanczos[(l & 7) + 1];
     ln.lzj = (double)(l & 7);
+    ln.k[kTiny] = pin(c.tiny32); ln.k[kLogLamS] = pin(c.log_lam_s32); ln.k[kLamS] = pin(c.lam_s);
+    ln.k[kLogLamN] = pin(c.log_lam_n32); ln.k[kLamN] = pin(c.lam_n); ln.k[kPi] = pin(c.pi32);
+    ln.k[kLog2Pi] = pin(c.log2pi32); ln.k[kLz0] = pin(c.lanczos[0]); ln.k[kHalfLog2Pi] = pin(c.half_log_2pi32);
   }
   static constexpr bool kVregMath = true;
   using MM = Math<kVregMath>;
@@ -370,20 +382,21 @@ struct SV : ModelDefaults {
     double ez[2] = {zs, zn};
     lane_batch<G, 2>(ez, l, [](double v) { return MM::exp(v); });
     const double sigma = ez[0], nu = ez[1];
-    const double ss = fmax(sigma, c.tiny32);
-    const double sdf = fmax(nu, c.tiny32);
+    const double ss = fmax(sigma, ln.k[kTiny]);
+    const double sdf = fmax(nu, ln.k[kTiny]);
     dv.template watch_exp_if<-100, 100>(true, ss);
     dv.template watch_exp_if<-100, 100>(true, sdf);
     const Recip rss = make_recip(ss), rsdf = make_recip(sdf);
-    const double t_sigma = (c.log_lam_s32 - c.lam_s * sigma) + zs;
-    const double t_nu = (c.log_lam_n32 - c.lam_n * nu) + zn;
+    const double t_sigma = (ln.k[kLogLamS] - ln.k[kLamS] * sigma) + zs;
+    const double t_nu = (ln.k[kLogLamN] - ln.k[kLamN] * nu) + zn;
     const double hp1 = (sdf + 1.0) / 2.0, h = sdf / 2.0;
     double d1, d0, lg1, lg0;
-    double lx[2] = {sdf * c.pi32, ss};   // in: arguments, out: their logarithms
-    lanczos_pair_d<MM, G>(c, l, ln.lzc, ln.lzj, hp1, h, lx, lg1, d1, lg0, d0, dv);
+    double lx[2] = {sdf * ln.k[kPi], ss};   // in: arguments, out: their logarithms
+    lanczos_pair_d<MM, G>(ln.k[kLz0], ln.k[kHalfLog2Pi], l, ln.lzc, ln.lzj,
+                          hp1, h, lx, lg1, d1, lg0, d0, dv);
     const double An = (lg1 - lg0) - 0.5 * lx[0];
     const double dAn = (0.5 * d1 - 0.5 * d0) - dv(0.5, rsdf);
-    const double cn = c.log2pi32 + 2.0 * lx[1];
+    const double cn = ln.k[kLog2Pi] + 2.0 * lx[1];
     double P[DPL], LL[DPL], E2[DPL], DN[DPL], de[DPL];
     bool valid[DPL];
     // previous-state values: dim i-1 is (lane l-1, slot k) or (lane G-1, slot k-1) when l == 0:
@@ -435,8 +448,8 @@ struct SV : ModelDefaults {
     const double sn = group_sum_slots<G, DPL>(DN, valid, l, 0.0);
     const bool in_s = (zs_raw > -200.0) && (zs_raw < 200.0);
     const bool in_n = (zn_raw > -200.0) && (zn_raw < 200.0);
-    const double g_s = in_s ? ((se - c.lam_s * sigma) + 1.0) : 0.0;
-    const double g_n = in_n ? ((sn * nu - c.lam_n * nu) + 1.0) : 0.0;
+    const double g_s = in_s ? ((se - ln.k[kLamS] * sigma) + 1.0) : 0.0;
+    const double g_n = in_n ? ((sn * nu - ln.k[kLamN] * nu) + 1.0) : 0.0;
 #pragma unroll
     for (int k = 0; k < DPL; k++) {
       const int i = l + k * G;
