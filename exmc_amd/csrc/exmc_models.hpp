@@ -284,13 +284,30 @@ struct SVConsts {
 // call l / 8, term l % 8 + 1; lzc / lzj are that lane's coefficient and offset), summed in the
 // reference's order from broadcasts; the four logarithms of the two calls plus the two the
 // caller needs (extra[0..1] in, their logs out) are two lane-batched evaluations.
+// Every 16-lane row of the wavefront holds the same sixteen (term, tdd) pairs (the coefficient
+// depends on l & 7, the argument on l & 8), so the four sums run inside each row as
+// v_fmac_f64_dpp row_newbcast chains -- acc + t = fma(t, 1, acc), acc - t = fma(t, -1, acc),
+// one instruction per term, in the reference's order -- and every lane ends up with all four
+// without a cross-row broadcast (the v_readlane form cost three instructions per term).
+#define EXMC_LZ1(I) \
+  "v_fmac_f64_dpp %[a1], %[t], %[one] row_newbcast:" #I " row_mask:0xf bank_mask:0xf\n\t" \
+  "v_fmac_f64_dpp %[d1], %[d], %[mone] row_newbcast:" #I " row_mask:0xf bank_mask:0xf\n\t"
+#define EXMC_LZ0(I) \
+  "v_fmac_f64_dpp %[a0], %[t], %[one] row_newbcast:" #I " row_mask:0xf bank_mask:0xf\n\t" \
+  "v_fmac_f64_dpp %[d0], %[d], %[mone] row_newbcast:" #I " row_mask:0xf bank_mask:0xf\n\t"
 template <class MM, int G, int... I>
 __device__ __forceinline__ void lanczos_sums(double term, double tdd, double c0, double& ag1,
                                              double& dag1, double& ag0, double& dag0,
                                              std::integer_sequence<int, I...>) {
   ag1 = c0; dag1 = 0.0; ag0 = c0; dag0 = 0.0;
-  ((ag1 = ag1 + group_bcast_c<G, I>(term), dag1 = dag1 - group_bcast_c<G, I>(tdd)), ...);
-  ((ag0 = ag0 + group_bcast_c<G, 8 + I>(term), dag0 = dag0 - group_bcast_c<G, 8 + I>(tdd)), ...);
+  const double one = seq_one();
+  double mone = -1.0;
+  __asm__("" : "+v"(mone));
+  __asm__("s_nop 1\n\t"
+          EXMC_LZ1(0) EXMC_LZ1(1) EXMC_LZ1(2) EXMC_LZ1(3) EXMC_LZ1(4) EXMC_LZ1(5) EXMC_LZ1(6) EXMC_LZ1(7)
+          EXMC_LZ0(8) EXMC_LZ0(9) EXMC_LZ0(10) EXMC_LZ0(11) EXMC_LZ0(12) EXMC_LZ0(13) EXMC_LZ0(14) EXMC_LZ0(15)
+          : [a1] "+v"(ag1), [d1] "+v"(dag1), [a0] "+v"(ag0), [d0] "+v"(dag0)
+          : [t] "v"(term), [d] "v"(tdd), [one] "v"(one), [mone] "v"(mone));
 }
 
 template <class MM, int G, class DV>
