@@ -118,8 +118,11 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 }
 
 // N independent all-reduce sums over the G-lane group, stage by stage (the N moves of a stage
-// are independent, so their latencies overlap).
-template <int G, int N>
+// are independent, so their latencies overlap). kLds (G = 64): the two cross-row stages go
+// through the LDS crossbar (ds_bpermute) -- two vector instructions per value instead of the
+// eleven of the v_readlane form, for kernels that are bound by vector issue and have a second
+// wave on the SIMD to cover the LDS round trips (a lone wave would sit them out).
+template <int G, int N, bool kLds = false>
 __device__ __forceinline__ void group_allsum_n(double (&v)[N]) {
   static_assert(G == 1 || G == 2 || G == 4 || G == 8 || G == 16 || G == 32 || G == 64, "G");
   if (G >= 2) {
@@ -138,6 +141,24 @@ __device__ __forceinline__ void group_allsum_n(double (&v)[N]) {
 #pragma unroll
     for (int j = 0; j < N; j++) v[j] = v[j] + dpp_move<kDppRowMirror>(v[j]);
   }
+  if constexpr (G == 64 && kLds) {
+    // v + v[l ^ 16], then + v[l ^ 32]: the same butterfly
+    const int lane = threadIdx.x & 63;
+    const int a16 = (lane ^ 16) << 2, a32 = (lane ^ 32) << 2;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      int lo = __double2loint(v[j]), hi = __double2hiint(v[j]);
+      const double o = __hiloint2double(__builtin_amdgcn_ds_bpermute(a16, hi), __builtin_amdgcn_ds_bpermute(a16, lo));
+      v[j] = v[j] + o;
+    }
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      int lo = __double2loint(v[j]), hi = __double2hiint(v[j]);
+      const double o = __hiloint2double(__builtin_amdgcn_ds_bpermute(a32, hi), __builtin_amdgcn_ds_bpermute(a32, lo));
+      v[j] = v[j] + o;
+    }
+    return;
+  }
   if (G >= 32) {
     const int lane = threadIdx.x & 63;
 #pragma unroll
@@ -151,10 +172,10 @@ __device__ __forceinline__ void group_allsum_n(double (&v)[N]) {
   }
 }
 
-template <int G>
+template <int G, bool kLds = false>
 __device__ __forceinline__ double group_allsum(double v) {
   double a[1] = {v};
-  group_allsum_n<G, 1>(a);
+  group_allsum_n<G, 1, kLds>(a);
   return a[0];
 }
 
@@ -502,7 +523,7 @@ struct Math {
 
 // init0 + the sum over the chain's dimensions: lane-partial sum over this lane's valid slots, lane 0
 // seeded with init0, then the butterfly -- or, for a kSeqSum group, init0 + v[dim 0] + v[dim 1] + ...
-template <int G, int DPL, int D = G * DPL>
+template <int G, int DPL, int D = G * DPL, bool kLds = false>
 __device__ __forceinline__ double group_sum_slots(const double (&v)[DPL], const bool (&valid)[DPL],
                                                   int l, double init0) {
   if constexpr (kSeqSum<G, D>) {
@@ -514,12 +535,12 @@ __device__ __forceinline__ double group_sum_slots(const double (&v)[DPL], const 
     double acc = (l == 0) ? init0 : 0.0;
 #pragma unroll
     for (int k = 0; k < DPL; k++) acc = valid[k] ? (acc + v[k]) : acc;
-    return group_allsum<G>(acc);
+    return group_allsum<G, kLds>(acc);
   }
 }
 
 // leapfrog.ex:39-42: 0.5 * sum(p * (M^-1 * p))
-template <int G, int DPL, int D = G * DPL>
+template <int G, int DPL, int D = G * DPL, bool kLds = false>
 __device__ __forceinline__ double kinetic_energy(const double (&p)[DPL], const double (&im)[DPL],
                                                  const bool (&valid)[DPL]) {
   if constexpr (kSeqSum<G, D>) {
@@ -530,7 +551,7 @@ __device__ __forceinline__ double kinetic_energy(const double (&p)[DPL], const d
     double acc = 0.0;
 #pragma unroll
     for (int k = 0; k < DPL; k++) acc = valid[k] ? (acc + p[k] * (im[k] * p[k])) : acc;
-    return 0.5 * group_allsum<G>(acc);
+    return 0.5 * group_allsum<G, kLds>(acc);
   }
 }
 
@@ -550,7 +571,7 @@ __device__ __forceinline__ void uturn_partials(const double (&rho)[DPL], const d
 }
 
 // tree.ex:1578-1588: rho-based U-turn test against two endpoint momenta
-template <int G, int DPL, int D = G * DPL>
+template <int G, int DPL, int D = G * DPL, bool kLds = false>
 __device__ __forceinline__ bool uturn(const double (&rho)[DPL], const double (&pa)[DPL],
                                       const double (&pb)[DPL], const double (&im)[DPL],
                                       const bool (&valid)[DPL]) {
@@ -561,7 +582,7 @@ __device__ __forceinline__ bool uturn(const double (&rho)[DPL], const double (&p
     row_seqsum<D>(s[0], s[1], v * pa[0], v * pb[0]);
   } else {
     uturn_partials<DPL>(rho, pa, pb, im, valid, s[0], s[1]);
-    group_allsum_n<G, 2>(s);
+    group_allsum_n<G, 2, kLds>(s);
   }
   return (s[0] < 0.0) || (s[1] < 0.0);
 }
@@ -572,7 +593,7 @@ __device__ __forceinline__ bool uturn(const double (&rho)[DPL], const double (&p
 //   check 3: rho3         against (pa3, pb3)
 // The tests have no side effects, so evaluating all three (instead of short-circuiting) leaves
 // every output unchanged. Returns {c1, c2 || c3}.
-template <int G, int DPL, int D = G * DPL>
+template <int G, int DPL, int D = G * DPL, bool kLds = false>
 __device__ __forceinline__ void uturn3(const double (&r1)[DPL], const double (&a1)[DPL],
                                        const double (&b1)[DPL], const double (&r2)[DPL],
                                        const double (&a2)[DPL], const double (&b2)[DPL],
@@ -590,7 +611,7 @@ __device__ __forceinline__ void uturn3(const double (&r1)[DPL], const double (&a
     uturn_partials<DPL>(r1, a1, b1, im, valid, s[0], s[1]);
     uturn_partials<DPL>(r2, a2, b2, im, valid, s[2], s[3]);
     uturn_partials<DPL>(r3, a3, b3, im, valid, s[4], s[5]);
-    group_allsum_n<G, 6>(s);
+    group_allsum_n<G, 6, kLds>(s);
   }
   c1 = (s[0] < 0.0) || (s[1] < 0.0);
   c23 = (s[2] < 0.0) || (s[3] < 0.0) || (s[4] < 0.0) || (s[5] < 0.0);

@@ -32,6 +32,9 @@ struct ModelDefaults {
   // tree bookkeeping is a real share of a leaf pass: sv 900 -> 695 ms, radon 194 -> 169 ms,
   // eight_schools ~20 -> ~17 ms; not for logistic, whose pass is nearly all model (158 -> 162 ms)
   static constexpr bool kPipeWarmup = true;
+  // 64-lane sums: the cross-row stages through ds_bpermute instead of v_readlane (exmc_device.hpp
+  // group_allsum_n): for kernels bound by vector issue with two waves per SIMD
+  static constexpr bool kXRowLds = false;
   // opts[:dense_mass] in the row layout (16 lanes, one dimension per lane): see RowDenseModel
   static constexpr bool kRowDense = false;
   // Resident waves per SIMD the sampling kernel's register allocation must allow (the second
@@ -351,6 +354,7 @@ struct SV : ModelDefaults {
   // one scratch access inside the leaf loop) two are, and the pair issues every ~3.5
   // (4096 chains x 200 draws: 1307 -> 950 ms)
   static constexpr int kNutsWavesPerSimd = (G == 64) ? 2 : 1;
+  static constexpr bool kXRowLds = (G == 64);
   using Consts = SVConsts;
   struct Lane {
     double r[DPL];
@@ -459,10 +463,10 @@ struct SV : ModelDefaults {
       nxt = (i + 1 < T) ? nxt : 0.0;
       g[k] = g[k] + (de[k] - nxt);
     }
-    const double sp = group_sum_slots<G, DPL>(P, valid, l, 0.0);
-    const double sl = group_sum_slots<G, DPL>(LL, valid, l, 0.0);
-    const double se = group_sum_slots<G, DPL>(E2, valid, l, 0.0);
-    const double sn = group_sum_slots<G, DPL>(DN, valid, l, 0.0);
+    const double sp = group_sum_slots<G, DPL, G * DPL, kXRowLds>(P, valid, l, 0.0);
+    const double sl = group_sum_slots<G, DPL, G * DPL, kXRowLds>(LL, valid, l, 0.0);
+    const double se = group_sum_slots<G, DPL, G * DPL, kXRowLds>(E2, valid, l, 0.0);
+    const double sn = group_sum_slots<G, DPL, G * DPL, kXRowLds>(DN, valid, l, 0.0);
     const bool in_s = (zs_raw > -200.0) && (zs_raw < 200.0);
     const bool in_n = (zn_raw > -200.0) && (zn_raw < 200.0);
     const double g_s = in_s ? ((se - ln.k[kLamS] * sigma) + 1.0) : 0.0;

@@ -208,7 +208,7 @@ __device__ __forceinline__ double mass_ke(const NutsLane<M, G>& L, const double 
   if constexpr (G == 1) {
     if (L.dm.cov) return kinetic_energy_dense<M::D>(L.dm.cov, p);
   }
-  return kinetic_energy<G, M::DPL, M::D>(p, L.im, L.valid);
+  return kinetic_energy<G, M::DPL, M::D, M::kXRowLds>(p, L.im, L.valid);
 }
 // q += eps * (M^-1 p_half)
 template <class M, int G>
@@ -237,7 +237,7 @@ __device__ __forceinline__ bool mass_uturn(const NutsLane<M, G>& L, const double
   if constexpr (G == 1) {
     if (L.dm.cov) return uturn_dense<M::D>(L.dm.cov, rho, pa, pb);
   }
-  return uturn<G, M::DPL, M::D>(rho, pa, pb, L.im, L.valid);
+  return uturn<G, M::DPL, M::D, M::kXRowLds>(rho, pa, pb, L.im, L.valid);
 }
 template <class M, int G>
 __device__ __forceinline__ void mass_uturn3(const NutsLane<M, G>& L, const double (&r1)[M::DPL],
@@ -262,7 +262,7 @@ __device__ __forceinline__ void mass_uturn3(const NutsLane<M, G>& L, const doubl
       return;
     }
   }
-  uturn3<G, M::DPL, M::D>(r1, a1, b1, r2, a2, b2, r3, a3, b3, L.im, L.valid, c1, c23);
+  uturn3<G, M::DPL, M::D, M::kXRowLds>(r1, a1, b1, r2, a2, b2, r3, a3, b3, L.im, L.valid, c1, c23);
 }
 
 // a chain's state between transitions
@@ -686,7 +686,7 @@ __device__ __forceinline__ bool pipe_integrate_transition(const typename M::Cons
     f.logp = M::logp_grad(mc, L.ln, L.l, q, g);
 #pragma unroll
     for (int k = 0; k < DPL; k++) p[k] = p[k] + h * g[k];
-    const double jlp = f.logp - kinetic_energy<G, DPL, M::D>(p, im, L.valid);
+    const double jlp = f.logp - kinetic_energy<G, DPL, M::D, M::kXRowLds>(p, im, L.valid);
     // tree.ex:1042-1048 without a branch: a non-finite joint log-probability is a divergence with
     // log-weight -1001 and no acceptance; fmin(dl, 0) is 0 for a NaN, so the exponential is defined
     const bool fin = exmc_isfinite(jlp);
