@@ -396,7 +396,9 @@ def _emit(g, D, s_out, gown, sg, scal_lp, nlr):
         elif op[0] == "neg":
             e = "-%s" % a[0]
         elif op[0] in cg._FN1:
-            e = "%s(%s)" % (cg._FN1[op[0]], a[0])
+            # the lane function holds a handful of transcendentals: they are inlined (EXMC_GENV_*),
+            # unlike the one-lane body's tens of calls (EXMC_GEN_*, exmc_models.hpp)
+            e = "%s(%s)" % (cg._FN1[op[0]].replace("EXMC_GEN_", "EXMC_GENV_"), a[0])
         elif op[0] in cg._FN2:
             e = "%s(%s, %s)" % (cg._FN2[op[0]], a[0], a[1])
         elif op[0] == "sel_gt":

@@ -1007,6 +1007,17 @@ static __host__ __device__ __noinline__ double exmc_gen_log1p_call(double x) { r
 #define EXMC_GEN_LOG exmc_gen_log_call
 #define EXMC_GEN_LOG1P exmc_gen_log1p_call
 #endif
+// the 16-lane plate layout's lane function: inlined unless the build asks for calls (the fence of
+// tests/test_gpu_codegen_inline.py covers the inlined form of the one-lane body as well)
+#ifdef EXMC_GENV_CALLED_MATH
+#define EXMC_GENV_EXP exmc_gen_exp_call
+#define EXMC_GENV_LOG exmc_gen_log_call
+#define EXMC_GENV_LOG1P exmc_gen_log1p_call
+#else
+#define EXMC_GENV_EXP exmc_exp
+#define EXMC_GENV_LOG exmc_log
+#define EXMC_GENV_LOG1P exmc_log1p
+#endif
 #include EXMC_CUSTOM_HEADER
 
 namespace exmc {

@@ -27,6 +27,9 @@ WRAPPER = """
 #define EXMC_GEN_EXP exmc_exp
 #define EXMC_GEN_LOG exmc_log
 #define EXMC_GEN_LOG1P exmc_log1p
+#define EXMC_GENV_EXP exmc_exp
+#define EXMC_GENV_LOG exmc_log
+#define EXMC_GENV_LOG1P exmc_log1p
 #include "%(header)s"
 int exmc_gen_check_dim(void) { return EXMC_GEN_D; }
 int exmc_gen_check_ndata(void) {
