@@ -778,7 +778,9 @@ struct Radon : ModelDefaults {
     int maxx;               // kChunks: most later chunks of any county
     Recip ten, five, c25;   // prior scales Normal(0, 10), Normal(0, 5), HalfCauchy(2.5)
     int xoff;               // LDS image of floor / y (offset in doubles), or -1: read from global
+    double kc[6];           // the model's scalar constants as (uniform) vector registers, see SV::Lane::k
   };
+  enum { kTiny = 0, kLog2Pi, kHc, kC1, kMu10, kN5 };
   // cooperative (whole workgroup); the caller synchronises afterwards
   __device__ static __forceinline__ bool stage_data(const Consts& c, double* dst) {
     const int N = (int)c.cs[J];
@@ -828,6 +830,13 @@ struct Radon : ModelDefaults {
     ln.ten = make_recip_literal(10.0);
     ln.five = make_recip_literal(5.0);
     ln.c25 = make_recip_literal(2.5);
+    const double src[6] = {c.tiny32, c.log2pi32, c.c_hc, c.c1, c.c_mu10, c.c_n5};
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      double v = src[i];
+      asm volatile("" : "+v"(v));
+      ln.kc[i] = v;
+    }
   }
   __device__ static __forceinline__ double logp_grad(const Consts& c, const Lane& ln, int l,
                                                      const double (&q)[DPL], double (&g)[DPL]) {
@@ -852,7 +861,7 @@ struct Radon : ModelDefaults {
     double ez[2] = {zsa, zsy};
     lane_batch<G, 2>(ez, l, [](double v) { return exmc_exp(v); });
     const double sa = ez[0], sy = ez[1];
-    const double ssy = fmax(sy, c.tiny32);
+    const double ssy = fmax(sy, ln.kc[kTiny]);
     dv.template watch_exp_if<-100, 100>(true, ssy);
     dv.watch(mu);
     dv.watch(gam);
@@ -864,11 +873,11 @@ struct Radon : ModelDefaults {
     const double za2 = za * za, zy2 = zy * zy;
     double lx[3] = {ssy, 1.0 + za2, 1.0 + zy2};
     lane_batch<G, 3>(lx, l, [](double v) { return exmc_log(v); });
-    const double cn = c.log2pi32 + 2.0 * lx[0];
+    const double cn = ln.kc[kLog2Pi] + 2.0 * lx[0];
     const double dsa = -dv(dv(2.0 * za, ln.c25), 1.0 + za2);
     const double dsy = -dv(dv(2.0 * zy, ln.c25), 1.0 + zy2);
-    const double t_sa = (c.c_hc - lx[1]) + zsa;
-    const double t_sy = (c.c_hc - lx[2]) + zsy;
+    const double t_sa = (ln.kc[kHc] - lx[1]) + zsa;
+    const double t_sy = (ln.kc[kHc] - lx[2]) + zsy;
     double s[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // lik, S, S*u, S*alpha_raw, F, Z2 partials
     double T[DPL];
     bool valid[DPL];
@@ -947,7 +956,7 @@ struct Radon : ModelDefaults {
         s[2] = s[2] + sj * ln.u[k];
         s[3] = s[3] + sj * ar;
       }
-      T[k] = -0.5 * (ar * ar + c.c1);
+      T[k] = -0.5 * (ar * ar + ln.kc[kC1]);
       g[k] = (-ar) + sj * sa;
     }
     group_allsum_n<G, 6>(s);
@@ -957,11 +966,11 @@ struct Radon : ModelDefaults {
 #pragma unroll
     for (int k = 0; k < DPL; k++) {
       const int j = l + k * G;
-      if (j == J) { T[k] = -0.5 * (zmu * zmu + c.c_mu10); g[k] = (-dv(zmu, ln.ten)) + s[1]; }
-      if (j == J + 1) { T[k] = -0.5 * (zg * zg + c.c_n5); g[k] = (-dv(zg, ln.five)) + s[2]; }
+      if (j == J) { T[k] = -0.5 * (zmu * zmu + ln.kc[kMu10]); g[k] = (-dv(zmu, ln.ten)) + s[1]; }
+      if (j == J + 1) { T[k] = -0.5 * (zg * zg + ln.kc[kN5]); g[k] = (-dv(zg, ln.five)) + s[2]; }
       if (j == J + 2) { T[k] = t_sa; g[k] = in_a ? ((dsa + s[3]) * sa + 1.0) : 0.0; }
       if (j == J + 3) { T[k] = t_sy; g[k] = in_y ? ((dsy * sy + s[5]) + 1.0) : 0.0; }
-      if (j == J + 4) { T[k] = -0.5 * (zb * zb + c.c_n5); g[k] = (-dv(zb, ln.five)) + s[4]; }
+      if (j == J + 4) { T[k] = -0.5 * (zb * zb + ln.kc[kN5]); g[k] = (-dv(zb, ln.five)) + s[4]; }
       if (j >= D) g[k] = 0.0;
     }
     return group_sum_slots<G, DPL>(T, valid, l, s[0]);
