@@ -99,22 +99,61 @@ class IR:
         return self._add(id_, dict(op="rv", dist=dist, params=dict(params), transform=transform))
 
     def obs(self, id_, rv_id, value, **opts):
+        """Builder.obs (builder.ex:38-102) with its meta: reduce (:sum | :mean | :logsumexp),
+        weight (scalar or vector), mask (vector of booleans), censored (:right | :left, or
+        :interval with value = {"lower": a, "upper": b})."""
         for k in opts:
-            if k not in ("reduce",):
+            if k not in ("reduce", "weight", "mask", "censored", "likelihood"):
                 raise CodegenError("obs option %r is not covered by the generator" % k)
-        v = np.asarray(value, dtype=np.float64)
+        cens = opts.get("censored")
+        if cens not in (None, "right", "left", "interval"):
+            raise CodegenError("censored: %r is not covered" % (cens,))
+        if cens == "interval":
+            if not (isinstance(value, dict) and set(value) == {"lower", "upper"}):
+                raise CodegenError("an interval-censored obs takes value = {'lower': a, 'upper': b}")
+            lo = np.asarray(value["lower"], dtype=np.float64)
+            hi = np.asarray(value["upper"], dtype=np.float64)
+            if lo.shape != hi.shape:
+                raise CodegenError("interval bounds differ in shape")
+            v = np.stack([lo, hi], axis=-1)       # [..., 2]
+            shape = lo.shape
+        else:
+            v = np.asarray(value, dtype=np.float64)
+            shape = v.shape
         reduce_ = opts.get("reduce")
-        if v.ndim > 0 and reduce_ is None:
+        if len(shape) > 0 and reduce_ is None:
             reduce_ = "sum"                      # builder.ex:97-102
-        if v.ndim > 1:
+        if len(shape) > 1:
             raise CodegenError("obs values are scalars or vectors")
-        if v.ndim == 1 and reduce_ != "sum":
-            raise CodegenError("vector obs needs reduce :sum")
-        return self._add(id_, dict(op="obs", target=rv_id, value=v))
+        if reduce_ not in (None, "sum", "mean", "logsumexp"):
+            raise CodegenError("reduce %r is not covered" % (reduce_,))
+        if len(shape) == 1 and reduce_ is None:
+            raise CodegenError("vector obs needs a reduce")
+        meta = dict(reduce=reduce_, censored=cens)
+        if opts.get("likelihood") is False:
+            meta["likelihood"] = False           # compiler.ex:244-245: the node contributes no term
+        if opts.get("weight") is not None:
+            w = np.asarray(opts["weight"], dtype=np.float64)
+            if w.ndim > 1 or (w.ndim == 1 and w.shape != shape):
+                raise CodegenError("weight must be a scalar or match the value")
+            meta["weight"] = w
+        if opts.get("mask") is not None:
+            mk = np.asarray(opts["mask"]).astype(bool)
+            if mk.shape != shape or len(shape) != 1:
+                raise CodegenError("mask must be a vector matching the value")
+            meta["mask"] = mk
+        return self._add(id_, dict(op="obs", target=rv_id, value=v, meta=meta))
 
-    def meas_obs(self, id_, rv_id, value, op_info):
+    def det(self, id_, fun, args):
+        """Builder.det (builder.ex:80-83): a deterministic node. It contributes no term
+        (compiler.ex:269); an obs of det("affine", [a, b, rv]) or det("matmul", [A, rv]) becomes a
+        meas_obs under `rewrite` (rewrite/lift_measurable_affine.ex, lift_measurable_matmul.ex)."""
+        return self._add(id_, dict(op="det", fun=fun, args=list(args)))
+
+    def meas_obs(self, id_, rv_id, value, op_info, meta=None):
         """Builder.meas_obs (builder.ex:69-82): an observation of a measurable function of an rv;
-        op_info = ("affine", a, b) for y = a x + b or ("matmul", A) for y = A x."""
+        op_info = ("affine", a, b) for y = a x + b or ("matmul", A) for y = A x. `meta` is an obs
+        node's meta carried over by the lifting passes (weight / mask / reduce)."""
         v = np.asarray(value, dtype=np.float64)
         if v.ndim > 1:
             raise CodegenError("meas_obs values are scalars or vectors")
@@ -128,7 +167,7 @@ class IR:
             info = ("matmul", a)
         else:
             raise CodegenError("meas_obs op %r is not covered" % (kind,))
-        return self._add(id_, dict(op="meas_obs", target=rv_id, value=v, info=info))
+        return self._add(id_, dict(op="meas_obs", target=rv_id, value=v, info=info, meta=meta))
 
 
 def simple_ir(y=None):
@@ -205,6 +244,7 @@ class _Graph:
     def exp(self, a): return self._node("exp", a)
     def log(self, a): return self._node("log", a)
     def log1p(self, a): return self._node("log1p", a)
+    def erf(self, a): return self._node("erf", a)
     def max(self, a, b): return self._node("max", a, b)
     def min(self, a, b): return self._node("min", a, b)
     def abs(self, a): return self._node("abs", a)
@@ -276,6 +316,8 @@ class _Grad:
                 self._acc(a[0], g.mul(gy, g.recip(a[0])))
             elif op == "log1p":
                 self._acc(a[0], g.mul(gy, g.recip(g.add(g.lit(1.0), a[0]))))
+            elif op == "erf":     # 2/sqrt(pi) * exp(-a^2)
+                self._acc(a[0], g.mul(gy, g.mul(g.lit(2.0 / math.sqrt(math.pi)), g.exp(g.neg(g.mul(a[0], a[0]))))))
             elif op == "max":
                 self._acc(a[0], g.sel_gt(a[0], a[1], gy, zero))
                 self._acc(a[1], g.sel_gt(a[1], a[0], gy, zero))
@@ -338,6 +380,52 @@ def _lgamma(g, x):
         ag = g.add(ag, g.div(g.lit(_f32(c)), g.add(x, g.lit(float(i)))))
     r = g.add(g.lit(HALF_LOG_2PI_F32), g.mul(g.sub(x, g.lit(0.5)), g.log(t)))
     return g.add(g.sub(r, t), g.log(ag))
+
+
+def _erfc(g, x):
+    # censored.ex:55-68 (Abramowitz & Stegun 7.1.26; every Nx.tensor(<float>) literal is f32)
+    ax = g.abs(x)
+    t_ = g.div(g.lit(1.0), g.add(g.lit(1.0), g.mul(g.lit(_f32(0.3275911)), ax)))
+    poly = g.lit(0.0)
+    for c in reversed([0.254829592, -0.284496736, 1.421413741, -1.453152027, 1.061405429]):
+        poly = g.add(g.lit(_f32(c)), g.mul(t_, poly))
+    res = g.mul(g.mul(t_, poly), g.exp(g.neg(g.mul(ax, ax))))
+    return g.sel_gt(g.lit(0.0), x, g.sub(g.lit(2.0), res), res)     # select(x < 0, 2 - r, r)
+
+
+def _normal_cdf(g, z):
+    # censored.ex:44-46
+    return g.mul(g.lit(0.5), _erfc(g, g.neg(g.div(z, g.lit(_f32(math.sqrt(2.0)))))))
+
+
+def _censored_loglik(g, kind, value, dist, p):
+    # censored.ex:14-42
+    tiny = g.lit(TINY_F32)
+    if dist == "weibull" and kind == "right":
+        k, lam = _need(p, dist, "k", "lambda")
+        z = g.sub(g.log(value), g.log(lam))              # weibull.ex:51-54 log_survival
+        return g.neg(g.exp(g.mul(k, z)))
+    if dist == "normal":
+        mu, sigma = _need(p, dist, "mu", "sigma")
+        ss = g.max(sigma, tiny)
+        if kind == "interval":
+            lo, hi = value
+            z_lo = g.div(g.sub(lo, mu), ss)
+            z_hi = g.div(g.sub(hi, mu), ss)
+            return g.log(g.sub(_normal_cdf(g, z_hi), _normal_cdf(g, z_lo)))
+        z = g.div(g.sub(value, mu), ss)
+        if kind == "left":
+            return g.log(_normal_cdf(g, z))
+        return g.log(_normal_cdf(g, g.neg(z)))             # log_sf(z) = log_cdf(-z)
+    raise CodegenError("censored: %s is not covered for distribution %r" % (kind, dist))
+
+
+def _logsumexp(g, xs):
+    # Nx.logsumexp (third-party Nx 0.10): the maximum, then log(sum(exp(x - max))) + max
+    m = xs[0]
+    for e in xs[1:]:
+        m = g.max(m, e)
+    return g.add(g.log(_sum_left(g, [g.exp(g.sub(e, m)) for e in xs])), m)
 
 
 def _need(params, dist, *names):
@@ -422,6 +510,24 @@ def _logpdf(g, dist, x, p):
     if dist == "poisson":         # poisson.ex:16-20
         (mu,) = _need(p, dist, "mu")
         return g.sub(g.sub(g.mul(x, g.log(mu)), mu), _lgamma(g, g.add(x, g.lit(1.0))))
+    if dist == "truncated_normal":   # truncated_normal.ex:16-40 (f32 literals like normal.ex; Nx.erf = exmc_erf)
+        _need(p, dist, "mu", "sigma", "lower", "upper")
+        ss = g.max(p["sigma"], tiny)
+        z = g.div(g.sub(x, p["mu"]), ss)
+        log_term = g.add(g.lit(LOG_2PI_F32), g.mul(g.lit(2.0), g.log(ss)))
+        normal = g.mul(g.lit(-0.5), g.add(g.mul(z, z), log_term))
+
+        def cdf(v):
+            return g.mul(g.lit(0.5), g.add(g.lit(1.0), g.erf(g.div(v, g.lit(_f32(math.sqrt(2.0)))))))
+        alpha = g.div(g.sub(p["lower"], p["mu"]), ss)
+        beta = g.div(g.sub(p["upper"], p["mu"]), ss)
+        return g.sub(normal, g.log(g.sub(cdf(beta), cdf(alpha))))
+    if dist == "mixture":         # mixture.ex:13-27
+        comps, cps, ws = _need(p, dist, "components", "params", "weights")
+        if not (isinstance(ws, list) and len(comps) == len(cps) == len(ws) and len(ws) >= 1):
+            raise CodegenError("mixture needs components, params and weights of equal length")
+        lps = [g.add(_logpdf(g, comps[k], x, cps[k]), g.log(ws[k])) for k in range(len(ws))]
+        return _logsumexp(g, lps)
     if dist == "uniform01":       # uniform01.ex:14-16
         _need(p, dist)
         return g.lit(0.0)
@@ -566,6 +672,51 @@ def _observed_targets(ir):
     return {n["target"] for n in ir.nodes.values() if n["op"] in ("obs", "meas_obs")}
 
 
+# Dist.transform/1 of each module under lib/exmc/dist (the default a 3-tuple rv node receives)
+DEFAULT_TRANSFORMS = dict(bernoulli="logit", beta="logit", uniform01="logit", dirichlet="stick_breaking",
+                          exponential="log", gamma="log", half_cauchy="log", lognormal="log", poisson="log",
+                          weibull="log", half_normal="softplus")
+
+
+def _default_transform(dist, params):
+    if dist == "mixture":                         # mixture.ex:34-36: the first component's
+        comps, cps = params.get("components") or [None], params.get("params") or [{}]
+        return _default_transform(comps[0], cps[0])
+    if dist == "custom":                          # custom.ex:92-95: the closure bundle's own field
+        return params.get("transform")
+    return DEFAULT_TRANSFORMS.get(dist)
+
+
+def rewrite(ir):
+    """Exmc.Rewrite.apply (rewrite.ex:13-34) up to the non-centred pass, which `generate` applies
+    itself: AttachDefaultTransforms (an rv written without a transform gets its distribution's
+    default -- observed rvs too, which moves their obs term to the unconstrained value of the
+    datum, compiler.ex:284-291), LiftMeasurableMatmul, LiftMeasurableAffine (obs of a det node ->
+    meas_obs, the obs meta carried over). NormalizeObs / PopulateObsMetadata only fill defaults
+    this IR already has (a weight of 1.0 multiplies exactly)."""
+    out = IR()
+    for id_, n in ir.nodes.items():
+        n = dict(n)
+        if n["op"] == "rv" and n["transform"] is None:
+            n["transform"] = _default_transform(n["dist"], n["params"])
+        elif n["op"] == "obs":
+            tgt = ir.nodes.get(n["target"])
+            if tgt is not None and tgt["op"] == "det":
+                fun, args = tgt["fun"], tgt["args"]
+                lifted = None
+                if fun == "matmul" and len(args) == 2 and isinstance(args[1], str):
+                    lifted = (args[1], ("matmul", args[0]))
+                elif fun == "affine" and len(args) == 3 and isinstance(args[2], str):
+                    lifted = (args[2], ("affine", args[0], args[1]))
+                if lifted is not None:
+                    if (n.get("meta") or {}).get("censored"):
+                        raise CodegenError("obs %r: a censored observation of a det node is not covered" % id_)
+                    tmp = IR().meas_obs(id_, lifted[0], n["value"], lifted[1], meta=n.get("meta"))
+                    n = tmp.nodes[id_]
+        out.nodes[id_] = n
+    return out
+
+
 def _apply_ncp(ir, ncp):
     """rewrite/non_centered_parameterization.ex:26-55"""
     nodes, info = dict(ir.nodes), {}
@@ -581,8 +732,12 @@ def _apply_ncp(ir, ncp):
     return nodes, info
 
 
-def generate(ir, ncp=True, vectorize=True):
-    """Compiler.compile_for_sampling (compiler.ex:46-58) as source text."""
+def generate(ir, ncp=True, vectorize=True, rewrite_passes=False):
+    """Compiler.compile_for_sampling (compiler.ex:46-58) as source text. `rewrite_passes` runs the
+    reference's IR passes first (`rewrite`); without it the IR is taken as already rewritten
+    (transforms explicit), which is what an exporter on the Elixir side sends."""
+    if rewrite_passes:
+        ir = rewrite(ir)
     nodes, ncp_info = _apply_ncp(ir, ncp)
     if len(nodes) > MAX_NODES_SORTED:
         raise CodegenError("more than %d nodes: the reference's term order is the hash order of "
@@ -638,7 +793,19 @@ def generate(ir, ncp=True, vectorize=True):
             return [g.datum(float(x)) for x in a]
         raise CodegenError("params are scalars, vectors or refs")
 
+    def resolve_params(dist, params):
+        if dist == "mixture":     # nested: one params map per component, a weight vector
+            cps = [resolve_params(c, pp) for c, pp in zip(params.get("components", []), params.get("params", []))]
+            ws = resolve_value(params.get("weights"))
+            return dict(components=list(params.get("components", [])), params=cps,
+                        weights=ws if isinstance(ws, list) else [ws])
+        return {k: resolve_value(v) for k, v in params.items()}
+
     def elementwise(dist, x, params):
+        if dist == "mixture":     # scalar params per component; only the value may be a vector
+            if isinstance(x, list):
+                return [_logpdf(g, dist, xi, params) for xi in x], True
+            return _logpdf(g, dist, x, params), False
         n = max([len(v) for v in [x] + list(params.values()) if isinstance(v, list)] + [0])
         if n == 0:
             return _logpdf(g, dist, x, params), False
@@ -661,9 +828,57 @@ def generate(ir, ncp=True, vectorize=True):
             raise CodegenError("a custom logpdf must return a scalar (reduce inside the closure)")
         return t
 
+    def const_x(tr, v, id_):
+        # compiler.ex:284-291, 327-334, 350-357: z = inverse_transform(value), x = Transform.apply(z),
+        # the log-Jacobian at z joins the term (all constants of the data). v: a float or a node.
+        d = v if isinstance(v, int) else g.datum(float(v))
+        if tr is None:
+            return d, None
+        if tr == "log":
+            z = g.log(d)
+        elif tr == "softplus":
+            if isinstance(v, int):
+                raise CodegenError("%r: a softplus-transformed target of a computed value is not covered" % id_)
+            z = g.datum(math.log(math.expm1(float(v))))      # Nx.log(Nx.expm1(x)), host libm
+        elif tr == "logit":
+            z = g.sub(g.log(d), g.log1p(g.neg(d)))
+        else:
+            raise CodegenError("%r: an observation of a %r-transformed rv is not covered" % (id_, tr))
+        return _apply_transform(g, tr, z), _log_abs_det_jacobian(g, tr, z)
+
+    def apply_obs_meta(elems, is_vec, meta, id_):
+        # compiler.ex:401-418: weight, mask, reduce
+        w = meta.get("weight")
+        if w is not None:
+            if is_vec:
+                elems = [g.mul(e, g.datum(float(w if w.ndim == 0 else w[i]))) for i, e in enumerate(elems)]
+            else:
+                if w.ndim != 0:
+                    raise CodegenError("obs %r: a vector weight on a scalar term" % id_)
+                elems = g.mul(elems, g.datum(float(w)))
+        mk = meta.get("mask")
+        if mk is not None:
+            if not is_vec or len(mk) != len(elems):
+                raise CodegenError("obs %r: mask does not match the term" % id_)
+            elems = [e if bool(mk[i]) else g.lit(0.0) for i, e in enumerate(elems)]
+        red = meta.get("reduce")
+        if not is_vec:
+            return elems
+        if red == "sum":
+            return _sum_left(g, elems)            # Nx.sum on the BinaryBackend: left to right
+        if red == "mean":
+            return g.div(_sum_left(g, elems), g.lit(float(len(elems))))
+        if red == "logsumexp":
+            return _logsumexp(g, elems)
+        raise CodegenError("obs %r: a vector-valued term needs a reduce" % id_)
+
     terms = []
     for id_ in sorted(nodes):                     # Map.values order, compiler.ex:176-180
         n = nodes[id_]
+        if n["op"] == "det":                      # compiler.ex:268-269
+            continue
+        if n["op"] in ("obs", "meas_obs") and (n.get("meta") or {}).get("likelihood") is False:
+            continue                              # compiler.ex:244-245
         if n["op"] == "rv":
             if id_ not in offset:
                 continue
@@ -680,8 +895,8 @@ def generate(ir, ncp=True, vectorize=True):
             if n["dist"] == "custom":
                 t = custom_logpdf(n["params"], x)
             else:
-                params = {k: resolve_value(v) for k, v in n["params"].items()}
-                if any(isinstance(v, list) for v in params.values()):
+                params = resolve_params(n["dist"], n["params"])
+                if n["dist"] != "mixture" and any(isinstance(v, list) for v in params.values()):
                     raise CodegenError("free RV %r has a vector param" % id_)
                 t = _logpdf(g, n["dist"], x, params)
             if n["transform"] is not None:
@@ -691,12 +906,12 @@ def generate(ir, ncp=True, vectorize=True):
             # compiler.ex:258-266, 342-369: eager -- the target's params are used as written (no
             # refs), so the whole term is a constant of the data
             tgt = nodes[n["target"]]
-            if tgt["op"] != "rv" or tgt["transform"] is not None or tgt["dist"] in VECTOR_DISTS + ("custom",):
+            if tgt["op"] != "rv" or tgt["dist"] in VECTOR_DISTS + ("custom",):
                 raise CodegenError("meas_obs %r: target not covered" % id_)
             if any(isinstance(v, str) for v in tgt["params"].values()):
                 raise CodegenError("meas_obs %r: the reference evaluates it eagerly, params must be constants" % id_)
-            params = {k: resolve_value(v) for k, v in tgt["params"].items()}
-            val, info = n["value"], n["info"]
+            params = resolve_params(tgt["dist"], tgt["params"])
+            val, info, tr = n["value"], n["info"], tgt["transform"]
             if info[0] == "affine":
                 a, b = g.datum(info[1]), g.datum(info[2])
                 conv = lambda v: g.div(g.sub(g.datum(float(v)), b), a)   # noqa: E731
@@ -706,36 +921,83 @@ def generate(ir, ncp=True, vectorize=True):
                 sol = np.linalg.solve(info[1], val)                  # jit_solve: third-party LinAlg
                 x = [g.datum(float(v)) for v in sol]
                 jac = g.datum(-math.log(abs(float(np.linalg.det(info[1])))))
+            tjac = None
+            if tr is not None:                    # compiler.ex:350-359, 371-382: (logp + jac) + meas_jac
+                pairs = [const_x(tr, v, id_) for v in (x if isinstance(x, list) else [x])]
+                x = [p_[0] for p_ in pairs] if isinstance(x, list) else pairs[0][0]
+                tjac = [p_[1] for p_ in pairs]
             t, vec = elementwise(tgt["dist"], x, params)
             if vec:
-                # logpdf of a vector value is a vector; combined = logp + jac broadcasts, then the
-                # term is reduced by sum_logps' Nx.sum (compiler.ex:396-397)
-                t = _sum_left(g, [g.add(e, jac) for e in t])
+                # logpdf of a vector value is a vector; combined = logp + jac broadcasts, the meta's
+                # reduce (or, without one, sum_logps' Nx.sum, compiler.ex:396-397) folds it
+                if tjac is not None:
+                    t = [g.add(e, tjac[i if len(tjac) > 1 else 0]) for i, e in enumerate(t)]
+                t = [g.add(e, jac) for e in t]
             else:
+                if tjac is not None:
+                    t = g.add(t, tjac[0])
                 t = g.add(t, jac)
-            terms.append(t)
+            meta = dict(n.get("meta") or {})
+            if vec and meta.get("reduce") is None:
+                meta["reduce"] = "sum"
+            terms.append(apply_obs_meta(t, vec, meta, id_))
         else:
             tgt = nodes[n["target"]]
             if tgt["op"] != "rv":
-                raise CodegenError("obs %r does not target an rv" % id_)
-            if tgt["transform"] is not None:
-                raise CodegenError("obs of a transformed rv is not covered")
-            val = n["value"]
-            x = g.datum(float(val)) if val.ndim == 0 else [g.datum(float(v)) for v in val]
+                # the reference gives such a node no term (compiler.ex:293); a det target that the
+                # lifting passes did not take is a model error here
+                raise CodegenError("obs %r does not target an rv (run the rewrite passes for det targets)" % id_)
+            val, meta = n["value"], n.get("meta") or dict(reduce="sum" if n["value"].ndim else None, censored=None)
+            cens = meta.get("censored")
+            tr = tgt["transform"]
+            if tr is not None and (cens == "interval" or tgt["dist"] in ("custom", "mv_normal", "gaussian_random_walk")):
+                raise CodegenError("obs %r: a transformed target with this distribution / censoring is not covered" % id_)
+            if tr is not None and cens:
+                # compiler.ex:274, 298-311 match the 3-tuple rv node only: on a target that carries a
+                # transform the 4-tuple clauses (:285, :325) run and the censoring is not applied
+                cens = None
+
+            vec = val.ndim > (1 if cens == "interval" else 0)
             if tgt["dist"] == "custom":
-                terms.append(custom_logpdf(tgt["params"], x))
-                continue
-            if tgt["dist"] in VECTOR_DISTS:
-                if val.ndim != 1:
-                    raise CodegenError("obs %r of a vector distribution needs a vector value" % id_)
-                terms.append(_logpdf_vector(g, tgt["dist"], x, tgt["params"], resolve_value))
-                continue
-            params = {k: resolve_value(v) for k, v in tgt["params"].items()}
-            t, vec = elementwise(tgt["dist"], x, params)
-            if vec:
-                if val.ndim == 0:
-                    raise CodegenError("scalar obs %r of a vector-valued target" % id_)
-                t = _sum_left(g, t)               # Nx.sum on the BinaryBackend: left to right
+                x = [g.datum(float(v)) for v in val] if vec else g.datum(float(val))
+                t = custom_logpdf(tgt["params"], x)
+                elems, is_vec = t, False
+            elif tgt["dist"] in VECTOR_DISTS:
+                if val.ndim != 1 or cens:
+                    raise CodegenError("obs %r of a vector distribution needs a plain vector value" % id_)
+                xs, jac = [g.datum(float(v)) for v in val], None
+                if tr == "stick_breaking":        # compiler.ex:424: z from the datum, the point rebuilt from z
+                    zs = [g.datum(float(v)) for v in inverse_stick_breaking(val)]
+                    xs, jac = _stick_breaking_forward(g, zs), _stick_breaking_ladj(g, zs)
+                elif tr is not None:
+                    raise CodegenError("obs %r: transform %r on a vector distribution is not covered" % (id_, tr))
+                elems = _logpdf_vector(g, tgt["dist"], xs, tgt["params"], resolve_value)
+                if jac is not None:
+                    elems = g.add(elems, jac)
+                is_vec = False
+            elif cens:
+                params = resolve_params(tgt["dist"], tgt["params"])
+                if any(isinstance(v, list) for v in params.values()):
+                    raise CodegenError("censored obs %r: vector params are not covered" % id_)
+                rows = val if vec else val[None, ...]
+                out = []
+                for r in rows:
+                    value = (g.datum(float(r[0])), g.datum(float(r[1]))) if cens == "interval" else g.datum(float(r))
+                    out.append(_censored_loglik(g, cens, value, tgt["dist"], params))
+                elems, is_vec = (out, True) if vec else (out[0], False)
+            else:
+                params = resolve_params(tgt["dist"], tgt["params"])
+                if vec:
+                    xs, jacs = zip(*[const_x(tr, v, id_) for v in val])
+                    elems, is_vec = elementwise(tgt["dist"], list(xs), params)
+                    if tr is not None:
+                        elems = [g.add(e, j) for e, j in zip(elems, jacs)]
+                else:
+                    x, jac = const_x(tr, val, id_)
+                    elems, is_vec = elementwise(tgt["dist"], x, params)
+                    if tr is not None:
+                        elems = [g.add(e, jac) for e in elems] if is_vec else g.add(elems, jac)
+            t = apply_obs_meta(elems, is_vec, meta, id_)
             terms.append(t)
     total = terms[0]                              # sum_logps, compiler.ex:394-395
     for t in terms[1:]:
@@ -761,8 +1023,15 @@ def generate(ir, ncp=True, vectorize=True):
     # the 16-lane layout, when the model has plates to spread over lanes (codegen_vec.py): the
     # plug-in then carries Custom<16> next to Custom<1> and defaults to it
     from . import codegen_vec
-    plain = all(n["op"] in ("rv", "obs") and (n["op"] != "rv" or n["dist"] not in VECTOR_DISTS + ("custom",))
-                for n in nodes.values())
+    def _plain_node(n):
+        if n["op"] == "rv":
+            return n["dist"] not in VECTOR_DISTS + ("custom", "mixture")
+        if n["op"] == "obs":
+            m = n.get("meta") or {}
+            return (m.get("reduce") in (None, "sum") and m.get("censored") is None and m.get("weight") is None
+                    and m.get("mask") is None and nodes[n["target"]].get("transform") is None)
+        return False
+    plain = all(_plain_node(n) for n in nodes.values())
     out.vec = codegen_vec.generate(ir, ncp=ncp) if (vectorize and plain) else None
     out.lanes = 1
     if out.vec is not None:
@@ -778,7 +1047,8 @@ def generate(ir, ncp=True, vectorize=True):
 # emission
 # ---------------------------------------------------------------------------------------------
 _BIN = {"add": "+", "sub": "-", "mul": "*", "div": "/"}
-_FN1 = {"exp": "EXMC_GEN_EXP", "log": "EXMC_GEN_LOG", "log1p": "EXMC_GEN_LOG1P", "abs": "fabs"}
+_FN1 = {"exp": "EXMC_GEN_EXP", "log": "EXMC_GEN_LOG", "log1p": "EXMC_GEN_LOG1P", "erf": "EXMC_GEN_ERF",
+        "abs": "fabs"}
 _FN2 = {"max": "fmax", "min": "fmin"}
 
 

@@ -1007,6 +1007,9 @@ struct RowDenseModel : M {
 static __host__ __device__ __noinline__ double exmc_gen_exp_call(double x) { return exmc_exp(x); }
 static __host__ __device__ __noinline__ double exmc_gen_log_call(double x) { return exmc_log(x); }
 static __host__ __device__ __noinline__ double exmc_gen_log1p_call(double x) { return exmc_log1p(x); }
+static __host__ __device__ __noinline__ double exmc_gen_erf_call(double x) { return exmc_erf(x); }
+#define EXMC_GEN_ERF exmc_gen_erf_call    // two unrolled loops: a call in either layout
+#define EXMC_GENV_ERF exmc_gen_erf_call
 #ifdef EXMC_GEN_INLINE_MATH   // tools/probe/gen_inline_repro.py: the inlined form under investigation
 #define EXMC_GEN_EXP exmc_exp
 #define EXMC_GEN_LOG exmc_log

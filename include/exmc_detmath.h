@@ -1,4 +1,4 @@
-/* exmc_detmath.h — bit-reproducible f64 exp / log / log1p.
+/* exmc_detmath.h — bit-reproducible f64 exp / log / log1p / erf.
  *
  * Why this exists: the reference sampler (lib/exmc/nuts/tree.ex:1045,1398,1490,1603
  * and the model log-densities, lib/exmc/dist/<name>.ex, lib/exmc/transform.ex:17-29)
@@ -225,6 +225,46 @@ EXMC_HD double exmc_log1p(double x) {
   double u = 1.0 + x;
   if (u == 1.0) return x;
   return exmc_log(u) + (x - (u - 1.0)) / u;
+}
+
+/* erf, for the generated TruncatedNormal term (lib/exmc/dist/truncated_normal.ex:27-40 calls Nx.erf,
+ * which is :math.erf on BinaryBackend and XLA's own polynomial under EXLA: backend-defined like exp
+ * and log, so this contract fixes one evaluation). No memorised coefficient table:
+ *   |x| < 3 : erf = 2/sqrt(pi) * exp(-y) * |x| * S(y), y = x^2,
+ *             S = 1 + (2y/3)(1 + (2y/5)(1 + ... (1 + 2y/(2N+1)))), every term positive (no
+ *             cancellation), N = 56 leaves a truncation below 2^-60 at y = 9;
+ *   3 <= |x| < 6 : erf = 1 - exp(-y)/sqrt(pi) / (|x| + (1/2)/(|x| + 1/(|x| + (3/2)/(|x| + ...)))),
+ *             Laplace's continued fraction for erfc cut at 24 partial quotients (relative error
+ *             below 1e-15 at |x| = 3, and erfc itself is below 2.3e-5 there);
+ *   |x| >= 6 : 1 (erfc(6) = 2e-17); NaN propagates; the sign is restored at the end.
+ * tests/test_detmath.py: within 1e-15 of scipy.special.erf, absolute and (below 3) relative. */
+EXMC_HD double exmc_erf(double x) {
+  if (x != x) return x;
+  const double ax = x < 0.0 ? -x : x;
+  double r;
+  if (ax >= 6.0) {
+    r = 1.0;
+  } else {
+    const double y = ax * ax;
+    const double e = exmc_exp(-y);
+    if (ax < 3.0) {
+      const double y2 = y + y;
+      double s = 1.0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+      for (int n = 56; n >= 1; --n) s = __builtin_fma(s * y2, 1.0 / (double)(2 * n + 1), 1.0);
+      r = ((1.12837916709551257390e+00 * e) * ax) * s;                          /* 2/sqrt(pi) */
+    } else {
+      double f = ax;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+      for (int k = 24; k >= 1; --k) f = ax + (0.5 * (double)k) / f;
+      r = 1.0 - (5.64189583547756286948e-01 * e) / f;                           /* 1/sqrt(pi) */
+    }
+  }
+  return x < 0.0 ? -r : r;
 }
 
 /* ---- the same functions for arguments whose range the call site proves ----

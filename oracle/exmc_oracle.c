@@ -75,6 +75,7 @@ double exo_log1p(double x, int mm) { return mm ? exmc_log1p(x) : log1p(x); }
 double exo_det_exp(double x) { return exmc_exp(x); }
 double exo_det_log(double x) { return exmc_log(x); }
 double exo_det_log1p(double x) { return exmc_log1p(x); }
+double exo_det_erf(double x) { return exmc_erf(x); }
 
 double exo_rng_normal(exo_rng* r, int mm) {
   /* normal_s: 256-layer ziggurat on one 58-bit word: bit 6 = sign, bits 7..57 = 51-bit R,

@@ -30,6 +30,8 @@ WRAPPER = """
 #define EXMC_GENV_EXP exmc_exp
 #define EXMC_GENV_LOG exmc_log
 #define EXMC_GENV_LOG1P exmc_log1p
+#define EXMC_GEN_ERF exmc_erf
+#define EXMC_GENV_ERF exmc_erf
 #include "%(header)s"
 int exmc_gen_check_dim(void) { return EXMC_GEN_D; }
 int exmc_gen_check_ndata(void) {

@@ -99,3 +99,42 @@ def simplex_ir(seed=7):
 
 
 SIMPLEX_INIT = dict(theta=[0.25, 0.25, 0.25, 0.25], rate=1.0, p=0.3, k=1.2, u=0.5)
+
+
+def survival_ir(seed=11):
+    """The Builder.obs meta and the remaining distributions (d = 6): right-censored Weibull survival
+    times and exact ones, left- / right- / interval-censored Normal measurements, a weighted and
+    masked vector obs, reduce :mean and :logsumexp, an observation of a :log-transformed rv, and a
+    two-component Normal mixture likelihood whose component means are free, and a TruncatedNormal
+    likelihood (exmc_erf)."""
+    rng = np.random.default_rng(seed)
+    ir = cg.IR()
+    ir.rv("k", "gamma", dict(alpha=2.0, beta=1.0), transform="log")
+    ir.rv("lam", "lognormal", dict(mu=0.5, sigma=0.8), transform="log")
+    ir.rv("m", "normal", dict(mu=0.0, sigma=2.0))
+    ir.rv("s", "half_normal", dict(sigma=1.5), transform="log")
+    ir.rv("m1", "normal", dict(mu=-1.0, sigma=1.0))
+    ir.rv("m2", "normal", dict(mu=2.0, sigma=1.0))
+    ir.rv("t_rv", "weibull", {"k": "k", "lambda": "lam"})
+    ir.obs("t_exact", "t_rv", rng.weibull(1.5, size=5) * 2.0 + 0.1)
+    ir.obs("t_cens", "t_rv", [2.5, 3.0, 3.0], censored="right")
+    ir.rv("x_rv", "normal", dict(mu="m", sigma="s"))
+    ir.obs("x_left", "x_rv", [-0.5, 0.2], censored="left")
+    ir.obs("x_right", "x_rv", 1.7, censored="right")
+    ir.obs("x_int", "x_rv", dict(lower=[-1.0, 0.0], upper=[0.5, 2.0]), censored="interval")
+    ir.obs("x_w", "x_rv", rng.normal(size=6), weight=[1.0, 0.5, 2.0, 1.0, 0.25, 3.0],
+           mask=[True, True, False, True, True, False])
+    ir.obs("x_mean", "x_rv", rng.normal(size=4) + 0.3, reduce="mean", weight=2.0)
+    ir.obs("x_lse", "x_rv", [0.1, 0.9, -0.4], reduce="logsumexp")
+    ir.rv("pos_rv", "lognormal", dict(mu="m", sigma=0.7), transform="log")
+    ir.obs("pos", "pos_rv", [0.8, 1.9])
+    ir.rv("mix_rv", "mixture", dict(components=["normal", "normal"],
+                                    params=[dict(mu="m1", sigma=0.6), dict(mu="m2", sigma=1.1)],
+                                    weights=[0.35, 0.65]))
+    ir.obs("mix", "mix_rv", rng.normal(size=7) * 1.5 + 0.5)
+    ir.rv("tn_rv", "truncated_normal", dict(mu="m", sigma="s", lower=-2.0, upper=3.0))
+    ir.obs("tn", "tn_rv", [-1.2, 0.4, 2.6])
+    return ir
+
+
+SURVIVAL_INIT = dict(k=1.2, lam=1.5, m=0.1, s=1.0, m1=-0.8, m2=1.7)

@@ -90,7 +90,7 @@ def lib():
         f = getattr(L, name)
         f.argtypes = [C.c_double, C.c_int]
         f.restype = C.c_double
-    for name in ("exo_det_exp", "exo_det_log", "exo_det_log1p"):
+    for name in ("exo_det_exp", "exo_det_log", "exo_det_log1p", "exo_det_erf"):
         f = getattr(L, name)
         f.argtypes = [C.c_double]
         f.restype = C.c_double

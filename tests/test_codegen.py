@@ -124,7 +124,7 @@ def test_generation_is_deterministic_and_rejects_what_it_does_not_cover():
             ir.rv("x%02d" % i, "normal", dict(mu=0.0, sigma=1.0))
         cg.generate(ir)
     with pytest.raises(cg.CodegenError):
-        cg.IR().rv("x", "normal", dict(mu=0.0, sigma=1.0)).obs("o", "x", [1.0], weight=2.0)
+        cg.IR().rv("x", "normal", dict(mu=0.0, sigma=1.0)).obs("o", "x", [1.0], censored="upper")
     with pytest.raises(cg.CodegenError):       # only observed nodes: nothing to sample
         cg.generate(cg.IR().rv("x", "normal", dict(mu=0.0, sigma=1.0)).obs("o", "x", 1.0))
 

@@ -114,6 +114,6 @@ def test_refusals():
     with pytest.raises(cg.CodegenError):
         cg.generate(ir)
     ir = cg.IR()
-    ir.rv("x", "truncated_normal", dict(mu=0.0, sigma=1.0, lower=-1.0, upper=1.0))   # needs erf: not covered
+    ir.rv("x", "inverse_gamma", dict(alpha=2.0, beta=1.0), transform="log")   # not one of lib/exmc/dist
     with pytest.raises(cg.CodegenError):
         cg.generate(ir)

@@ -46,6 +46,22 @@ def test_det_log1p_within_one_ulp_of_libm():
     assert _ulps(got, np.log1p(xs)).max() <= 1.0
 
 
+def test_det_erf_against_scipy():
+    from scipy import special
+    L = O.lib()
+    rng = np.random.default_rng(3)
+    xs = np.concatenate([rng.uniform(-7, 7, 60000), rng.normal(0, 1, 40000), np.exp(rng.uniform(-40, 1.1, 20000)),
+                         [2.9999999999, 3.0, 5.9999999, 6.0, -3.0, -6.0]])
+    got = np.array([L.exo_det_erf(float(x)) for x in xs])
+    ref = special.erf(xs)
+    assert np.abs(got - ref).max() <= 1e-15
+    small = np.abs(xs) < 3
+    assert (np.abs(got[small] / ref[small] - 1.0)).max() <= 1e-15
+    assert np.array_equal(got, -np.array([L.exo_det_erf(float(-x)) for x in xs]))     # odd, exactly
+    assert L.exo_det_erf(0.0) == 0.0 and L.exo_det_erf(40.0) == 1.0 and L.exo_det_erf(-math.inf) == -1.0
+    assert math.isnan(L.exo_det_erf(math.nan))
+
+
 def test_det_math_special_values():
     L = O.lib()
     assert L.exo_det_exp(0.0) == 1.0

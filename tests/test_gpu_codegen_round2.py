@@ -96,3 +96,46 @@ def test_simplex_model_bit_exact(simplex):
     th = trace["theta"]
     assert th.shape == (80, 4) and np.allclose(th.sum(axis=1), 1.0) and np.all(th > 0)
     assert np.all(trace["rate"] > 0) and np.all((trace["p"] > 0) & (trace["p"] < 1))
+
+
+@pytest.fixture(scope="module")
+def survival(hip):
+    spec = cg.compile_ir(GM.survival_ir(), name="gen_survival", default_init=GM.SURVIVAL_INIT)
+    assert spec.gen.lanes == 1 and spec.d == 6
+    return spec, sampler.compile(spec), GC.model(spec.gen, 1)
+
+
+def test_obs_meta_model_bit_exact(survival):
+    """Builder.obs meta (censored right / left / interval, weight, mask, reduce :mean and
+    :logsumexp), an observation of a :log-transformed rv and a Mixture likelihood
+    (tests/gen_models.py::survival_ir; values against scipy in tests/test_codegen_obs_meta.py)."""
+    spec, comp, om = survival
+    rng = np.random.default_rng(9)
+    n = 200
+    q = np.ascontiguousarray(rng.normal(size=(n, spec.d)) * 1.5)
+    q[0] = spec.to_unconstrained(spec.default_init)
+    q[1, :] = 30.0
+    q[2, :] = -30.0
+    q[3, :] = 0.0
+    lp, g = np.zeros(n), np.zeros((n, spec.d))
+    comp.check(comp.L.exmc_hip_logp_grad_host(comp.h, _dp(q), n, 1, _dp(lp), _dp(g)))
+    for i in range(n):
+        lpo, go = om.logp_grad(q[i], O.Cfg(1, 1))
+        assert (lp[i] == lpo) or (np.isnan(lp[i]) and np.isnan(lpo)), i
+        assert np.array_equal(g[i], go, equal_nan=True), i
+    q0 = spec.to_unconstrained(spec.default_init)
+    trace, stats = sampler.sample(spec, spec.default_init, dict(num_warmup=150, num_samples=80, seed=3))
+    t, st = O.sample(om, q0, num_warmup=150, num_samples=80, seed=3, cfg=O.Cfg(1, 1))
+    assert st.step_size == stats["step_size"]
+    assert np.array_equal(t["draws"], stats["raw"]["draws"][0])
+    assert np.array_equal(t["n_steps"], stats["raw"]["n_steps"][0])
+    assert np.all(trace["k"] > 0) and np.all(trace["s"] > 0)
+    # the two mixture means stay on their own sides (priors at -1 and 2, weights 0.35 / 0.65)
+    assert trace["m1"].mean() < trace["m2"].mean()
+    opts = dict(num_warmup=100, num_samples=20, seed=12)
+    tuning = sampler.warmup(comp, spec.default_init, opts)
+    _, _, extra = sampler.sample_compiled_tuned(comp, tuning, spec.default_init, opts, num_chains=96)
+    tc, _ = O.sample_chains(om, 96, init_q=q0, num_warmup=100, num_samples=20, seed=12, n_threads=8,
+                            cfg=O.Cfg(1, 1))
+    assert np.array_equal(tc["draws"], extra["raw"]["draws"])
+    assert np.array_equal(tc["n_steps"], extra["raw"]["n_steps"])
