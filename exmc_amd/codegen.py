@@ -1300,9 +1300,9 @@ class GeneratedSpec(ModelSpec):
         return x
 
 
-def compile_ir(ir, ncp=True, name="generated", default_init=None, verbose=False):
+def compile_ir(ir, ncp=True, name="generated", default_init=None, verbose=False, rewrite_passes=False):
     """IR -> GeneratedSpec with its plug-in library built. Needs hipcc (no fallback)."""
-    gen = generate(ir, ncp=ncp)
+    gen = generate(ir, ncp=ncp, rewrite_passes=rewrite_passes)
     so = build_plugin(gen, verbose=verbose)
     return GeneratedSpec(gen, so, name=name, default_init=default_init)
 
@@ -1312,6 +1312,9 @@ def compile_ir(ir, ncp=True, name="generated", default_init=None, verbose=False)
 #   model.json: {"ncp": true, "nodes": {"mu": {"op": "rv", "dist": "normal",
 #                "params": {"mu": 0.0, "sigma": 5.0}, "transform": null}, ...,
 #                "y_obs": {"op": "obs", "target": "y", "value": [2.1, 1.8]}}}
+#   ("rewrite": true runs the reference's IR passes first; obs nodes take reduce / weight / mask /
+#   censored / likelihood, {"op": "det", "fun": "affine", "args": [a, b, "x"]} and
+#   {"op": "meas_obs", "target": "x", "value": [...], "info": ["affine", a, b]} are accepted)
 #   out_dir gets exmc_gen_model.h, libexmc_hip_gen.so and model.json (d, var_names = the flat
 #   order, transforms, ncp_info, data = what exmc_hip_model_create takes with EXMC_MODEL_CUSTOM).
 # ---------------------------------------------------------------------------------------------
@@ -1321,8 +1324,12 @@ def ir_from_json(doc):
         if n.get("op") == "rv":
             ir.rv(id_, n["dist"], n["params"], transform=n.get("transform"))
         elif n.get("op") == "obs":
-            opts = {k: n[k] for k in ("reduce", "weight", "mask", "censored") if n.get(k) is not None}
+            opts = {k: n[k] for k in ("reduce", "weight", "mask", "censored", "likelihood") if n.get(k) is not None}
             ir.obs(id_, n["target"], n["value"], **opts)
+        elif n.get("op") == "det":
+            ir.det(id_, n["fun"], n["args"])
+        elif n.get("op") == "meas_obs":
+            ir.meas_obs(id_, n["target"], n["value"], tuple(n["info"]))
         else:
             raise CodegenError("node %r: op %r is not covered" % (id_, n.get("op")))
     return ir
@@ -1336,7 +1343,7 @@ def main(argv=None):
     if len(argv) < 2:
         raise SystemExit("usage: python -m exmc_amd.codegen model.json out_dir [--no-build]")
     doc = json.load(open(argv[0]))
-    gen = generate(ir_from_json(doc), ncp=doc.get("ncp", True))
+    gen = generate(ir_from_json(doc), ncp=doc.get("ncp", True), rewrite_passes=doc.get("rewrite", False))
     os.makedirs(argv[1], exist_ok=True)
     with open(os.path.join(argv[1], "exmc_gen_model.h"), "w") as f:
         f.write(gen.header)

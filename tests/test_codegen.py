@@ -168,7 +168,15 @@ def test_json_front_door(tmp_path):
     assert meta["digest"] == ref.digest and meta["d"] == 2 and meta["var_names"] == ["mu", "sigma"]
     assert (tmp_path / "out" / "exmc_gen_model.h").read_text() == ref.header
     with pytest.raises(cg.CodegenError):
-        cg.ir_from_json({"nodes": {"x": {"op": "det"}}})
+        cg.ir_from_json({"nodes": {"x": {"op": "data"}}})
+    # "rewrite": the reference's passes run first -- the same model written without its transform
+    del doc["nodes"]["sigma"]["transform"]
+    doc["rewrite"] = True
+    doc["nodes"]["shift"] = {"op": "det", "fun": "affine", "args": [1.0, 0.0, "mu"]}
+    src.write_text(json.dumps(doc))
+    cg.main([str(src), str(tmp_path / "out2"), "--no-build"])
+    meta2 = json.loads((tmp_path / "out2" / "model.json").read_text())
+    assert meta2["transforms"] == {"sigma": "log"} and meta2["d"] == 2
 
 
 def test_plates_across_lanes_agree_with_the_one_lane_form():
