@@ -12,6 +12,7 @@ OK, ERR_BADARG, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED = range(5)
 EXPORTS = [
     "exmc_hip_last_error", "exmc_hip_device_count", "exmc_hip_model_create",
     "exmc_hip_model_destroy", "exmc_hip_model_dim", "exmc_hip_model_default_lanes", "exmc_hip_model_default_warmup_lanes",
+    "exmc_hip_model_default_dense_lanes",
     "exmc_hip_model_stream", "exmc_hip_logp_grad_host", "exmc_hip_multi_step",
     "exmc_hip_multi_step_host", "exmc_hip_transitions_host", "exmc_hip_warmup",
     "exmc_hip_sample_chains", "exmc_hip_sample_chains_host", "exmc_hip_sample_host",
@@ -77,6 +78,7 @@ def bind(path):
     L.exmc_hip_model_set_flat_order.argtypes = [vp, C.POINTER(C.c_int32), C.c_int]
     L.exmc_hip_model_default_lanes.argtypes = [vp]
     L.exmc_hip_model_default_warmup_lanes.argtypes = [vp]
+    L.exmc_hip_model_default_dense_lanes.argtypes = [vp]
     L.exmc_hip_model_stream.argtypes = [vp]
     L.exmc_hip_model_stream.restype = vp
     L.exmc_hip_logp_grad_host.argtypes = [vp, dp, C.c_int, C.c_int, dp, dp]

@@ -625,6 +625,8 @@ __device__ __forceinline__ void uturn3(const double (&r1)[DPL], const double (&a
 struct DenseMass {
   const double* cov = nullptr;
   const double* chol = nullptr;
+  const double* covp = nullptr;    // the lane layouts' permuted operands (LaneDense below)
+  const double* cholp = nullptr;
 };
 
 template <int D>
@@ -717,6 +719,131 @@ __device__ __forceinline__ double momentum_rowdense(const RowDense<D>& m, int l,
   double acc = z, p = 0.0;
   rowdense_backsub<D>(m, l, acc, p);
   return p;
+}
+
+// ---- the same operations for the lane layouts (a chain over G lanes, DPL dimensions per lane,
+// kernel dimension i = lane + k G; sv, radon, logistic). cov and chol belong to the reference's
+// FLAT vector (PointMap order), and every contraction runs in ascending flat index, so the
+// operands are kept as
+//   covp [D][GD]: covp[s GD + i]  = cov[rank(i)][s]     (GD = G DPL; columns i >= D are zero)
+//   cholp[D][GD]: cholp[j GD + i] = chol[j][rank(i)]
+// i.e. row s holds what every kernel dimension needs at step s of its chain, and the G lanes of a
+// group read it as one coalesced line. The vector being contracted goes through a D-double strip of
+// LDS in flat order (xs; one strip per group and vector), each step one broadcast read. A wave
+// executes its LDS instructions in order, so a wave-level fence between the writes and the reads
+// is all the exchange needs. ----
+struct LaneDense {
+  const double* covp = nullptr;
+  const double* cholp = nullptr;
+  double* xs = nullptr;   // LDS: this group's 3 D doubles
+};
+
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// out = M^-1 x for N vectors at once (the three rho of a merge share the sweep over covp)
+template <int G, int DPL, int D, int N>
+__device__ __forceinline__ void lane_dense_times(const LaneDense& ld, int l, const int (&rank)[DPL],
+                                                 const bool (&valid)[DPL], const double (&x)[N][DPL],
+                                                 double (&out)[N][DPL]) {
+  constexpr int GD = G * DPL;
+  wave_lds_fence();   // the previous sweep's reads are behind us
+#pragma unroll
+  for (int n = 0; n < N; n++)
+#pragma unroll
+    for (int k = 0; k < DPL; k++)
+      if (valid[k]) ld.xs[n * D + rank[k]] = x[n][k];
+  wave_lds_fence();
+  double acc[N][DPL];
+#pragma unroll
+  for (int n = 0; n < N; n++)
+#pragma unroll
+    for (int k = 0; k < DPL; k++) acc[n][k] = 0.0;
+  const double* row = ld.covp + l;
+#pragma unroll 2
+  for (int s = 0; s < D; s++) {
+    double c[DPL];
+#pragma unroll
+    for (int k = 0; k < DPL; k++) c[k] = row[(size_t)s * GD + k * G];
+#pragma unroll
+    for (int n = 0; n < N; n++) {
+      const double xv = ld.xs[n * D + s];
+#pragma unroll
+      for (int k = 0; k < DPL; k++) acc[n][k] = __builtin_fma(xv, c[k], acc[n][k]);
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < N; n++)
+#pragma unroll
+    for (int k = 0; k < DPL; k++) out[n][k] = acc[n][k];
+}
+
+template <int G, int DPL, int D, bool kLds>
+__device__ __forceinline__ double kinetic_energy_lanedense(const LaneDense& ld, int l, const int (&rank)[DPL],
+                                                           const bool (&valid)[DPL], const double (&p)[DPL]) {
+  static_assert(!kSeqSum<G, D>, "the lane layouts sum through the butterfly");
+  double x[1][DPL], mp[1][DPL];
+#pragma unroll
+  for (int k = 0; k < DPL; k++) x[0][k] = p[k];
+  lane_dense_times<G, DPL, D, 1>(ld, l, rank, valid, x, mp);
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < DPL; k++) acc = valid[k] ? (acc + p[k] * mp[0][k]) : acc;
+  return 0.5 * group_allsum<G, kLds>(acc);
+}
+
+// the lane partials of the two dot products of a U-turn test, v = M^-1 rho given
+template <int DPL>
+__device__ __forceinline__ void uturn_partials_v(const double (&v)[DPL], const double (&pa)[DPL],
+                                                 const double (&pb)[DPL], const bool (&valid)[DPL],
+                                                 double& sa, double& sb) {
+  sa = 0.0;
+  sb = 0.0;
+#pragma unroll
+  for (int k = 0; k < DPL; k++) {
+    sa = valid[k] ? (sa + v[k] * pa[k]) : sa;
+    sb = valid[k] ? (sb + v[k] * pb[k]) : sb;
+  }
+}
+
+// solve L^T p = z on the flat vector by back substitution: at step j the accumulator of flat entry j
+// is final, its quotient by L[j][j] is p_j, and every entry r < j takes fma(-L[j][r], p_j, acc).
+// perm: flat entry -> kernel dimension (null = identity); base = first lane of this group.
+template <int G, int DPL, int D>
+__device__ __forceinline__ void lane_dense_momentum(const LaneDense& ld, const int32_t* perm, int l, int base,
+                                                    const int (&rank)[DPL], const double (&z)[DPL],
+                                                    double (&p)[DPL]) {
+  constexpr int GD = G * DPL;
+  double acc[DPL];
+#pragma unroll
+  for (int k = 0; k < DPL; k++) {
+    acc[k] = z[k];
+    p[k] = 0.0;
+  }
+  const double* row = ld.cholp + l;
+#pragma nounroll
+  for (int j = D - 1; j >= 0; j--) {
+    const int dim = perm ? perm[j] : j;
+    const int ks = dim / G;
+    double c[DPL];
+#pragma unroll
+    for (int k = 0; k < DPL; k++) c[k] = row[(size_t)j * GD + k * G];
+    double a = acc[0], cd = c[0];
+#pragma unroll
+    for (int k = 1; k < DPL; k++) {
+      a = (k == ks) ? acc[k] : a;
+      cd = (k == ks) ? c[k] : cd;
+    }
+    const double pj = __shfl(a / cd, base | (dim & (G - 1)), 64);   // the owner's quotient
+#pragma unroll
+    for (int k = 0; k < DPL; k++) {
+      p[k] = (rank[k] == j) ? pj : p[k];
+      acc[k] = (rank[k] < j) ? __builtin_fma(-c[k], pj, acc[k]) : acc[k];
+    }
+  }
 }
 
 }  // namespace exmc

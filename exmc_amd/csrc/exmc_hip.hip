@@ -115,6 +115,13 @@ struct exmc_hip_model {
   DevBuf io;        // staging for host vectors
   DevBuf scores;    // ess_bulk: the rank-normalised copy of the caller's trace
   DevBuf dense;     // opts[:dense_mass]: cov[D][D], chol[D][D] while a dense mass is in force
+  // lane layouts (LaneDenseModel): the same two matrices with their columns permuted to kernel
+  // dimensions, [D][GD] each, built from the host copies for the lane count of the launch; the
+  // warmup kernel's global workspace; rank of each kernel dimension in the flat vector
+  DevBuf densep, densews;
+  int densep_gd = 0;
+  std::vector<double> h_dense;
+  std::vector<int32_t> h_rank;
   DevBuf esswork;   // ESS: [count | EssTailItem...] of the series that go on to ess_tail_kernel
   bool dense_on = false;
   int state_chains = 0;
@@ -250,7 +257,31 @@ int dispatch(exmc_hip_model* m, int lanes, F&& f) {
 // the layouts that carry a dense mass matrix: a whole chain in one lane, or eight_schools' row
 // layout (16 lanes, one dimension per lane) through RowDenseModel
 bool dense_layout_ok(const exmc_hip_model* m, int lanes) {
-  return lanes == 1 || (m->kind == EXMC_MODEL_EIGHT_SCHOOLS && lanes == 16);
+  return lanes == 1 || (m->kind == EXMC_MODEL_EIGHT_SCHOOLS && lanes == 16) ||
+         (m->kind == EXMC_MODEL_SV && lanes == 64) || (m->kind == EXMC_MODEL_RADON && lanes == 64) ||
+         (m->kind == EXMC_MODEL_LOGISTIC && lanes == 16);
+}
+
+// covp[s GD + i] = cov[rank(i)][s], cholp[j GD + i] = chol[j][rank(i)], zero columns past D
+// (exmc_device.hpp LaneDense), for the GD = lanes x dimensions-per-lane of the launch
+int ensure_densep(exmc_hip_model* m, int GD) {
+  if (m->densep_gd == GD) return EXMC_OK;
+  const int d = m->d;
+  if (m->h_dense.size() != 2 * (size_t)d * d) return fail(EXMC_ERR_BADARG, "no dense mass is set");
+  std::vector<double> h(2 * (size_t)d * GD, 0.0);
+  const double* cov = m->h_dense.data();
+  const double* chol = cov + (size_t)d * d;
+  for (int s = 0; s < d; s++)
+    for (int i = 0; i < d; i++) {
+      const int r = m->h_rank.empty() ? i : m->h_rank[i];
+      h[(size_t)s * GD + i] = cov[(size_t)r * d + s];
+      h[(size_t)d * GD + (size_t)s * GD + i] = chol[(size_t)s * d + r];
+    }
+  int rc = m->densep.ensure(h.size() * 8);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpy(m->densep.p, h.data(), h.size() * 8, hipMemcpyHostToDevice));
+  m->densep_gd = GD;
+  return EXMC_OK;
 }
 
 // dispatch for the launches whose mass-dependent operations depend on the dense mode
@@ -259,6 +290,12 @@ int dispatch_mass(exmc_hip_model* m, int lanes, bool dense, F&& f) {
 #if !defined(EXMC_ONLY_CUSTOM) && !defined(EXMC_DEV_ONLY)
   if (dense && m->kind == EXMC_MODEL_EIGHT_SCHOOLS && lanes == 16)
     return f(Tag<RowDenseModel<EightSchools<16>>, 16, 6>{}, m->es);
+  if (dense && m->kind == EXMC_MODEL_SV && lanes == 64)
+    return f(Tag<LaneDenseModel<SV<64>, 64>, 64, 2>{}, m->sv);
+  if (dense && m->kind == EXMC_MODEL_RADON && lanes == 64)
+    return f(Tag<LaneDenseModel<Radon<64>, 64>, 64, 2>{}, m->rd);
+  if (dense && m->kind == EXMC_MODEL_LOGISTIC && lanes == 16)
+    return f(Tag<LaneDenseModel<Logistic<16>, 16>, 16, 2>{}, m->lg);
 #endif
   return dispatch(m, lanes, f);
 }
@@ -307,6 +344,8 @@ int set_flat_order(exmc_hip_model* m, const int32_t* perm) {
     h[d + perm[r]] = r;
     identity = identity && perm[r] == r;
   }
+  m->h_rank.assign(h.begin() + d, h.end());
+  m->densep_gd = 0;
   if (identity) {
     m->flat_set = false;
     return EXMC_OK;
@@ -396,10 +435,17 @@ int launch_nuts(exmc_hip_model* m, int lanes, int C, int n_draws, int draw_offse
     P.nor_r = EXMC_NOR_R;
     P.flat = flat_order(m);
     if (m->dense_on) {
-      if (T::G != 1 && !M::kRowDense)
-        return fail(EXMC_ERR_UNSUPPORTED, "a dense mass matrix needs lanes_per_chain = 1 (eight_schools: 1 or 16)");
+      if (T::G != 1 && !M::kRowDense && !M::kLaneDense)
+        return fail(EXMC_ERR_UNSUPPORTED, "no dense mass matrix for this model at this lanes_per_chain");
       P.dm.cov = m->dense.as<double>();
       P.dm.chol = m->dense.as<double>() + (size_t)m->d * m->d;
+      if constexpr (M::kLaneDense) {
+        constexpr int GD = T::G * M::DPL;
+        rc = ensure_densep(m, GD);
+        if (rc) return rc;
+        P.dm.covp = m->densep.as<double>();
+        P.dm.cholp = m->densep.as<double>() + (size_t)m->d * GD;
+      }
     }
     if constexpr (M::kPipeNutsLevels > 0) {
       // wave pairs (tree + integrator), fewer stack levels in LDS to make room for the mailbox.
@@ -733,6 +779,7 @@ int run_warmup_device(exmc_hip_model* m, int lanes, exmc_hip_opts o, exmc_hip_tu
   auto wins = build_windows(P.init_buffer, P.adapt_end, dense ? std::max(25, 10 * d) : 25);
   if (wins.size() > 32) return fail(EXMC_ERR_BADARG, "num_warmup needs more than 32 windows");
   P.dense = dense ? 1 : 0;
+  P.dense_ws = nullptr;
   P.n_windows = (int)wins.size();
   for (int k = 0; k < 32; k++) {
     P.win_start[k] = k < P.n_windows ? wins[k].first : -1;
@@ -765,8 +812,14 @@ int run_warmup_device(exmc_hip_model* m, int lanes, exmc_hip_opts o, exmc_hip_tu
     const char* re = std::getenv("EXMC_HIP_WARMUP_REPLICAS");
     int reps = re ? std::atoi(re) : 32;
     reps = reps < 1 ? 1 : (reps > 256 ? 256 : reps);
-    if (dense && T::G != 1 && !M::kRowDense)
-      return fail(EXMC_ERR_UNSUPPORTED, "a dense mass matrix needs lanes_per_chain = 1 (eight_schools: 1 or 16)");
+    if (dense && T::G != 1 && !M::kRowDense && !M::kLaneDense)
+      return fail(EXMC_ERR_UNSUPPORTED, "no dense mass matrix for this model at this lanes_per_chain");
+    if constexpr (M::kLaneDense) {
+      reps = 1;   // one global workspace
+      int r3 = m->densews.ensure(LaneDenseWs<T::G, M::DPL, M::D>::doubles() * 8);
+      if (r3) return r3;
+      P.dense_ws = m->densews.as<double>();
+    }
     P.stack_stride = (size_t)kSpill * nuts_nslot<M>() * kNutsBlock;
     int r2 = m->stack.ensure(P.stack_stride * 8 * (size_t)reps);
     if (r2) return r2;
@@ -788,7 +841,7 @@ int run_warmup_device(exmc_hip_model* m, int lanes, exmc_hip_opts o, exmc_hip_tu
     const char* pe = std::getenv("EXMC_HIP_WARMUP_PIPE");
     const bool pipe = !dense && ((pe && pe[0] == '1') || (M::kPipeWarmup && !(pe && pe[0] == '0'))) &&
                       lds_bytes + pipe_lds_doubles<M::DPL>() * 8 <= 160 * 1024;
-    if (dense) lds_bytes += 3 * (size_t)d * d * 8;   // m2, cov, chol behind everything else
+    if (dense && !M::kLaneDense) lds_bytes += 3 * (size_t)d * d * 8;   // m2, cov, chol behind everything else
     if (lds_bytes > 160 * 1024) return fail(EXMC_ERR_UNSUPPORTED, "dense warmup state does not fit in LDS");
     if (pipe) {
       lds_bytes += pipe_lds_doubles<M::DPL>() * 8;
@@ -1074,6 +1127,15 @@ int exmc_hip_model_default_warmup_lanes(const exmc_hip_model* m) {
   if (m->kind == EXMC_MODEL_LOGISTIC) return 64;
   return default_lanes(m->kind);
 }
+int exmc_hip_model_default_dense_lanes(const exmc_hip_model* m) {
+  if (!m) return -1;
+  switch (m->kind) {
+    case EXMC_MODEL_SV: return 64;
+    case EXMC_MODEL_RADON: return 64;
+    case EXMC_MODEL_LOGISTIC: return 16;
+    default: return 1;
+  }
+}
 void* exmc_hip_model_stream(const exmc_hip_model* m) { return m ? (void*)m->stream : nullptr; }
 double exmc_hip_last_kernel_ms(const exmc_hip_model* m) { return m ? m->last_ms : 0.0; }
 
@@ -1287,6 +1349,9 @@ int exmc_hip_model_set_dense_mass(exmc_hip_model* m, const double* cov, const do
   if (rc) return rc;
   HIP_TRY(hipMemcpy(m->dense.p, cov, (size_t)d * d * 8, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(m->dense.as<double>() + (size_t)d * d, chol, (size_t)d * d * 8, hipMemcpyHostToDevice));
+  m->h_dense.assign(cov, cov + (size_t)d * d);
+  m->h_dense.insert(m->h_dense.end(), chol, chol + (size_t)d * d);
+  m->densep_gd = 0;
   m->dense_on = true;
   m->res_C = 0;
   return EXMC_OK;
@@ -1305,7 +1370,7 @@ int exmc_hip_warmup_dense(exmc_hip_model* m, const double* init_q, exmc_hip_opts
   HIP_TRY(hipSetDevice(m->device));
   const int lanes = resolve_lanes(m, o.lanes_per_chain);
   if (!dense_layout_ok(m, lanes))
-    return fail(EXMC_ERR_UNSUPPORTED, "a dense mass matrix needs lanes_per_chain = 1 (eight_schools: 1 or 16)");
+    return fail(EXMC_ERR_UNSUPPORTED, "no dense mass matrix for this model at this lanes_per_chain (1; eight_schools and logistic 16; sv and radon 64)");
   m->dense_on = false;   // Phase I runs on the identity diagonal (sampler.ex:560-575)
   int rc = ensure_state(m, 1);
   if (rc) return rc;

@@ -37,6 +37,10 @@ struct ModelDefaults {
   static constexpr bool kXRowLds = false;
   // opts[:dense_mass] in the row layout (16 lanes, one dimension per lane): see RowDenseModel
   static constexpr bool kRowDense = false;
+  // opts[:dense_mass] in a lane layout (a chain over G lanes, DPL dimensions per lane): see
+  // LaneDenseModel; kDenseLdsDoubles = the LDS strips its contractions exchange vectors through
+  static constexpr bool kLaneDense = false;
+  static constexpr int kDenseLdsDoubles = 0;
   // Resident waves per SIMD the sampling kernel's register allocation must allow (the second
   // launch bound). 2 caps the kernel at 256 vector registers: what the allocator would have kept
   // in accumulator registers goes to scratch instead. Worth it when the configuration launches
@@ -985,6 +989,20 @@ struct RowDenseModel : M {
   static constexpr bool kRowDense = true;
   static constexpr bool kPipeWarmup = false;   // the dense warmup is the one-wave form
   static_assert(M::DPL == 1 && M::D <= 12, "row layout: one dimension per lane, D <= 12");
+};
+
+// The lane layouts (sv, radon, logistic: d = 102, 90, 21 over 64 or 16 lanes) with a dense mass
+// matrix: the same compile-time switch, the contractions of exmc_device.hpp lane_dense_* (operands
+// permuted on the host so that flat-order chains read coalesced rows). One wave per SIMD: the
+// sweeps over the d x d operands are what the kernel does most, not the model.
+template <class M, int G>
+struct LaneDenseModel : M {
+  static constexpr bool kLaneDense = true;
+  static constexpr bool kPipeWarmup = false;   // the dense warmup is the one-wave form
+  static constexpr int kNutsWavesPerSimd = 1;
+  static constexpr int kPipeNutsLevels = 0;
+  static constexpr int kDenseLdsDoubles = (64 / G) * 3 * M::D;
+  static_assert(G >= 16 && M::DPL * G >= M::D && !M::kCoop, "a lane layout that holds the whole chain");
 };
 
 }  // namespace exmc

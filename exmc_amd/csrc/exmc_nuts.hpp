@@ -146,7 +146,7 @@ __host__ __device__ constexpr int nuts_nslot() { return 5 * M::DPL + 3; }
 template <class M, int LDSL>
 __host__ __device__ constexpr size_t nuts_lds_data_offset() {   // in doubles
   return (size_t)LDSL * nuts_nslot<M>() * kNutsBlock + kZigLdsBytes / 8 +
-         (size_t)M::kExtraLdsDoubles;
+         (size_t)M::kExtraLdsDoubles + (size_t)M::kDenseLdsDoubles;
 }
 template <class M, int LDSL>
 __host__ __device__ constexpr size_t nuts_lds_bytes() {
@@ -191,6 +191,7 @@ struct NutsLane {
   DenseMass dm;          // opts[:dense_mass], one-lane-per-chain layouts; cov == null: diagonal
   RowDense<M::kRowDense ? M::D : 1> rd;   // opts[:dense_mass], row layout (M::kRowDense): this lane's
                                           // row of M^-1 and column of its Cholesky factor
+  LaneDense ld;          // opts[:dense_mass], lane layouts (M::kLaneDense); covp == null: diagonal
   int l;
   double* lstk;      // this lane's column of the LDS stack
   double* gstk;      // this lane's column of the global spill stack
@@ -207,6 +208,9 @@ __device__ __forceinline__ double mass_ke(const NutsLane<M, G>& L, const double 
   if constexpr (M::kRowDense) return kinetic_energy_rowdense<M::D>(L.rd, p[0]);
   if constexpr (G == 1) {
     if (L.dm.cov) return kinetic_energy_dense<M::D>(L.dm.cov, p);
+  }
+  if constexpr (M::kLaneDense) {
+    if (L.ld.covp) return kinetic_energy_lanedense<G, M::DPL, M::D, M::kXRowLds>(L.ld, L.l, L.rank, L.valid, p);
   }
   return kinetic_energy<G, M::DPL, M::D, M::kXRowLds>(p, L.im, L.valid);
 }
@@ -227,6 +231,17 @@ __device__ __forceinline__ void mass_drift(const NutsLane<M, G>& L, double eps, 
       return;
     }
   }
+  if constexpr (M::kLaneDense) {
+    if (L.ld.covp) {
+      double x[1][M::DPL], mp[1][M::DPL];
+#pragma unroll
+      for (int k = 0; k < M::DPL; k++) x[0][k] = ph[k];
+      lane_dense_times<G, M::DPL, M::D, 1>(L.ld, L.l, L.rank, L.valid, x, mp);
+#pragma unroll
+      for (int k = 0; k < M::DPL; k++) q[k] = q[k] + eps * mp[0][k];
+      return;
+    }
+  }
 #pragma unroll
   for (int k = 0; k < M::DPL; k++) q[k] = q[k] + eps * (L.im[k] * ph[k]);
 }
@@ -236,6 +251,17 @@ __device__ __forceinline__ bool mass_uturn(const NutsLane<M, G>& L, const double
   if constexpr (M::kRowDense) return uturn_rowdense<M::D>(L.rd, rho[0], pa[0], pb[0]);
   if constexpr (G == 1) {
     if (L.dm.cov) return uturn_dense<M::D>(L.dm.cov, rho, pa, pb);
+  }
+  if constexpr (M::kLaneDense) {
+    if (L.ld.covp) {
+      double x[1][M::DPL], v[1][M::DPL], s[2];
+#pragma unroll
+      for (int k = 0; k < M::DPL; k++) x[0][k] = rho[k];
+      lane_dense_times<G, M::DPL, M::D, 1>(L.ld, L.l, L.rank, L.valid, x, v);
+      uturn_partials_v<M::DPL>(v[0], pa, pb, L.valid, s[0], s[1]);
+      group_allsum_n<G, 2, M::kXRowLds>(s);
+      return (s[0] < 0.0) || (s[1] < 0.0);
+    }
   }
   return uturn<G, M::DPL, M::D, M::kXRowLds>(rho, pa, pb, L.im, L.valid);
 }
@@ -259,6 +285,25 @@ __device__ __forceinline__ void mass_uturn3(const NutsLane<M, G>& L, const doubl
       const bool c2 = uturn_dense<M::D>(L.dm.cov, r2, a2, b2);
       const bool c3 = uturn_dense<M::D>(L.dm.cov, r3, a3, b3);
       c23 = c2 || c3;
+      return;
+    }
+  }
+  if constexpr (M::kLaneDense) {
+    if (L.ld.covp) {
+      double x[3][M::DPL], v[3][M::DPL], s[6];
+#pragma unroll
+      for (int k = 0; k < M::DPL; k++) {
+        x[0][k] = r1[k];
+        x[1][k] = r2[k];
+        x[2][k] = r3[k];
+      }
+      lane_dense_times<G, M::DPL, M::D, 3>(L.ld, L.l, L.rank, L.valid, x, v);
+      uturn_partials_v<M::DPL>(v[0], a1, b1, L.valid, s[0], s[1]);
+      uturn_partials_v<M::DPL>(v[1], a2, b2, L.valid, s[2], s[3]);
+      uturn_partials_v<M::DPL>(v[2], a3, b3, L.valid, s[4], s[5]);
+      group_allsum_n<G, 6, M::kXRowLds>(s);
+      c1 = (s[0] < 0.0) || (s[1] < 0.0);
+      c23 = (s[2] < 0.0) || (s[3] < 0.0) || (s[4] < 0.0) || (s[5] < 0.0);
       return;
     }
   }
@@ -423,6 +468,12 @@ __device__ __forceinline__ void momentum_from_variates(const NutsLane<M, G>& L, 
   if constexpr (G == 1) {
     if (L.dm.chol) {
       dense_momentum<M::D>(L.dm.chol, z, p);
+      return;
+    }
+  }
+  if constexpr (M::kLaneDense) {
+    if (L.ld.cholp) {
+      lane_dense_momentum<G, M::DPL, M::D>(L.ld, L.perm, L.l, (threadIdx.x & 63) & ~(G - 1), L.rank, z, p);
       return;
     }
   }
@@ -1156,6 +1207,12 @@ __device__ __forceinline__ void lane_setup(NutsLane<M, G>& L, const typename M::
   L.perm = flat.perm;
   L.dm = dm;
   if constexpr (M::kRowDense) rowdense_load<M, G>(L, dm.cov, dm.chol, 1);
+  if constexpr (M::kLaneDense) {
+    L.ld.covp = dm.covp;
+    L.ld.cholp = dm.cholp;
+    L.ld.xs = lds + (size_t)LDSL * nuts_nslot<M>() * kNutsBlock + kZigLdsBytes / 8 + M::kExtraLdsDoubles +
+              (size_t)((threadIdx.x & 63) / G) * 3 * D;
+  }
 }
 
 template <class M, int G>
@@ -1389,6 +1446,7 @@ struct WarmupParams {
   const double* sqrt_inv_mass0;   // identity mass and the initial step-size search
   int dense;                // opts[:dense_mass]: dense Welford windows (lanes_per_chain = 1, one-wave form);
                             // the dynamic LDS then ends with 3 D^2 doubles (m2, cov, chol)
+  double* dense_ws;         // lane layouts (M::kLaneDense): LaneDenseWs::doubles() of global workspace
   double* out;              // [0] eps_final (< 0: a window covariance was not positive definite),
                             // [1] divergences, [2] leapfrogs, [3..3+D) inv_mass, dense: cov, chol [D][D] each
   const uint64_t* zig_ki;
@@ -1464,6 +1522,112 @@ __device__ __forceinline__ bool dense_finalize_serial(const double* m2, double* 
   return ok;
 }
 
+// ---- dense Welford windows in a lane layout (M::kLaneDense): the window's co-moment matrix, the
+// covariance, its factor and their permuted copies (exmc_device.hpp LaneDense) live in a global
+// workspace of 3 D^2 + 2 D GD doubles; rows and columns are flat entries. The chain's G lanes
+// share the element-wise work; what one lane writes and another reads is separated by an
+// agent-scope fence (a single wave: program order does the rest). ----
+__device__ __forceinline__ void wave_global_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+template <int G, int DPL, int D>
+struct LaneDenseWs {
+  static constexpr int GD = G * DPL;
+  double *m2, *cov, *chol, *covp, *cholp;
+  __device__ __forceinline__ void bind(double* ws) {
+    m2 = ws;
+    cov = m2 + D * D;
+    chol = cov + D * D;
+    covp = chol + D * D;
+    cholp = covp + D * GD;
+  }
+  static constexpr size_t doubles() { return 3 * (size_t)D * D + 2 * (size_t)D * GD; }
+};
+
+// mass_matrix.ex:56-72: m2[a][b] = fma(delta_a, delta2_b, m2[a][b]) over flat entries; lane l owns
+// the columns b = l, l + G, ... of every row, so an element is always updated by the same lane
+template <int G, int DPL, int D>
+__device__ __forceinline__ void lane_dense_welford(double* m2, double* xs, int l, const int (&rank)[DPL],
+                                                   const bool (&valid)[DPL], const double (&dl)[DPL],
+                                                   const double (&dl2)[DPL]) {
+  wave_lds_fence();
+#pragma unroll
+  for (int k = 0; k < DPL; k++)
+    if (valid[k]) {
+      xs[rank[k]] = dl[k];
+      xs[D + rank[k]] = dl2[k];
+    }
+  wave_lds_fence();
+  for (int a = 0; a < D; a++) {
+    const double da = xs[a];
+    for (int b = l; b < D; b += G) m2[a * D + b] = __builtin_fma(da, xs[D + b], m2[a * D + b]);
+  }
+}
+
+// mass_matrix.ex:105-140 as dense_finalize_serial states it, the element-wise parts spread over the
+// G lanes and the factor built column by column: entry (a, b) still accumulates
+// fma(-L[a][k], L[b][k], .) in ascending k. rank_of: kernel dimension -> flat entry (null = identity).
+template <int G, int DPL, int D>
+__device__ __forceinline__ bool lane_dense_finalize(const LaneDenseWs<G, DPL, D>& w, double* xs, int l,
+                                                    const int32_t* rank_of, int wn) {
+  constexpr int GD = G * DPL;
+  constexpr int T = (D + G - 1) / G;
+  const double alpha = 5.0 / (wn + 5.0);
+  for (int e = l; e < D * D; e += G) {
+    const int a = e / D, b = e - a * D;
+    if (wn < 3) {
+      w.cov[e] = w.chol[e] = (a == b) ? 1.0 : 0.0;
+    } else {
+      const double v = w.m2[e] / ((double)(wn - 1) * 1.0);
+      const double dg = (a == b) ? fmax(v, 1.0e-6) : 0.0;
+      w.cov[e] = (1.0 - alpha) * v + alpha * dg;
+      w.chol[e] = 0.0;
+    }
+  }
+  wave_global_fence();
+  bool ok = true;
+  if (wn >= 3) {
+    for (int b = 0; b < D; b++) {
+      double acc[T];
+#pragma unroll
+      for (int t = 0; t < T; t++) {
+        const int a = l + t * G;
+        acc[t] = 0.0;
+        if (a >= b && a < D) {
+          double s = w.cov[a * D + b];
+          for (int k = 0; k < b; k++) s = __builtin_fma(-w.chol[a * D + k], w.chol[b * D + k], s);
+          acc[t] = s;
+          if (a == b) {
+            ok = ok && (s > 0.0);
+            const double dgl = __dsqrt_rn(s);
+            w.chol[b * D + b] = dgl;
+            xs[0] = dgl;
+          }
+        }
+      }
+      wave_lds_fence();
+      const double dgl = xs[0];
+#pragma unroll
+      for (int t = 0; t < T; t++) {
+        const int a = l + t * G;
+        if (a > b && a < D) w.chol[a * D + b] = acc[t] / dgl;
+      }
+      wave_global_fence();   // column b is read by every later column; xs[0] is free again
+    }
+  }
+  for (int e = l; e < D * GD; e += G) {
+    const int s_ = e / GD, i = e - s_ * GD;
+    const int r = (i < D) ? (rank_of ? rank_of[i] : i) : 0;
+    w.covp[e] = (i < D) ? w.cov[r * D + s_] : 0.0;
+    w.cholp[e] = (i < D) ? w.chol[s_ * D + r] : 0.0;
+  }
+  wave_global_fence();
+  return ok;
+}
+
 // kPipe: two waves, the second one integrating one leaf ahead of the tree (see PipeBox above).
 template <class M, int G, int LDSL, bool kPipe = false>
 __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock)
@@ -1522,7 +1686,16 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock)
   bool dense_ok = true;
   // where the dense mode is built: a whole chain in one lane, or the row layout (M::kRowDense: the
   // window's co-moment rows in registers m2r, one row per lane; LDS holds what finalize exchanges)
-  constexpr bool kDenseHere = (G == 1 || M::kRowDense) && !kPipe;
+  constexpr bool kLaneDenseHere = M::kLaneDense && !kPipe;
+  LaneDenseWs<G, DPL, D> lw;
+  bool lane_dense = false;
+  if constexpr (kLaneDenseHere) {
+    if (P.dense) {
+      lane_dense = true;
+      lw.bind(P.dense_ws);
+    }
+  }
+  constexpr bool kDenseHere = (G == 1 || M::kRowDense) && !kPipe && !M::kLaneDense;
   constexpr int kRowN = M::kRowDense ? D : 1;
   double m2r[kRowN];
 #pragma unroll
@@ -1594,6 +1767,10 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock)
               for (int e = 0; e < D * D; e++) dn_m2[e] = 0.0;
             }
           }
+          if constexpr (kLaneDenseHere) {
+            if (lane_dense)
+              for (int e = L.l; e < D * D; e += G) lw.m2[e] = 0.0;   // each element by the lane that updates it
+          }
           da.init(eps, P.target_accept);
           in_window = true;
         }
@@ -1634,6 +1811,9 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock)
               }
             }
           }
+          if constexpr (kLaneDenseHere) {
+            if (lane_dense) lane_dense_welford<G, DPL, D>(lw.m2, L.ld.xs, L.l, L.rank, L.valid, dl, dl2);
+          }
           wn = nn;
         }
         if (i + 1 == P.win_end[win]) {
@@ -1666,6 +1846,19 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock)
                 L.dm.cov = dn_cov;
                 L.dm.chol = dn_chol;
               }
+              dense_done = true;
+            }
+          }
+          if constexpr (kLaneDenseHere) {
+            if (lane_dense) {
+              L.ld.covp = L.ld.cholp = nullptr;
+              const bool ok = lane_dense_finalize<G, DPL, D>(lw, L.ld.xs, L.l, P.flat.rank, wn);
+              dense_ok = dense_ok && (__all(ok ? 1 : 0) != 0);
+#pragma unroll
+              for (int k = 0; k < DPL; k++)
+                L.im[k] = L.valid[k] ? lw.cov[L.rank[k] * D + L.rank[k]] : 1.0;   // inv_mass_diag_out
+              L.ld.covp = lw.covp;
+              L.ld.cholp = lw.cholp;
               dense_done = true;
             }
           }
@@ -1734,6 +1927,17 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock)
         P.out[3 + D + D * D + e] = dn_chol[e];
       }
       if (!dense_ok) P.out[0] = -1.0;
+    }
+  }
+  if constexpr (kLaneDenseHere) {
+    if (lane_dense) {
+      const bool have = L.ld.covp != nullptr;   // no window ran: the identity
+      for (int e = L.l; e < D * D; e += G) {
+        const double id = ((e / D) == (e % D)) ? 1.0 : 0.0;
+        P.out[3 + D + e] = have ? lw.cov[e] : id;
+        P.out[3 + D + D * D + e] = have ? lw.chol[e] : id;
+      }
+      if (!dense_ok && L.l == 0) P.out[0] = -1.0;
     }
   }
 }

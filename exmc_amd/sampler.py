@@ -68,6 +68,10 @@ class Compiled:
         return self.L.exmc_hip_model_default_warmup_lanes(self.h)
 
     @property
+    def default_dense_lanes(self):
+        return self.L.exmc_hip_model_default_dense_lanes(self.h)
+
+    @property
     def last_kernel_ms(self):
         return self.L.exmc_hip_last_kernel_ms(self.h)
 
@@ -177,7 +181,7 @@ def sample_compiled(compiled, init_values=None, opts=None):
         d = spec.d
         cov, chol = np.zeros((d, d)), np.zeros((d, d))
         compiled.check(L.exmc_hip_sample_dense_host(compiled.h, None if iq is None else _dp(iq),
-                                                    _c_opts(o, lanes=o.get("lanes_per_chain") or 1),
+                                                    _c_opts(o, lanes=o.get("lanes_per_chain") or compiled.default_dense_lanes),
                                                     tr, C.byref(tun), _dp(cov), _dp(chol), C.byref(div)))
         trace = _build_trace(spec, t["draws"][0])
         stats = dict(step_size=tun.epsilon, inv_mass_diag=np.array(tun.inv_mass[:d]), chol_cov=chol, cov=cov,
@@ -232,7 +236,7 @@ def warmup(compiled, init_values=None, opts=None):
         d = compiled.d
         cov, chol = np.zeros((d, d)), np.zeros((d, d))
         compiled.check(L.exmc_hip_warmup_dense(compiled.h, None if iq is None else _dp(iq),
-                                               _c_opts(o, lanes=o.get("lanes_per_chain", 1) or 1),
+                                               _c_opts(o, lanes=o.get("lanes_per_chain") or compiled.default_dense_lanes),
                                                C.byref(tun), _dp(cov), _dp(chol)))
         return dict(epsilon=tun.epsilon, inv_mass=cov, cov=cov, chol_cov=chol,
                     inv_mass_diag=np.array(tun.inv_mass[:d]), warmup_divergences=tun.warmup_divergences)
@@ -259,7 +263,7 @@ def sample_compiled_tuned(compiled, tuning, init_values=None, opts=None, num_cha
     tun = _tuning_struct(tuning, spec.d)
     _apply_mass(compiled, tuning)
     if tuning.get("chol_cov") is not None and not o.get("lanes_per_chain"):
-        o["lanes_per_chain"] = 1          # the layout every model kind carries a dense mass in
+        o["lanes_per_chain"] = compiled.default_dense_lanes   # the layout this kind carries a dense mass in
     lf = C.c_int64()
     dv = C.c_int32()
     iq = _init_q(spec, init_values)

@@ -115,6 +115,10 @@ int exmc_hip_model_default_lanes(const exmc_hip_model* m);
  * from the sampling layout (logistic: 64). The tuning it returns is layout-independent; chains
  * that continue the warmup chain itself (sample_host, stream) keep one layout for both phases. */
 int exmc_hip_model_default_warmup_lanes(const exmc_hip_model* m);
+/* lanes_per_chain of the layout that carries a dense mass matrix (opts[:dense_mass]) for this
+ * model: 1 where a whole chain fits one lane (eight_schools -- 16 also works --, simple, generated
+ * models), the lane layout of the kinds that have no one-lane form (sv 64, radon 64, logistic 16). */
+int exmc_hip_model_default_dense_lanes(const exmc_hip_model* m);
 /* the model handle's HIP stream (hipStream_t as void*) */
 void* exmc_hip_model_stream(const exmc_hip_model* m);
 

@@ -688,18 +688,24 @@ void exo_constrain(const exo_model* m, const double* q, double* x) {
  * mode. What is restated here is the documented intent (DECISIONS.md 37; Betancourt's criterion
  * rho . (M^-1 p+-) < 0 as the comment at tree.ex:1572-1577 states it): v = M^-1 rho by the dense
  * product, momentum p = L^-T z (sampler.ex:412-427), kinetic energy and position update through
- * M^-1 p (leapfrog.ex:39-61). Products accumulate with fma in ascending index, as the device does. */
+ * M^-1 p (leapfrog.ex:39-61). Products accumulate with fma in ascending index, as the device does.
+ *
+ * Order: the reference's covariance is that of its flat vector (PointMap order, sampler.ex:682-705
+ * feeds Welford the flat q), so cov / chol are indexed by FLAT entries here as well, and every
+ * contraction runs in ascending flat index. tl_flat (m->flat, or NULL = identity) maps flat entry r
+ * to its kernel dimension; the vectors of this file stay in kernel order. */
 static __thread const double* tl_cov = NULL;
+static __thread const int* tl_flat = NULL;
 
 static void mass_times(const double* im, const double* x, int d, double* out) {
   if (!tl_cov) {
     for (int i = 0; i < d; i++) out[i] = im[i] * x[i];
     return;
   }
-  for (int i = 0; i < d; i++) {
+  for (int r = 0; r < d; r++) {
     double acc = 0.0;
-    for (int j = 0; j < d; j++) acc = fma(x[j], tl_cov[(size_t)i * d + j], acc);
-    out[i] = acc;
+    for (int s = 0; s < d; s++) acc = fma(x[tl_flat ? tl_flat[s] : s], tl_cov[(size_t)r * d + s], acc);
+    out[tl_flat ? tl_flat[r] : r] = acc;
   }
 }
 
@@ -1054,16 +1060,17 @@ static void sample_momentum(const exo_model* m, exo_rng* rng, const double* im, 
     }
     return;
   }
-  /* sampler.ex:412-427: z_1..z_d, then solve L^T p = z (L^T upper triangular) by back substitution;
-   * z_r belongs to flat entry r, the factor is that of the covariance in kernel order (the kinds
-   * with a dense path on the device have kernel order = flat order) */
-  double z[EXO_MAX_D];
-  for (int r = 0; r < d; r++) z[m->flat[r]] = exo_rng_normal(rng, mm);
+  /* sampler.ex:412-427: z_1..z_d, then solve L^T p = z (L^T upper triangular) by back substitution,
+   * all of it on the flat vector (the factor is that of the flat covariance); entry r of the
+   * solution is the momentum of kernel dimension flat[r] */
+  double z[EXO_MAX_D], pf[EXO_MAX_D];
+  for (int r = 0; r < d; r++) z[r] = exo_rng_normal(rng, mm);
   for (int i = d - 1; i >= 0; i--) {
     double acc = z[i];
-    for (int j = d - 1; j > i; j--) acc = fma(-tl_chol[(size_t)j * d + i], p[j], acc);
-    p[i] = acc / tl_chol[(size_t)i * d + i];
+    for (int j = d - 1; j > i; j--) acc = fma(-tl_chol[(size_t)j * d + i], pf[j], acc);
+    pf[i] = acc / tl_chol[(size_t)i * d + i];
   }
+  for (int r = 0; r < d; r++) p[m->flat[r]] = pf[r];
 }
 
 typedef struct {
@@ -1150,14 +1157,16 @@ static void wd_init(welford_dense* w, int d, double* m2_store) {
   for (int i = 0; i < d; i++) w->mean[i] = 0.0;
   for (int i = 0; i < d * d; i++) m2_store[i] = 0.0;
 }
-static void wd_update(welford_dense* w, const double* q) {
-  /* mass_matrix.ex:56-72: m2 += outer(delta, delta2), accumulated with fma */
+static void wd_update(welford_dense* w, const double* q, const int* flat) {
+  /* mass_matrix.ex:56-72: m2 += outer(delta, delta2), accumulated with fma; rows and columns are
+   * flat entries (flat[r] = the kernel dimension of entry r, NULL = identity) */
   int d = w->d, nn = w->n + 1;
   double delta[EXO_MAX_D], delta2[EXO_MAX_D];
   for (int i = 0; i < d; i++) {
-    delta[i] = q[i] - w->mean[i];
+    double qi = q[flat ? flat[i] : i];
+    delta[i] = qi - w->mean[i];
     double nm = w->mean[i] + delta[i] / ((double)nn * 1.0);
-    delta2[i] = q[i] - nm;
+    delta2[i] = qi - nm;
     w->mean[i] = nm;
   }
   for (int i = 0; i < d; i++)
@@ -1229,12 +1238,12 @@ static double run_warmup_dense(const exo_model* m, cstate* s, double eps, double
       step_info info;
       nuts_step(m, s, da_current(&da), im, cap, &info, c);
       exo_da_update(&da, info.accept);
-      if (s->divergences == div_before) wd_update(&wf, s->q);
+      if (s->divergences == div_before) wd_update(&wf, s->q, m->flat);
     }
-    tl_cov = NULL; tl_chol = NULL;
+    tl_cov = NULL; tl_chol = NULL; tl_flat = NULL;
     if (wd_finalize(&wf, cov, chol) != 0) { free(m2); return -1.0; }   /* not positive definite */
-    for (int i = 0; i < d; i++) im[i] = cov[(size_t)i * d + i];
-    tl_cov = cov; tl_chol = chol;
+    for (int r = 0; r < d; r++) im[m->flat[r]] = cov[(size_t)r * d + r];
+    tl_cov = cov; tl_chol = chol; tl_flat = m->flat;
     *dense_on = 1;
     eps = find_reasonable_epsilon(m, s, im, c);
   }
@@ -1359,12 +1368,12 @@ int exo_warmup_dense(const exo_model* m, const double* init_q, exo_opts o, exo_s
                      double* chol, exo_cfg c) {
   cstate s;
   int d = m->d, on = 0;
-  tl_cov = NULL; tl_chol = NULL;
+  tl_cov = NULL; tl_chol = NULL; tl_flat = NULL;
   init_chain(m, init_q, o.seed, &s, c);
   for (int i = 0; i < d; i++) st->inv_mass[i] = 1.0;
   double eps = find_reasonable_epsilon(m, &s, st->inv_mass, c);
   st->step_size = run_warmup_dense(m, &s, eps, st->inv_mass, cov, chol, &on, o, c);
-  tl_cov = NULL; tl_chol = NULL;
+  tl_cov = NULL; tl_chol = NULL; tl_flat = NULL;
   if (!on) {   /* no window ran: identity covariance, as finalize of an empty Welford would give */
     for (int i = 0; i < d * d; i++) cov[i] = chol[i] = 0.0;
     for (int i = 0; i < d; i++) cov[(size_t)i * d + i] = chol[(size_t)i * d + i] = 1.0;
@@ -1379,27 +1388,27 @@ int exo_sample_tuned_dense(const exo_model* m, const double* init_q, double epsi
   /* sample_compiled_tuned with tuning.chol_cov (sampler.ex:260-335) for one chain */
   cstate s;
   int d = m->d;
-  tl_cov = NULL; tl_chol = NULL;
+  tl_cov = NULL; tl_chol = NULL; tl_flat = NULL;
   init_chain(m, init_q, o.seed, &s, c);
-  for (int i = 0; i < d; i++) st->inv_mass[i] = cov[(size_t)i * d + i];
+  for (int r = 0; r < d; r++) st->inv_mass[m->flat[r]] = cov[(size_t)r * d + r];
   st->step_size = epsilon;
   st->total_leapfrogs = 0;
-  tl_cov = cov; tl_chol = chol;
+  tl_cov = cov; tl_chol = chol; tl_flat = m->flat;
   run_sampling(m, &s, epsilon, st->inv_mass, o, tr, 0, &st->total_leapfrogs, c);
-  tl_cov = NULL; tl_chol = NULL;
+  tl_cov = NULL; tl_chol = NULL; tl_flat = NULL;
   st->divergences = s.divergences;
   return 0;
 }
 
 /* one product / solve each, for the unit tests */
 void exo_dense_mass_times(const double* cov, const double* x, int d, double* out) {
-  tl_cov = cov;
+  tl_cov = cov; tl_flat = NULL;
   mass_times(NULL, x, d, out);
   tl_cov = NULL;
 }
 int exo_dense_check_uturn(const double* cov, const double* rho, const double* pl, const double* pr, int d,
                           exo_cfg c) {
-  tl_cov = cov;
+  tl_cov = cov; tl_flat = NULL;
   int r = exo_check_uturn(rho, pl, pr, NULL, d, c);
   tl_cov = NULL;
   return r;
@@ -1414,7 +1423,7 @@ void exo_welford_dense_finalize(const double* draws, int n, int d, double* cov, 
   double* m2 = (double*)malloc(sizeof(double) * d * d);
   welford_dense w;
   wd_init(&w, d, m2);
-  for (int i = 0; i < n; i++) wd_update(&w, draws + (size_t)i * d);
+  for (int i = 0; i < n; i++) wd_update(&w, draws + (size_t)i * d, NULL);
   wd_finalize(&w, cov, chol);
   free(m2);
 }

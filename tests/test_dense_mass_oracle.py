@@ -104,3 +104,37 @@ def test_dense_equals_diagonal_in_one_dimension():
     t2, _ = O.sample_tuned(m, 0.8, np.array([var]), np.zeros(1), num_samples=200, seed=3)
     assert np.allclose(t1["draws"], t2["draws"], rtol=1e-12, atol=1e-14)
     assert np.array_equal(t1["tree_depth"], t2["tree_depth"])
+
+
+def test_dense_mass_lives_on_the_flat_vector():
+    """The reference's covariance is that of its flat vector (sampler.ex:682-705), whose order is the
+    string sort of the ids (point_map.ex:30-60): for sv that is nu, s_1, s_10, s_100, s_11, ...,
+    sigma while the kernel order is s_1..s_100, sigma, nu. cov / chol are indexed by flat entries;
+    the momentum solves L^T p = z on the flat vector, draw r belonging to flat entry r."""
+    import test_golden_traces as TG
+    from exmc_amd import models
+    spec = models.sv(TG.GOLD["sv_returns"])
+    m = O.model_for(spec)
+    d = spec.d
+    flat = np.asarray(m.flat_order())            # flat entry -> kernel dimension
+    assert flat[0] == d - 1 and flat[-1] == d - 2 and flat[1] == 0     # nu first, sigma last, then s_1
+    rng = np.random.default_rng(4)
+    A = rng.normal(size=(d, d)) * 0.1
+    cov = np.ascontiguousarray(A @ A.T + np.eye(d))
+    chol = np.ascontiguousarray(np.linalg.cholesky(cov))
+    r1, r2 = O.Rng(), O.Rng()
+    O.lib().exo_rng_seed(C.byref(r1), 5)
+    O.lib().exo_rng_seed(C.byref(r2), 5)
+    z = np.array([O.lib().exo_rng_normal(C.byref(r1), 0) for _ in range(d)])
+    p = np.zeros(d)
+    O.lib().exo_dense_momentum(m.h, O.dptr(chol), C.byref(r2), O.dptr(p), 0)
+    assert np.allclose(chol.T @ p[flat], z, rtol=1e-11, atol=1e-12)   # p in kernel order, the solve in flat order
+    # a warmup window's covariance: its diagonal is the flat-order variance of the chain
+    q0 = spec.to_unconstrained(spec.default_init)
+    st, wcov, wchol = O.warmup_dense(m, q0, num_warmup=200, seed=3, cfg=O.Cfg(1, 64))
+    assert np.array_equal(np.diag(wcov), np.asarray(st.inv_mass[:d])[flat])
+    assert np.allclose(wchol @ wchol.T, wcov, rtol=1e-10)
+    # nu and sigma (flat entries 0 and d-1) are the scale parameters: far larger posterior variance
+    # in the window than any latent volatility; in kernel order they are the last two dimensions
+    dg = np.diag(wcov)
+    assert dg[0] != dg[1] and np.argmax(np.asarray(st.inv_mass[:d])) in (d - 1, d - 2)

@@ -549,3 +549,44 @@ def test_dense_mass_bit_exact(hip, name, lanes):
     if name == "eight_schools":
         with pytest.raises(Exception):
             sampler.warmup(comp, spec.default_init, dict(opts, lanes_per_chain=8))
+
+
+@pytest.mark.parametrize("name,lanes,W", [("logistic", 16, 500), ("radon", 64, 400), ("sv", 64, 300)])
+def test_dense_mass_lane_layouts_bit_exact(hip, name, lanes, W):
+    """opts[:dense_mass] for the kinds that live in a lane layout (d = 21, 90, 102 over 16 / 64
+    lanes, exmc_models.hpp LaneDenseModel): the covariance and its factor belong to the reference's
+    FLAT vector (sampler.ex:682-705 feeds Welford the flat q; sv and logistic have a kernel order
+    that is not the flat order), every contraction runs in ascending flat index. Dense Welford
+    window + Cholesky on the device, p = L^-T z, M^-1 p, U-turn through M^-1 rho: tuning and every
+    per-draw output equal the checker's."""
+    import test_golden_traces as TG
+    spec = {"sv": lambda: models.sv(TG.GOLD["sv_returns"]), "logistic": models.logistic, "radon": models.radon}[name]()
+    comp = sampler.compile(spec)
+    om = O.model_for(spec)
+    assert comp.default_dense_lanes == lanes
+    opts = dict(num_warmup=W, num_samples=25, seed=13, dense_mass=True)      # the layout is the library's choice
+    tuning = sampler.warmup(comp, spec.default_init, opts)
+    q0 = spec.to_unconstrained(spec.default_init)
+    st, cov, chol = O.warmup_dense(om, q0, num_warmup=W, seed=13, cfg=O.Cfg(1, lanes))
+    assert st.step_size == tuning["epsilon"]
+    assert np.array_equal(cov, tuning["cov"]) and np.array_equal(chol, tuning["chol_cov"])
+    flat = np.asarray(om.flat_order())                                         # flat entry -> kernel dimension
+    assert np.array_equal(np.diag(cov), tuning["inv_mass_diag"][flat])
+    assert np.abs(cov - np.diag(np.diag(cov))).max() > 0
+    _, _, extra = sampler.sample_compiled_tuned(comp, tuning, spec.default_init, opts, num_chains=6)
+    raw = extra["raw"]
+    for c in range(6):
+        t, _ = O.sample_tuned_dense(om, st.step_size, cov, chol, q0, num_samples=25, seed=13 + 7919 * c,
+                                    cfg=O.Cfg(1, lanes))
+        for k in ("draws", "tree_depth", "n_steps", "divergent", "energy", "accept_prob"):
+            assert np.array_equal(t[k], raw[k][c]), (name, c, k)
+    # sample/3: the warmup chain goes on sampling under the dense mass
+    tr1, st1 = sampler.sample(spec, spec.default_init, dict(opts, num_samples=15))
+    assert st1["step_size"] == st.step_size and np.array_equal(st1["cov"], cov)
+    assert np.array_equal(st1["chol_cov"], chol) and np.all(np.isfinite(st1["raw"]["draws"]))
+    # a diagonal tuning on the same handle afterwards: the dense mass is no longer in force
+    diag = sampler.warmup(comp, spec.default_init, dict(num_warmup=60, seed=13, lanes_per_chain=lanes))
+    _, _, e2 = sampler.sample_compiled_tuned(comp, diag, spec.default_init,
+                                             dict(num_samples=8, seed=13, lanes_per_chain=lanes), num_chains=2)
+    t2, _ = O.sample_tuned(om, diag["epsilon"], diag["inv_mass"], q0, num_samples=8, seed=13, cfg=O.Cfg(1, lanes))
+    assert np.array_equal(t2["draws"], e2["raw"]["draws"][0])
