@@ -18,6 +18,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include <utility>
 
@@ -735,8 +736,22 @@ __device__ __forceinline__ double momentum_rowdense(const RowDense<D>& m, int l,
 struct LaneDense {
   const double* covp = nullptr;
   const double* cholp = nullptr;
-  double* xs = nullptr;   // LDS: this group's 3 D doubles
+  double* xs = nullptr;     // LDS: this group's 3 D doubles
+  double* covl = nullptr;   // LDS image of covp without its padding columns, [D][D] (+ 64 doubles
+                            // that the slots past D may read), for models whose image is small
+                            // enough not to cost resident waves (kImage); null: sweeps read covp
 };
+
+// (re)build the LDS image from covp: every group of the wave writes the same values
+template <int G, int DPL, int D>
+__device__ __forceinline__ void lane_dense_stage(const LaneDense& ld, int l) {
+  constexpr int GD = G * DPL;
+  for (int e = l; e < D * D; e += G) {
+    const int s = e / D, i = e - s * D;
+    ld.covl[e] = ld.covp[(size_t)s * GD + i];
+  }
+  for (int e = l; e < 64; e += G) ld.covl[D * D + e] = 0.0;
+}
 
 __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -745,7 +760,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 }
 
 // out = M^-1 x for N vectors at once (the three rho of a merge share the sweep over covp)
-template <int G, int DPL, int D, int N>
+template <int G, int DPL, int D, int N, bool kImage>
 __device__ __forceinline__ void lane_dense_times(const LaneDense& ld, int l, const int (&rank)[DPL],
                                                  const bool (&valid)[DPL], const double (&x)[N][DPL],
                                                  double (&out)[N][DPL]) {
@@ -762,33 +777,44 @@ __device__ __forceinline__ void lane_dense_times(const LaneDense& ld, int l, con
   for (int n = 0; n < N; n++)
 #pragma unroll
     for (int k = 0; k < DPL; k++) acc[n][k] = 0.0;
-  const double* row = ld.covp + l;
-#pragma unroll 2
-  for (int s = 0; s < D; s++) {
-    double c[DPL];
+  // rows in blocks of kB: the loads of a block are in flight together (a lone wave sits out one
+  // L2 round trip per block), the fma chains then run in ascending s
+  constexpr int kB = kImage ? 8 : 16;
+  const double* row = (kImage ? ld.covl : ld.covp) + l;
+  constexpr int kRow = kImage ? D : GD;
+  auto block = [&](int s0, auto nb) {
+    constexpr int NB = decltype(nb)::value;
+    double c[NB][DPL];
 #pragma unroll
-    for (int k = 0; k < DPL; k++) c[k] = row[(size_t)s * GD + k * G];
+    for (int b = 0; b < NB; b++)
 #pragma unroll
-    for (int n = 0; n < N; n++) {
-      const double xv = ld.xs[n * D + s];
+      for (int k = 0; k < DPL; k++) c[b][k] = row[(size_t)(s0 + b) * kRow + k * G];
 #pragma unroll
-      for (int k = 0; k < DPL; k++) acc[n][k] = __builtin_fma(xv, c[k], acc[n][k]);
-    }
-  }
+    for (int b = 0; b < NB; b++)
+#pragma unroll
+      for (int n = 0; n < N; n++) {
+        const double xv = ld.xs[n * D + s0 + b];
+#pragma unroll
+        for (int k = 0; k < DPL; k++) acc[n][k] = __builtin_fma(xv, c[b][k], acc[n][k]);
+      }
+  };
+#pragma nounroll
+  for (int s0 = 0; s0 + kB <= D; s0 += kB) block(s0, std::integral_constant<int, kB>{});
+  if constexpr (D % kB != 0) block(D - D % kB, std::integral_constant<int, D % kB>{});
 #pragma unroll
   for (int n = 0; n < N; n++)
 #pragma unroll
-    for (int k = 0; k < DPL; k++) out[n][k] = acc[n][k];
+    for (int k = 0; k < DPL; k++) out[n][k] = valid[k] ? acc[n][k] : 0.0;   // slots past D read the next row
 }
 
-template <int G, int DPL, int D, bool kLds>
+template <int G, int DPL, int D, bool kLds, bool kImage>
 __device__ __forceinline__ double kinetic_energy_lanedense(const LaneDense& ld, int l, const int (&rank)[DPL],
                                                            const bool (&valid)[DPL], const double (&p)[DPL]) {
   static_assert(!kSeqSum<G, D>, "the lane layouts sum through the butterfly");
   double x[1][DPL], mp[1][DPL];
 #pragma unroll
   for (int k = 0; k < DPL; k++) x[0][k] = p[k];
-  lane_dense_times<G, DPL, D, 1>(ld, l, rank, valid, x, mp);
+  lane_dense_times<G, DPL, D, 1, kImage>(ld, l, rank, valid, x, mp);
   double acc = 0.0;
 #pragma unroll
   for (int k = 0; k < DPL; k++) acc = valid[k] ? (acc + p[k] * mp[0][k]) : acc;
@@ -824,13 +850,19 @@ __device__ __forceinline__ void lane_dense_momentum(const LaneDense& ld, const i
     p[k] = 0.0;
   }
   const double* row = ld.cholp + l;
+  double cn[DPL];   // the next row, loaded one step ahead of its use
+#pragma unroll
+  for (int k = 0; k < DPL; k++) cn[k] = row[(size_t)(D - 1) * GD + k * G];
 #pragma nounroll
   for (int j = D - 1; j >= 0; j--) {
     const int dim = perm ? perm[j] : j;
     const int ks = dim / G;
     double c[DPL];
 #pragma unroll
-    for (int k = 0; k < DPL; k++) c[k] = row[(size_t)j * GD + k * G];
+    for (int k = 0; k < DPL; k++) {
+      c[k] = cn[k];
+      cn[k] = row[(size_t)(j > 0 ? j - 1 : 0) * GD + k * G];
+    }
     double a = acc[0], cd = c[0];
 #pragma unroll
     for (int k = 1; k < DPL; k++) {

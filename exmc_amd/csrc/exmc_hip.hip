@@ -470,6 +470,9 @@ int launch_nuts(exmc_hip_model* m, int lanes, int C, int n_draws, int draw_offse
     }
     if (timed) HIP_TRY(hipEventRecord(m->ev0, m->stream));
     const size_t lds_bytes = nuts_lds_bytes<M, T::LDSL>();
+    if (lds_bytes > 64 * 1024)   // the lane layouts' dense mass keeps M^-1 in LDS
+      HIP_TRY(hipFuncSetAttribute((const void*)nuts_kernel<M, T::G, T::LDSL>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     hipLaunchKernelGGL((nuts_kernel<M, T::G, T::LDSL>), grid, dim3(kNutsBlock), lds_bytes,
                        m->stream, P, mc);
     HIP_TRY(hipGetLastError());

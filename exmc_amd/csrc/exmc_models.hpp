@@ -40,6 +40,7 @@ struct ModelDefaults {
   // opts[:dense_mass] in a lane layout (a chain over G lanes, DPL dimensions per lane): see
   // LaneDenseModel; kDenseLdsDoubles = the LDS strips its contractions exchange vectors through
   static constexpr bool kLaneDense = false;
+  static constexpr bool kDenseImage = false;
   static constexpr int kDenseLdsDoubles = 0;
   // Resident waves per SIMD the sampling kernel's register allocation must allow (the second
   // launch bound). 2 caps the kernel at 256 vector registers: what the allocator would have kept
@@ -1001,7 +1002,10 @@ struct LaneDenseModel : M {
   static constexpr bool kPipeWarmup = false;   // the dense warmup is the one-wave form
   static constexpr int kNutsWavesPerSimd = 1;
   static constexpr int kPipeNutsLevels = 0;
-  static constexpr int kDenseLdsDoubles = (64 / G) * 3 * M::D;
+  // M^-1 goes to LDS when that costs no resident wave (logistic: 3.5 KB); sv / radon (83 / 65 KB)
+  // would leave one wave per CU, measured 2x slower than four waves per CU sweeping it from L2
+  static constexpr bool kDenseImage = M::D * M::D * 8 <= 16 * 1024;
+  static constexpr int kDenseLdsDoubles = (64 / G) * 3 * M::D + (kDenseImage ? M::D * M::D + 64 : 0);
   static_assert(G >= 16 && M::DPL * G >= M::D && !M::kCoop, "a lane layout that holds the whole chain");
 };
 

@@ -210,7 +210,7 @@ __device__ __forceinline__ double mass_ke(const NutsLane<M, G>& L, const double 
     if (L.dm.cov) return kinetic_energy_dense<M::D>(L.dm.cov, p);
   }
   if constexpr (M::kLaneDense) {
-    if (L.ld.covp) return kinetic_energy_lanedense<G, M::DPL, M::D, M::kXRowLds>(L.ld, L.l, L.rank, L.valid, p);
+    if (L.ld.covp) return kinetic_energy_lanedense<G, M::DPL, M::D, M::kXRowLds, M::kDenseImage>(L.ld, L.l, L.rank, L.valid, p);
   }
   return kinetic_energy<G, M::DPL, M::D, M::kXRowLds>(p, L.im, L.valid);
 }
@@ -236,7 +236,7 @@ __device__ __forceinline__ void mass_drift(const NutsLane<M, G>& L, double eps, 
       double x[1][M::DPL], mp[1][M::DPL];
 #pragma unroll
       for (int k = 0; k < M::DPL; k++) x[0][k] = ph[k];
-      lane_dense_times<G, M::DPL, M::D, 1>(L.ld, L.l, L.rank, L.valid, x, mp);
+      lane_dense_times<G, M::DPL, M::D, 1, M::kDenseImage>(L.ld, L.l, L.rank, L.valid, x, mp);
 #pragma unroll
       for (int k = 0; k < M::DPL; k++) q[k] = q[k] + eps * mp[0][k];
       return;
@@ -257,7 +257,7 @@ __device__ __forceinline__ bool mass_uturn(const NutsLane<M, G>& L, const double
       double x[1][M::DPL], v[1][M::DPL], s[2];
 #pragma unroll
       for (int k = 0; k < M::DPL; k++) x[0][k] = rho[k];
-      lane_dense_times<G, M::DPL, M::D, 1>(L.ld, L.l, L.rank, L.valid, x, v);
+      lane_dense_times<G, M::DPL, M::D, 1, M::kDenseImage>(L.ld, L.l, L.rank, L.valid, x, v);
       uturn_partials_v<M::DPL>(v[0], pa, pb, L.valid, s[0], s[1]);
       group_allsum_n<G, 2, M::kXRowLds>(s);
       return (s[0] < 0.0) || (s[1] < 0.0);
@@ -297,7 +297,7 @@ __device__ __forceinline__ void mass_uturn3(const NutsLane<M, G>& L, const doubl
         x[1][k] = r2[k];
         x[2][k] = r3[k];
       }
-      lane_dense_times<G, M::DPL, M::D, 3>(L.ld, L.l, L.rank, L.valid, x, v);
+      lane_dense_times<G, M::DPL, M::D, 3, M::kDenseImage>(L.ld, L.l, L.rank, L.valid, x, v);
       uturn_partials_v<M::DPL>(v[0], a1, b1, L.valid, s[0], s[1]);
       uturn_partials_v<M::DPL>(v[1], a2, b2, L.valid, s[2], s[3]);
       uturn_partials_v<M::DPL>(v[2], a3, b3, L.valid, s[4], s[5]);
@@ -1210,8 +1210,15 @@ __device__ __forceinline__ void lane_setup(NutsLane<M, G>& L, const typename M::
   if constexpr (M::kLaneDense) {
     L.ld.covp = dm.covp;
     L.ld.cholp = dm.cholp;
-    L.ld.xs = lds + (size_t)LDSL * nuts_nslot<M>() * kNutsBlock + kZigLdsBytes / 8 + M::kExtraLdsDoubles +
-              (size_t)((threadIdx.x & 63) / G) * 3 * D;
+    double* dl = lds + (size_t)LDSL * nuts_nslot<M>() * kNutsBlock + kZigLdsBytes / 8 + M::kExtraLdsDoubles;
+    L.ld.xs = dl + (size_t)((threadIdx.x & 63) / G) * 3 * D;
+    if constexpr (M::kDenseImage) {
+      L.ld.covl = dl + (size_t)(64 / G) * 3 * D;
+      if (dm.covp) {
+        lane_dense_stage<G, DPL, D>(L.ld, L.l);
+        wave_lds_fence();
+      }
+    }
   }
 }
 
@@ -1859,6 +1866,10 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock)
                 L.im[k] = L.valid[k] ? lw.cov[L.rank[k] * D + L.rank[k]] : 1.0;   // inv_mass_diag_out
               L.ld.covp = lw.covp;
               L.ld.cholp = lw.cholp;
+              if constexpr (M::kDenseImage) {
+                lane_dense_stage<G, DPL, D>(L.ld, L.l);
+                wave_lds_fence();
+              }
               dense_done = true;
             }
           }
