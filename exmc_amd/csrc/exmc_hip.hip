@@ -119,6 +119,7 @@ struct exmc_hip_model {
   // dimensions, [D][GD] each, built from the host copies for the lane count of the launch; the
   // warmup kernel's global workspace; rank of each kernel dimension in the flat vector
   DevBuf densep, densews;
+  DevBuf migboard;  // chain migration board of the sampling kernel (exmc_nuts.hpp)
   int densep_gd = 0;
   std::vector<double> h_dense;
   std::vector<int32_t> h_rank;
@@ -434,6 +435,21 @@ int launch_nuts(exmc_hip_model* m, int lanes, int C, int n_draws, int draw_offse
     P.zig_ki = zig_ki(m); P.zig_wi = zig_wi(m); P.zig_fi = zig_fi(m);
     P.nor_r = EXMC_NOR_R;
     P.flat = flat_order(m);
+    P.mig = nullptr;
+    if constexpr (M::kMigrate) {
+      // worth it when the launch puts two chains on a SIMD (more waves than the 1024 SIMDs) and
+      // runs long enough to have a tail; EXMC_HIP_MIGRATE=0 / 1 forces it off / on
+      const char* me = std::getenv("EXMC_HIP_MIGRATE");
+      const bool on = me ? (me[0] == '1') : ((int)grid.x > 1024 && n_draws >= 100);
+      if (on) {
+        const size_t nb = mig_board_ints(grid.x) * sizeof(int);
+        rc = m->migboard.ensure(nb);
+        if (rc) return rc;
+        HIP_TRY(hipMemsetAsync(m->migboard.p, 0, nb, m->stream));
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)m->migboard.p, C, 1, m->stream));   // board[0] = chains left
+        P.mig = m->migboard.as<int>();
+      }
+    }
     if (m->dense_on) {
       if (T::G != 1 && !M::kRowDense && !M::kLaneDense)
         return fail(EXMC_ERR_UNSUPPORTED, "no dense mass matrix for this model at this lanes_per_chain");
@@ -477,6 +493,12 @@ int launch_nuts(exmc_hip_model* m, int lanes, int C, int n_draws, int draw_offse
                        m->stream, P, mc);
     HIP_TRY(hipGetLastError());
     if (timed) HIP_TRY(hipEventRecord(m->ev1, m->stream));
+    if (P.mig && std::getenv("EXMC_HIP_MIGRATE_STATS")) {
+      int h[4];
+      HIP_TRY(hipMemcpyAsync(h, P.mig, sizeof(h), hipMemcpyDeviceToHost, m->stream));
+      HIP_TRY(hipStreamSynchronize(m->stream));
+      fprintf(stderr, "[exmc migrate] chains left %d, moved %d, hosts %d\n", h[0], h[2], h[3]);
+    }
     return (int)EXMC_OK;
   });
 }

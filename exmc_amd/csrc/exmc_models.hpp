@@ -47,6 +47,9 @@ struct ModelDefaults {
   // in accumulator registers goes to scratch instead. Worth it when the configuration launches
   // more waves than SIMDs and the spilled values are per-transition state, not leaf-pass state.
   static constexpr int kNutsWavesPerSimd = 1;
+  // one chain per wave, two waves per SIMD: a chain may move to a SIMD that has run empty while
+  // its own SIMD still holds two chains (exmc_nuts.hpp "chain migration")
+  static constexpr bool kMigrate = false;
   // > 0: the sampling kernel runs as wave pairs too, with this many tree-stack levels in LDS
   static constexpr int kPipeNutsLevels = 0;
 };
@@ -360,6 +363,7 @@ struct SV : ModelDefaults {
   // (4096 chains x 200 draws: 1307 -> 950 ms)
   static constexpr int kNutsWavesPerSimd = (G == 64) ? 2 : 1;
   static constexpr bool kXRowLds = (G == 64);
+  static constexpr bool kMigrate = (G == 64);
   using Consts = SVConsts;
   struct Lane {
     double r[DPL];

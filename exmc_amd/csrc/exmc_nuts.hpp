@@ -132,7 +132,38 @@ struct NutsParams {
   double nor_r;
   FlatOrder flat;
   DenseMass dm;   // opts[:dense_mass] in force (lanes_per_chain = 1 only)
+  int* mig;       // chain migration (Model::kMigrate): a zeroed MigBoard, or null
 };
+
+// ---- chain migration (sv: one chain per wave, 2048 waves = two per SIMD) ----
+// The launch ends with its slowest chain, and the per-chain leapfrog totals spread (sd 13 % of the
+// mean): towards the end some SIMDs still hold two chains, at half speed each, while others have
+// run empty. A chain is a serial Markov sequence, but WHERE its next transition runs is free: its
+// state between transitions is (q, g, logp, rng), 2 d + 3 doubles. So a wave that finishes the
+// last chain of its SIMD stays as a host and advertises itself; a wave that starts a transition
+// while its SIMD holds two live chains and a host is advertised stores its chain, hands
+// (chain, draws done) to the host's mailbox and exits; the host loads the chain and goes on --
+// same arithmetic, same generator state, bit-identical draws. All of it is wave-uniform scalar
+// work on global words; a host polls with s_sleep on a SIMD nobody else uses.
+//   board[0]              remaining chains (set by the host to C before the launch)
+//   board[1]              the advertised host: 0 or its workgroup index + 1
+//   board[2], board[3]    statistics: chains moved, waves that became hosts
+//   board[8 .. 8+16384)   live chains per SIMD, indexed by (XCC_ID, SE, SH, CU, SIMD)
+//   board[16392 + 2 b]    mailbox of workgroup b: chain + 1 (0: empty), draws done
+constexpr int kMigSimds = 16384;
+constexpr int kMigLive = 8;
+constexpr int kMigMail = kMigLive + kMigSimds;
+__host__ __device__ constexpr size_t mig_board_ints(size_t n_workgroups) { return kMigMail + 2 * n_workgroups; }
+
+__device__ __forceinline__ int mig_simd_uid() {
+  unsigned xcc, hw;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+  return (int)(((xcc & 0xf) << 10) | (((hw >> 8) & 0xff) << 2) | ((hw >> 4) & 0x3));
+}
+__device__ __forceinline__ int mig_load(int* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 constexpr int kMaxLevels = 12;
 constexpr int kNutsBlock = 64;      // one wavefront per workgroup
@@ -1313,19 +1344,23 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock, M::kNutsW
     return Cursor{on ? (char*)base + index * elem : (char*)P.scratch,
                   on ? (long long)(row_elems * elem) : 0LL};
   };
-  const size_t row0 = (size_t)P.draw_offset;
-  const size_t stat0 = row0 * C + chain;
   const bool own = (l == 0);
   Cursor c_draw[DPL];
+  Cursor c_logp, c_depth, c_steps, c_div, c_acc, c_energy;
+  // point the cursors at trace row `row` of chain `ch`
+  auto bind = [&](int ch, size_t row) {
+    const size_t stat0 = row * C + ch;
 #pragma unroll
-  for (int k = 0; k < DPL; k++)
-    c_draw[k] = cursor(P.tr.draws, L.valid[k], 8, (row0 * D + (l + k * G)) * C + chain, (size_t)D * C);
-  Cursor c_logp = cursor(P.tr.logp, own, 8, stat0, C);
-  Cursor c_depth = cursor(P.tr.tree_depth, own, 4, stat0, C);
-  Cursor c_steps = cursor(P.tr.n_steps, own, 4, stat0, C);
-  Cursor c_div = cursor(P.tr.divergent, own, 4, stat0, C);
-  Cursor c_acc = cursor(P.tr.accept_prob, own, 8, stat0, C);
-  Cursor c_energy = cursor(P.tr.energy, own, 8, stat0, C);
+    for (int k = 0; k < DPL; k++)
+      c_draw[k] = cursor(P.tr.draws, L.valid[k], 8, (row * D + (l + k * G)) * C + ch, (size_t)D * C);
+    c_logp = cursor(P.tr.logp, own, 8, stat0, C);
+    c_depth = cursor(P.tr.tree_depth, own, 4, stat0, C);
+    c_steps = cursor(P.tr.n_steps, own, 4, stat0, C);
+    c_div = cursor(P.tr.divergent, own, 4, stat0, C);
+    c_acc = cursor(P.tr.accept_prob, own, 8, stat0, C);
+    c_energy = cursor(P.tr.energy, own, 8, stat0, C);
+  };
+  bind(chain, (size_t)P.draw_offset);
   auto sink = [&](int, const double (&sq)[DPL], double slogp, int depth, int t_n, bool t_div,
                   double t_acc, double jlp0) {
 #pragma unroll
@@ -1356,6 +1391,92 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock, M::kNutsW
   if constexpr (kPipe) {
     nuts_run<M, G, LDSL>(mc, L, st, P.n_draws, P.eps, P.max_depth, sink, &pipe);
     if (pipe.pending) pipe.sync();   // the integrator wave's last barrier (momentum variates nobody takes)
+  } else if constexpr (M::kMigrate && G == 64) {
+    if (P.mig != nullptr && P.n_draws > 0) {
+      // chain migration (see MigBoard above); everything here is wave-uniform
+      int* const board = P.mig;
+      int* const live = board + kMigLive + mig_simd_uid();
+      int* const mail = board + kMigMail + 2 * (int)blockIdx.x;
+      int cur = chain, done = 0;
+      if (lane == 0) atomicAdd(live, 1);
+      for (;;) {
+        // one transition at a time; the two words looked at after it are loaded before it
+        int host_adv = 0, n_live = 0;
+        if (lane == 0) {
+          host_adv = mig_load(board + 1);
+          n_live = mig_load(live);
+        }
+        nuts_run<M, G, LDSL>(mc, L, st, 1, P.eps, P.max_depth, sink);
+        done++;
+        if (done == P.n_draws) {
+          chain_store<M, G>(P.st, C, cur, l, st);
+          int last = 0;
+          if (lane == 0) {
+            atomicSub(board, 1);
+            last = (atomicSub(live, 1) == 1) ? 1 : 0;
+          }
+          last = __builtin_amdgcn_readfirstlane(last);
+          if (!last) break;
+          if (lane == 0) atomicAdd(board + 3, 1);
+          // the SIMD has run empty: stay as a host until a chain arrives or none is left
+          int got = 0, advertised = 0;
+          // (one poll per ~100 us and per host, by one lane: a thousand hosts polling one word
+          // every few microseconds saturate its L2 channel and slow every running chain)
+          for (int spin = 0; spin < (1 << 18); spin++) {
+            int a = advertised, m0 = 0, left = 1;
+            if (lane == 0) {
+              left = mig_load(board);
+              if (!a && mig_load(board + 1) == 0) a = (atomicCAS(board + 1, 0, (int)blockIdx.x + 1) == 0) ? 1 : 0;
+              m0 = mig_load(mail);
+            }
+            advertised = __builtin_amdgcn_readfirstlane(a);
+            got = __builtin_amdgcn_readfirstlane(m0);
+            if (got != 0 || __builtin_amdgcn_readfirstlane(left) <= 0) break;
+#pragma unroll 1
+            for (int z = 0; z < 32; z++) __builtin_amdgcn_s_sleep(127);
+          }
+          if (got == 0) break;
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          cur = got - 1;
+          done = __builtin_amdgcn_readfirstlane(mig_load(mail + 1));
+          if (lane == 0) {
+            __hip_atomic_store(mail, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            atomicAdd(live, 1);
+          }
+          chain_load<M, G>(P.st, C, cur, l, st);
+          bind(cur, (size_t)P.draw_offset + (size_t)done);
+          continue;
+        }
+        if (__builtin_amdgcn_readfirstlane((host_adv != 0 && n_live >= 2) ? 1 : 0)) {
+          // claim the right to leave (one of the two), then the advertised host
+          int h = 0;
+          if (lane == 0) {
+            if (atomicCAS(live, 2, 1) == 2) {
+              h = atomicExch(board + 1, 0);
+              if (h == 0) atomicAdd(live, 1);   // somebody else took the host: stay
+            }
+          }
+          h = __builtin_amdgcn_readfirstlane(h);
+          if (h != 0) {
+            if (lane == 0) atomicAdd(board + 2, 1);
+            chain_store<M, G>(P.st, C, cur, l, st);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            if (lane == 0) {
+              int* const hm = board + kMigMail + 2 * (h - 1);
+              __hip_atomic_store(hm + 1, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(hm, cur + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            break;
+          }
+        }
+      }
+      if (l == 0 && P.counters) {
+        atomicAdd(&P.counters[0], lf_total);
+        atomicAdd(&P.counters[1], div_total);
+      }
+      return;
+    }
+    nuts_run<M, G, LDSL>(mc, L, st, P.n_draws, P.eps, P.max_depth, sink);
   } else {
     nuts_run<M, G, LDSL>(mc, L, st, P.n_draws, P.eps, P.max_depth, sink);
   }

@@ -590,3 +590,32 @@ def test_dense_mass_lane_layouts_bit_exact(hip, name, lanes, W):
                                              dict(num_samples=8, seed=13, lanes_per_chain=lanes), num_chains=2)
     t2, _ = O.sample_tuned(om, diag["epsilon"], diag["inv_mass"], q0, num_samples=8, seed=13, cfg=O.Cfg(1, lanes))
     assert np.array_equal(t2["draws"], e2["raw"]["draws"][0])
+
+
+def test_chain_migration_bit_exact(hip, monkeypatch, capfd):
+    """sv's sampling kernel (one chain per wave, two waves per SIMD) lets a chain move, between
+    transitions, to a SIMD that has run empty (exmc_nuts.hpp "chain migration"): the chain's state
+    (q, g, logp, generator) crosses through the state arrays, so every output is the same with the
+    mode forced on, forced off, and in the checker -- and chains do move."""
+    import test_golden_traces as TG
+    spec = models.sv(TG.GOLD["sv_returns"])
+    comp = sampler.compile(spec)
+    om = O.model_for(spec)
+    opts = dict(num_warmup=150, num_samples=30, seed=5)
+    tuning = sampler.warmup(comp, spec.default_init, opts)
+    res = {}
+    monkeypatch.setenv("EXMC_HIP_MIGRATE_STATS", "1")
+    for mig in ("0", "1"):
+        monkeypatch.setenv("EXMC_HIP_MIGRATE", mig)
+        _, _, extra = sampler.sample_compiled_tuned(comp, tuning, spec.default_init, opts, num_chains=2048)
+        res[mig] = extra["raw"]
+    err = capfd.readouterr().err
+    moved = [int(ln.split("moved")[1].split(",")[0]) for ln in err.splitlines() if "[exmc migrate]" in ln]
+    assert moved and moved[-1] > 0 and "chains left 0" in err, err
+    for k in ("draws", "n_steps", "tree_depth", "energy", "accept_prob", "divergent", "logp"):
+        assert np.array_equal(res["0"][k], res["1"][k]), k
+    q0 = spec.to_unconstrained(spec.default_init)
+    for c in (0, 7, 1024, 2047):
+        t, _ = O.sample_tuned(om, tuning["epsilon"], tuning["inv_mass"], q0, num_samples=30, seed=5 + 7919 * c,
+                              cfg=O.Cfg(1, 64))
+        assert np.array_equal(t["draws"], res["1"]["draws"][c]), c
