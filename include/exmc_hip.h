@@ -160,9 +160,13 @@ int exmc_hip_warmup(exmc_hip_model* m, const double* init_q, exmc_hip_opts opts,
  * mass then stays in force on the handle -- momentum p = L^-T z, M^-1 p by the dense product, the
  * U-turn rule through v = M^-1 rho -- for sample_chains / chains_advance / sample_host / stream until
  * exmc_hip_model_clear_dense_mass. exmc_hip_model_set_dense_mass installs a (cov, chol) pair from an
- * earlier run (sample_compiled_tuned with tuning.chol_cov). Layouts: lanes_per_chain = 1, and
- * eight_schools with 16 lanes per chain (matrix rows in registers); EXMC_ERR_UNSUPPORTED otherwise. (The reference raises inside its first dense transition for d >= 2,
- * DESIGN.md "Dense mass"; this is the documented intent of the mode.) */
+ * earlier run (sample_compiled_tuned with tuning.chol_cov). cov and chol are indexed by the entries
+ * of the reference's FLAT vector (the order exmc_hip_model_set_flat_order states; sampler.ex:682-705
+ * feeds Welford the flat q), tuning->inv_mass stays in kernel order. Layouts: lanes_per_chain = 1
+ * where the kind has a one-lane form, eight_schools with 16 lanes per chain (matrix rows in
+ * registers), sv 64, radon 64 and logistic 16 (exmc_hip_model_default_dense_lanes names the kind's
+ * layout); EXMC_ERR_UNSUPPORTED otherwise. (The reference raises inside its first dense transition
+ * for d >= 2, DESIGN.md "Dense mass"; this is the documented intent of the mode.) */
 int exmc_hip_warmup_dense(exmc_hip_model* m, const double* init_q, exmc_hip_opts opts,
                           exmc_hip_tuning* tuning, double* cov, double* chol);
 int exmc_hip_model_set_dense_mass(exmc_hip_model* m, const double* cov, const double* chol, int d);
