@@ -98,6 +98,20 @@ ERL_NIF_TERM enif_make_resource(ErlNifEnv*, void* obj);
 void* enif_alloc(size_t size);
 void enif_free(void* ptr);
 
+/* process-independent environments, messages and threads (erl_nif: enif_alloc_env, enif_send,
+ * enif_thread_create): what a NIF library needs to send from a thread of its own */
+typedef struct { ERL_NIF_TERM pid; } ErlNifPid;
+typedef struct ErlDrvTid_* ErlNifTid;
+typedef struct { int suggested_stack_size; } ErlNifThreadOpts;
+ErlNifEnv* enif_alloc_env(void);
+void enif_free_env(ErlNifEnv*);
+void enif_clear_env(ErlNifEnv*);
+int enif_send(ErlNifEnv* caller_env, const ErlNifPid* to_pid, ErlNifEnv* msg_env, ERL_NIF_TERM msg);
+int enif_get_local_pid(ErlNifEnv*, ERL_NIF_TERM, ErlNifPid* pid);
+int enif_thread_create(char* name, ErlNifTid* tid, void* (*func)(void*), void* args, ErlNifThreadOpts* opts);
+int enif_thread_join(ErlNifTid, void** exit_value);
+int enif_keep_resource(void* obj);
+
 #define ERL_NIF_INIT(NAME, FUNCS, LOAD, RELOAD, UPGRADE, UNLOAD)                              \
   ErlNifEntry* nif_init(void);                                                                \
   ErlNifEntry* nif_init(void) {                                                               \

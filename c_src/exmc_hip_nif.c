@@ -9,13 +9,17 @@
  *   warmup/6                run_warmup of the shared chain (sampler.ex:537-762, 1068-1080)
  *   sample_chains/10        sample_chains_vectorized_compiled's sampling loop (sampler.ex:1082-1130)
  *   sample/7                sample/3 for one chain (sampler.ex:126-257)
- *   stream_begin/6, stream_next/2   sample_stream/4 (sampler.ex:1186-1277)
+ *   stream_begin/6, stream_next/2   sample_stream/4 (sampler.ex:1186-1277), pulled in chunks
+ *   stream_run/3            sample_stream/4's sender: one launch, a message per finished draw
  *
  * Binaries are native-endian f64 (int32 for the integer statistics), row-major
  * [chain][draw][dim]; every call that waits on the GPU is a dirty IO-bound job; errors are
  * {:error, message} from model_create and raised {:exmc_hip_error, code, message} elsewhere.
  * Build as exmc_native_tree_nif.c (one shared object per NIF module, as OTP requires). */
+#define _POSIX_C_SOURCE 200809L   /* nanosleep */
 #include "exmc_nif_util.h"
+
+#include <time.h>
 
 static ErlNifResourceType* MODEL_RT;
 static int g_device = 0;
@@ -339,6 +343,89 @@ static ERL_NIF_TERM stream_next(ErlNifEnv* env, int argc, const ERL_NIF_TERM arg
   return tuple2(env, trace_map(env, &b), enif_make_int(env, dv));
 }
 
+/* stream_run(ref, n_draws, pid) -> :ok. The sender of sample_stream/4 (sampler.ex:1240-1277): ONE
+ * launch draws the next n_draws transitions of the resident chain (exmc_hip_stream_start: the
+ * kernel writes every finished draw into page-locked host memory and publishes its count); a thread
+ * of this library polls the count and sends
+ *   {:exmc_sample, i, q :: f64 binary, {tree_depth, n_steps, divergent, accept_prob, energy}}
+ * for i = 1..n as the draws appear, then {:exmc_done, n, divergences}. The handle is busy until
+ * that last message (it is kept alive by the thread; the Elixir side constrains q and builds the
+ * point map as it does for stream_next's rows). */
+typedef struct {
+  model_res* res;
+  ErlNifPid pid;
+  int n, d;
+  exmc_hip_trace view;
+  const volatile int32_t* progress;
+} stream_job;
+
+static void* stream_sender(void* arg) {
+  stream_job* j = (stream_job*)arg;
+  ErlNifEnv* env = enif_alloc_env();
+  const double* draws = (const double*)j->view.draws;
+  const struct timespec nap = {0, 100000};   /* 100 us */
+  int sent = 0;
+  while (sent < j->n) {
+    const int ready = *j->progress;          /* rows [0, ready) are final */
+    if (ready <= sent) {
+      nanosleep(&nap, NULL);
+      continue;
+    }
+    for (; sent < ready; sent++) {
+      ERL_NIF_TERM st[5] = {enif_make_int(env, ((const int32_t*)j->view.tree_depth)[sent]),
+                            enif_make_int(env, ((const int32_t*)j->view.n_steps)[sent]),
+                            make_bool(env, ((const int32_t*)j->view.divergent)[sent] != 0),
+                            enif_make_double(env, ((const double*)j->view.accept_prob)[sent]),
+                            enif_make_double(env, ((const double*)j->view.energy)[sent])};
+      ERL_NIF_TERM msg[4] = {enif_make_atom(env, "exmc_sample"), enif_make_int(env, sent + 1),
+                             make_f64_bin(env, draws + (size_t)sent * j->d, (size_t)j->d),
+                             enif_make_tuple_from_array(env, st, 5)};
+      enif_send(NULL, &j->pid, env, enif_make_tuple_from_array(env, msg, 4));
+      enif_clear_env(env);
+    }
+  }
+  int32_t dv = 0;
+  const int rc = exmc_hip_stream_finish(j->res->m, &dv);
+  enif_send(NULL, &j->pid, env,
+            tuple3(env, enif_make_atom(env, rc == EXMC_OK ? "exmc_done" : "exmc_error"), enif_make_int(env, j->n),
+                   enif_make_int(env, rc == EXMC_OK ? dv : rc)));
+  enif_free_env(env);
+  enif_release_resource(j->res);
+  enif_free(j);
+  return NULL;
+}
+
+static ERL_NIF_TERM stream_run(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  void* obj;
+  int n;
+  ErlNifPid pid;
+  (void)argc;
+  if (!enif_get_resource(env, argv[0], MODEL_RT, &obj) || !((model_res*)obj)->m ||
+      !enif_get_int(env, argv[1], &n) || n < 1 || !enif_get_local_pid(env, argv[2], &pid))
+    return enif_make_badarg(env);
+  stream_job* j = (stream_job*)enif_alloc(sizeof(stream_job));
+  if (!j) return enif_make_badarg(env);
+  j->res = (model_res*)obj;
+  j->pid = pid;
+  j->n = n;
+  j->d = exmc_hip_model_dim(j->res->m);
+  int rc = exmc_hip_stream_start(j->res->m, n, &j->view, &j->progress);
+  if (rc != EXMC_OK) {
+    enif_free(j);
+    return raise_hip(env, rc);
+  }
+  enif_keep_resource(j->res);   /* the thread's reference */
+  ErlNifTid tid;
+  if (enif_thread_create((char*)"exmc_hip_stream", &tid, stream_sender, j, NULL) != 0) {
+    int32_t dv;
+    (void)exmc_hip_stream_finish(j->res->m, &dv);
+    enif_release_resource(j->res);
+    enif_free(j);
+    return enif_raise_exception(env, enif_make_atom(env, "thread_create_failed"));
+  }
+  return enif_make_atom(env, "ok");   /* detached in effect: the thread frees its job and ends after :exmc_done */
+}
+
 static ErlNifFunc nif_funcs[] = {
     {"model_create", 2, model_create, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"model_set_flat_order", 2, model_set_flat_order, ERL_NIF_DIRTY_JOB_IO_BOUND},
@@ -353,6 +440,7 @@ static ErlNifFunc nif_funcs[] = {
     {"sample", 7, sample, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"stream_begin", 6, stream_begin, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"stream_next", 2, stream_next, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"stream_run", 3, stream_run, ERL_NIF_DIRTY_JOB_IO_BOUND},
 };
 
 static int on_load(ErlNifEnv* env, void** priv, ERL_NIF_TERM info) {

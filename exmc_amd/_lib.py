@@ -21,7 +21,7 @@ EXPORTS = [
     "exmc_hip_traj_create", "exmc_hip_traj_destroy", "exmc_hip_traj_get_endpoint_host",
     "exmc_hip_traj_build_and_merge_host", "exmc_hip_traj_is_terminated_host",
     "exmc_hip_traj_get_result_host", "exmc_hip_build_subtree_host",
-    "exmc_hip_stream_begin", "exmc_hip_stream_next_host", "exmc_hip_rhat", "exmc_hip_ess_bulk",
+    "exmc_hip_stream_begin", "exmc_hip_stream_next_host", "exmc_hip_stream_start", "exmc_hip_stream_finish", "exmc_hip_rhat", "exmc_hip_ess_bulk",
     "exmc_hip_model_set_flat_order", "exmc_hip_warmup_from", "exmc_hip_sample_warm_host",
     "exmc_hip_warmup_dense", "exmc_hip_model_set_dense_mass", "exmc_hip_model_clear_dense_mass",
     "exmc_hip_sample_dense_host",
@@ -110,6 +110,8 @@ def bind(path):
         C.c_int, dp, dp, C.c_int, C.POINTER(C.c_uint64), dp, dp, dp, ip, ip, dp, ip]
     L.exmc_hip_stream_begin.argtypes = [vp, dp, Opts, C.POINTER(Tuning)]
     L.exmc_hip_stream_next_host.argtypes = [vp, C.c_int, Trace, ip]
+    L.exmc_hip_stream_start.argtypes = [vp, C.c_int, C.POINTER(Trace), C.POINTER(ip)]
+    L.exmc_hip_stream_finish.argtypes = [vp, ip]
     up = C.POINTER(C.c_uint64)
     L.exmc_hip_traj_create.argtypes = [C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, C.POINTER(vp)]
     L.exmc_hip_traj_destroy.argtypes = [vp]

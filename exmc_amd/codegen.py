@@ -86,6 +86,18 @@ LANCZOS = [0.99999999999980993, 676.5203681218851, -1259.1392167224028, 771.3234
 class IR:
     def __init__(self):
         self.nodes = {}
+        self.data_tensor = None
+
+    def data(self, tensor):
+        """Builder.data (builder.ex:19-21): the model's observation tensor (rank 0, 1 or 2). A
+        param written as the string "__obs_data" resolves to it (compiler.ex:103-118). Like every
+        other constant of a generated model it travels in the data array exmc_hip_model_create
+        receives, not in the generated text: the same plug-in serves any data of the same shape."""
+        t = np.asarray(tensor, dtype=np.float64)
+        if t.ndim > 2:
+            raise CodegenError("Builder.data takes a scalar, a vector or a matrix")
+        self.data_tensor = t
+        return self
 
     def _add(self, id_, node):
         if not isinstance(id_, str):
@@ -714,6 +726,7 @@ def rewrite(ir):
                     tmp = IR().meas_obs(id_, lifted[0], n["value"], lifted[1], meta=n.get("meta"))
                     n = tmp.nodes[id_]
         out.nodes[id_] = n
+    out.data_tensor = ir.data_tensor
     return out
 
 
@@ -784,6 +797,13 @@ def generate(ir, ncp=True, vectorize=True, rewrite_passes=False):
         return _apply_transform(g, nodes[id_]["transform"], z)
 
     def resolve_value(v, stack=()):
+        if isinstance(v, str) and v == "__obs_data":       # compiler.ex:114-118: the IR's data tensor
+            t = ir.data_tensor
+            if t is None:
+                raise CodegenError('"__obs_data" is referenced but the IR has no data (Builder.data)')
+            if t.ndim == 2:
+                return [[g.datum(float(x)) for x in row] for row in t]
+            return g.datum(float(t)) if t.ndim == 0 else [g.datum(float(x)) for x in t]
         if isinstance(v, str):
             return resolve_ref(v, stack)
         a = np.asarray(v, dtype=np.float64)
@@ -1320,6 +1340,8 @@ def compile_ir(ir, ncp=True, name="generated", default_init=None, verbose=False,
 # ---------------------------------------------------------------------------------------------
 def ir_from_json(doc):
     ir = IR()
+    if doc.get("data") is not None:
+        ir.data(doc["data"])
     for id_, n in doc["nodes"].items():
         if n.get("op") == "rv":
             ir.rv(id_, n["dist"], n["params"], transform=n.get("transform"))

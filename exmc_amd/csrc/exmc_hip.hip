@@ -120,6 +120,10 @@ struct exmc_hip_model {
   // warmup kernel's global workspace; rank of each kernel dimension in the flat vector
   DevBuf densep, densews;
   DevBuf migboard;  // chain migration board of the sampling kernel (exmc_nuts.hpp)
+  // push-style stream: page-locked host memory [progress word | trace of the run in flight]
+  void* pin_host = nullptr;
+  size_t pin_bytes = 0;
+  bool stream_in_flight = false;
   int densep_gd = 0;
   std::vector<double> h_dense;
   std::vector<int32_t> h_rank;
@@ -408,8 +412,24 @@ int launch_init(exmc_hip_model* m, int lanes, int C, int chain_lo, uint64_t seed
   });
 }
 
+// the kernels a push-style stream may run: each kind in its default layout
+template <class M> inline constexpr bool kStreamKernel = false;
+#if !defined(EXMC_ONLY_CUSTOM) && !defined(EXMC_DEV_ONLY)
+template <> inline constexpr bool kStreamKernel<EightSchools<16>> = true;
+template <> inline constexpr bool kStreamKernel<Simple<1>> = true;
+template <> inline constexpr bool kStreamKernel<SV<64>> = true;
+template <> inline constexpr bool kStreamKernel<Logistic<16>> = true;
+template <> inline constexpr bool kStreamKernel<Radon<64>> = true;
+#endif
+#ifdef EXMC_CUSTOM_HEADER
+template <> inline constexpr bool kStreamKernel<Custom<1>> = true;
+#ifdef EXMC_GEN_VEC
+template <> inline constexpr bool kStreamKernel<Custom<16>> = true;
+#endif
+#endif
+
 int launch_nuts(exmc_hip_model* m, int lanes, int C, int n_draws, int draw_offset, double eps,
-                int max_depth, TraceDev tr, bool timed) {
+                int max_depth, TraceDev tr, bool timed, int* progress = nullptr) {
   if (max_depth < 1 || max_depth > kMaxLevels) return fail(EXMC_ERR_BADARG, "max_tree_depth out of range");
   return dispatch_mass(m, lanes, m->dense_on, [&](auto tag, const auto& mc) {
     using T = decltype(tag);
@@ -435,7 +455,21 @@ int launch_nuts(exmc_hip_model* m, int lanes, int C, int n_draws, int draw_offse
     P.zig_ki = zig_ki(m); P.zig_wi = zig_wi(m); P.zig_fi = zig_fi(m);
     P.nor_r = EXMC_NOR_R;
     P.flat = flat_order(m);
+    P.progress = progress;
     P.mig = nullptr;
+    if (progress) {
+      if constexpr (kStreamKernel<M>) {
+        if (timed) HIP_TRY(hipEventRecord(m->ev0, m->stream));
+        const size_t lds_s = nuts_lds_bytes<M, T::LDSL>();
+        hipLaunchKernelGGL((nuts_kernel<M, T::G, T::LDSL, false, true>), grid, dim3(kNutsBlock), lds_s,
+                           m->stream, P, mc);
+        HIP_TRY(hipGetLastError());
+        if (timed) HIP_TRY(hipEventRecord(m->ev1, m->stream));
+        return (int)EXMC_OK;
+      } else {
+        return fail(EXMC_ERR_UNSUPPORTED, "a push-style stream runs in the model kind's default layout, diagonal mass");
+      }
+    }
     if constexpr (M::kMigrate) {
       // worth it when the launch puts two chains on a SIMD (more waves than the 1024 SIMDs) and
       // runs long enough to have a tail; EXMC_HIP_MIGRATE=0 / 1 forces it off / on
@@ -1139,6 +1173,7 @@ void exmc_hip_model_destroy(exmc_hip_model* m) {
   if (m->ev0) (void)hipEventDestroy(m->ev0);
   if (m->ev1) (void)hipEventDestroy(m->ev1);
   if (m->stream) (void)hipStreamDestroy(m->stream);
+  if (m->pin_host) (void)hipHostFree(m->pin_host);
   delete m;
 }
 
@@ -1590,6 +1625,59 @@ int exmc_hip_stream_next_host(exmc_hip_model* m, int n_draws, exmc_hip_trace tr,
   if (rc) return rc;
   if (divergences) *divergences = div;
   return download_trace(m, L, n_draws, 1, tr);
+}
+
+int exmc_hip_stream_start(exmc_hip_model* m, int n_draws, exmc_hip_trace* view,
+                          const volatile int32_t** progress) {
+  if (check_model(m)) return EXMC_ERR_BADARG;
+  if (m->res_C != 1) return fail(EXMC_ERR_BADARG, "no stream: call exmc_hip_stream_begin");
+  if (n_draws < 1 || !view || !progress) return fail(EXMC_ERR_BADARG, "bad arguments");
+  if (m->stream_in_flight) return fail(EXMC_ERR_BADARG, "a stream run is in flight: call exmc_hip_stream_finish");
+  if (m->dense_on) return fail(EXMC_ERR_UNSUPPORTED, "a push-style stream runs under the diagonal mass");
+  HIP_TRY(hipSetDevice(m->device));
+  const TraceLayout L = trace_layout(n_draws, m->d, 1);
+  const size_t need = 64 + L.total;
+  if (m->pin_bytes < need) {
+    if (m->pin_host) (void)hipHostFree(m->pin_host);
+    m->pin_host = nullptr;
+    m->pin_bytes = 0;
+    HIP_TRY(hipHostMalloc(&m->pin_host, need, hipHostMallocMapped | hipHostMallocPortable));
+    m->pin_bytes = need;
+  }
+  std::memset(m->pin_host, 0, 64);
+  void* dev = nullptr;
+  HIP_TRY(hipHostGetDevicePointer(&dev, m->pin_host, 0));
+  int rc = reset_counters(m);
+  if (rc) return rc;
+  rc = launch_nuts(m, m->res_lanes, 1, n_draws, 0, m->res_eps, m->res_max_depth,
+                   trace_view((char*)dev + 64, L), true, (int*)dev);
+  if (rc) return rc;
+  m->stream_in_flight = true;
+  // with one chain the device layout [draw][dim][chain] is the host layout [draw][dim]
+  const TraceDev h = trace_view((char*)m->pin_host + 64, L);
+  view->draws = h.draws;
+  view->logp = h.logp;
+  view->tree_depth = h.tree_depth;
+  view->n_steps = h.n_steps;
+  view->divergent = h.divergent;
+  view->accept_prob = h.accept_prob;
+  view->energy = h.energy;
+  *progress = (const volatile int32_t*)m->pin_host;
+  return EXMC_OK;
+}
+
+int exmc_hip_stream_finish(exmc_hip_model* m, int32_t* divergences) {
+  if (check_model(m)) return EXMC_ERR_BADARG;
+  if (!m->stream_in_flight) return fail(EXMC_ERR_BADARG, "no stream run in flight");
+  HIP_TRY(hipSetDevice(m->device));
+  m->stream_in_flight = false;
+  int rc = finish_timing(m);
+  if (rc) return rc;
+  int32_t div = 0;
+  rc = read_counters(m, nullptr, &div);
+  if (rc) return rc;
+  if (divergences) *divergences = div;
+  return EXMC_OK;
 }
 
 int exmc_hip_build_full_tree_host(int device, int C, int d, const double* q0, const double* p0,

@@ -133,6 +133,7 @@ struct NutsParams {
   FlatOrder flat;
   DenseMass dm;   // opts[:dense_mass] in force (lanes_per_chain = 1 only)
   int* mig;       // chain migration (Model::kMigrate): a zeroed MigBoard, or null
+  int* progress;  // kStream launches: where chain 0's count of finished draws is published (host memory)
 };
 
 // ---- chain migration (sv: one chain per wave, 2048 waves = two per SIMD) ----
@@ -1291,7 +1292,10 @@ __device__ __forceinline__ void chain_store(const ChainState& s, int C, int chai
 // wave 1 integrates one leaf ahead (PipeBox above). With two waves per SIMD the barrier waits and
 // the bubbles of one wave (taken branches, > 4-clock issues, LDS round trips) are the other's
 // issue slots.
-template <class M, int G, int LDSL, bool kPipe = false>
+// kStream: the trace lives in page-locked host memory and every finished draw is published there
+// (sample_stream's per-draw notification, sampler.ex:1186-1277): after the draw's stores a
+// system-scope release, then the count of finished draws of chain 0 in P.progress.
+template <class M, int G, int LDSL, bool kPipe = false, bool kStream = false>
 __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock, M::kNutsWavesPerSimd)
     nuts_kernel(NutsParams P, typename M::Consts mc) {
   constexpr int D = M::D, DPL = M::DPL;
@@ -1329,6 +1333,7 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock, M::kNutsW
   chain_load<M, G>(P.st, C, chain, L.l, st);
 
   unsigned long long lf_total = 0, div_total = 0;
+  int n_published = 0;
   const int l = L.l;
   // Trace cursors: one per-lane pointer per output, stepped by one trace row per draw. An output
   // the caller left null (or that this lane does not own) points at an 8-byte scratch word with
@@ -1384,6 +1389,11 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock, M::kNutsW
     c_energy.p += c_energy.step;
     lf_total += (unsigned long long)t_n;
     div_total += t_div ? 1u : 0u;
+    if constexpr (kStream) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // system scope: the host may read this draw's row
+      n_published++;
+      if (tid == 0) __hip_atomic_store(P.progress, n_published, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   };
 #ifdef EXMC_XCC_PROBE
   const long long wave_c0 = clock64();

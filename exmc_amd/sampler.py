@@ -319,7 +319,11 @@ def sample_stream(ir, receiver, init_values=None, opts=None):
     ("exmc_sample", i, point_map, step_stat) for i = 1..n then ("exmc_done", n). The warmup runs
     first; the draws are then produced `stream_chunk` (default 50) at a time by the resident chain
     (exmc_hip_stream_begin / _next_host) and delivered as each chunk lands, so the receiver sees
-    samples while the chain is still running. The stream equals sample/3's draws bit for bit."""
+    samples while the chain is still running. opts["stream_push"]: one launch for all draws that
+    writes every finished draw into page-locked host memory and publishes its count
+    (exmc_hip_stream_start / _finish); this function polls the count and delivers each draw as it
+    appears -- the per-draw notification of sampler.ex:1240-1270 without a launch per message.
+    Either way the stream equals sample/3's draws bit for bit."""
     o = _merge_opts(opts)
     compiled = ir if isinstance(ir, Compiled) else Compiled(ir, device=o.get("device", 0))
     spec = compiled.spec
@@ -331,6 +335,40 @@ def sample_stream(ir, receiver, init_values=None, opts=None):
     compiled.check(L.exmc_hip_stream_begin(compiled.h, None if iq is None else _dp(iq), _c_opts(o),
                                        C.byref(tun)))
     sent = 0
+    if o.get("stream_push"):
+        import time
+        view = _lib.Trace()
+        prog = C.POINTER(C.c_int32)()
+        compiled.check(L.exmc_hip_stream_start(compiled.h, n, C.byref(view), C.byref(prog)))
+
+        def col(ptr, ctype, width=1):
+            a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(n * width,))
+            return a.reshape(n, width) if width > 1 else a
+        draws = col(view.draws, C.c_double, spec.d)
+        raw = dict(tree_depth=col(view.tree_depth, C.c_int32)[None, :], n_steps=col(view.n_steps, C.c_int32)[None, :],
+                   divergent=col(view.divergent, C.c_int32)[None, :], accept_prob=col(view.accept_prob, C.c_double)[None, :],
+                   energy=col(view.energy, C.c_double)[None, :])
+        ss = SampleStats(raw, 0)
+        seen = []                                  # the counts this poll loop observed (tests look at it)
+        deadline = time.monotonic() + float(o.get("stream_timeout_s", 600.0))
+        while sent < n:
+            ready = int(prog[0])                   # rows [0, ready) are final (system-scope release on the device)
+            if ready > sent:
+                seen.append(ready)
+                x = spec.constrain(np.array(draws[sent:ready]))
+                for i in range(sent, ready):
+                    point_map = {name: float(x[i - sent, j]) for j, name in enumerate(spec.var_names)}
+                    receiver(("exmc_sample", i + 1, point_map, ss[i]))
+                sent = ready
+            elif time.monotonic() > deadline:
+                raise TimeoutError("stream: no draw within stream_timeout_s")
+            else:
+                time.sleep(0.0002)
+        div = C.c_int32()
+        compiled.check(L.exmc_hip_stream_finish(compiled.h, C.byref(div)))
+        receiver(("exmc_done", n))
+        compiled.last_stream_counts = seen
+        return "ok"
     while sent < n:
         m = min(chunk, n - sent)
         t, tr = _host_trace(1, m, spec.d)

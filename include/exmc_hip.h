@@ -228,6 +228,19 @@ int exmc_hip_stream_begin(exmc_hip_model* m, const double* init_q, exmc_hip_opts
                           exmc_hip_tuning* tuning_out);
 int exmc_hip_stream_next_host(exmc_hip_model* m, int n_draws, exmc_hip_trace trace_host,
                               int32_t* divergences);
+/* sample_stream/4, push style -- the reference sends {:exmc_sample, i, point, stat} after every
+ * transition (sampler.ex:1240-1270). _start queues ONE launch for the next n_draws transitions of the
+ * resident chain and returns at once; the kernel writes each finished draw straight into page-locked
+ * host memory owned by the handle and then publishes, with a system-scope release, the number of
+ * finished draws in *progress. `view` receives pointers into that memory ([n_draws][d] draws,
+ * [n_draws] stats): rows [0, *progress) are final and may be read while the launch is still running
+ * (the binding's thread polls the word and sends the messages; the library never calls back into the
+ * VM). _finish waits for the launch, reports the divergences and leaves the memory valid until the
+ * next _start or the handle's destruction. The rows equal exmc_hip_stream_next_host's bit for bit.
+ * Runs in the kind's default layout under the diagonal mass (EXMC_ERR_UNSUPPORTED otherwise). */
+int exmc_hip_stream_start(exmc_hip_model* m, int n_draws, exmc_hip_trace* view,
+                          const volatile int32_t** progress);
+int exmc_hip_stream_finish(exmc_hip_model* m, int32_t* divergences);
 
 /* Exmc.Diagnostics.ess (lib/exmc/diagnostics.ex:42-52, 123-167) of every (dim, chain) series of
  * a device trace [draw][dim][chain]: ess_dev [dim][chain]. */

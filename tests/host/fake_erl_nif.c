@@ -3,9 +3,11 @@
  * c_src/ can be loaded and their functions CALLED from the tests without a BEAM (there is no
  * Erlang/OTP in this image). Terms are indices into a table; nothing is garbage collected
  * (fk_reset clears the table between calls). It is not a VM and is never shipped. */
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include "../../c_src/erl_nif_decl.h"
 
@@ -34,7 +36,20 @@ static struct enif_environment_t g_env;
 struct enif_resource_type_t { ErlNifResourceDtor* dtor; char name[64]; };
 typedef struct { struct enif_resource_type_t* type; int refc; } res_hdr;
 
+/* terms made by a sender thread (enif_send) share the table: one lock around its growth; the
+ * harness does not touch terms while a sender runs (fk_mailbox_wait only counts) */
+static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
+static ERL_NIF_TERM* g_mail;
+static size_t g_mail_n, g_mail_cap;
+
+static ERL_NIF_TERM new_term_locked(int type);
 static ERL_NIF_TERM new_term(int type) {
+  pthread_mutex_lock(&g_lock);
+  ERL_NIF_TERM t = new_term_locked(type);
+  pthread_mutex_unlock(&g_lock);
+  return t;
+}
+static ERL_NIF_TERM new_term_locked(int type) {
   if (g_n + 1 >= g_cap) {
     g_cap = g_cap ? 2 * g_cap : 1024;
     g_terms = (term*)realloc(g_terms, g_cap * sizeof(term));
@@ -58,6 +73,22 @@ void fk_reset(void) {
   g_n = 0;
   g_exception = 0;
   g_badarg = 0;
+  g_mail_n = 0;
+}
+/* the mailbox of the one fake process: messages in arrival order */
+size_t fk_mailbox_len(void) {
+  pthread_mutex_lock(&g_lock);
+  size_t n = g_mail_n;
+  pthread_mutex_unlock(&g_lock);
+  return n;
+}
+ERL_NIF_TERM fk_mailbox_get(size_t i) { return i < g_mail_n ? g_mail[i] : 0; }
+int fk_mailbox_wait(size_t n, int timeout_ms) {   /* 1 when n messages have arrived */
+  for (int waited = 0; waited < timeout_ms; waited++) {
+    if (fk_mailbox_len() >= n) return 1;
+    usleep(1000);
+  }
+  return fk_mailbox_len() >= n;
 }
 ERL_NIF_TERM fk_atom(const char* name) { return enif_make_atom(&g_env, name); }
 ERL_NIF_TERM fk_double(double x) { return enif_make_double(&g_env, x); }
@@ -197,5 +228,34 @@ void enif_release_resource(void* obj) {
 ERL_NIF_TERM enif_make_resource(ErlNifEnv* e, void* obj) {
   (void)e; ERL_NIF_TERM t = new_term(T_RES); T(t)->obj = obj; ((res_hdr*)obj - 1)->refc++; return t;
 }
+int enif_keep_resource(void* obj) { ((res_hdr*)obj - 1)->refc++; return 1; }
+ErlNifEnv* enif_alloc_env(void) { return (ErlNifEnv*)calloc(1, sizeof(struct enif_environment_t)); }
+void enif_free_env(ErlNifEnv* e) { free(e); }
+void enif_clear_env(ErlNifEnv* e) { (void)e; }   /* nothing is collected before fk_reset */
+int enif_get_local_pid(ErlNifEnv* e, ERL_NIF_TERM t, ErlNifPid* pid) {
+  (void)e;
+  if (!T(t) || T(t)->type != T_INT) return 0;    /* the harness names its one process by an integer */
+  pid->pid = t;
+  return 1;
+}
+int enif_send(ErlNifEnv* caller, const ErlNifPid* to, ErlNifEnv* msg_env, ERL_NIF_TERM msg) {
+  (void)caller; (void)to; (void)msg_env;
+  pthread_mutex_lock(&g_lock);
+  if (g_mail_n + 1 >= g_mail_cap) {
+    g_mail_cap = g_mail_cap ? 2 * g_mail_cap : 256;
+    g_mail = (ERL_NIF_TERM*)realloc(g_mail, g_mail_cap * sizeof(ERL_NIF_TERM));
+  }
+  g_mail[g_mail_n++] = msg;
+  pthread_mutex_unlock(&g_lock);
+  return 1;
+}
+int enif_thread_create(char* name, ErlNifTid* tid, void* (*func)(void*), void* args, ErlNifThreadOpts* opts) {
+  (void)name; (void)opts;
+  pthread_t t;
+  int rc = pthread_create(&t, NULL, func, args);
+  if (rc == 0) { pthread_detach(t); *tid = (ErlNifTid)(size_t)1; }
+  return rc;
+}
+int enif_thread_join(ErlNifTid tid, void** exit_value) { (void)tid; if (exit_value) *exit_value = NULL; return 0; }
 void* enif_alloc(size_t size) { return malloc(size); }
 void enif_free(void* ptr) { free(ptr); }

@@ -46,7 +46,7 @@ def build(outdir):
     if outdir in _cache:
         return _cache[outdir]
     fake = os.path.join(outdir, "libfake_erl_nif.so")
-    subprocess.check_call(["gcc", "-std=gnu11", "-O1", "-Wall", "-Wextra", "-fPIC", "-shared", "-o", fake,
+    subprocess.check_call(["gcc", "-std=gnu11", "-O1", "-Wall", "-Wextra", "-fPIC", "-shared", "-pthread", "-o", fake,
                            os.path.join(ROOT, "tests", "host", "fake_erl_nif.c")])
     shims = {}
     for mod, src in (("NativeTree", "exmc_native_tree_nif.c"), ("HipNative", "exmc_hip_nif.c")):
@@ -74,6 +74,9 @@ def build(outdir):
     F.fk_badarg.restype = C.c_int
     F.fk_load.argtypes = [C.POINTER(Entry)]
     F.fk_call.argtypes = [C.POINTER(Entry), C.c_char_p, C.c_uint, C.POINTER(tt)]; F.fk_call.restype = tt
+    F.fk_mailbox_len.restype = C.c_size_t
+    F.fk_mailbox_get.argtypes = [C.c_size_t]; F.fk_mailbox_get.restype = tt
+    F.fk_mailbox_wait.argtypes = [C.c_size_t, C.c_int]; F.fk_mailbox_wait.restype = C.c_int
     mods = {}
     for mod, so in shims.items():
         L = C.CDLL(so, mode=os.RTLD_LAZY)
@@ -163,6 +166,15 @@ class Module:
         if exc:
             raise Raised(self.from_term(exc))
         return self.from_term(r)
+
+
+def mailbox(mod, n, timeout_ms=60000):
+    """The first n messages the fake runtime's one process received through enif_send (waits for
+    them; no term is touched while a sender thread may still be running)."""
+    F = mod.F
+    if not F.fk_mailbox_wait(n, timeout_ms):
+        raise TimeoutError("%d of %d messages" % (F.fk_mailbox_len(), n))
+    return [mod.from_term(F.fk_mailbox_get(i)) for i in range(n)]
 
 
 class _Term:

@@ -153,3 +153,39 @@ def test_dirichlet_observation_on_its_default_transform():
     want = (stats.gamma.logpdf(math.exp(0.3), 2.0) + 0.3 + stats.norm.logpdf(1.0, math.exp(0.3), 1.0)
             + stats.dirichlet.logpdf(x, [2.0, 3.0, 1.5]) + math.log(abs(np.linalg.det(jac))))
     assert abs(_lp(gen, [0.3])[0] - want) <= 2e-5 * (1 + abs(want))
+
+
+def test_builder_data_resolves_obs_data_refs():
+    """Builder.data (builder.ex:19-21) + a Custom distribution whose params name "__obs_data"
+    (compiler.ex:103-118): the tensor reaches the closure as constants of the data array, so two
+    data sets of one shape share the generated text."""
+    def model(y):
+        def logpdf(o, x, p):           # sum_i N(y_i | x, sigma) over the data tensor, up to its constant
+            terms = []
+            for yi in p["y"]:
+                z = o.div(o.sub(yi, x), p["sigma"])
+                terms.append(o.mul(o.lit(-0.5), o.mul(z, z)))
+            return o.sub(o.sum(terms), o.mul(o.lit(float(len(p["y"]))), o.log(p["sigma"])))
+        ir = cg.IR().data(y)
+        ir.rv("sigma", "half_cauchy", dict(scale=2.0), transform="log")
+        ir.rv("m", "custom", dict(logpdf=logpdf, y="__obs_data", sigma="sigma"))
+        return cg.generate(ir)
+    y1, y2 = np.array([0.3, -1.2, 2.2, 0.9]), np.array([5.0, 4.0, 6.5, 5.5])
+    g1, g2 = model(y1), model(y2)
+    assert g1.header == g2.header and not np.array_equal(g1.data, g2.data)
+    for gen, y in ((g1, y1), (g2, y2)):
+        q = np.array([0.7, -0.2])                          # m, log sigma
+        sg = math.exp(q[1])
+        want = (stats.halfcauchy.logpdf(sg, scale=2.0) + q[1]
+                + np.sum(-0.5 * ((y - q[0]) / sg) ** 2) - len(y) * math.log(sg))
+        lp, grad = _lp(gen, q)
+        assert abs(lp - want) <= 2e-6 * (1 + abs(want))
+        assert abs(grad[0] - np.sum((y - q[0]) / sg ** 2)) <= 1e-9 * (1 + abs(grad[0]))
+    with pytest.raises(cg.CodegenError):
+        ir = cg.IR()
+        ir.rv("m", "custom", dict(logpdf=lambda o, x, p: x, y="__obs_data"))
+        cg.generate(ir)
+    # a matrix arrives as rows
+    ir = cg.IR().data([[1.0, 2.0], [3.0, 4.0]])
+    ir.rv("m", "custom", dict(logpdf=lambda o, x, p: o.mul(o.neg(o.mul(x, x)), p["a"][1][0]), a="__obs_data"))
+    assert abs(_lp(cg.generate(ir), [0.5])[0] + 0.75) < 1e-15

@@ -132,6 +132,21 @@ def test_build_full_tree_bin_cases(hip, mods):
     assert r["divergent"] is True and r["n_steps"] <= c["expect"]["n_steps_le"]
 
 
+def sampler_rows_after(spec, num_warmup, seed, skip, n):
+    """Rows [skip, skip + n) of the chain stream_begin(nil, num_warmup, 10, 0.8, seed) starts, through
+    the Python mirror's chunked stream (the same C ABI)."""
+    import ctypes as C
+    from exmc_amd import _lib
+    comp = sampler.compile(spec)
+    tun = _lib.Tuning()
+    comp.check(comp.L.exmc_hip_stream_begin(comp.h, None, sampler._c_opts(sampler._merge_opts(
+        dict(num_warmup=num_warmup, seed=seed, max_tree_depth=10, target_accept=0.8))), C.byref(tun)))
+    t, tr = sampler._host_trace(1, skip + n, spec.d)
+    dv = C.c_int32()
+    comp.check(comp.L.exmc_hip_stream_next_host(comp.h, skip + n, tr, C.byref(dv)))
+    return {k: v[:, skip:] for k, v in t.items()}, tun
+
+
 def test_hip_native_equals_the_python_mirror(hip, mods):
     """model_create -> warmup -> sample_chains / sample / stream through the NIF functions."""
     hn = mods["HipNative"]
@@ -165,6 +180,18 @@ def test_hip_native_equals_the_python_mirror(hip, mods):
     assert H.f64(rows["draws"]).shape == (5 * spec.d,) and tun3["epsilon"] > 0
     with pytest.raises(H.BadArg):
         hn.call("warmup", ref, np.zeros(3), 10, 10, 0.8, 1)
+    # the sender of sample_stream/4: one launch, a message per finished draw from a thread of the
+    # library (enif_send), then {:exmc_done, n, divergences}; the rows continue the resident chain
+    more, _ = sampler_rows_after(spec, 50, 3, 5, 12)
+    assert hn.call("stream_run", ref, 12, 1) == H.Atom("ok")          # 1 = the harness's one process
+    msgs = H.mailbox(hn, 13)
+    assert msgs[-1][0] == H.Atom("exmc_done") and msgs[-1][1] == 12
+    for i, (tag, idx, qb, st) in enumerate(msgs[:-1]):
+        assert tag == H.Atom("exmc_sample") and idx == i + 1 and len(st) == 5
+        assert np.array_equal(H.f64(qb), more["draws"][0][i])
+        assert st[1] == int(more["n_steps"][0][i]) and st[4] == float(more["energy"][0][i])
+    with pytest.raises(H.BadArg):
+        hn.call("stream_run", ref, 0, 1)
     # warm start and the dense mass through the shim = the Python mirror of the same C ABI
     ws = hn.call("warmup_from", ref, q0, 200, 10, 0.8, 7, tun["epsilon"], H.f64(tun["inv_mass"]))
     _, st = sampler.sample(spec, spec.default_init, dict(num_warmup=200, num_samples=5, seed=7, lanes_per_chain=16,

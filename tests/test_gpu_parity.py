@@ -619,3 +619,43 @@ def test_chain_migration_bit_exact(hip, monkeypatch, capfd):
         t, _ = O.sample_tuned(om, tuning["epsilon"], tuning["inv_mass"], q0, num_samples=30, seed=5 + 7919 * c,
                               cfg=O.Cfg(1, 64))
         assert np.array_equal(t["draws"], res["1"]["draws"][c]), c
+
+
+@pytest.mark.parametrize("name", ["eight_schools", "sv"])
+def test_sample_stream_push_equals_sample(hip, name):
+    """sample_stream/4 with the per-draw notification of sampler.ex:1240-1270 as ONE launch
+    (exmc_hip_stream_start / _finish): the kernel writes each finished draw into page-locked host
+    memory and publishes the count with a system-scope release; the receiver is handed every draw
+    while the launch is still running. Same messages as the chunked form and as sample/3; for sv
+    (milliseconds per transition) the poll loop must have seen the count grow in several steps."""
+    import test_golden_traces as TG
+    spec = models.eight_schools() if name == "eight_schools" else models.sv(TG.GOLD["sv_returns"])
+    n = 60 if name == "sv" else 200
+    opts = dict(num_warmup=120, num_samples=n, seed=8, stream_push=True)
+    comp = sampler.compile(spec)
+    trace, stats = sampler.sample_compiled(comp, spec.default_init, dict(opts, stream_push=False))
+    msgs = []
+    assert sampler.sample_stream(comp, msgs.append, spec.default_init, opts) == "ok"
+    assert msgs[-1] == ("exmc_done", n) and len(msgs) == n + 1
+    for i, (tag, idx, point, stat) in enumerate(msgs[:-1]):
+        assert tag == "exmc_sample" and idx == i + 1
+        assert all(point[k] == float(trace[k][i]) for k in point)
+        assert stat == stats["sample_stats"][i]
+    counts = comp.last_stream_counts
+    assert counts[-1] == n and all(a < b for a, b in zip(counts, counts[1:]))
+    if name == "sv":
+        assert len(counts) >= 5, counts            # delivered while running, not at the end
+    # the resident chain goes on: a second push run continues where the first ended
+    more = []
+    sampler_opts = dict(opts, num_samples=10)
+    L = comp.L
+    view, prog = _lib.Trace(), C.POINTER(C.c_int32)()
+    comp.check(L.exmc_hip_stream_start(comp.h, 10, C.byref(view), C.byref(prog)))
+    with pytest.raises(Exception):                  # one run in flight at a time
+        comp.check(L.exmc_hip_stream_start(comp.h, 10, C.byref(view), C.byref(prog)))
+    div = C.c_int32()
+    comp.check(L.exmc_hip_stream_finish(comp.h, C.byref(div)))
+    assert prog[0] == 10
+    t2, s2 = sampler.sample_compiled(comp, spec.default_init, dict(opts, stream_push=False, num_samples=n + 10))
+    got = np.ctypeslib.as_array(C.cast(view.draws, C.POINTER(C.c_double)), shape=(10 * spec.d,)).reshape(10, spec.d)
+    assert np.array_equal(got, s2["raw"]["draws"][0][n:])
