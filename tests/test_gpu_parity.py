@@ -659,3 +659,39 @@ def test_sample_stream_push_equals_sample(hip, name):
     t2, s2 = sampler.sample_compiled(comp, spec.default_init, dict(opts, stream_push=False, num_samples=n + 10))
     got = np.ctypeslib.as_array(C.cast(view.draws, C.POINTER(C.c_double)), shape=(10 * spec.d,)).reshape(10, spec.d)
     assert np.array_equal(got, s2["raw"]["draws"][0][n:])
+
+
+def test_dense_mass_lane_layout_edge_cases(hip):
+    """The lane-layout dense mode at its corners (logistic, 16 lanes): a warmup too short for any
+    window leaves the identity covariance (mass_matrix.ex:105-109 via an empty Welford) and the
+    sampler then runs the dense operations on it -- the same draws as the diagonal identity mass
+    up to the order of the sums, and bit-identical to the checker; a caller-supplied (cov, chol)
+    pair; max_tree_depth = 1; the kernel order differing from the flat order throughout."""
+    spec = models.logistic()
+    comp = sampler.compile(spec)
+    om = O.model_for(spec)
+    d = spec.d
+    q0 = spec.to_unconstrained(spec.default_init)
+    opts = dict(num_warmup=40, num_samples=12, seed=21, dense_mass=True)
+    tuning = sampler.warmup(comp, spec.default_init, opts)
+    st, cov, chol = O.warmup_dense(om, q0, num_warmup=40, seed=21, cfg=O.Cfg(1, 16))
+    assert np.array_equal(cov, np.eye(d)) and np.array_equal(tuning["cov"], np.eye(d))
+    assert st.step_size == tuning["epsilon"]
+    _, _, extra = sampler.sample_compiled_tuned(comp, tuning, spec.default_init, opts, num_chains=3)
+    for c in range(3):
+        t, _ = O.sample_tuned_dense(om, st.step_size, cov, chol, q0, num_samples=12, seed=21 + 7919 * c, cfg=O.Cfg(1, 16))
+        assert np.array_equal(t["draws"], extra["raw"]["draws"][c]) and np.array_equal(t["n_steps"], extra["raw"]["n_steps"][c])
+    # a caller's pair (a random SPD matrix on the flat vector), depth-1 trees
+    rng = np.random.default_rng(6)
+    A = rng.normal(size=(d, d)) * 0.05
+    cov2 = np.ascontiguousarray(A @ A.T + 0.02 * np.eye(d))
+    chol2 = np.ascontiguousarray(np.linalg.cholesky(cov2))
+    tun2 = dict(epsilon=0.05, inv_mass=cov2, cov=cov2, chol_cov=chol2)
+    o2 = dict(num_samples=20, seed=4, max_tree_depth=1)
+    _, _, e2 = sampler.sample_compiled_tuned(comp, tun2, spec.default_init, o2, num_chains=5)
+    for c in range(5):
+        t, _ = O.sample_tuned_dense(om, 0.05, cov2, chol2, q0, num_samples=20, max_tree_depth=1, seed=4 + 7919 * c,
+                                    cfg=O.Cfg(1, 16))
+        for k in ("draws", "n_steps", "energy", "accept_prob"):
+            assert np.array_equal(t[k], e2["raw"][k][c]), (c, k)
+    assert e2["raw"]["n_steps"].max() <= 1
