@@ -902,17 +902,19 @@ int run_warmup_device(exmc_hip_model* m, int lanes, exmc_hip_opts o, exmc_hip_tu
                       lds_bytes + pipe_lds_doubles<M::DPL>() * 8 <= 160 * 1024;
     if (dense && !M::kLaneDense) lds_bytes += 3 * (size_t)d * d * 8;   // m2, cov, chol behind everything else
     if (lds_bytes > 160 * 1024) return fail(EXMC_ERR_UNSUPPORTED, "dense warmup state does not fit in LDS");
-    if (pipe) {
-      lds_bytes += pipe_lds_doubles<M::DPL>() * 8;
-      if (lds_bytes > 64 * 1024)
-        HIP_TRY(hipFuncSetAttribute((const void*)warmup_kernel<M, T::G, T::LDSL, true>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-      HIP_TRY(hipEventRecord(m->ev0, m->stream));
-      hipLaunchKernelGGL((warmup_kernel<M, T::G, T::LDSL, true>), dim3(reps), dim3(2 * kNutsBlock),
-                         lds_bytes, m->stream, P, mc);
-      HIP_TRY(hipGetLastError());
-      HIP_TRY(hipEventRecord(m->ev1, m->stream));
-      return (int)EXMC_OK;
+    if constexpr (!M::kLaneDense && !M::kRowDense) {   // the dense variants have no two-wave form
+      if (pipe) {
+        lds_bytes += pipe_lds_doubles<M::DPL>() * 8;
+        if (lds_bytes > 64 * 1024)
+          HIP_TRY(hipFuncSetAttribute((const void*)warmup_kernel<M, T::G, T::LDSL, true>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        HIP_TRY(hipEventRecord(m->ev0, m->stream));
+        hipLaunchKernelGGL((warmup_kernel<M, T::G, T::LDSL, true>), dim3(reps), dim3(2 * kNutsBlock),
+                           lds_bytes, m->stream, P, mc);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(m->ev1, m->stream));
+        return (int)EXMC_OK;
+      }
     }
     if (lds_bytes > 64 * 1024)
       HIP_TRY(hipFuncSetAttribute((const void*)warmup_kernel<M, T::G, T::LDSL>,
