@@ -695,3 +695,40 @@ def test_dense_mass_lane_layout_edge_cases(hip):
         for k in ("draws", "n_steps", "energy", "accept_prob"):
             assert np.array_equal(t[k], e2["raw"][k][c]), (c, k)
     assert e2["raw"]["n_steps"].max() <= 1
+
+
+def test_resident_chains_advance_in_pieces_with_migration(hip, monkeypatch):
+    """exmc_hip_chains_init / _advance (the bench's path: device-resident traces, draw offsets) for
+    sv with chain migration forced on: 2048 chains advanced by 120 and then 80 draws write the same
+    trace as one launch of 200 draws and as the launches with the mode off -- a chain that moved
+    in the first piece starts the second from the state its host stored."""
+    import torch
+    import test_golden_traces as TG
+    spec = models.sv(TG.GOLD["sv_returns"])
+    comp = sampler.compile(spec)
+    L = comp.L
+    d, Cn, S = spec.d, 2048, 200
+    tuning = sampler.warmup(comp, spec.default_init, dict(num_warmup=150, seed=5))
+    tun = sampler._tuning_struct(tuning, d)
+    sampler._apply_mass(comp, tuning)
+    iq = np.ascontiguousarray(spec.to_unconstrained(spec.default_init))
+    opts = sampler._c_opts(sampler._merge_opts(dict(num_warmup=0, num_samples=S, seed=5)))
+    dev = torch.device("cuda:0")
+    out = {}
+    for name, mig, pieces in (("whole_off", "0", [(200, 0)]), ("whole_on", "1", [(200, 0)]), ("pieces_on", "1", [(120, 0), (80, 120)])):
+        monkeypatch.setenv("EXMC_HIP_MIGRATE", mig)
+        draws = torch.zeros((S, d, Cn), dtype=torch.float64, device=dev)
+        nst = torch.zeros((S, Cn), dtype=torch.int32, device=dev)
+        tr = _lib.Trace(draws.data_ptr(), None, None, nst.data_ptr(), None, None, None)
+        lf, dv = C.c_int64(), C.c_int32()
+        comp.check(L.exmc_hip_chains_init(comp.h, C.byref(tun), _dp(iq), Cn, 0, Cn, opts))
+        total = 0
+        for n, off in pieces:
+            comp.check(L.exmc_hip_chains_advance(comp.h, n, off, tr, C.byref(lf), C.byref(dv)))
+            total += lf.value
+        torch.cuda.synchronize()
+        out[name] = (draws.cpu().numpy(), nst.cpu().numpy(), total)
+    for name in ("whole_on", "pieces_on"):
+        assert np.array_equal(out[name][0], out["whole_off"][0]), name
+        assert np.array_equal(out[name][1], out["whole_off"][1]) and out[name][2] == out["whole_off"][2], name
+    assert out["whole_off"][2] == int(out["whole_off"][1].sum())
