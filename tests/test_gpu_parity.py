@@ -601,7 +601,7 @@ def test_chain_migration_bit_exact(hip, monkeypatch, capfd):
     spec = models.sv(TG.GOLD["sv_returns"])
     comp = sampler.compile(spec)
     om = O.model_for(spec)
-    opts = dict(num_warmup=150, num_samples=30, seed=5)
+    opts = dict(num_warmup=150, num_samples=50, seed=5)
     tuning = sampler.warmup(comp, spec.default_init, opts)
     res = {}
     monkeypatch.setenv("EXMC_HIP_MIGRATE_STATS", "1")
@@ -616,7 +616,7 @@ def test_chain_migration_bit_exact(hip, monkeypatch, capfd):
         assert np.array_equal(res["0"][k], res["1"][k]), k
     q0 = spec.to_unconstrained(spec.default_init)
     for c in (0, 7, 1024, 2047):
-        t, _ = O.sample_tuned(om, tuning["epsilon"], tuning["inv_mass"], q0, num_samples=30, seed=5 + 7919 * c,
+        t, _ = O.sample_tuned(om, tuning["epsilon"], tuning["inv_mass"], q0, num_samples=50, seed=5 + 7919 * c,
                               cfg=O.Cfg(1, 64))
         assert np.array_equal(t["draws"], res["1"]["draws"][c]), c
 
