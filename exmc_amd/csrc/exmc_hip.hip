@@ -1170,8 +1170,10 @@ int exmc_hip_model_set_flat_order(exmc_hip_model* m, const int32_t* perm, int d)
 void exmc_hip_model_destroy(exmc_hip_model* m) {
   if (!m) return;
   (void)hipSetDevice(m->device);
+  if (m->stream) (void)hipStreamSynchronize(m->stream);   // a stream run may still be writing its page-locked trace
   m->zig.release(); m->tuning.release(); m->state.release(); m->stack.release();
   m->misc.release(); m->trace.release(); m->io.release(); m->data.release(); m->flat.release(); m->scores.release(); m->dense.release(); m->esswork.release();
+  m->densep.release(); m->densews.release(); m->migboard.release();
   if (m->ev0) (void)hipEventDestroy(m->ev0);
   if (m->ev1) (void)hipEventDestroy(m->ev1);
   if (m->stream) (void)hipStreamDestroy(m->stream);
