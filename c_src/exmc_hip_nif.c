@@ -365,12 +365,15 @@ static void* stream_sender(void* arg) {
   const double* draws = (const double*)j->view.draws;
   const struct timespec nap = {0, 100000};   /* 100 us */
   int sent = 0;
+  long idle_naps = 0;
   while (sent < j->n) {
     const int ready = *j->progress;          /* rows [0, ready) are final */
     if (ready <= sent) {
+      if (++idle_naps > 6000000L) break;     /* ten minutes without a draw: give up, report below */
       nanosleep(&nap, NULL);
       continue;
     }
+    idle_naps = 0;
     for (; sent < ready; sent++) {
       ERL_NIF_TERM st[5] = {enif_make_int(env, ((const int32_t*)j->view.tree_depth)[sent]),
                             enif_make_int(env, ((const int32_t*)j->view.n_steps)[sent]),
@@ -386,9 +389,10 @@ static void* stream_sender(void* arg) {
   }
   int32_t dv = 0;
   const int rc = exmc_hip_stream_finish(j->res->m, &dv);
+  const int ok = rc == EXMC_OK && sent == j->n;
   enif_send(NULL, &j->pid, env,
-            tuple3(env, enif_make_atom(env, rc == EXMC_OK ? "exmc_done" : "exmc_error"), enif_make_int(env, j->n),
-                   enif_make_int(env, rc == EXMC_OK ? dv : rc)));
+            tuple3(env, enif_make_atom(env, ok ? "exmc_done" : "exmc_error"), enif_make_int(env, sent),
+                   enif_make_int(env, ok ? dv : rc)));
   enif_free_env(env);
   enif_release_resource(j->res);
   enif_free(j);
