@@ -189,3 +189,32 @@ def test_builder_data_resolves_obs_data_refs():
     ir = cg.IR().data([[1.0, 2.0], [3.0, 4.0]])
     ir.rv("m", "custom", dict(logpdf=lambda o, x, p: o.mul(o.neg(o.mul(x, x)), p["a"][1][0]), a="__obs_data"))
     assert abs(_lp(cg.generate(ir), [0.5])[0] + 0.75) < 1e-15
+
+
+def test_json_front_door_carries_det_meas_obs_and_data(tmp_path):
+    import json
+    doc = {"rewrite": True, "data": [0.5, 1.5], "nodes": {
+        "m": {"op": "rv", "dist": "normal", "params": {"mu": 0.0, "sigma": 2.0}},
+        "s": {"op": "rv", "dist": "half_cauchy", "params": {"scale": 1.0}},              # default :log
+        "y_rv": {"op": "rv", "dist": "normal", "params": {"mu": "m", "sigma": "s"}},
+        "y": {"op": "obs", "target": "y_rv", "value": [0.1, 0.4, -0.3], "weight": [1.0, 2.0, 0.5]},
+        "x": {"op": "rv", "dist": "normal", "params": {"mu": 1.0, "sigma": 0.5}},
+        "ax": {"op": "det", "fun": "affine", "args": [2.0, -1.0, "x"]},
+        "ax_obs": {"op": "obs", "target": "ax", "value": [0.5, 1.5]},
+        "z": {"op": "rv", "dist": "normal", "params": {"mu": 0.0, "sigma": 1.0}},
+        "z_obs": {"op": "meas_obs", "target": "z", "value": 0.7, "info": ["affine", 1.0, 0.2]}}}
+    src = tmp_path / "m.json"
+    src.write_text(json.dumps(doc))
+    cg.main([str(src), str(tmp_path / "out"), "--no-build"])
+    meta = json.loads((tmp_path / "out" / "model.json").read_text())
+    assert meta["var_names"] == ["m", "s"] and meta["transforms"] == {"s": "log"}
+    gen = cg.generate(cg.ir_from_json(doc), rewrite_passes=True)
+    assert gen.digest == meta["digest"]
+    q = np.array([0.2, -0.1])
+    s_ = math.exp(q[1])
+    w = np.array([1.0, 2.0, 0.5])
+    want = (stats.norm.logpdf(q[0], 0, 2) + stats.halfcauchy.logpdf(s_, scale=1.0) + q[1]
+            + np.sum(stats.norm.logpdf([0.1, 0.4, -0.3], q[0], s_) * w)
+            + np.sum(stats.norm.logpdf((np.array([0.5, 1.5]) + 1.0) / 2.0, 1.0, 0.5) - math.log(2.0))
+            + stats.norm.logpdf(0.5, 0.0, 1.0))
+    assert abs(_lp(gen, q)[0] - want) <= 2e-6 * (1 + abs(want))
