@@ -60,11 +60,30 @@ def make_spec(name):
         init = {n: 0.0 for n in ["mu"] + ["theta_%d" % j for j in range(8)]}
         init["tau"] = 1.0
         return codegen.compile_ir(codegen.eight_schools_ir(), name=name, default_init=init), 488
+    if name in ("gen_sv", "gen_radon", "gen_logistic"):
+        # the BASELINE configs above d = 20 compiled from Builder node lists (the lane layout of
+        # exmc_amd/codegen_lanes.py) instead of their hand-written kinds: same data, same names
+        from exmc_amd import codegen
+        hand, nbytes = make_spec(name[4:])
+        if name == "gen_sv":
+            ir, ncp, lanes = codegen.sv_ir(hand.data), False, 64
+        elif name == "gen_logistic":
+            n = hand.n_obs
+            ir, ncp, lanes = codegen.logistic_ir(hand.data[:n * 20].reshape(n, 20), hand.data[n * 20:]), True, 16
+        else:
+            J = 85
+            start = hand.data[J:2 * J + 1].astype(int)
+            nobs = int(start[-1])
+            cty = [v for v in hand.var_names if v.startswith("alpha_raw")]
+            ir = codegen.radon_ir(hand.data[:J], start, hand.data[2 * J + 1:2 * J + 1 + nobs],
+                                  hand.data[2 * J + 1 + nobs:], names=cty)
+            ncp, lanes = False, 64
+        return codegen.compile_ir(ir, ncp=ncp, name=name, default_init=hand.default_init, lanes=lanes), nbytes
     raise SystemExit("unknown model %s" % name)
 
 
 DEFAULT_CHAINS_PER_GPU = {"eight_schools": 4096, "logistic": 8192, "sv": 2048, "radon": 1024,
-                          "gen_eight_schools": 4096}
+                          "gen_eight_schools": 4096, "gen_sv": 2048, "gen_radon": 1024, "gen_logistic": 8192}
 
 
 def measured_traffic(model, chains, steps, lanes):
@@ -167,7 +186,7 @@ def spawn_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
-def cpu_baseline(spec, init, K, n_chains_total, budget_s=15.0):
+def cpu_baseline(spec, init, K, n_chains_total, budget_s=15.0, max_chains=None):
     """The CPU checker (oracle/, libm mode = the reference's own arithmetic, one chain per host
     thread) on a bounded sample of the same workload. A reported baseline, not the target."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -176,7 +195,8 @@ def cpu_baseline(spec, init, K, n_chains_total, budget_s=15.0):
         # a generated model's CPU form is its own generated text compiled for the host; it only
         # exists in the deterministic-math spelling
         import gen_checker
-        om, cfg = gen_checker.model(spec.gen), O.Cfg(1, 1)
+        gl = spec.gen.lanes if getattr(spec.gen, "lane_layout", None) is not None else 1
+        om, cfg = gen_checker.model(spec.gen, gl), O.Cfg(1, gl)
     else:
         om, cfg = O.model_for(spec), O.Cfg(0, 1)
     q0 = spec.to_unconstrained(init)
@@ -188,6 +208,8 @@ def cpu_baseline(spec, init, K, n_chains_total, budget_s=15.0):
     O.sample_chains(om, 2, init_q=q0, num_warmup=1000, num_samples=K, seed=42, cfg=cfg)
     per_chain = max(time.perf_counter() - t0 - one, 1e-6)
     n = int(max(cores, min(n_chains_total, budget_s * cores / per_chain)))
+    if max_chains:
+        n = min(n, max(cores, max_chains))
     n -= n % cores
     n = max(n, cores)
     t0 = time.perf_counter()
@@ -239,7 +261,9 @@ def main():
                     help="skip the batched-leapfrog roofline leg (development builds without that layout)")
     ap.add_argument("--gather-traces", action="store_true",
                     help="all-gather the full [S][d][C] traces for split R-hat instead of the "
-                         "per-chain half-chain statistics")
+                         "per-chain half-chain statistics (sv does by default: BASELINE.json's config)")
+    ap.add_argument("--no-sv-leg", action="store_true",
+                    help="default run only: skip the sv(d=102) leg that rides on the eight_schools line")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -265,16 +289,34 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    spec, bytes_per_leapfrog = make_spec(args.model)
+    out = run_model(args, args.model, rank, local_rank, world, dev, dist, barrier, primary=True)
+    if args.model == "eight_schools" and not args.no_sv_leg and not args.dense_mass:
+        # BASELINE.json's metric names two models: the line the driver records carries the sv(d=102)
+        # leg too -- 2048 chains per GPU (16384 over 8), the same 1000-draw protocol, the finished
+        # traces all-gathered over RCCL as the config says, its CPU leg on a smaller sample
+        sv = run_model(args, "sv", rank, local_rank, world, dev, dist, barrier, primary=False)
+        if rank == 0:
+            out["models"] = {"sv": sv}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_model(args, model, rank, local_rank, world, dev, dist, barrier, primary):
+    """One model through the protocol; returns the result object on rank 0 (None elsewhere)."""
+    spec, bytes_per_leapfrog = make_spec(model)
+    gather_traces = args.gather_traces or model in ("sv", "gen_sv")
     K, W, d = args.steps, args.warmup, spec.d
     B = args.draws_per_step
     if K < 1 or B < 1 or W < 0:
         raise SystemExit("--steps and --draws-per-step must be >= 1, --warmup >= 0")
     S = K * B                      # draws per chain in the timed region
-    Cper = args.chains_per_gpu or DEFAULT_CHAINS_PER_GPU[args.model]
+    Cper = (args.chains_per_gpu if primary else 0) or DEFAULT_CHAINS_PER_GPU[model]
     Ctot = Cper * world
     comp = sampler.compile(spec, {"device": local_rank})
-    lanes = args.lanes or comp.default_lanes
+    lanes = (args.lanes if primary else 0) or comp.default_lanes
     opts = sampler._merge_opts(dict(num_warmup=args.adapt, num_samples=S, seed=42,
                                     lanes_per_chain=lanes))
     if args.dense_mass:
@@ -287,7 +329,7 @@ def main():
     # broadcast is needed) ---
     # (a 2-iteration throwaway call first, untimed like the W warmup steps of the sampling region:
     # it pays for loading the code object and the first-launch setup, not for adaptation)
-    warm_lanes = args.warmup_lanes or args.lanes or comp.default_warmup_lanes
+    warm_lanes = ((args.warmup_lanes or args.lanes) if primary else 0) or comp.default_warmup_lanes
     sampler.warmup(comp, init, dict(opts, num_warmup=2, warmup_lanes=warm_lanes))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -295,7 +337,7 @@ def main():
     adapt_s = time.perf_counter() - t0
     tun = sampler._tuning_struct(tuning, d)
     if rank == 0:
-        log("adaptation: eps=%.5f, %d iterations in %.3f s" % (tuning["epsilon"], args.adapt, adapt_s))
+        log("%s adaptation: eps=%.5f, %d iterations in %.3f s" % (model, tuning["epsilon"], args.adapt, adapt_s))
 
     # --- resident chains + trace buffers in HBM ---
     draws = torch.empty((S, d, Cper), dtype=torch.float64, device=dev)
@@ -346,23 +388,30 @@ def main():
     ess_s = time.perf_counter() - t0      # the call returns when the kernel has finished
     ess_ms = comp.last_kernel_ms
     ess_sum = ess.sum(dim=1)
-    if not args.gather_traces:
-        # local diagnostics, like the ESS kernel: per-chain half-chain mean / variance
-        hm, hv, hn = xd.half_chain_stats(draws)
+    # the sufficient-statistics route is always timed (it is what R-hat needs); sv also runs the
+    # trace all-gather BASELINE.json's config names, and that is the one its ESS/s wall clock counts
+    hm, hv, hn = xd.half_chain_stats(draws)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     xd.reduce_sum(ess_sum, dist)
-    if args.gather_traces:
+    gather_stats_s = gather_traces_s = None
+    if gather_traces:
         all_draws = xd.gather_traces(draws, dist)
         torch.cuda.synchronize()
-        gather_s = time.perf_counter() - t0
+        gather_s = gather_traces_s = time.perf_counter() - t0
         rhat = xd.split_rhat(all_draws)
+        del all_draws
+        t1 = time.perf_counter()
+        ghm, ghv = xd.gather_chain_stats(hm, dist), xd.gather_chain_stats(hv, dist)
+        torch.cuda.synchronize()
+        gather_stats_s = time.perf_counter() - t1
+        rhat_stats = xd.split_rhat_from_stats(ghm, ghv, hn)
     else:
         # the exchange: per-chain sufficient statistics of the finished traces give
         # the same split R-hat with ~1 MB per rank on the wire instead of the [S][d][C] draws
         hm, hv = xd.gather_chain_stats(hm, dist), xd.gather_chain_stats(hv, dist)
         torch.cuda.synchronize()
-        gather_s = time.perf_counter() - t0
+        gather_s = gather_stats_s = time.perf_counter() - t0
         rhat = xd.split_rhat_from_stats(hm, hv, hn)
         if world == 1:
             # one GPU holds every chain: Diagnostics.rhat in the reference's summation order on
@@ -393,7 +442,7 @@ def main():
             "config": {"workload": "%s d=%d, %d chains/GPU (%d total), %d draws/chain (%d steps of %d "
                                    "draws) after one shared %d-iteration warmup, max_tree_depth 10, "
                                    "target_accept 0.8%s"
-                                   % (args.model, d, Cper, Ctot, S, K, B, args.adapt,
+                                   % (model, d, Cper, Ctot, S, K, B, args.adapt,
                                       ", dense mass matrix" if args.dense_mass else ""),
                        "draws_per_step": B, "draws_per_chain": S,
                        "lanes_per_chain": lanes, "warmup_lanes_per_chain": warm_lanes, "seed": 42},
@@ -401,6 +450,9 @@ def main():
             "ess_min_total": ess_min,
             "ess_wall_s": {"adaptation": adapt_s, "sampling": elapsed, "ess_kernel": ess_s,
                            "gather": gather_s},
+            "gather": {"counted": "traces" if gather_traces else "chain_stats",
+                       "traces_s": gather_traces_s, "chain_stats_s": gather_stats_s,
+                       "bytes_per_rank": int(draws.numel() * 8) if gather_traces else int(2 * hm.numel() * 8 / world)},
             "rhat_max": float(rhat.max()),
             "divergent_transitions": divs,
             "mean_leapfrogs_per_draw": leapfrogs / (S * Ctot),
@@ -408,26 +460,30 @@ def main():
             "ess_kernel_ms": ess_ms,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(args.model, Cper, S, lanes),
+                         "traffic": measured_traffic(model, Cper, S, lanes),
                          "kernel": "nuts_kernel", "launches": 1, "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_leapfrog": bytes_per_leapfrog,
                          "leapfrogs_per_launch": local_lf},
         }
-        ri = issue_roofline(args.model, Cper, S, lanes, kernel_ms, local_lf) if world == 1 else None
+        if gather_traces:
+            out["rhat_max_from_chain_stats"] = float(rhat_stats.max())
+        ri = issue_roofline(model, Cper, S, lanes, kernel_ms, local_lf) if world == 1 else None
         if ri:
             out["roofline_issue"] = ri
-        if world == 1 and args.model == "eight_schools" and not args.no_multi_step:
+        if world == 1 and model == "eight_schools" and not args.no_multi_step:
             # the B2 batched-leapfrog contract at a batch that fills the chip (not the timed path)
             out["roofline_multi_step"] = multi_step_roofline(comp, spec, dev)
         if world == 1 and not args.no_cpu:
-            cb = cpu_baseline(spec, init, S, Ctot)
+            # the second model's CPU leg is bounded tighter (sv: about one second per chain per core)
+            cb = cpu_baseline(spec, init, S, Ctot, budget_s=15.0 if primary else 8.0,
+                              max_chains=None if primary else 256)
             out["cpu_baseline"] = cb
             out["gpu_over_cpu"] = {"leapfrog_steps_per_s": value / cb["value"],
                                    "ess_per_s": out["ess_per_s"] / cb["ess_per_s"]}
-        print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        comp.close()
+        return out
+    comp.close()
+    return None
 
 
 if __name__ == "__main__":

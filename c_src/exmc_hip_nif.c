@@ -24,11 +24,21 @@
 static ErlNifResourceType* MODEL_RT;
 static int g_device = 0;
 
-typedef struct { exmc_hip_model* m; } model_res;
+/* tid / has_tid: the sender thread of the last stream_run (ERTS threads are joinable: it is joined
+ * by the next stream_run and by the destructor) */
+typedef struct { exmc_hip_model* m; ErlNifTid tid; int has_tid; } model_res;
+
+static void join_sender(model_res* r) {
+  /* the destructor runs on whichever thread drops the last reference -- possibly the sender
+   * itself, which cannot join itself and ends right after */
+  if (r->has_tid && !enif_equal_tids(enif_thread_self(), r->tid)) (void)enif_thread_join(r->tid, NULL);
+  r->has_tid = 0;
+}
 
 static void model_dtor(ErlNifEnv* env, void* obj) {
   (void)env;
   model_res* r = (model_res*)obj;
+  join_sender(r);
   if (r->m) exmc_hip_model_destroy(r->m);
   r->m = NULL;
 }
@@ -63,6 +73,7 @@ static ERL_NIF_TERM model_create(ErlNifEnv* env, int argc, const ERL_NIF_TERM ar
                   enif_make_string(env, exmc_hip_last_error(), ERL_NIF_LATIN1));
   model_res* r = (model_res*)enif_alloc_resource(MODEL_RT, sizeof(model_res));
   r->m = m;
+  r->has_tid = 0;
   ERL_NIF_TERM ref = enif_make_resource(env, r);
   enif_release_resource(r);
   return tuple2(env, enif_make_atom(env, "ok"), ref);
@@ -349,8 +360,9 @@ static ERL_NIF_TERM stream_next(ErlNifEnv* env, int argc, const ERL_NIF_TERM arg
  * of this library polls the count and sends
  *   {:exmc_sample, i, q :: f64 binary, {tree_depth, n_steps, divergent, accept_prob, energy}}
  * for i = 1..n as the draws appear, then {:exmc_done, n, divergences}. The handle is busy until
- * that last message (it is kept alive by the thread; the Elixir side constrains q and builds the
- * point map as it does for stream_next's rows). */
+ * that last message: the library refuses every other call on it with {:exmc_hip_error, _, "a stream
+ * run is in flight ..."} (the handle is kept alive by the thread; the Elixir side constrains q and
+ * builds the point map as it does for stream_next's rows). */
 typedef struct {
   model_res* res;
   ErlNifPid pid;
@@ -414,20 +426,21 @@ static ERL_NIF_TERM stream_run(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv
   j->n = n;
   j->d = exmc_hip_model_dim(j->res->m);
   int rc = exmc_hip_stream_start(j->res->m, n, &j->view, &j->progress);
-  if (rc != EXMC_OK) {
+  if (rc != EXMC_OK) {          /* includes: the previous run's sender has not finished yet */
     enif_free(j);
     return raise_hip(env, rc);
   }
+  join_sender(j->res);          /* the previous sender has called stream_finish: it is ending */
   enif_keep_resource(j->res);   /* the thread's reference */
-  ErlNifTid tid;
-  if (enif_thread_create((char*)"exmc_hip_stream", &tid, stream_sender, j, NULL) != 0) {
+  if (enif_thread_create((char*)"exmc_hip_stream", &j->res->tid, stream_sender, j, NULL) != 0) {
     int32_t dv;
     (void)exmc_hip_stream_finish(j->res->m, &dv);
     enif_release_resource(j->res);
     enif_free(j);
     return enif_raise_exception(env, enif_make_atom(env, "thread_create_failed"));
   }
-  return enif_make_atom(env, "ok");   /* detached in effect: the thread frees its job and ends after :exmc_done */
+  j->res->has_tid = 1;
+  return enif_make_atom(env, "ok");   /* the thread frees its job and ends after :exmc_done; it is joined later */
 }
 
 static ErlNifFunc nif_funcs[] = {

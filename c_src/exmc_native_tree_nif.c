@@ -337,18 +337,20 @@ static ERL_NIF_TERM get_result(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv
   return result_map(env, argv, 1);
 }
 
+/* every function reads the trajectory resource from the device (blocking copies): all are dirty
+ * IO-bound jobs, including the accessors that were plain memory reads in the Rust crate */
 static ErlNifFunc nif_funcs[] = {
     {"init_trajectory_bin", 4, init_trajectory_bin, ERL_NIF_DIRTY_JOB_IO_BOUND},
-    {"is_terminated", 1, is_terminated, 0},
-    {"get_endpoint_bin", 2, get_endpoint_bin, 0},
+    {"is_terminated", 1, is_terminated, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"get_endpoint_bin", 2, get_endpoint_bin, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"build_and_merge_bin", 11, build_and_merge_bin, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"build_subtree_bin", 10, build_subtree_bin, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"build_full_tree_bin", 17, build_full_tree_bin, ERL_NIF_DIRTY_JOB_IO_BOUND},
-    {"get_result_bin", 1, get_result_bin, 0},
+    {"get_result_bin", 1, get_result_bin, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"init_trajectory", 4, init_trajectory, ERL_NIF_DIRTY_JOB_IO_BOUND},
-    {"get_endpoint", 2, get_endpoint, 0},
+    {"get_endpoint", 2, get_endpoint, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"build_and_merge", 11, build_and_merge, ERL_NIF_DIRTY_JOB_IO_BOUND},
-    {"get_result", 1, get_result, 0},
+    {"get_result", 1, get_result, ERL_NIF_DIRTY_JOB_IO_BOUND},
 };
 
 static int on_load(ErlNifEnv* env, void** priv, ERL_NIF_TERM info) {

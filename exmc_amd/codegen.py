@@ -55,11 +55,22 @@ from .models import ModelSpec
 
 CUSTOM = 6
 MAX_D = 20   # one lane per chain: 5*D+3 doubles per tree node, one level must fit LDS
+MAX_D_LANES = 256   # EXMC_HIP_MAX_D (include/exmc_hip.h): the lane layout, DPL = ceil(D / lanes)
 MAX_NODES_SORTED = 32
 
 
 class CodegenError(ValueError):
     pass
+
+
+class F32(float):
+    """A param written Nx.tensor(<float>) without a type: an f32 tensor. Its value is the f32
+    rounding, and an operation whose operands are all such constants yields an f32 tensor again
+    (Nx's type inference; the BinaryBackend computes in Erlang floats and stores f32), e.g.
+    Nx.log(lambda) of exponential.ex:16 for lambda = Nx.tensor(50.0)."""
+
+    def __new__(cls, x):
+        return super().__new__(cls, float(np.float32(x)))
 
 
 def _f32(x):
@@ -211,28 +222,132 @@ def eight_schools_ir(y=None, sigma=None):
     return ir
 
 
+def sv_ir(returns):
+    """Stochastic volatility as STANDARD_BENCHMARKS.md:51-61 describes it ("100 separate Normal
+    random variables connected by string references"): sigma ~ Exponential(50), nu ~
+    Exponential(0.1) (both Nx.tensor(<float>) = f32, both :log), s_1 ~ N(0, sigma), s_t ~ N(s_{t-1},
+    sigma), r_t ~ StudentT(nu, 0, exp(s_t)) observed. The benchmark's script is not in the
+    reference repository; the likelihood is written here the way its sibling scripts write theirs
+    (a Custom closure over refs, validate_posteriordb.exs:279-295): the sum of student_t.ex's
+    logpdf over the returns. Compile with ncp=False (the hand-written kind is centred too)."""
+    r = [float(v) for v in returns]
+    T = len(r)
+    ir = IR()
+    ir.rv("sigma", "exponential", {"lambda": F32(50.0)}, transform="log")
+    ir.rv("nu", "exponential", {"lambda": F32(0.1)}, transform="log")
+    ir.rv("s_1", "normal", dict(mu=0.0, sigma="sigma"))
+    for t in range(2, T + 1):
+        ir.rv("s_%d" % t, "normal", dict(mu="s_%d" % (t - 1), sigma="sigma"))
+
+    def lik(o, _x, p):
+        return o.sum([o.logpdf("student_t", o.data(r[t - 1]),
+                               dict(df=p["nu"], loc=o.lit(0.0), scale=o.exp(p["s_%d" % t])))
+                      for t in range(1, T + 1)])
+    params = {"s_%d" % t: "s_%d" % t for t in range(1, T + 1)}
+    params.update(nu="nu", logpdf=lik)
+    ir.rv("returns", "custom", params)
+    ir.obs("returns_obs", "returns", 0.0)
+    return ir
+
+
+def logistic_ir(X, y):
+    """Logistic regression (STANDARD_BENCHMARKS.md:41-49, :187 "20-way Nx.stack + 500 x 20 matvec"):
+    alpha, beta_j ~ N(0, 10); y_n ~ Bernoulli(sigmoid(alpha + X beta)) as a Custom closure over the
+    21 refs -- Nx.sigmoid, bernoulli.ex's clipped logpdf, Nx.sum over the observations."""
+    X = np.asarray(X, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    n, k = X.shape
+    ir = IR()
+    ir.rv("alpha", "normal", dict(mu=0.0, sigma=10.0))
+    for j in range(1, k + 1):
+        ir.rv("beta_%d" % j, "normal", dict(mu=0.0, sigma=10.0))
+
+    def lik(o, _x, p):
+        beta = [p["beta_%d" % j] for j in range(1, k + 1)]
+        terms = []
+        for i in range(n):
+            eta = p["alpha"]
+            for j in range(k):
+                eta = o.add(eta, o.mul(o.data(X[i, j]), beta[j]))
+            terms.append(o.logpdf("bernoulli", o.data(y[i]), dict(p=o.sigmoid(eta))))
+        return o.sum(terms)
+    params = {"beta_%d" % j: "beta_%d" % j for j in range(1, k + 1)}
+    params.update(alpha="alpha", logpdf=lik)
+    ir.rv("y", "custom", params)
+    ir.obs("y_obs", "y", 0.0)
+    return ir
+
+
+def radon_ir(u, start, floor, y, names=None):
+    """The radon varying-intercept model of notebooks/09_radon_bhm.livemd ("The Radon Model"; its
+    benchmark/radon_model.exs is not in the reference repository): five hyper-parameters, 85
+    alpha_raw_j ~ N(0, 1), alpha_j = mu_alpha + gamma_u u_j + sigma_alpha alpha_raw_j "reconstructed
+    inside a Custom dist closure", y_ij ~ N(alpha_j + beta floor_ij, sigma_y). `start` are the
+    county offsets into floor / y; names[j] = id of county j's intercept."""
+    u = np.asarray(u, dtype=np.float64)
+    start = np.asarray(start).astype(int)
+    J = len(u)
+    names = ["alpha_raw_%d" % j for j in range(J)] if names is None else list(names)
+    ir = IR()
+    ir.rv("mu_alpha", "normal", dict(mu=0.0, sigma=10.0))
+    ir.rv("gamma_u", "normal", dict(mu=0.0, sigma=5.0))
+    ir.rv("sigma_alpha", "half_cauchy", dict(scale=2.5), transform="log")
+    ir.rv("sigma_y", "half_cauchy", dict(scale=2.5), transform="log")
+    ir.rv("beta", "normal", dict(mu=0.0, sigma=5.0))
+    for nm in names:
+        ir.rv(nm, "normal", dict(mu=0.0, sigma=1.0))
+
+    def lik(o, _x, p):
+        terms = []
+        for j in range(J):
+            alpha = o.add(o.add(p["mu_alpha"], o.mul(p["gamma_u"], o.data(u[j]))),
+                          o.mul(p["sigma_alpha"], p[names[j]]))
+            for i in range(start[j], start[j + 1]):
+                mean = o.add(alpha, o.mul(p["beta"], o.data(floor[i])))
+                terms.append(o.logpdf("normal", o.data(y[i]), dict(mu=mean, sigma=p["sigma_y"])))
+        return o.sum(terms)
+    params = {nm: nm for nm in names}
+    params.update(mu_alpha="mu_alpha", gamma_u="gamma_u", sigma_alpha="sigma_alpha", sigma_y="sigma_y",
+                  beta="beta", logpdf=lik)
+    ir.rv("radon", "custom", params)
+    ir.obs("radon_obs", "radon", 0.0)
+    return ir
+
+
 # ---------------------------------------------------------------------------------------------
 # expression graph (hash-consed; a vector is a python list of scalar nodes)
 # ---------------------------------------------------------------------------------------------
 class _Graph:
+    # leaves and whether they depend on the data only; `red j` is reduced sum j of the lane layout
+    # (codegen_lanes.py): a run-time value the differentiation does not look into
+    LEAF_CONST = {"lit": True, "data": True, "q": False, "red": False}
+
     def __init__(self):
         self.ops = []      # (op, args) with args = tuple of node indices / payload
         self.const = []    # depends on data only
         self.key = {}
         self.data = []     # raw model data, in first-use order
+        self.sums = {}     # result of a left-to-right sum -> its summands (_sum_left)
+        self.f32 = set()   # data nodes that are f32 tensors (class F32)
+
+    _F32_FOLD = {"add": lambda a, b: a + b, "sub": lambda a, b: a - b, "mul": lambda a, b: a * b,
+                 "div": lambda a, b: a / b, "neg": lambda a: -a, "log": math.log, "exp": math.exp}
+
+    def datum32(self, x):
+        i = self.datum(float(np.float32(x)))
+        self.f32.add(i)
+        return i
 
     def _node(self, op, *args):
+        if self.f32 and op in self._F32_FOLD and all(a in self.f32 for a in args):
+            vals = [self.data[self.ops[a][1]] for a in args]
+            return self.datum32(self._F32_FOLD[op](*vals))
         k = (op,) + args
         i = self.key.get(k)
         if i is None:
             i = len(self.ops)
             self.ops.append(k)
-            if op == "lit" or op == "data":
-                c = True
-            elif op == "q":
-                c = False
-            else:
-                c = all(self.const[a] for a in args)
+            c = self.LEAF_CONST[op] if op in self.LEAF_CONST else all(self.const[a] for a in args)
             self.const.append(c)
             self.key[k] = i
         return i
@@ -341,7 +456,7 @@ class _Grad:
             elif op == "sel_gt":
                 self._acc(a[2], g.sel_gt(a[0], a[1], gy, zero))
                 self._acc(a[3], g.sel_gt(a[0], a[1], zero, gy))
-            elif op in ("q", "qown"):
+            elif op in ("q", "qown", "ext", "gat", "red"):
                 pass
             else:
                 raise CodegenError("no gradient rule for %s" % op)
@@ -600,6 +715,8 @@ def _sum_left(g, xs):
     acc = xs[0]                                   # Nx.sum on the BinaryBackend: left to right
     for e in xs[1:]:
         acc = g.add(acc, e)
+    if len(xs) > 1:
+        g.sums[acc] = list(xs)                    # the lane layout spreads the summands over lanes
     return acc
 
 
@@ -658,6 +775,10 @@ class Ops:
 
     def lit(self, x): return self._g.lit(float(x))
     def f32(self, x): return self._g.lit(_f32(x))          # Nx.tensor(<float>) defaults to f32
+    def data(self, x): return self._g.datum(float(x))      # a datum captured by the closure
+    def sigmoid(self, a):                                  # Nx.sigmoid: 1 / (1 + exp(-x))
+        g = self._g
+        return g.div(g.lit(1.0), g.add(g.lit(1.0), g.exp(g.neg(a))))
     def add(self, a, b): return self._g.add(a, b)
     def sub(self, a, b): return self._g.sub(a, b)
     def mul(self, a, b): return self._g.mul(a, b)
@@ -670,6 +791,15 @@ class Ops:
     def max(self, a, b): return self._g.max(a, b)
     def min(self, a, b): return self._g.min(a, b)
     def sum(self, xs): return _sum_left(self._g, list(xs))   # Nx.sum: left to right
+
+    def logpdf(self, dist, x, params):
+        """Exmc.Dist.<dist>.logpdf(x, params) called from inside a closure (the reference's closures
+        call the distribution modules the same way, e.g. benchmark/reliability_model.exs)."""
+        return _logpdf(self._g, dist, x, dict(params))
+
+    def dot(self, xs, ys):
+        """Nx.dot of two vectors on the BinaryBackend: products summed left to right."""
+        return _sum_left(self._g, [self._g.mul(a, b) for a, b in zip(xs, ys)])
 
 
 # ---------------------------------------------------------------------------------------------
@@ -745,16 +875,20 @@ def _apply_ncp(ir, ncp):
     return nodes, info
 
 
-def generate(ir, ncp=True, vectorize=True, rewrite_passes=False):
+def generate(ir, ncp=True, vectorize=True, rewrite_passes=False, lanes=None):
     """Compiler.compile_for_sampling (compiler.ex:46-58) as source text. `rewrite_passes` runs the
     reference's IR passes first (`rewrite`); without it the IR is taken as already rewritten
-    (transforms explicit), which is what an exporter on the Elixir side sends."""
+    (transforms explicit), which is what an exporter on the Elixir side sends. `lanes` = 16 / 32 /
+    64 asks for the lane layout of codegen_lanes.py (a chain over that many lanes, several
+    dimensions per lane); models above MAX_D free dimensions get it by themselves.
+
+    Term order: Map.values of the node map (compiler.ex:176-180) = ids sorted as strings for up to
+    MAX_NODES_SORTED nodes. A larger Erlang map iterates in the order of its internal hash, which
+    is not restated: terms are taken in sorted-id order there too, a reordering of the final sum
+    (a few ulp of the log-density; the gradient's entries are sums over the same terms)."""
     if rewrite_passes:
         ir = rewrite(ir)
     nodes, ncp_info = _apply_ncp(ir, ncp)
-    if len(nodes) > MAX_NODES_SORTED:
-        raise CodegenError("more than %d nodes: the reference's term order is the hash order of "
-                           "an Erlang map, which is not restated" % MAX_NODES_SORTED)
     for id_, n in nodes.items():
         if n["op"] == "obs" and n["target"] not in nodes:
             raise CodegenError("obs %r targets unknown node %r" % (id_, n["target"]))
@@ -775,10 +909,15 @@ def generate(ir, ncp=True, vectorize=True, rewrite_passes=False):
             flat_names.extend("%s[%d]" % (id_, i) for i in range(ln))
         else:
             flat_names.append(id_)
-    if len(flat_names) > MAX_D:
-        raise CodegenError("%d free dimensions; the one-lane-per-chain kernels take at most %d"
-                           % (len(flat_names), MAX_D))
+    if len(flat_names) > MAX_D_LANES:
+        raise CodegenError("%d free dimensions; the kernels take at most %d" % (len(flat_names), MAX_D_LANES))
+    if lanes is None and len(flat_names) > MAX_D:
+        lanes = 64 if len(flat_names) > 32 else 16
+    if lanes is not None and lanes not in (16, 32, 64):
+        raise CodegenError("lanes must be 16, 32 or 64")
+    one_lane = len(flat_names) <= MAX_D
     g = _Graph()
+    custom_roots = set()      # terms that are the result of a Custom closure (a hand-written reduction)
 
     def resolve_ref(id_, stack=()):
         # compiler.ex:447-463
@@ -806,6 +945,8 @@ def generate(ir, ncp=True, vectorize=True, rewrite_passes=False):
             return g.datum(float(t)) if t.ndim == 0 else [g.datum(float(x)) for x in t]
         if isinstance(v, str):
             return resolve_ref(v, stack)
+        if isinstance(v, F32):
+            return g.datum32(v)
         a = np.asarray(v, dtype=np.float64)
         if a.ndim == 0:
             return g.datum(float(a))
@@ -846,6 +987,7 @@ def generate(ir, ncp=True, vectorize=True, rewrite_passes=False):
         t = fn(ops, x, rest)
         if isinstance(t, list):
             raise CodegenError("a custom logpdf must return a scalar (reduce inside the closure)")
+        custom_roots.add(t)
         return t
 
     def const_x(tr, v, id_):
@@ -1025,11 +1167,6 @@ def generate(ir, ncp=True, vectorize=True, rewrite_passes=False):
     if g.const[total]:
         raise CodegenError("the log-density does not depend on the free variables")
 
-    n_fwd = len(g.ops)
-    ad = _Grad(g, total)
-    ad.run(n_fwd)
-    grads = [ad.adj.get(g.key.get(("q", k))) for k in range(len(flat_names))]
-
     out = Generated()
     out.d = len(flat_names)
     out.var_names = flat_names
@@ -1038,8 +1175,18 @@ def generate(ir, ncp=True, vectorize=True, rewrite_passes=False):
     out.simplex_entries = {i: vector_entries[i] for i in vector_entries if nodes[i]["dist"] == "dirichlet"}
     out.transforms = {i: nodes[i]["transform"] for i in free if nodes[i]["transform"]}
     out.ncp_info = ncp_info
-    out.data = np.asarray(g.data, dtype=np.float64)
-    out.header = _emit(g, total, grads, out.d)
+    out.lanes = 1
+    out.vec = out.lane_layout = None
+    if one_lane:
+        n_fwd = len(g.ops)
+        ad = _Grad(g, total)
+        ad.run(n_fwd)
+        grads = [ad.adj.get(g.key.get(("q", k))) for k in range(len(flat_names))]
+        out.data = np.asarray(g.data, dtype=np.float64)
+        out.header = _emit(g, total, grads, out.d)
+    else:
+        out.data = np.zeros(0)
+        out.header = _emit_no_one_lane(out.d)
     # the 16-lane layout, when the model has plates to spread over lanes (codegen_vec.py): the
     # plug-in then carries Custom<16> next to Custom<1> and defaults to it
     from . import codegen_vec
@@ -1052,12 +1199,20 @@ def generate(ir, ncp=True, vectorize=True, rewrite_passes=False):
                     and m.get("mask") is None and nodes[n["target"]].get("transform") is None)
         return False
     plain = all(_plain_node(n) for n in nodes.values())
-    out.vec = codegen_vec.generate(ir, ncp=ncp) if (vectorize and plain) else None
-    out.lanes = 1
+    if lanes is None and len(nodes) <= MAX_NODES_SORTED:
+        out.vec = codegen_vec.generate(ir, ncp=ncp) if (vectorize and plain) else None
     if out.vec is not None:
         out.header += "\n" + out.vec["text"]
         out.data = np.concatenate([out.data, out.vec["vdata"]])
         out.lanes = codegen_vec.G
+    if lanes is not None:
+        # several dimensions per lane (codegen_lanes.py): any d, the repeated terms over the lanes
+        from . import codegen_lanes
+        out.lane_layout = codegen_lanes.generate(g, terms, custom_roots, out.d, lanes)
+        out.header += "\n#define EXMC_GEN_LOFF %d   /* where the lane layout's table starts in data */\n" \
+                      % out.data.size + out.lane_layout["text"]
+        out.data = np.concatenate([out.data, out.lane_layout["data"]])
+        out.lanes = lanes
     out.digest = hashlib.sha256(out.header.encode()).hexdigest()[:16]
     out.n_ops = out.header.count("\n")
     return out
@@ -1075,6 +1230,16 @@ _FN2 = {"max": "fmax", "min": "fmin"}
 def _lds_levels(d):
     per_level = (5 * d + 3) * 64 * 8
     return max(1, min(6, (56 * 1024) // per_level))
+
+
+def _emit_no_one_lane(d):
+    """Header of a model that exists in the lane layout only (d > MAX_D)."""
+    L = ["/* generated by exmc_amd/codegen.py -- do not edit. Included twice over: by",
+         " * exmc_amd/csrc/exmc_models.hpp (device functor, -DEXMC_CUSTOM_HEADER) and by the host",
+         " * checker tests build from the same text. */",
+         "#define EXMC_GEN_D %d" % d, "#define EXMC_GEN_NDATA 0", "#define EXMC_GEN_NCONST 1",
+         "#define EXMC_GEN_LDS_LEVELS 1", ""]
+    return "\n".join(L) + "\n"
 
 
 def _emit(g, total, grads, d):
@@ -1150,6 +1315,7 @@ def _emit(g, total, grads, d):
     L.append(" * exmc_amd/csrc/exmc_models.hpp (device functor Custom<1>, -DEXMC_CUSTOM_HEADER) and by")
     L.append(" * the host checker tests build from the same text. */")
     L.append("#define EXMC_GEN_D %d" % d)
+    L.append("#define EXMC_GEN_ONE_LANE 1")
     L.append("#define EXMC_GEN_NDATA %d" % len(g.data))
     L.append("#define EXMC_GEN_NCONST %d" % max(1, len(slot)))
     L.append("#define EXMC_GEN_LDS_LEVELS %d" % _lds_levels(d))
@@ -1201,17 +1367,24 @@ def build_plugin(gen, force=False, verbose=False):
     d, hdr, so = plugin_paths(gen)
     os.makedirs(d, exist_ok=True)
     if not os.path.exists(hdr) or open(hdr).read() != gen.header:
-        with open(hdr, "w") as f:
+        with open("%s.%d.tmp" % (hdr, os.getpid()), "w") as f:
             f.write(gen.header)
+        os.replace(f.name, hdr)
     if not force and os.path.exists(so):
         t = os.path.getmtime(so)
         if all(os.path.getmtime(p) <= t for p in _build.DEPS + [hdr]):
             return so
+    tmp = "%s.%d.tmp" % (so, os.getpid())       # two processes may build the same model: publish atomically
     cmd = [_build.hipcc()] + _build.FLAGS + _extra_flags() + ["-DEXMC_ONLY_CUSTOM", '-DEXMC_CUSTOM_HEADER="%s"' % hdr,
-                                              "-o", so, _build.SRC]
+                                              "-o", tmp, _build.SRC]
     if verbose:
         print(" ".join(cmd))
-    subprocess.check_call(cmd, cwd=os.path.dirname(_build.SRC))
+    try:
+        subprocess.check_call(cmd, cwd=os.path.dirname(_build.SRC))
+        os.replace(tmp, so)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return so
 
 
@@ -1320,9 +1493,11 @@ class GeneratedSpec(ModelSpec):
         return x
 
 
-def compile_ir(ir, ncp=True, name="generated", default_init=None, verbose=False, rewrite_passes=False):
-    """IR -> GeneratedSpec with its plug-in library built. Needs hipcc (no fallback)."""
-    gen = generate(ir, ncp=ncp, rewrite_passes=rewrite_passes)
+def compile_ir(ir, ncp=True, name="generated", default_init=None, verbose=False, rewrite_passes=False,
+               lanes=None):
+    """IR -> GeneratedSpec with its plug-in library built. Needs hipcc (no fallback). `lanes`:
+    see `generate`."""
+    gen = generate(ir, ncp=ncp, rewrite_passes=rewrite_passes, lanes=lanes)
     so = build_plugin(gen, verbose=verbose)
     return GeneratedSpec(gen, so, name=name, default_init=default_init)
 

@@ -1,0 +1,550 @@
+"""Several dimensions per lane: the lane layout for generated models of any size (d > 16).
+
+The one-lane layout of codegen.py holds the whole position in one lane's registers (d <= 20) and the
+plate layout of codegen_vec.py gives every dimension a lane of a 16-lane row (d <= 16). The three
+larger BASELINE models are hand-written lane layouts (exmc_models.hpp: SV<64>, Radon<64>,
+Logistic<16>): a chain over G lanes, dimension i in slot i / G of lane i % G, the model's repeated
+terms spread over the lanes. This module derives that layout from the expression graph of ANY
+Builder IR (compiler.ex:176-269 walks the same nodes), so that stochastic volatility (a 100-step
+random walk with StudentT observations), the radon model (85 county intercepts, 919 observations)
+and the 500 x 20 logistic regression compile from node lists like every smaller model.
+
+  * The log-density is a sum of terms (compiler.ex:394-395). Terms that are themselves sums -- a
+    vector observation's elements, the steps of a GaussianRandomWalk, the reduction inside a Custom
+    closure -- are split into their summands: the *units*.
+  * Units whose expression DAGs are identical up to their leaves form a *family*. Inside a family a
+    node that is the SAME graph node in every unit (the graph is hash-consed, so a shared
+    hyper-parameter and everything computed from shared hyper-parameters alone is one node) is
+    *uniform*: it is evaluated once per leapfrog, outside the family's loop, by every lane alike.
+    The remaining nodes are the family's template; its leaves are uniform values, per-unit
+    constants (columns of a table folded from the data when the model is generated) and free
+    variables that differ from unit to unit (*gathered*: read through a per-unit index).
+  * Unit u of a family runs on lane u % G in slot u / G of a counted loop. The position is
+    published in an LDS strip of d doubles per chain, so a gathered leaf is one LDS read at a
+    per-unit address and a shared variable a broadcast read.
+  * Reverse mode per family (codegen._Grad on the template): the adjoints of the uniform inputs are
+    summed per lane over its slots and cross the chain group in ONE butterfly together with the
+    lane's partial log-density; the adjoints of gathered leaves go to a per-family LDS strip, one
+    cell per unit, and the lane that owns a dimension adds the cells that belong to it in a fixed
+    order (family, leaf position, unit) read from an index table padded to the widest lane.
+  * The uniform part (hyper-priors, everything derived from shared variables, terms that occur
+    once) is differentiated as in the one-lane layout, seeded with the reduced adjoints.
+
+Numeric contract: the lane contract of DESIGN.md section 2 -- per lane left to right over its slots,
+then the xor butterfly over the group -- so the sum of a family's terms is NOT the reference's
+left-to-right Nx.sum (nor, for models above 32 nodes, the hash order of an Erlang map, which is not
+restated: terms are taken in sorted-id order); the difference is rounding of a sum (a few ulp of
+the log-density). The host checker (tests/gen_checker.py) runs the same text over G virtual lanes
+in that order and the GPU equals it bit for bit; against the hand-written models of the oracle the
+generated log-density and gradient agree to 1e-12 relative.
+"""
+import math
+
+import numpy as np
+
+from . import codegen as cg
+
+MIN_FAMILY = 4          # fewer units than this are evaluated by every lane (the uniform part)
+
+
+class _LGraph(cg._Graph):
+    """_Graph with the template's leaves: `ext j` (uniform dynamic input j), `uc k` (uniform
+    constant k), `col c` (column c of the family's table), `gat p` (gathered variable p) and,
+    in the uniform graph, `red j` (reduced sum j after the butterfly)."""
+
+    LEAF_CONST = {"lit": True, "data": True, "q": False, "ext": False, "uc": True, "col": True,
+                  "gat": False, "red": False}
+
+    def _node(self, op, *args):
+        k = (op,) + args
+        i = self.key.get(k)
+        if i is None:
+            i = len(self.ops)
+            self.ops.append(k)
+            c = self.LEAF_CONST[op] if op in self.LEAF_CONST else all(self.const[a] for a in args)
+            self.const.append(c)
+            self.key[k] = i
+        return i
+
+
+_LEAVES = ("lit", "data", "q", "ext", "uc", "col", "gat", "red")
+
+
+def _np_eval(g, nodes, leaf):
+    """Values of the const nodes `nodes` (and what they need) with numpy float64 semantics;
+    leaf(op) gives the value of a leaf (a scalar or an array over units). exp / log of a constant
+    of the data come from numpy here (a rounding-level difference in a constant, like the
+    Cholesky of codegen's MvNormal)."""
+    memo = {}
+    order, seen, stack = [], set(), list(nodes)
+    while stack:
+        n = stack.pop()
+        if n in seen:
+            continue
+        op = g.ops[n]
+        if op[0] in _LEAVES:
+            seen.add(n)
+            memo[n] = np.float64(float.fromhex(op[1])) if op[0] == "lit" else leaf(op)
+            continue
+        pend = [a for a in op[1:] if a not in seen]
+        if pend:
+            stack.append(n)
+            stack.extend(pend)
+        else:
+            seen.add(n)
+            order.append(n)
+    f64 = lambda x: np.asarray(x, dtype=np.float64)   # noqa: E731
+    with np.errstate(all="ignore"):
+        for n in order:
+            op = g.ops[n]
+            a = [f64(memo[x]) for x in op[1:]]
+            k = op[0]
+            if k == "add": v = a[0] + a[1]
+            elif k == "sub": v = a[0] - a[1]
+            elif k == "mul": v = a[0] * a[1]
+            elif k == "div": v = a[0] / a[1]
+            elif k == "neg": v = -a[0]
+            elif k == "exp": v = np.exp(a[0])
+            elif k == "log": v = np.log(a[0])
+            elif k == "log1p": v = np.log1p(a[0])
+            elif k == "erf":
+                from scipy.special import erf
+                v = erf(a[0])
+            elif k == "abs": v = np.abs(a[0])
+            elif k == "max": v = np.fmax(a[0], a[1])
+            elif k == "min": v = np.fmin(a[0], a[1])
+            elif k == "sel_gt": v = np.where(a[0] > a[1], a[2], a[3])
+            else:
+                raise cg.CodegenError("cannot fold %s" % k)
+            memo[n] = v
+    return memo
+
+
+def _flatten(g, root, full):
+    """The summands of a term: through registered sums (codegen._sum_left) and through `add` nodes
+    that lead to one; the result of a Custom closure that holds no registered sum is a reduction
+    written by hand (Enum.reduce with Nx.add, validate_posteriordb.exs:279-295) and is split at
+    every `add` at its top."""
+    worthy = {}
+
+    def is_worthy(n):
+        stack = [n]
+        while stack:
+            x = stack[-1]
+            if x in worthy:
+                stack.pop()
+                continue
+            if x in g.sums:
+                worthy[x] = True
+                stack.pop()
+            elif g.ops[x][0] == "add":
+                a, b = g.ops[x][1:]
+                if a in worthy and b in worthy:
+                    worthy[x] = worthy[a] or worthy[b]
+                    stack.pop()
+                else:
+                    stack.extend(c for c in (a, b) if c not in worthy)
+            else:
+                worthy[x] = False
+                stack.pop()
+        return worthy[n]
+
+    full = full and not is_worthy(root)
+    out, stack = [], [root]
+    while stack:
+        n = stack.pop()
+        if n in g.sums:
+            stack.extend(reversed(g.sums[n]))
+        elif g.ops[n][0] == "add" and (full or is_worthy(n)):
+            stack.extend(reversed(g.ops[n][1:]))
+        else:
+            out.append(n)
+    return out
+
+
+def _signature(g, root):
+    """(shape, ids): the unit's DAG in post-order with local numbering; shape is what two units of
+    a family share, ids[k] the graph node behind local index k."""
+    local, shape, ids = {}, [], []
+    stack = [(root, False)]
+    while stack:
+        n, done = stack.pop()
+        if n in local:
+            continue
+        op = g.ops[n]
+        if op[0] in ("lit", "q", "data"):
+            local[n] = len(shape)
+            shape.append(("lit", op[1]) if op[0] == "lit" else (op[0],))
+            ids.append(n)
+        elif not done:
+            stack.append((n, True))
+            stack.extend((a, False) for a in reversed(op[1:]) if a not in local)
+        else:
+            local[n] = len(shape)
+            shape.append((op[0],) + tuple(local[a] for a in op[1:]))
+            ids.append(n)
+    return tuple(shape), ids
+
+
+class _Family:
+    pass
+
+
+def plan(g, term_roots, custom_roots, D, G):
+    """Units, families and the uniform remainder of the graph `g` whose terms are `term_roots`."""
+    units = []
+    for t in term_roots:
+        units.extend(_flatten(g, t, t in custom_roots))
+    by_shape, sigs = {}, {}
+    for pos, u in enumerate(units):
+        if g.const[u]:
+            continue
+        shape, ids = _signature(g, u)
+        sigs[pos] = ids
+        by_shape.setdefault(shape, []).append(pos)
+    families, in_family = [], set()
+    for shape, members in by_shape.items():
+        if len(members) < MIN_FAMILY:
+            continue
+        first = sigs[members[0]]
+        uniform = [all(sigs[m][k] == first[k] for m in members) for k in range(len(shape))]
+        if uniform[-1]:
+            continue            # the same node n times: n uniform terms
+        f = _Family()
+        f.shape, f.members, f.uniform = shape, members, uniform
+        f.ids = [sigs[m] for m in members]
+        families.append(f)
+        in_family.update(members)
+    families.sort(key=lambda f: f.members[0])
+    scalar_units = [units[p] for p in range(len(units)) if p not in in_family]
+    return families, scalar_units
+
+
+def generate(g, term_roots, custom_roots, D, G):
+    """-> dict(text, data, lanes, dpl, ...) for the lane layout."""
+    if G not in (16, 32, 64):
+        raise cg.CodegenError("lanes per chain must be 16, 32 or 64")
+    DPL = (D + G - 1) // G
+    families, scalar_units = plan(g, term_roots, custom_roots, D, G)
+    # ---- uniform constants: one table for the uniform part and every template ----
+    uc_of, uc_vals = {}, []
+
+    def uc_slot(key, value):
+        if key not in uc_of:
+            uc_of[key] = len(uc_vals)
+            uc_vals.append(float(value))
+        return uc_of[key]
+
+    def g_const_value(n):
+        return float(_np_eval(g, [n], lambda op: np.float64(g.data[op[1]]))[n])
+
+    # ---- templates ----
+    boundary = []            # distinct uniform dynamic nodes read by templates, in first-use order
+    b_index = {}
+    sh_off = D + 1           # LDS strip: [q (D)] [zero cell] [adjoint strips ...]
+    dcols, icols = [], []    # table columns (each NPAD long), in emission order
+    for f in families:
+        n, shape = len(f.members), f.shape
+        S = (n + G - 1) // G
+        f.n, f.S, f.npad = n, S, S * G
+        root = len(shape) - 1
+        # nodes of the template: reachable from the root without passing a uniform node
+        need, stack = set(), [root]
+        while stack:
+            k = stack.pop()
+            if k in need:
+                continue
+            need.add(k)
+            if not f.uniform[k] and shape[k][0] not in ("lit", "q", "data"):
+                stack.extend(shape[k][1:])
+        T = _LGraph()
+        tmap, f.raw_cols, f.gather = {}, [], []     # raw data columns; gathered q indices per unit
+        for k in sorted(need):
+            node0 = f.ids[0][k]
+            kind = shape[k][0]
+            if kind == "lit":
+                tmap[k] = T._node("lit", shape[k][1])
+            elif f.uniform[k]:
+                if g.const[node0]:
+                    tmap[k] = T._node("uc", uc_slot(("node", node0), g_const_value(node0)))
+                else:
+                    if node0 not in b_index:
+                        b_index[node0] = len(boundary)
+                        boundary.append(node0)
+                    tmap[k] = T._node("ext", b_index[node0])
+            elif kind == "q":
+                f.gather.append([g.ops[ids[k]][1] for ids in f.ids])
+                tmap[k] = T._node("gat", len(f.gather) - 1)
+            elif kind == "data":
+                vals = [g.data[g.ops[ids[k]][1]] for ids in f.ids]
+                if all(v == vals[0] for v in vals):
+                    tmap[k] = T._node("uc", uc_slot(("val", float(vals[0]).hex()), vals[0]))
+                else:
+                    f.raw_cols.append(np.asarray(vals, dtype=np.float64))
+                    tmap[k] = T._node("col", -len(f.raw_cols))      # raw columns: negative ids
+            else:
+                tmap[k] = T._node(kind, *[tmap[a] for a in shape[k][1:]])
+        f.T, f.troot = T, tmap[root]
+        n_fwd = len(T.ops)
+        ad = cg._Grad(T, f.troot)
+        ad.run(n_fwd)
+        f.ext_adj = {}          # boundary index -> adjoint node
+        for key, node in list(T.key.items()):
+            if key[0] == "ext" and ad.adj.get(node) is not None:
+                f.ext_adj[key[1]] = ad.adj[node]
+        f.gat_adj = [ad.adj.get(T.key[("gat", p)]) for p in range(len(f.gather))]
+        # fold what depends on constants only (per-unit data, uniform constants) into columns
+        outputs = [f.troot] + list(f.ext_adj.values()) + [a for a in f.gat_adj if a is not None]
+        live, stack = set(), list(outputs)
+        while stack:
+            i = stack.pop()
+            if i in live:
+                continue
+            live.add(i)
+            if T.ops[i][0] not in _LEAVES and not T.const[i]:
+                stack.extend(T.ops[i][1:])
+        fold = sorted(i for i in live if T.const[i] and T.ops[i][0] not in ("lit", "uc"))
+        raw = f.raw_cols
+
+        def leaf(op, raw=raw):
+            if op[0] == "col":
+                return raw[-op[1] - 1]
+            if op[0] == "uc":
+                return np.float64(uc_vals[op[1]])
+            raise cg.CodegenError("unexpected leaf %r in a constant" % (op,))
+        vals = _np_eval(T, fold, leaf)
+        f.cols, f.col_of = [], {}
+        for i in fold:
+            v = np.broadcast_to(np.asarray(vals[i], dtype=np.float64), (n,))
+            if np.all(v == v[0]):
+                f.col_of[i] = ("uc", uc_slot(("val", float(v[0]).hex()), v[0]))
+            else:
+                f.col_of[i] = ("col", len(f.cols))
+                f.cols.append(np.array(v))
+        f.live = live
+        # LDS strips of the gathered adjoints, table offsets
+        f.strip = []
+        for p in range(len(f.gather)):
+            f.strip.append(sh_off if f.gat_adj[p] is not None else -1)
+            if f.gat_adj[p] is not None:
+                sh_off += f.npad
+    lsh = sh_off
+
+    # ---- the uniform part: scalar units + the boundary nodes, differentiated with the reduced
+    # adjoints as seeds (U = scalar_lp + sum_j red_j * b_j) ----
+    n_split = len(g.ops)
+    scalar_lp = None
+    for t in scalar_units:
+        scalar_lp = t if scalar_lp is None else g.add(t, scalar_lp)
+    if scalar_lp is None:
+        scalar_lp = g.lit(0.0)
+    n_split = len(g.ops)
+    # reduced values: s[0] = log-density of the families, s[1 + j] = adjoint of boundary node j
+    acc_of = {}
+    for f in families:
+        for j in sorted(f.ext_adj):
+            if j not in acc_of:
+                acc_of[j] = 1 + len(acc_of)
+    NS = 1 + len(acc_of)
+    U = scalar_lp
+    for j, s in sorted(acc_of.items(), key=lambda kv: kv[1]):
+        U = g.add(U, g.mul(g._node("red", s), boundary[j]))
+    ug = {}
+    if not g.const[U]:
+        ad = cg._Grad(g, U)
+        ad.run(len(g.ops))
+        for i in range(D):
+            qn = g.key.get(("q", i))
+            if qn is not None and ad.adj.get(qn) is not None:
+                ug[i] = ad.adj[qn]
+
+    # liveness of the uniform graph
+    outputs = [scalar_lp] + list(ug.values()) + [b for b in boundary]
+    live, stack = set(), list(outputs)
+    while stack:
+        i = stack.pop()
+        if i in live:
+            continue
+        live.add(i)
+        if g.ops[i][0] not in _LEAVES and not g.const[i]:
+            stack.extend(g.ops[i][1:])
+    for i in sorted(live):
+        if g.const[i] and g.ops[i][0] != "lit":
+            uc_slot(("node", i), g_const_value(i))
+
+    # ---- gather lists of the owner lanes (padded to the widest lane per slot) ----
+    contrib = [[] for _ in range(D)]
+    for f in families:
+        for p in range(len(f.gather)):
+            if f.strip[p] < 0:
+                continue
+            for u, var in enumerate(f.gather[p]):
+                contrib[var].append(f.strip[p] + u)
+    width = [0] * DPL
+    for i in range(D):
+        width[i // G] = max(width[i // G], len(contrib[i]))
+    zero_cell = D
+    ell_off, ell = [], []
+    for k in range(DPL):
+        ell_off.append(len(ell))
+        for j in range(width[k]):
+            for l in range(G):
+                i = l + k * G
+                ell.append(contrib[i][j] if (i < D and j < len(contrib[i])) else zero_cell)
+
+    # ---- table layout: [uc][double columns][int32 columns (gather indices, owner lists)] ----
+    NUC = max(1, len(uc_vals))
+    doff = NUC
+    for f in families:
+        f.doff = doff
+        doff += len(f.cols) * f.npad
+    ints = []
+    for f in families:
+        f.ioff = len(ints)
+        for p in range(len(f.gather)):
+            col = list(f.gather[p]) + [f.gather[p][0]] * (f.npad - f.n)
+            ints.extend(col)
+    ell_base = len(ints)
+    ints.extend(ell)
+    if len(ints) % 2:
+        ints.append(0)
+    dtab = [np.asarray(uc_vals + [0.0] * (NUC - len(uc_vals)), dtype=np.float64)]
+    for f in families:
+        for c in f.cols:
+            dtab.append(np.concatenate([c, np.full(f.npad - f.n, c[0])]))
+    data = np.concatenate(dtab + [np.asarray(ints, dtype=np.int32).view(np.float64)]) \
+        if ints else np.concatenate(dtab)
+    ioff_doubles = doff
+
+    # ---- emission ----
+    def lit_text(hexv):
+        s = repr(float.fromhex(hexv))
+        if "inf" in s or "nan" in s:
+            raise cg.CodegenError("non-finite literal")
+        return "(%s)" % s if s.startswith("-") else s
+
+    fn1 = {k: v.replace("EXMC_GEN_", "EXMC_GENL_") for k, v in cg._FN1.items()}
+    fn1["abs"] = "fabs"
+
+    def expr(op, a):
+        if op in cg._BIN:
+            return "%s %s %s" % (a[0], cg._BIN[op], a[1])
+        if op == "neg":
+            return "-%s" % a[0]
+        if op in fn1:
+            return "%s(%s)" % (fn1[op], a[0])
+        if op in cg._FN2:
+            return "%s(%s, %s)" % (cg._FN2[op], a[0], a[1])
+        if op == "sel_gt":
+            return "(%s > %s) ? %s : %s" % tuple(a)
+        raise cg.CodegenError("cannot emit %s" % op)
+
+    def uref(i):
+        op = g.ops[i]
+        if op[0] == "lit":
+            return lit_text(op[1])
+        if op[0] == "red":
+            return "s[%d]" % op[1]
+        if g.const[i]:
+            return "lt[%d]" % uc_of[("node", i)]
+        return "u%d" % i
+
+    def ustmts(lo, hi):
+        out = []
+        if lo == 0:     # the shared variables: broadcast reads of the position strip
+            out.extend("  const double u%d = EXMC_GEN_SH(%d);" % (i, g.ops[i][1])
+                       for i in sorted(live) if g.ops[i][0] == "q")
+        for i in sorted(live):
+            if lo <= i < hi and not g.const[i] and g.ops[i][0] not in _LEAVES:
+                op = g.ops[i]
+                out.append("  const double u%d = %s;" % (i, expr(op[0], [uref(x) for x in op[1:]])))
+        return out
+
+    L = []
+    L.append("/* lane layout (exmc_amd/codegen_lanes.py): %d lanes per chain, %d dimensions per lane;"
+             % (G, DPL))
+    L.append(" * %d famil%s of repeated terms (%s units), %d uniform term%s. lt = [%d uniform constants]"
+             % (len(families), "y" if len(families) == 1 else "ies",
+                " + ".join(str(f.n) for f in families) or "0", len(scalar_units),
+                "" if len(scalar_units) == 1 else "s", NUC))
+    L.append(" * [per-unit columns][int32: gather indices, owner lists]; EXMC_GEN_SH(i) = double i of the")
+    L.append(" * chain's LDS strip: [position (d)][0.0][adjoint strips]. */")
+    L.append("#define EXMC_GEN_LANES %d" % G)
+    L.append("#define EXMC_GEN_DPL %d" % DPL)
+    L.append("#define EXMC_GEN_LSH %d" % lsh)
+    L.append("#define EXMC_GEN_NS %d" % NS)
+    L.append("#define EXMC_GEN_NLT %d" % data.size)
+    L.append("")
+    L.append("EXMC_GEN_FN double exmc_gen_lanes(const double* lt, int l, double* g EXMC_GEN_CTX_DECL) {")
+    L.append("  const int* it = (const int*)(lt + %d);" % ioff_doubles)
+    L.append("  EXMC_GEN_SH(%d) = 0.0;" % zero_cell)
+    L.extend(ustmts(0, n_split))
+    L.append("  double s[EXMC_GEN_NS];")
+    L.append("  for (int j = 0; j < EXMC_GEN_NS; j++) s[j] = 0.0;")
+    for fi, f in enumerate(families):
+        T = f.T
+
+        def tref(i, T=T, f=f):
+            op = T.ops[i]
+            if op[0] == "lit":
+                return lit_text(op[1])
+            if op[0] == "uc":
+                return "lt[%d]" % op[1]
+            if i in f.col_of:
+                kind, k = f.col_of[i]
+                return "lt[%d]" % k if kind == "uc" else "c%d" % k
+            if op[0] == "ext":
+                return uref(boundary[op[1]])
+            if op[0] == "gat":
+                return "v%d" % op[1]
+            return "t%d" % i
+        L.append("  /* family %d: %d units, %d per lane */" % (fi, f.n, f.S))
+        L.append("  for (int sl = 0; sl < %d; sl++) {" % f.S)
+        L.append("    const int un = sl * %d + l;" % G)
+        if f.n < f.npad:
+            L.append("    const int on = un < %d;" % f.n)
+        for p in range(len(f.gather)):
+            L.append("    const double v%d = EXMC_GEN_SH(it[%d + un]);" % (p, f.ioff + p * f.npad))
+        for c in range(len(f.cols)):
+            L.append("    const double c%d = lt[%d + un];" % (c, f.doff + c * f.npad))
+        for i in sorted(f.live):
+            op = T.ops[i]
+            if T.const[i] or op[0] in _LEAVES:
+                continue
+            L.append("    const double t%d = %s;" % (i, expr(op[0], [tref(x) for x in op[1:]])))
+
+        def accum(slot, val, f=f):
+            if f.n < f.npad:
+                return "    s[%d] = on ? (s[%d] + %s) : s[%d];" % (slot, slot, val, slot)
+            return "    s[%d] = s[%d] + %s;" % (slot, slot, val)
+        L.append(accum(0, tref(f.troot)))
+        for j in sorted(f.ext_adj):
+            L.append(accum(acc_of[j], tref(f.ext_adj[j])))
+        for p in range(len(f.gather)):
+            if f.strip[p] >= 0:
+                L.append("    EXMC_GEN_SH(%d + un) = %s;" % (f.strip[p], tref(f.gat_adj[p])))
+        L.append("  }")
+    L.append("  EXMC_GEN_ALLSUM(s);")
+    L.extend(ustmts(n_split, len(g.ops)))
+    L.append("  EXMC_GEN_FENCE();")
+    for k in range(DPL):
+        L.append("  {")
+        L.append("    const int dim = l + %d;" % (k * G))
+        L.append("    double acc = 0.0;")
+        if width[k] > 0:
+            L.append("    for (int j = 0; j < %d; j++) acc = acc + EXMC_GEN_SH(it[%d + j * %d + l]);"
+                     % (width[k], ell_base + ell_off[k], G))
+        sel = "0.0"
+        for i in sorted(ug, reverse=True):
+            if i // G == k:
+                sel = "(dim == %d) ? %s : (%s)" % (i, uref(ug[i]), sel)
+        L.append("    const double ugs = %s;" % sel)
+        L.append("    g[%d] = acc + ugs;" % k)
+        L.append("    (void)dim;")
+        L.append("  }")
+    L.append("  return %s + s[0];" % uref(scalar_lp))
+    L.append("}")
+    text = "\n".join(L) + "\n"
+    return dict(text=text, data=data, lanes=G, dpl=DPL, lsh=lsh, n_families=len(families),
+                family_sizes=[f.n for f in families], n_scalar_units=len(scalar_units),
+                n_reduced=NS, n_boundary=len(boundary), gather_width=width)

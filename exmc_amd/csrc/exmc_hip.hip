@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -123,7 +124,7 @@ struct exmc_hip_model {
   // push-style stream: page-locked host memory [progress word | trace of the run in flight]
   void* pin_host = nullptr;
   size_t pin_bytes = 0;
-  bool stream_in_flight = false;
+  std::atomic<bool> stream_in_flight{false};
   int densep_gd = 0;
   std::vector<double> h_dense;
   std::vector<int32_t> h_rank;
@@ -183,10 +184,16 @@ template <class F>
 int dispatch(exmc_hip_model* m, int lanes, F&& f) {
   switch (m->kind) {
 #ifdef EXMC_CUSTOM_HEADER
-    case EXMC_MODEL_CUSTOM:   // a generated model (exmc_amd/codegen.py), one lane per chain
-      if (lanes == 1) return f(Tag<Custom<1>, 1, EXMC_GEN_LDS_LEVELS>{}, m->cu);
+    case EXMC_MODEL_CUSTOM:   // a generated model (exmc_amd/codegen.py)
+#ifdef EXMC_GEN_ONE_LANE
+      if (lanes == 1) return f(Tag<Custom<1>, 1, EXMC_GEN_LDS_LEVELS>{}, m->cu);   // one lane per chain
+#endif
 #ifdef EXMC_GEN_VEC
       if (lanes == 16) return f(Tag<Custom<16>, 16, 6>{}, m->cu);   // plates across lanes
+#endif
+#ifdef EXMC_GEN_LANES
+      if (lanes == EXMC_GEN_LANES)   // several dimensions per lane (codegen_lanes.py)
+        return f(Tag<Custom<EXMC_GEN_LANES>, EXMC_GEN_LANES, (EXMC_GEN_DPL > 1 ? 2 : 6)>{}, m->cu);
 #endif
       break;
 #endif
@@ -312,7 +319,9 @@ int default_lanes(int kind) {
     case EXMC_MODEL_SV: return 64;
     case EXMC_MODEL_LOGISTIC: return 16;
     case EXMC_MODEL_RADON: return 64;
-#ifdef EXMC_GEN_VEC
+#if defined(EXMC_GEN_LANES)
+    case EXMC_MODEL_CUSTOM: return EXMC_GEN_LANES;
+#elif defined(EXMC_GEN_VEC)
     case EXMC_MODEL_CUSTOM: return 16;
 #endif
     default: return 1;
@@ -422,9 +431,14 @@ template <> inline constexpr bool kStreamKernel<Logistic<16>> = true;
 template <> inline constexpr bool kStreamKernel<Radon<64>> = true;
 #endif
 #ifdef EXMC_CUSTOM_HEADER
+#ifdef EXMC_GEN_ONE_LANE
 template <> inline constexpr bool kStreamKernel<Custom<1>> = true;
+#endif
 #ifdef EXMC_GEN_VEC
 template <> inline constexpr bool kStreamKernel<Custom<16>> = true;
+#endif
+#ifdef EXMC_GEN_LANES
+template <> inline constexpr bool kStreamKernel<Custom<EXMC_GEN_LANES>> = true;
 #endif
 #endif
 
@@ -951,8 +965,18 @@ int run_warmup_device(exmc_hip_model* m, int lanes, exmc_hip_opts o, exmc_hip_tu
   return EXMC_OK;
 }
 
+// Every entry point that touches the handle's buffers, stream or counters goes through here. While
+// a push-style stream run is in flight (exmc_hip_stream_start .. _finish) the launch is writing the
+// page-locked trace and owns ev0 / ev1 and the counters: everything else is refused until
+// exmc_hip_stream_finish has been called (the poller may be a thread of the caller's own).
+int check_handle(const exmc_hip_model* m) {
+  if (!m) return fail(EXMC_ERR_BADARG, "null model handle");
+  return EXMC_OK;
+}
 int check_model(const exmc_hip_model* m) {
   if (!m) return fail(EXMC_ERR_BADARG, "null model handle");
+  if (m->stream_in_flight.load(std::memory_order_acquire))
+    return fail(EXMC_ERR_BADARG, "a stream run is in flight on this handle: call exmc_hip_stream_finish first");
   return EXMC_OK;
 }
 
@@ -1056,10 +1080,12 @@ int exmc_hip_model_create(int kind, int d, const double* data, int n_data, int d
     }
 #ifdef EXMC_CUSTOM_HEADER
     case EXMC_MODEL_CUSTOM: {
+      int kGenData = EXMC_GEN_NDATA;
 #ifdef EXMC_GEN_VEC
-      constexpr int kGenData = EXMC_GEN_NDATA + EXMC_GEN_NVU + 16 * EXMC_GEN_NLR;
-#else
-      constexpr int kGenData = EXMC_GEN_NDATA;
+      kGenData += EXMC_GEN_NVU + 16 * EXMC_GEN_NLR;
+#endif
+#ifdef EXMC_GEN_LANES
+      kGenData += EXMC_GEN_NLT;
 #endif
       if (n_data != kGenData || (n_data > 0 && !data)) { delete m; return fail(EXMC_ERR_BADARG, "generated model: data length differs from the one it was generated for"); }
       m->d = EXMC_GEN_D;
@@ -1144,13 +1170,21 @@ int exmc_hip_model_create(int kind, int d, const double* data, int n_data, int d
 #else
     std::vector<double> folded(EXMC_GEN_NCONST);
 #endif
+#ifdef EXMC_GEN_ONE_LANE
     exmc_gen_fold(data, folded.data());
+#endif
+    const size_t n_folded = folded.size();
+#ifdef EXMC_GEN_LANES
+    // the lane layout's tables were folded when the model was generated: they travel as they are
+    folded.insert(folded.end(), data + EXMC_GEN_LOFF, data + EXMC_GEN_LOFF + EXMC_GEN_NLT);
+#endif
     rc = m->data.ensure(folded.size() * 8);
     if (rc) return bail(rc);
     if (hipMemcpy(m->data.p, folded.data(), folded.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
       return bail(fail(EXMC_ERR_HIP, "model data upload failed"));
     m->cu.c = m->data.as<double>();
     m->cu.vc = m->data.as<double>() + EXMC_GEN_NCONST;
+    m->cu.lt = m->data.as<double>() + n_folded;
   }
 #endif
   rc = default_flat_order(m);
@@ -1533,6 +1567,9 @@ int exmc_hip_sample_warm_host(exmc_hip_model* m, const double* init_q, exmc_hip_
                               exmc_hip_tuning* tuning_out, int32_t* divergences) {
   if (check_model(m)) return EXMC_ERR_BADARG;
   if (o.num_samples < 1) return fail(EXMC_ERR_BADARG, "num_samples must be >= 1");
+  // this call runs the DIAGONAL adaptation itself: a dense mass left on the handle by an earlier
+  // exmc_hip_warmup_dense / _model_set_dense_mass belongs to that run's tuning, not to this one
+  m->dense_on = false;
   exmc_hip_tuning tun;
   // leaves chain 0's state in m->state
   int rc = warm_start ? exmc_hip_warmup_from(m, init_q, o, warm_start, &tun)
@@ -1593,6 +1630,7 @@ int exmc_hip_sample_dense_host(exmc_hip_model* m, const double* init_q, exmc_hip
 int exmc_hip_stream_begin(exmc_hip_model* m, const double* init_q, exmc_hip_opts o,
                           exmc_hip_tuning* tuning_out) {
   if (check_model(m)) return EXMC_ERR_BADARG;
+  m->dense_on = false;   // the diagonal adaptation follows (see exmc_hip_sample_warm_host)
   exmc_hip_tuning tun;
   int rc = exmc_hip_warmup(m, init_q, o, &tun);  // leaves chain 0's state in m->state
   if (rc) return rc;
@@ -1633,10 +1671,9 @@ int exmc_hip_stream_next_host(exmc_hip_model* m, int n_draws, exmc_hip_trace tr,
 
 int exmc_hip_stream_start(exmc_hip_model* m, int n_draws, exmc_hip_trace* view,
                           const volatile int32_t** progress) {
-  if (check_model(m)) return EXMC_ERR_BADARG;
+  if (check_model(m)) return EXMC_ERR_BADARG;   // includes: no other stream run in flight
   if (m->res_C != 1) return fail(EXMC_ERR_BADARG, "no stream: call exmc_hip_stream_begin");
   if (n_draws < 1 || !view || !progress) return fail(EXMC_ERR_BADARG, "bad arguments");
-  if (m->stream_in_flight) return fail(EXMC_ERR_BADARG, "a stream run is in flight: call exmc_hip_stream_finish");
   if (m->dense_on) return fail(EXMC_ERR_UNSUPPORTED, "a push-style stream runs under the diagonal mass");
   HIP_TRY(hipSetDevice(m->device));
   const TraceLayout L = trace_layout(n_draws, m->d, 1);
@@ -1656,7 +1693,7 @@ int exmc_hip_stream_start(exmc_hip_model* m, int n_draws, exmc_hip_trace* view,
   rc = launch_nuts(m, m->res_lanes, 1, n_draws, 0, m->res_eps, m->res_max_depth,
                    trace_view((char*)dev + 64, L), true, (int*)dev);
   if (rc) return rc;
-  m->stream_in_flight = true;
+  m->stream_in_flight.store(true, std::memory_order_release);
   // with one chain the device layout [draw][dim][chain] is the host layout [draw][dim]
   const TraceDev h = trace_view((char*)m->pin_host + 64, L);
   view->draws = h.draws;
@@ -1671,14 +1708,14 @@ int exmc_hip_stream_start(exmc_hip_model* m, int n_draws, exmc_hip_trace* view,
 }
 
 int exmc_hip_stream_finish(exmc_hip_model* m, int32_t* divergences) {
-  if (check_model(m)) return EXMC_ERR_BADARG;
-  if (!m->stream_in_flight) return fail(EXMC_ERR_BADARG, "no stream run in flight");
-  HIP_TRY(hipSetDevice(m->device));
-  m->stream_in_flight = false;
-  int rc = finish_timing(m);
-  if (rc) return rc;
+  if (check_handle(m)) return EXMC_ERR_BADARG;
+  if (!m->stream_in_flight.load(std::memory_order_acquire)) return fail(EXMC_ERR_BADARG, "no stream run in flight");
+  // the handle stays busy until the launch has drained, whatever the calls below return
+  int rc = (hipSetDevice(m->device) == hipSuccess) ? finish_timing(m) : fail(EXMC_ERR_HIP, "hipSetDevice failed");
   int32_t div = 0;
-  rc = read_counters(m, nullptr, &div);
+  if (!rc) rc = read_counters(m, nullptr, &div);
+  if (rc) (void)hipStreamSynchronize(m->stream);
+  m->stream_in_flight.store(false, std::memory_order_release);
   if (rc) return rc;
   if (divergences) *divergences = div;
   return EXMC_OK;

@@ -1085,6 +1085,23 @@ static __host__ __device__ __noinline__ double exmc_gen_erf_call(double x) { ret
 #define EXMC_GENV_LOG exmc_log
 #define EXMC_GENV_LOG1P exmc_log1p
 #endif
+// the lane layout (exmc_amd/codegen_lanes.py): its exp / log are inlined unless the build asks for
+// calls; its LDS strip is the chain group's part of the functor's scratch (EXMC_GEN_SH), the
+// butterfly of its partial sums group_allsum_n, its fence the wave-level LDS fence
+#ifdef EXMC_GENL_CALLED_MATH
+#define EXMC_GENL_EXP exmc_gen_exp_call
+#define EXMC_GENL_LOG exmc_gen_log_call
+#define EXMC_GENL_LOG1P exmc_gen_log1p_call
+#else
+#define EXMC_GENL_EXP exmc_exp
+#define EXMC_GENL_LOG exmc_log
+#define EXMC_GENL_LOG1P exmc_log1p
+#endif
+#define EXMC_GENL_ERF exmc_gen_erf_call
+#define EXMC_GEN_CTX_DECL , int shoff
+#define EXMC_GEN_SH(i) exmc::exmc_dyn_lds[shoff + (i)]
+#define EXMC_GEN_ALLSUM(s) exmc::group_allsum_n<EXMC_GEN_LANES, EXMC_GEN_NS>(s)
+#define EXMC_GEN_FENCE() exmc::wave_lds_fence()
 #include EXMC_CUSTOM_HEADER
 
 namespace exmc {
@@ -1092,11 +1109,15 @@ namespace exmc {
 struct CustomConsts {
   const double* c;    // folded constants of the one-lane form
   const double* vc;   // 16-lane form: [EXMC_GEN_NVC uniform][16][EXMC_GEN_NLC per lane]
+  const double* lt;   // lane layout: [uniform constants][per-unit columns][int32 index tables]
 };
 
 template <int G>
-struct Custom : ModelDefaults {
-  static_assert(G == 1, "the generic form of a generated model is one lane per chain");
+struct Custom;
+
+#ifdef EXMC_GEN_ONE_LANE
+template <>
+struct Custom<1> : ModelDefaults {
   static constexpr int D = EXMC_GEN_D;
   static constexpr int DPL = D;
   using Consts = CustomConsts;
@@ -1107,6 +1128,38 @@ struct Custom : ModelDefaults {
     return exmc_gen_logp_grad(c.c, q, g);
   }
 };
+#endif
+
+#ifdef EXMC_GEN_LANES
+// Several dimensions per lane (exmc_amd/codegen_lanes.py): a chain over G lanes, dimension i in
+// slot i / G of lane i % G. The position goes to the chain's LDS strip; the generated function
+// walks the model's families of repeated terms (unit u on lane u % G), reduces the partial sums in
+// one butterfly and gathers this lane's gradient entries from the adjoint strips.
+template <>
+struct Custom<EXMC_GEN_LANES> : ModelDefaults {
+  static constexpr int G = EXMC_GEN_LANES;
+  static constexpr int D = EXMC_GEN_D;
+  static constexpr int DPL = EXMC_GEN_DPL;
+  static_assert(DPL * G >= D, "every dimension has a slot");
+  static constexpr bool kVregMath = true;   // the tree's own exp / log (nuts_run)
+  static constexpr bool kPipeWarmup = false;
+  static constexpr int kExtraLdsDoubles = (64 / G) * EXMC_GEN_LSH;
+  using Consts = CustomConsts;
+  struct Lane {
+    double* sh;   // the wavefront's scratch (attach_scratch / lane_setup)
+  };
+  __device__ static __forceinline__ void load(const Consts&, int, Lane& ln) { ln.sh = nullptr; }
+  __device__ static __forceinline__ double logp_grad(const Consts& c, const Lane& ln, int l,
+                                                     const double (&q)[DPL], double (&g)[DPL]) {
+    const int shoff = (int)(ln.sh - exmc_dyn_lds) + (int)((threadIdx.x & 63) / G) * EXMC_GEN_LSH;
+#pragma unroll
+    for (int k = 0; k < DPL; k++)
+      if (l + k * G < D) exmc_dyn_lds[shoff + l + k * G] = q[k];
+    wave_lds_fence();
+    return exmc_gen_lanes(c.lt, l, g, shoff);
+  }
+};
+#endif
 
 #ifdef EXMC_GEN_VEC
 // Plates across lanes (exmc_amd/codegen_vec.py): lane l owns dimension l and evaluates the units

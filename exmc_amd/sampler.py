@@ -332,6 +332,8 @@ def sample_stream(ir, receiver, init_values=None, opts=None):
     chunk = max(1, int(o.get("stream_chunk", 50)))
     tun = _lib.Tuning()
     iq = _init_q(spec, init_values)
+    # (stream_begin runs the diagonal adaptation and clears a dense mass an earlier call left on the
+    # handle: the stream equals sample/3 whatever ran before)
     compiled.check(L.exmc_hip_stream_begin(compiled.h, None if iq is None else _dp(iq), _c_opts(o),
                                        C.byref(tun)))
     sent = 0
@@ -348,24 +350,31 @@ def sample_stream(ir, receiver, init_values=None, opts=None):
         raw = dict(tree_depth=col(view.tree_depth, C.c_int32)[None, :], n_steps=col(view.n_steps, C.c_int32)[None, :],
                    divergent=col(view.divergent, C.c_int32)[None, :], accept_prob=col(view.accept_prob, C.c_double)[None, :],
                    energy=col(view.energy, C.c_double)[None, :])
-        ss = SampleStats(raw, 0)
         seen = []                                  # the counts this poll loop observed (tests look at it)
         deadline = time.monotonic() + float(o.get("stream_timeout_s", 600.0))
-        while sent < n:
-            ready = int(prog[0])                   # rows [0, ready) are final (system-scope release on the device)
-            if ready > sent:
-                seen.append(ready)
-                x = spec.constrain(np.array(draws[sent:ready]))
-                for i in range(sent, ready):
-                    point_map = {name: float(x[i - sent, j]) for j, name in enumerate(spec.var_names)}
-                    receiver(("exmc_sample", i + 1, point_map, ss[i]))
-                sent = ready
-            elif time.monotonic() > deadline:
-                raise TimeoutError("stream: no draw within stream_timeout_s")
-            else:
-                time.sleep(0.0002)
-        div = C.c_int32()
-        compiled.check(L.exmc_hip_stream_finish(compiled.h, C.byref(div)))
+        # Whatever happens below (a timeout, the receiver raising), the run is finished on the
+        # library side before this function returns: the launch drains, the handle leaves its
+        # "stream run in flight" state, and nothing handed to the receiver aliases the page-locked
+        # trace the next run may reuse or free (rows are copied out first).
+        try:
+            while sent < n:
+                ready = int(prog[0])               # rows [0, ready) are final (system-scope release on the device)
+                if ready > sent:
+                    seen.append(ready)
+                    x = spec.constrain(np.array(draws[sent:ready]))
+                    rows = SampleStats({k: np.array(v[:, sent:ready]) for k, v in raw.items()}, 0)
+                    for i in range(sent, ready):
+                        point_map = {name: float(x[i - sent, j]) for j, name in enumerate(spec.var_names)}
+                        receiver(("exmc_sample", i + 1, point_map, rows[i - sent]))
+                    sent = ready
+                elif time.monotonic() > deadline:
+                    raise TimeoutError("stream: no draw within stream_timeout_s")
+                else:
+                    time.sleep(0.0002)
+        finally:
+            div = C.c_int32()
+            rc = L.exmc_hip_stream_finish(compiled.h, C.byref(div))
+        compiled.check(rc)
         receiver(("exmc_done", n))
         compiled.last_stream_counts = seen
         return "ok"

@@ -32,20 +32,69 @@ WRAPPER = """
 #define EXMC_GENV_LOG1P exmc_log1p
 #define EXMC_GEN_ERF exmc_erf
 #define EXMC_GENV_ERF exmc_erf
+#define EXMC_GENL_EXP exmc_exp
+#define EXMC_GENL_LOG exmc_log
+#define EXMC_GENL_LOG1P exmc_log1p
+#define EXMC_GENL_ERF exmc_erf
+/* the lane layout (exmc_amd/codegen_lanes.py) on virtual lanes: every lane runs the function up to
+ * the butterfly (pass 0: its partial sums are collected), the sums are added in the order of the
+ * device's xor butterfly, every lane runs it again to the end (pass 1) */
+typedef struct { double* sh; int pass; double* S; const double* R; } exmc_gen_ctx;
+#define EXMC_GEN_CTX_DECL , exmc_gen_ctx* ctx
+#define EXMC_GEN_SH(i) ctx->sh[i]
+#define EXMC_GEN_ALLSUM(s) do { \
+    if (ctx->pass == 0) { memcpy(ctx->S + (size_t)l * EXMC_GEN_NS, s, sizeof(double) * EXMC_GEN_NS); return 0.0; } \
+    memcpy(s, ctx->R, sizeof(double) * EXMC_GEN_NS); } while (0)
+#define EXMC_GEN_FENCE()
 #include "%(header)s"
 int exmc_gen_check_dim(void) { return EXMC_GEN_D; }
 int exmc_gen_check_ndata(void) {
+  int n = EXMC_GEN_NDATA;
 #ifdef EXMC_GEN_VEC
-  return EXMC_GEN_NDATA + EXMC_GEN_NVU + 16 * EXMC_GEN_NLR;
-#else
-  return EXMC_GEN_NDATA;
+  n += EXMC_GEN_NVU + 16 * EXMC_GEN_NLR;
 #endif
+#ifdef EXMC_GEN_LANES
+  n += EXMC_GEN_NLT;
+#endif
+  return n;
 }
+#ifdef EXMC_GEN_ONE_LANE
 double exmc_gen_check(const double* data, const double* q, double* g) {
   double c[EXMC_GEN_NCONST];
   exmc_gen_fold(data, c);
   return exmc_gen_logp_grad(c, q, g);
 }
+#endif
+#ifdef EXMC_GEN_LANES
+/* Custom<EXMC_GEN_LANES> of exmc_amd/csrc/exmc_models.hpp: dimension i in slot i / G of lane i mod G */
+int exmc_gen_check_lanes(void) { return EXMC_GEN_LANES; }
+double exmc_gen_checkL(const double* data, const double* q, double* g) {
+  enum { G = EXMC_GEN_LANES };
+  const double* lt = data + EXMC_GEN_LOFF;
+  double sh[EXMC_GEN_LSH], S[G * EXMC_GEN_NS], R[EXMC_GEN_NS], gl[EXMC_GEN_DPL], lp = 0.0;
+  exmc_gen_ctx ctx = {sh, 0, S, R};
+  for (int i = 0; i < EXMC_GEN_LSH; i++) sh[i] = 0.0;
+  for (int i = 0; i < EXMC_GEN_D; i++) sh[i] = q[i];
+  for (int l = 0; l < G; l++) (void)exmc_gen_lanes(lt, l, gl, &ctx);
+  for (int k = 0; k < EXMC_GEN_NS; k++) {   /* group_allsum_n: xor butterfly over the G lanes */
+    double part[G], nxt[G];
+    for (int l = 0; l < G; l++) part[l] = S[l * EXMC_GEN_NS + k];
+    for (int m = 1; m < G; m <<= 1) {
+      for (int l = 0; l < G; l++) nxt[l] = part[l] + part[l ^ m];
+      memcpy(part, nxt, sizeof part);
+    }
+    R[k] = part[0];
+  }
+  ctx.pass = 1;
+  for (int l = 0; l < G; l++) {
+    const double v = exmc_gen_lanes(lt, l, gl, &ctx);
+    if (l == 0) lp = v;
+    for (int k = 0; k < EXMC_GEN_DPL; k++)
+      if (l + k * G < EXMC_GEN_D) g[l + k * G] = gl[k];
+  }
+  return lp;
+}
+#endif
 #ifdef EXMC_GEN_VEC
 /* Custom<16> of exmc_amd/csrc/exmc_models.hpp on 16 virtual lanes */
 double exmc_gen_check16(const double* data, const double* q, double* g) {
@@ -100,7 +149,7 @@ def build(gen):
 
 def _lib(gen):
     L = C.CDLL(build(gen))
-    for name in ("exmc_gen_check", "exmc_gen_check16"):
+    for name in ("exmc_gen_check", "exmc_gen_check16", "exmc_gen_checkL"):
         if hasattr(L, name):
             f = getattr(L, name)
             f.restype = C.c_double
@@ -116,11 +165,22 @@ def model(gen, lanes=None):
     L = _lib(gen)
     assert L.exmc_gen_check_dim() == gen.d and L.exmc_gen_check_ndata() == gen.data.size
     m = O.Model(O.EXO_MODEL_CUSTOM, gen.d, gen.data)
-    fn = C.cast(L.exmc_gen_check16 if lanes == 16 else L.exmc_gen_check, C.c_void_p)
+    fn = C.cast(_entry(gen, L, lanes), C.c_void_p)
     O.lib().exo_model_set_custom(m.h, fn)
     m.gen_lib = L
     m.lanes = lanes
     return m
+
+
+def _entry(gen, L, lanes):
+    """The checker function of a layout: one lane, the 16-lane plate layout, or the lane layout."""
+    if getattr(gen, "lane_layout", None) is not None and lanes == gen.lane_layout["lanes"]:
+        return L.exmc_gen_checkL
+    if lanes == 16:
+        return L.exmc_gen_check16
+    if lanes != 1:
+        raise ValueError("the generated model has no %d-lane layout" % lanes)
+    return L.exmc_gen_check
 
 
 def logp_grad(gen, q, lanes=1):
@@ -128,5 +188,5 @@ def logp_grad(gen, q, lanes=1):
     q = np.ascontiguousarray(q, dtype=np.float64)
     g = np.zeros(gen.d)
     data = np.ascontiguousarray(gen.data)
-    f = L.exmc_gen_check16 if lanes == 16 else L.exmc_gen_check
+    f = _entry(gen, L, lanes)
     return f(O.dptr(data), O.dptr(q), O.dptr(g)), g

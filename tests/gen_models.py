@@ -138,3 +138,36 @@ def survival_ir(seed=11):
 
 
 SURVIVAL_INIT = dict(k=1.2, lam=1.5, m=0.1, s=1.0, m1=-0.8, m2=1.7)
+
+
+# ---- the three larger BASELINE configs as Builder IR (exmc_amd/codegen.py sv_ir / radon_ir /
+# logistic_ir) next to their hand-written kinds: same variable names, so an init map or a point of
+# one is a point of the other after a permutation ----
+def sv_returns(seed=3):
+    return np.random.default_rng(seed).normal(size=100) * 0.02
+
+
+def baseline_pair(which):
+    """(ir, ncp, hand-written ModelSpec, lanes of the generated layout)"""
+    from exmc_amd import models
+    if which == "sv":
+        r = sv_returns()
+        return cg.sv_ir(r), False, models.sv(r), 64
+    if which == "logistic":
+        X, y = models.logistic_data()
+        return cg.logistic_ir(X, y), True, models.logistic(X, y), 16
+    if which == "radon":
+        spec = models.radon()
+        J = 85
+        d = spec.data
+        start = d[J:2 * J + 1].astype(int)
+        n = start[-1]
+        names = [v for v in spec.var_names if v.startswith("alpha_raw")]
+        ir = cg.radon_ir(d[:J], start, d[2 * J + 1:2 * J + 1 + n], d[2 * J + 1 + n:], names=names)
+        return ir, False, spec, 64
+    raise ValueError(which)
+
+
+def to_spec_order(gen, spec):
+    """idx with q_generated = q_handwritten[idx] (the generated kernel order is the flat order)."""
+    return [spec.var_names.index(n) for n in gen.var_names]

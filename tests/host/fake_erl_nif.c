@@ -253,9 +253,11 @@ int enif_thread_create(char* name, ErlNifTid* tid, void* (*func)(void*), void* a
   (void)name; (void)opts;
   pthread_t t;
   int rc = pthread_create(&t, NULL, func, args);
-  if (rc == 0) { pthread_detach(t); *tid = (ErlNifTid)(size_t)1; }
+  if (rc == 0) *tid = (ErlNifTid)(size_t)t;
   return rc;
 }
-int enif_thread_join(ErlNifTid tid, void** exit_value) { (void)tid; if (exit_value) *exit_value = NULL; return 0; }
+int enif_thread_join(ErlNifTid tid, void** exit_value) { return pthread_join((pthread_t)(size_t)tid, exit_value); }
+ErlNifTid enif_thread_self(void) { return (ErlNifTid)(size_t)pthread_self(); }
+int enif_equal_tids(ErlNifTid a, ErlNifTid b) { return pthread_equal((pthread_t)(size_t)a, (pthread_t)(size_t)b); }
 void* enif_alloc(size_t size) { return malloc(size); }
 void enif_free(void* ptr) { free(ptr); }

@@ -118,10 +118,14 @@ def test_generation_is_deterministic_and_rejects_what_it_does_not_cover():
         cg.generate(cg.IR().rv("x", "normal", dict(mu="nope", sigma=1.0)))
     with pytest.raises(cg.CodegenError):
         cg.generate(cg.IR().rv("x", "normal", dict(mu=0.0, sigma=1.0), transform="stick_breaking"))
+    ir = cg.IR()                               # above the one-lane limit: the lane layout (round 3)
+    for i in range(cg.MAX_D + 1):
+        ir.rv("x%02d" % i, "normal", dict(mu=0.0, sigma=1.0))
+    assert cg.generate(ir).lanes == 16
     with pytest.raises(cg.CodegenError):
         ir = cg.IR()
-        for i in range(cg.MAX_D + 1):
-            ir.rv("x%02d" % i, "normal", dict(mu=0.0, sigma=1.0))
+        for i in range(cg.MAX_D_LANES + 1):
+            ir.rv("x%03d" % i, "normal", dict(mu=0.0, sigma=1.0))
         cg.generate(ir)
     with pytest.raises(cg.CodegenError):
         cg.IR().rv("x", "normal", dict(mu=0.0, sigma=1.0)).obs("o", "x", [1.0], censored="upper")

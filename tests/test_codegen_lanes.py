@@ -1,0 +1,164 @@
+"""The lane layout of generated models (exmc_amd/codegen_lanes.py) on the CPU:
+stochastic volatility, radon and the logistic regression built from Builder node lists
+(codegen.sv_ir / radon_ir / logistic_ir) against the HAND-WRITTEN models of the oracle
+(oracle/exmc_oracle.c logp_sv / logp_radon / logp_logistic, reference arithmetic: libm, left to
+right) -- an independent restatement of the same densities -- and against central differences.
+The generated text runs on virtual lanes (tests/gen_checker.py), as it does on the GPU."""
+import numpy as np
+import pytest
+
+import gen_checker as GC
+import gen_models as GM
+import oracle as O
+from exmc_amd import codegen as cg, codegen_lanes as cl
+
+
+def _gen(which, lanes=None):
+    ir, ncp, spec, dl = GM.baseline_pair(which)
+    return cg.generate(ir, ncp=ncp, lanes=lanes or dl), spec
+
+
+@pytest.mark.parametrize("which,lanes", [("sv", 64), ("sv", 32), ("radon", 64), ("logistic", 16),
+                                         ("logistic", 64)])
+def test_generated_equals_the_handwritten_oracle_model(which, lanes):
+    gen, spec = _gen(which, lanes)
+    assert gen.d == spec.d and sorted(gen.var_names) == sorted(spec.var_names)
+    assert gen.var_names == sorted(gen.var_names)           # PointMap order (point_map.ex:37)
+    m = O.model_for(spec)
+    idx = GM.to_spec_order(gen, spec)
+    rng = np.random.default_rng(5)
+    q0 = spec.to_unconstrained(spec.default_init)
+    scale = 0.1 if which == "sv" else 0.3
+    # logistic: the reference's Bernoulli term differentiates y log p + (1 - y) log(1 - p) through
+    # p (y / p - (1 - y) / (1 - p), as Nx's AD does); the hand-written kind uses the closed form
+    # y - p. Where p saturates the two differ by the cancellation in 1 - p, so its points stay
+    # at moderate linear predictors
+    spread = 1 if which == "logistic" else 4
+    for t in range(200):
+        qs = q0 + scale * rng.normal(size=spec.d) * (1.0 + (t % spread))
+        lp_o, g_o = m.logp_grad(qs, O.Cfg(0, 1))
+        lp_g, g_g = GC.logp_grad(gen, qs[idx], lanes=lanes)
+        assert abs(lp_g - lp_o) <= 1e-12 * max(1.0, abs(lp_o)), (which, t, lp_g, lp_o)
+        # an entry of the gradient is a sum of per-term adjoints that cancel (sv's d/d log nu: a hundred
+        # terms of the size of the largest entry), so the bound is relative to the gradient's scale
+        go = g_o[idx]
+        assert np.all(np.abs(g_g - go) <= 1e-12 * max(1.0, np.max(np.abs(go)))), (which, t)
+
+
+@pytest.mark.parametrize("which", ["sv", "radon", "logistic"])
+def test_generated_gradient_against_central_differences(which):
+    gen, spec = _gen(which)
+    lanes = gen.lanes
+    idx = GM.to_spec_order(gen, spec)
+    q = (spec.to_unconstrained(spec.default_init) + 0.05 * np.random.default_rng(2).normal(size=spec.d))[idx]
+    _, g = GC.logp_grad(gen, q, lanes=lanes)
+    for i in list(range(0, gen.d, 7)) + [gen.d - 1]:
+        h = 1e-6
+        qp, qm = q.copy(), q.copy()
+        qp[i] += h
+        qm[i] -= h
+        fd = (GC.logp_grad(gen, qp, lanes=lanes)[0] - GC.logp_grad(gen, qm, lanes=lanes)[0]) / (2 * h)
+        assert abs(fd - g[i]) <= 2e-5 * max(1.0, abs(g[i])), (which, i, fd, g[i])
+
+
+def test_structure_found_in_the_graphs():
+    """What the hand-written kernels exploit is found from the node lists: sv = the 100 StudentT
+    terms + the 99 random-walk steps (s_1's prior has another shape and stays uniform, like the two
+    hyper-priors); radon = 88 Normal priors (85 intercepts + 3 hyper-parameters, their constants
+    per unit) + 919 observations gathering their county's intercept; logistic = 21 priors + 500
+    observations whose 21 inputs are all shared (no gather: 21 reduced adjoints + the density)."""
+    sv, _ = _gen("sv")
+    assert sv.lane_layout["family_sizes"] == [100, 99] and sv.lane_layout["n_scalar_units"] == 3
+    assert sv.lane_layout["gather_width"] == [3, 3]          # s_t: its own term, step t, step t + 1
+    rd, _ = _gen("radon")
+    assert rd.lane_layout["family_sizes"] == [88, 919] and rd.lane_layout["n_scalar_units"] == 2
+    lg, _ = _gen("logistic")
+    assert lg.lane_layout["family_sizes"] == [21, 500] and lg.lane_layout["n_reduced"] == 22
+    assert lg.lane_layout["dpl"] == 2 and sv.lane_layout["dpl"] == 2 and rd.lane_layout["dpl"] == 2
+
+
+def test_models_above_the_one_lane_limit_pick_the_lane_layout_themselves():
+    ir, ncp, spec, _ = GM.baseline_pair("radon")
+    gen = cg.generate(ir, ncp=ncp)
+    assert gen.lanes == 64 and "EXMC_GEN_ONE_LANE" not in gen.header and gen.lane_layout is not None
+    ir, ncp, spec, _ = GM.baseline_pair("logistic")
+    assert cg.generate(ir, ncp=ncp).lanes == 16            # d = 21: 16 lanes, two dimensions per lane
+    with pytest.raises(cg.CodegenError):
+        cg.generate(GM.simple_ir(), lanes=8)
+
+
+@pytest.mark.parametrize("name", ["zoo", "walk", "eight_schools", "simple"])
+def test_lane_layout_of_small_models_equals_their_one_lane_layout(name):
+    """The lane layout is general: models of the one-lane tests (every distribution and transform,
+    refs, the non-centred rewrite, vector obs, a random walk, MvNormal, a Custom closure, meas_obs)
+    give the same density and gradient in both layouts up to the order of the sums."""
+    ir = dict(zoo=GM.zoo_ir, walk=GM.walk_ir, eight_schools=GM.eight_schools_ir, simple=GM.simple_ir)[name]()
+    gen = cg.generate(ir, lanes=16)
+    assert "EXMC_GEN_ONE_LANE" in gen.header and gen.lane_layout is not None and gen.vec is None
+    rng = np.random.default_rng(8)
+    for t in range(40):
+        q = rng.normal(size=gen.d) * 0.8
+        lp1, g1 = GC.logp_grad(gen, q, lanes=1)
+        lpl, gl = GC.logp_grad(gen, q, lanes=16)
+        assert abs(lp1 - lpl) <= 1e-12 * max(1.0, abs(lp1)), (name, t)
+        assert np.all(np.abs(g1 - gl) <= 1e-11 * np.maximum(1.0, np.abs(g1))), (name, t)
+
+
+def test_a_reduction_written_by_hand_is_split_into_units():
+    """validate_posteriordb.exs:279-295 reduces with Enum.reduce / Nx.add, not Nx.sum: a closure
+    result without a registered sum is split at every add at its top."""
+    y = np.random.default_rng(1).normal(size=24)
+    ir = cg.IR()
+    ir.rv("mu", "normal", dict(mu=0.0, sigma=5.0))
+    ir.rv("tau", "half_cauchy", dict(scale=5.0), transform="log")
+    for j in range(24):
+        ir.rv("t_%02d" % j, "normal", dict(mu=0.0, sigma=1.0))
+
+    def lik(o, _x, p):
+        acc = o.lit(0.0)
+        for j in range(24):
+            theta = o.add(p["mu"], o.mul(p["tau"], p["t_%02d" % j]))
+            z = o.div(o.sub(o.data(y[j]), theta), o.data(1.0 + 0.1 * j))
+            acc = o.add(acc, o.sub(o.mul(o.lit(-0.5), o.mul(z, z)), o.log(o.data(1.0 + 0.1 * j))))
+        return acc
+    params = {"t_%02d" % j: "t_%02d" % j for j in range(24)}
+    params.update(mu="mu", tau="tau", logpdf=lik)
+    ir.rv("lik", "custom", params)
+    ir.obs("lik_obs", "lik", 0.0)
+    gen = cg.generate(ir, lanes=16)
+    assert gen.d == 26 and sorted(gen.lane_layout["family_sizes"]) == [24, 25]
+    q = np.random.default_rng(3).normal(size=26) * 0.5
+    lp, g = GC.logp_grad(gen, q, lanes=16)
+    # closed form
+    assert gen.var_names == ["mu"] + ["t_%02d" % j for j in range(24)] + ["tau"]
+    mu, ltau, tau, th = q[0], q[25], np.exp(q[25]), q[1:25]
+    s = 1.0 + 0.1 * np.arange(24)
+    ref = (-0.5 * ((mu / 5) ** 2 + np.log(np.float32(2 * np.pi)) + 2 * np.log(5.0))
+           + np.log(2 / np.pi) - np.log(5.0) - np.log1p((tau / 5) ** 2) + ltau
+           + np.sum(-0.5 * (th ** 2 + np.log(np.float32(2 * np.pi))))
+           + np.sum(-0.5 * ((y - (mu + tau * th)) / s) ** 2 - np.log(s)))
+    assert abs(lp - ref) < 1e-6 * abs(ref)
+
+
+def test_f32_params_follow_nx_type_inference():
+    """Nx.log of Nx.tensor(50.0) (f32) is an f32 tensor: exponential.ex:16 with the benchmark's
+    untyped literals gives f32(log 50), which is what the hand-written sv kind carries."""
+    g = cg._Graph()
+    lam = g.datum32(0.1)
+    assert g.data[g.ops[lam][1]] == float(np.float32(0.1))
+    ll = g.log(lam)
+    assert ll in g.f32 and g.data[g.ops[ll][1]] == float(np.float32(np.log(float(np.float32(0.1)))))
+    x = g.q(0)
+    assert g.mul(lam, x) not in g.f32          # f32 x f64 -> f64, computed at run time
+
+
+def test_flatten_rules():
+    g = cg._Graph()
+    a, b, c, d = (g.q(i) for i in range(4))
+    s = cg._sum_left(g, [g.exp(a), g.exp(b), g.exp(c)])
+    t = g.add(g.log(d), s)                                   # e.g. logp_init + sum(steps)
+    assert cl._flatten(g, t, False) == [g.log(d), g.exp(a), g.exp(b), g.exp(c)]
+    u = g.add(g.add(g.exp(a), g.exp(b)), g.exp(c))            # an add chain without a registered sum ...
+    g.sums.clear()
+    assert cl._flatten(g, u, False) == [u]                   # ... is one term of the model,
+    assert cl._flatten(g, u, True) == [g.exp(a), g.exp(b), g.exp(c)]   # a reduction inside a closure

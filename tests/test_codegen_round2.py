@@ -111,9 +111,12 @@ def test_refusals():
     with pytest.raises(cg.CodegenError):
         cg.generate(ir)
     ir = cg.IR()
-    ir.rv("x", "gaussian_random_walk", dict(sigma=1.0, steps=25))       # 25 flat dimensions > 20
-    with pytest.raises(cg.CodegenError):
-        cg.generate(ir)
+    ir.rv("x", "gaussian_random_walk", dict(sigma=1.0, steps=25))       # 25 flat dimensions > 20:
+    gen = cg.generate(ir)                                               # the lane layout since round 3
+    assert gen.lanes == 16 and gen.lane_layout["family_sizes"] == [24]
+    x = np.cumsum(np.random.default_rng(0).normal(size=25))
+    want = sum(stats.norm.logpdf(d, 0.0, 1.0) for d in np.diff(np.concatenate([[0.0], x])))
+    assert abs(GC.logp_grad(gen, x, lanes=16)[0] - want) < 1e-6
     ir = cg.IR()
     ir.rv("a", "normal", dict(mu=0.0, sigma=1.0))
     ir.rv("k_rv", "normal", dict(mu="a", sigma=1.0))

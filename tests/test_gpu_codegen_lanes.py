@@ -1,0 +1,105 @@
+"""GPU parity for the lane layout of generated models (exmc_amd/codegen_lanes.py): stochastic
+volatility, radon and the logistic regression compiled from Builder node lists, through the C ABI
+of their plug-in libraries, against the CPU oracle running the same generated text on virtual
+lanes (tests/gen_checker.py) -- bit for bit -- and against the hand-written kinds of the oracle
+(an independent restatement of the same densities) to 1e-12."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import gen_checker as GC
+import gen_models as GM
+import oracle as O
+from exmc_amd import codegen as cg, sampler
+
+pytestmark = pytest.mark.gpu
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+_cache = {}
+
+
+def _compiled(which, hip):
+    if which not in _cache:
+        if which in ("zoo16", "walk16"):
+            ir = GM.zoo_ir() if which == "zoo16" else GM.walk_ir()
+            init = GM.ZOO_INIT if which == "zoo16" else GM.WALK_INIT
+            spec = cg.compile_ir(ir, name=which, default_init=init, lanes=16)
+            hand = None
+        else:
+            ir, ncp, hand, lanes = GM.baseline_pair(which)
+            spec = cg.compile_ir(ir, ncp=ncp, name="gen_" + which, default_init=hand.default_init, lanes=lanes)
+        lanes = spec.gen.lanes
+        _cache[which] = (spec, sampler.compile(spec), GC.model(spec.gen, lanes), hand, lanes)
+    return _cache[which]
+
+
+@pytest.mark.parametrize("which", ["sv", "radon", "logistic", "zoo16", "walk16"])
+def test_lane_layout_logp_grad_bit_exact(which, hip):
+    spec, comp, om, hand, lanes = _compiled(which, hip)
+    assert comp.default_lanes == lanes
+    rng = np.random.default_rng(11)
+    n = 200
+    scale = 0.1 if which == "sv" else 0.4
+    q0 = spec.to_unconstrained(spec.default_init)
+    q = np.ascontiguousarray(q0[None, :] + rng.normal(size=(n, spec.d)) * scale)
+    q[0] = q0
+    q[1, :] = 250.0      # beyond every clamp
+    q[2, :] = -250.0
+    q[3, :] = 0.0
+    q[4] = q0 + rng.normal(size=spec.d) * 8.0
+    lp = np.zeros(n)
+    g = np.zeros((n, spec.d))
+    comp.check(comp.L.exmc_hip_logp_grad_host(comp.h, _dp(q), n, lanes, _dp(lp), _dp(g)))
+    cfg = O.Cfg(1, lanes)
+    for c in range(n):
+        olp, og = om.logp_grad(q[c], cfg)
+        assert olp == lp[c] or (np.isnan(olp) and np.isnan(lp[c])), (which, c, olp, lp[c])
+        assert np.array_equal(og, g[c], equal_nan=True), (which, c)
+    if hand is not None:
+        hm = O.model_for(hand)
+        idx = GM.to_spec_order(spec.gen, hand)
+        inv = np.argsort(idx)
+        for c in range(5, 60):
+            hlp, hg = hm.logp_grad(q[c][inv], O.Cfg(0, 1))
+            assert abs(hlp - lp[c]) <= 1e-12 * max(1.0, abs(hlp)), (which, c)
+            assert np.all(np.abs(hg[idx] - g[c]) <= 2e-12 * max(1.0, np.max(np.abs(hg)))), (which, c)
+
+
+@pytest.mark.parametrize("which", ["sv", "radon", "logistic", "walk16"])
+def test_lane_layout_sample_bit_exact(which, hip):
+    """Sampler.sample/3 end to end (on-device adaptation + sampling) on the generated lane kernels."""
+    spec, comp, om, _, lanes = _compiled(which, hip)
+    nw, ns = (120, 60) if which == "sv" else (150, 100)
+    opts = dict(num_warmup=nw, num_samples=ns, seed=17, lanes_per_chain=lanes)
+    trace, stats = sampler.sample_compiled(comp, spec.default_init, opts)
+    q0 = spec.to_unconstrained(spec.default_init)
+    t, st = O.sample(om, init_q=q0, num_warmup=nw, num_samples=ns, seed=17, cfg=O.Cfg(1, lanes))
+    assert stats["step_size"] == st.step_size
+    raw = stats["raw"]
+    assert np.array_equal(raw["tree_depth"][0], t["tree_depth"])
+    assert np.array_equal(raw["n_steps"][0], t["n_steps"])
+    assert np.array_equal(raw["divergent"][0], t["divergent"])
+    assert np.array_equal(raw["draws"][0], t["draws"])
+    assert np.array_equal(raw["energy"][0], t["energy"])
+
+
+@pytest.mark.parametrize("which", ["sv", "logistic"])
+def test_lane_layout_chain_batches_bit_exact(which, hip):
+    """A batch of chains after the shared warmup (logistic: four chains per wavefront, each with
+    its own LDS strip; sv: one chain per wavefront)."""
+    spec, comp, om, _, lanes = _compiled(which, hip)
+    nc, nw, ns = (24, 100, 30) if which == "sv" else (70, 120, 60)
+    opts = dict(num_warmup=nw, num_samples=ns, seed=42, init_values=spec.default_init)
+    _, stats = sampler.sample_chains_compiled(comp, nc, opts)
+    q0 = spec.to_unconstrained(spec.default_init)
+    t, st = O.sample_chains(om, nc, init_q=q0, num_warmup=nw, num_samples=ns, seed=42,
+                            cfg=O.Cfg(1, lanes), n_threads=8)
+    raw = stats[0]["extra"]["raw"]
+    assert stats[0]["step_size"] == st.step_size
+    for k in ("draws", "logp", "tree_depth", "n_steps", "divergent", "accept_prob", "energy"):
+        assert np.array_equal(raw[k], t[k]), k

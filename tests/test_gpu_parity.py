@@ -653,12 +653,48 @@ def test_sample_stream_push_equals_sample(hip, name):
     comp.check(L.exmc_hip_stream_start(comp.h, 10, C.byref(view), C.byref(prog)))
     with pytest.raises(Exception):                  # one run in flight at a time
         comp.check(L.exmc_hip_stream_start(comp.h, 10, C.byref(view), C.byref(prog)))
+    # ... and nothing else on the handle either: the launch owns its stream, events, counters and
+    # trace until stream_finish (a poller may be a thread of the caller's own)
+    q1 = np.zeros((1, spec.d))
+    lp1, g1 = np.zeros(1), np.zeros((1, spec.d))
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))   # noqa: E731
+    assert L.exmc_hip_logp_grad_host(comp.h, dp(q1), 1, 0, dp(lp1), dp(g1)) != 0
+    assert b"in flight" in L.exmc_hip_last_error()
+    with pytest.raises(Exception):
+        sampler.warmup(comp, spec.default_init, dict(opts, num_warmup=5))
     div = C.c_int32()
     comp.check(L.exmc_hip_stream_finish(comp.h, C.byref(div)))
     assert prog[0] == 10
+    assert L.exmc_hip_logp_grad_host(comp.h, dp(q1), 1, 0, dp(lp1), dp(g1)) == 0
     t2, s2 = sampler.sample_compiled(comp, spec.default_init, dict(opts, stream_push=False, num_samples=n + 10))
     got = np.ctypeslib.as_array(C.cast(view.draws, C.POINTER(C.c_double)), shape=(10 * spec.d,)).reshape(10, spec.d)
     assert np.array_equal(got, s2["raw"]["draws"][0][n:])
+
+
+def test_stream_push_always_finishes_its_run(hip):
+    """A receiver that raises (or a timeout) must not leave the handle with a run in flight: the
+    library side is finished before sample_stream returns, and the handle works afterwards."""
+    spec = models.eight_schools()
+    comp = sampler.compile(spec)
+    opts = dict(num_warmup=60, num_samples=40, seed=3, stream_push=True)
+
+    class Boom(Exception):
+        pass
+
+    def bad(msg):
+        if msg[0] == "exmc_sample" and msg[1] == 3:
+            raise Boom()
+    with pytest.raises(Boom):
+        sampler.sample_stream(comp, bad, spec.default_init, opts)
+    msgs = []
+    assert sampler.sample_stream(comp, msgs.append, spec.default_init, opts) == "ok"
+    assert len(msgs) == 41
+    # a dense mass left on the handle by an earlier run does not leak into the stream
+    sampler.sample_compiled(comp, spec.default_init, dict(num_warmup=150, num_samples=5, seed=3, dense_mass=True,
+                                                         lanes_per_chain=16))
+    again = []
+    assert sampler.sample_stream(comp, again.append, spec.default_init, opts) == "ok"
+    assert again == msgs
 
 
 def test_dense_mass_lane_layout_edge_cases(hip):
