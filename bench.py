@@ -78,7 +78,12 @@ def make_spec(name):
             ir = codegen.radon_ir(hand.data[:J], start, hand.data[2 * J + 1:2 * J + 1 + nobs],
                                   hand.data[2 * J + 1 + nobs:], names=cty)
             ncp, lanes = False, 64
-        return codegen.compile_ir(ir, ncp=ncp, name=name, default_init=hand.default_init, lanes=lanes), nbytes
+        # radon's 1024 chains are 1024 wavefronts, one per SIMD: no second wave to make room for
+        # (the generated sv and logistic kernels measure faster uncapped too: under the 256-register
+        # cap their model bodies spill inside the leaf loop, profiles/r3_gen; EXMC_GEN_WPS=2 for A/B runs)
+        wps = int(os.environ.get("EXMC_GEN_WPS", "1"))
+        return codegen.compile_ir(ir, ncp=ncp, name=name, default_init=hand.default_init, lanes=lanes,
+                                  waves_per_simd=wps), nbytes
     raise SystemExit("unknown model %s" % name)
 
 

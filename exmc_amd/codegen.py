@@ -875,7 +875,7 @@ def _apply_ncp(ir, ncp):
     return nodes, info
 
 
-def generate(ir, ncp=True, vectorize=True, rewrite_passes=False, lanes=None):
+def generate(ir, ncp=True, vectorize=True, rewrite_passes=False, lanes=None, waves_per_simd=1):
     """Compiler.compile_for_sampling (compiler.ex:46-58) as source text. `rewrite_passes` runs the
     reference's IR passes first (`rewrite`); without it the IR is taken as already rewritten
     (transforms explicit), which is what an exporter on the Elixir side sends. `lanes` = 16 / 32 /
@@ -1208,9 +1208,11 @@ def generate(ir, ncp=True, vectorize=True, rewrite_passes=False, lanes=None):
     if lanes is not None:
         # several dimensions per lane (codegen_lanes.py): any d, the repeated terms over the lanes
         from . import codegen_lanes
-        out.lane_layout = codegen_lanes.generate(g, terms, custom_roots, out.d, lanes)
-        out.header += "\n#define EXMC_GEN_LOFF %d   /* where the lane layout's table starts in data */\n" \
-                      % out.data.size + out.lane_layout["text"]
+        out.lane_layout = codegen_lanes.generate(g, terms, custom_roots, out.d, lanes, waves_per_simd)
+        # (the lane function is a section of its own that its users include once per table placement)
+        out.header = "#ifndef EXMC_GEN_LANES_SECTION\n" + out.header + \
+                     "\n#define EXMC_GEN_LOFF %d   /* where the lane layout's table starts in data */\n" \
+                     % out.data.size + out.lane_layout["text"]
         out.data = np.concatenate([out.data, out.lane_layout["data"]])
         out.lanes = lanes
     out.digest = hashlib.sha256(out.header.encode()).hexdigest()[:16]
@@ -1494,10 +1496,10 @@ class GeneratedSpec(ModelSpec):
 
 
 def compile_ir(ir, ncp=True, name="generated", default_init=None, verbose=False, rewrite_passes=False,
-               lanes=None):
-    """IR -> GeneratedSpec with its plug-in library built. Needs hipcc (no fallback). `lanes`:
-    see `generate`."""
-    gen = generate(ir, ncp=ncp, rewrite_passes=rewrite_passes, lanes=lanes)
+               lanes=None, waves_per_simd=1):
+    """IR -> GeneratedSpec with its plug-in library built. Needs hipcc (no fallback). `lanes`,
+    `waves_per_simd`: see `generate` / codegen_lanes.generate."""
+    gen = generate(ir, ncp=ncp, rewrite_passes=rewrite_passes, lanes=lanes, waves_per_simd=waves_per_simd)
     so = build_plugin(gen, verbose=verbose)
     return GeneratedSpec(gen, so, name=name, default_init=default_init)
 

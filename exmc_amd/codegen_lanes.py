@@ -190,6 +190,94 @@ class _Family:
     pass
 
 
+def _nonzero_const(g, n):
+    """A constant node whose value is finite and not zero (so that its reciprocal is a constant too)."""
+    v = float(_np_eval(g, [n], lambda op: np.float64(g.data[op[1]]))[n])
+    return math.isfinite(v) and v != 0.0 and math.isfinite(1.0 / v)
+
+
+def _forward_tangents(g, roots):
+    """{node: {shared variable index: tangent node}} for every non-constant node the roots need.
+    Local rules mirror codegen._Grad (max / min pass the tangent on strict inequality only)."""
+    need, stack = set(), list(roots)
+    while stack:
+        n = stack.pop()
+        if n in need or g.const[n]:
+            continue
+        need.add(n)
+        if g.ops[n][0] not in _LEAVES:
+            stack.extend(g.ops[n][1:])
+    zero = g.lit(0.0)
+    tan = {}
+
+    def both(ta, tb, fa, fb, fab):
+        out = {}
+        for v in set(ta) | set(tb):
+            if v in ta and v in tb:
+                out[v] = fab(ta[v], tb[v])
+            elif v in ta:
+                out[v] = fa(ta[v])
+            else:
+                out[v] = fb(tb[v])
+        return out
+    for n in sorted(need):
+        op = g.ops[n]
+        k = op[0]
+        if k == "q":
+            tan[n] = {op[1]: g.lit(1.0)}
+            continue
+        if k in _LEAVES:
+            tan[n] = {}
+            continue
+        a = op[1:]
+        t = [tan.get(x, {}) for x in a]
+        ident = lambda x: x   # noqa: E731
+        if k == "add":
+            r = both(t[0], t[1], ident, ident, g.add)
+        elif k == "sub":
+            r = both(t[0], t[1], ident, g.neg, g.sub)
+        elif k == "neg":
+            r = {v: g.neg(x) for v, x in t[0].items()}
+        elif k == "mul":
+            r = both(t[0], t[1], lambda x: g.mul(x, a[1]), lambda y: g.mul(a[0], y),
+                     lambda x, y: g.add(g.mul(x, a[1]), g.mul(a[0], y)))
+        elif k == "div":
+            if not t[0] and g.const[a[0]] and _nonzero_const(g, a[0]):
+                # c / b with a constant numerator: d/db = -y^2 / c, and 1 / c is folded with the data --
+                # no second division at run time (a Lanczos series is eight such terms)
+                rc = g.recip(a[0])
+                r = {v: g.neg(g.mul(g.mul(g.mul(n, n), rc), y)) for v, y in t[1].items()}
+            else:
+                rb = g.recip(a[1])
+                r = both(t[0], t[1], lambda x: g.mul(x, rb), lambda y: g.neg(g.mul(g.mul(n, y), rb)),
+                         lambda x, y: g.mul(g.sub(x, g.mul(n, y)), rb))
+        elif k == "exp":
+            r = {v: g.mul(n, x) for v, x in t[0].items()}
+        elif k == "log":
+            ra = g.recip(a[0])
+            r = {v: g.mul(x, ra) for v, x in t[0].items()}
+        elif k == "log1p":
+            ra = g.recip(g.add(g.lit(1.0), a[0]))
+            r = {v: g.mul(x, ra) for v, x in t[0].items()}
+        elif k == "erf":
+            d = g.mul(g.lit(2.0 / math.sqrt(math.pi)), g.exp(g.neg(g.mul(a[0], a[0]))))
+            r = {v: g.mul(x, d) for v, x in t[0].items()}
+        elif k == "abs":
+            r = {v: g.sel_gt(a[0], zero, x, g.sel_gt(zero, a[0], g.neg(x), zero)) for v, x in t[0].items()}
+        elif k in ("max", "min"):
+            first, second = (a[0], a[1]) if k == "max" else (a[1], a[0])
+            r = both(t[0], t[1], lambda x: g.sel_gt(first, second, x, zero),
+                     lambda y: g.sel_gt(second, first, y, zero),
+                     lambda x, y: g.add(g.sel_gt(first, second, x, zero), g.sel_gt(second, first, y, zero)))
+        elif k == "sel_gt":
+            r = both(t[2], t[3], lambda x: g.sel_gt(a[0], a[1], x, zero), lambda y: g.sel_gt(a[0], a[1], zero, y),
+                     lambda x, y: g.sel_gt(a[0], a[1], x, y))
+        else:
+            raise cg.CodegenError("no tangent rule for %s" % k)
+        tan[n] = r
+    return tan
+
+
 def plan(g, term_roots, custom_roots, D, G):
     """Units, families and the uniform remainder of the graph `g` whose terms are `term_roots`."""
     units = []
@@ -220,8 +308,15 @@ def plan(g, term_roots, custom_roots, D, G):
     return families, scalar_units
 
 
-def generate(g, term_roots, custom_roots, D, G):
-    """-> dict(text, data, lanes, dpl, ...) for the lane layout."""
+def generate(g, term_roots, custom_roots, D, G, waves_per_simd=1):
+    """-> dict(text, data, lanes, dpl, ...) for the lane layout. waves_per_simd: resident waves per
+    SIMD the sampling kernel's register allocation must allow (ModelDefaults::kNutsWavesPerSimd):
+    1 leaves the allocator the whole file; 2 caps it at 256 vector registers, which can pay when a
+    launch has more wavefronts than the chip has SIMDs (chains x lanes / 64 > 1024) -- it does for
+    the hand-written sv and logistic kinds, it does not for their generated forms, whose bodies
+    then spill inside the leaf loop (profiles/r3_gen)."""
+    if waves_per_simd not in (1, 2):
+        raise cg.CodegenError("waves_per_simd must be 1 or 2")
     if G not in (16, 32, 64):
         raise cg.CodegenError("lanes per chain must be 16, 32 or 64")
     DPL = (D + G - 1) // G
@@ -346,17 +441,24 @@ def generate(g, term_roots, custom_roots, D, G):
             if j not in acc_of:
                 acc_of[j] = 1 + len(acc_of)
     NS = 1 + len(acc_of)
-    U = scalar_lp
-    for j, s in sorted(acc_of.items(), key=lambda kv: kv[1]):
-        U = g.add(U, g.mul(g._node("red", s), boundary[j]))
+    # Forward mode for the uniform part: it has few inputs (the shared variables) and is evaluated
+    # BEFORE the family loops, while its reduced adjoint seeds only exist after them -- a reverse
+    # sweep would keep every intermediate of e.g. two Lanczos series alive across the loops (a
+    # hundred vector registers in the sampling kernel). Tangents d node / d shared variable are
+    # computed next to the values instead; what stays live is the Jacobian of the boundary nodes:
+    #   d logp / d q_i = d scalar_lp / d q_i + sum_j red_j * d b_j / d q_i
+    fwd_roots = [scalar_lp] + list(boundary)
+    tan = _forward_tangents(g, fwd_roots)
     ug = {}
-    if not g.const[U]:
-        ad = cg._Grad(g, U)
-        ad.run(len(g.ops))
-        for i in range(D):
-            qn = g.key.get(("q", i))
-            if qn is not None and ad.adj.get(qn) is not None:
-                ug[i] = ad.adj[qn]
+    for i in range(D):
+        acc = tan.get(scalar_lp, {}).get(i)
+        for j, sl_ in sorted(acc_of.items(), key=lambda kv: kv[1]):
+            tj = tan.get(boundary[j], {}).get(i)
+            if tj is not None:
+                term = g.mul(g._node("red", sl_), tj)
+                acc = term if acc is None else g.add(acc, term)
+        if acc is not None:
+            ug[i] = acc
 
     # liveness of the uniform graph
     outputs = [scalar_lp] + list(ug.values()) + [b for b in boundary]
@@ -384,19 +486,24 @@ def generate(g, term_roots, custom_roots, D, G):
     for i in range(D):
         width[i // G] = max(width[i // G], len(contrib[i]))
     zero_cell = D
-    ell_off, ell = [], []
+    # per lane contiguous: [lane][slot k][j < width[k]] -- a lane's whole list is NELL ints, which the
+    # device functor keeps in registers when it is short (Lane::ell)
+    ell_off, NELL = [], 0
     for k in range(DPL):
-        ell_off.append(len(ell))
-        for j in range(width[k]):
-            for l in range(G):
-                i = l + k * G
+        ell_off.append(NELL)
+        NELL += width[k]
+    ell = []
+    for l in range(G):
+        for k in range(DPL):
+            i = l + k * G
+            for j in range(width[k]):
                 ell.append(contrib[i][j] if (i < D and j < len(contrib[i])) else zero_cell)
 
     # ---- table layout: [uc][double columns][int32 columns (gather indices, owner lists)] ----
     NUC = max(1, len(uc_vals))
     doff = NUC
     for f in families:
-        f.doff = doff
+        f.doff = doff                     # row-major: unit u's constants are len(cols) consecutive doubles
         doff += len(f.cols) * f.npad
     ints = []
     for f in families:
@@ -410,8 +517,10 @@ def generate(g, term_roots, custom_roots, D, G):
         ints.append(0)
     dtab = [np.asarray(uc_vals + [0.0] * (NUC - len(uc_vals)), dtype=np.float64)]
     for f in families:
-        for c in f.cols:
-            dtab.append(np.concatenate([c, np.full(f.npad - f.n, c[0])]))
+        if f.cols:
+            rows = np.stack(f.cols, axis=1)                       # [n][ncol]
+            rows = np.concatenate([rows, np.repeat(rows[:1], f.npad - f.n, axis=0)])
+            dtab.append(rows.ravel())
     data = np.concatenate(dtab + [np.asarray(ints, dtype=np.int32).view(np.float64)]) \
         if ints else np.concatenate(dtab)
     ioff_doubles = doff
@@ -439,6 +548,41 @@ def generate(g, term_roots, custom_roots, D, G):
             return "(%s > %s) ? %s : %s" % tuple(a)
         raise cg.CodegenError("cannot emit %s" % op)
 
+    def fuse_plan(gr, nodes, pinned):
+        """Contraction at emission (the lane layout's own numeric contract, like the fma chains of the
+        hand-written kernels): a product with a single consumer that is a sum or a difference is
+        emitted as one fused multiply-add. -> {consumer: (form, product)}, set of absorbed products."""
+        uses = {}
+        for i in nodes:
+            for a in gr.ops[i][1:]:
+                uses[a] = uses.get(a, 0) + 1
+        plan, gone = {}, set()
+        for i in nodes:
+            op = gr.ops[i]
+            if op[0] not in ("add", "sub"):
+                continue
+            for side in (1, 0):
+                m = op[1 + side]
+                if (m in nodes and gr.ops[m][0] == "mul" and uses.get(m, 0) == 1 and m not in pinned
+                        and m not in gone and not gr.const[m]):
+                    plan[i] = (op[0], side, m)
+                    gone.add(m)
+                    break
+        # an output that is a product nobody else reads is fused into its accumulation
+        acc_mul = set(m for m in pinned if m in nodes and gr.ops[m][0] == "mul" and uses.get(m, 0) == 0
+                      and not gr.const[m])
+        return plan, gone, acc_mul
+
+    def fused(gr, i, plan, ref):
+        kind, side, m = plan[i]
+        a, b = (ref(x) for x in gr.ops[m][1:])
+        other = ref(gr.ops[i][2 - side])
+        if kind == "add":
+            return "EXMC_GEN_FMA(%s, %s, %s)" % (a, b, other)
+        if side == 1:                               # other - a * b
+            return "EXMC_GEN_FMA(-(%s), %s, %s)" % (a, b, other)
+        return "EXMC_GEN_FMA(%s, %s, -(%s))" % (a, b, other)     # a * b - other
+
     def uref(i):
         op = g.ops[i]
         if op[0] == "lit":
@@ -446,18 +590,23 @@ def generate(g, term_roots, custom_roots, D, G):
         if op[0] == "red":
             return "s[%d]" % op[1]
         if g.const[i]:
-            return "lt[%d]" % uc_of[("node", i)]
+            return "EXMC_GEN_LT(%d)" % uc_of[("node", i)]
         return "u%d" % i
+
+    u_nodes = set(i for i in live if not g.const[i] and g.ops[i][0] not in _LEAVES)
+    u_pinned = set([scalar_lp] + list(ug.values()) + list(boundary))
+    u_plan, u_gone, _ = fuse_plan(g, u_nodes, u_pinned)
 
     def ustmts(lo, hi):
         out = []
         if lo == 0:     # the shared variables: broadcast reads of the position strip
             out.extend("  const double u%d = EXMC_GEN_SH(%d);" % (i, g.ops[i][1])
                        for i in sorted(live) if g.ops[i][0] == "q")
-        for i in sorted(live):
-            if lo <= i < hi and not g.const[i] and g.ops[i][0] not in _LEAVES:
+        for i in sorted(u_nodes):
+            if lo <= i < hi and i not in u_gone:
                 op = g.ops[i]
-                out.append("  const double u%d = %s;" % (i, expr(op[0], [uref(x) for x in op[1:]])))
+                e = fused(g, i, u_plan, uref) if i in u_plan else expr(op[0], [uref(x) for x in op[1:]])
+                out.append("  const double u%d = %s;" % (i, e))
         return out
 
     L = []
@@ -474,9 +623,17 @@ def generate(g, term_roots, custom_roots, D, G):
     L.append("#define EXMC_GEN_LSH %d" % lsh)
     L.append("#define EXMC_GEN_NS %d" % NS)
     L.append("#define EXMC_GEN_NLT %d" % data.size)
+    L.append("#define EXMC_GEN_NELL %d   /* ints of a lane's owner list */" % max(1, NELL))
+    L.append("#define EXMC_GEN_ELL_OFF %d   /* ... of lane l at ((const int*)lt)[EXMC_GEN_ELL_OFF + l * EXMC_GEN_NELL] */"
+             % (2 * ioff_doubles + ell_base))
+    L.append("#define EXMC_GEN_WAVES_PER_SIMD %d" % waves_per_simd)
     L.append("")
-    L.append("EXMC_GEN_FN double exmc_gen_lanes(const double* lt, int l, double* g EXMC_GEN_CTX_DECL) {")
-    L.append("  const int* it = (const int*)(lt + %d);" % ioff_doubles)
+    L.append("#define EXMC_GEN_IOFF %d   /* the int32 tables start at double EXMC_GEN_IOFF of lt */" % ioff_doubles)
+    L.append("")
+    L.append("#else   /* EXMC_GEN_LANES_SECTION: the lane function itself. Included once per table placement")
+    L.append("       * with EXMC_GEN_LANES_NAME, EXMC_GEN_LT(i) (double i of the table) and EXMC_GEN_IT(i) (int32 i")
+    L.append("       * of its index part) defined by the includer: global memory, or an LDS image of it */")
+    L.append("EXMC_GEN_FN double EXMC_GEN_LANES_NAME(const double* lt, const int* el, int l, double* g EXMC_GEN_CTX_DECL) {")
     L.append("  EXMC_GEN_SH(%d) = 0.0;" % zero_cell)
     L.extend(ustmts(0, n_split))
     L.append("  double s[EXMC_GEN_NS];")
@@ -489,10 +646,10 @@ def generate(g, term_roots, custom_roots, D, G):
             if op[0] == "lit":
                 return lit_text(op[1])
             if op[0] == "uc":
-                return "lt[%d]" % op[1]
+                return "EXMC_GEN_LT(%d)" % op[1]
             if i in f.col_of:
                 kind, k = f.col_of[i]
-                return "lt[%d]" % k if kind == "uc" else "c%d" % k
+                return "EXMC_GEN_LT(%d)" % k if kind == "uc" else "c%d" % k
             if op[0] == "ext":
                 return uref(boundary[op[1]])
             if op[0] == "gat":
@@ -502,27 +659,40 @@ def generate(g, term_roots, custom_roots, D, G):
         L.append("  for (int sl = 0; sl < %d; sl++) {" % f.S)
         L.append("    const int un = sl * %d + l;" % G)
         if f.n < f.npad:
-            L.append("    const int on = un < %d;" % f.n)
+            L.append("    if (un < %d) {" % f.n)
         for p in range(len(f.gather)):
-            L.append("    const double v%d = EXMC_GEN_SH(it[%d + un]);" % (p, f.ioff + p * f.npad))
+            L.append("    const double v%d = EXMC_GEN_SH(EXMC_GEN_IT(%d + un));" % (p, f.ioff + p * f.npad))
+        if f.cols:
+            L.append("    const int row = %d + un * %d;" % (f.doff, len(f.cols)))
         for c in range(len(f.cols)):
-            L.append("    const double c%d = lt[%d + un];" % (c, f.doff + c * f.npad))
-        for i in sorted(f.live):
-            op = T.ops[i]
-            if T.const[i] or op[0] in _LEAVES:
-                continue
-            L.append("    const double t%d = %s;" % (i, expr(op[0], [tref(x) for x in op[1:]])))
+            L.append("    const double c%d = EXMC_GEN_LT(row + %d);" % (c, c))
+        t_nodes = set(i for i in f.live if not T.const[i] and T.ops[i][0] not in _LEAVES)
+        t_pinned = set([f.troot] + list(f.ext_adj.values()) + [a for a in f.gat_adj if a is not None])
+        t_plan, t_gone, t_accmul = fuse_plan(T, t_nodes, t_pinned)
+        n_use = {}
+        for x in [f.troot] + list(f.ext_adj.values()):
+            n_use[x] = n_use.get(x, 0) + 1
+        t_accmul = set(m for m in t_accmul if n_use.get(m, 0) == 1 and m not in [a for a in f.gat_adj if a is not None])
 
-        def accum(slot, val, f=f):
-            if f.n < f.npad:
-                return "    s[%d] = on ? (s[%d] + %s) : s[%d];" % (slot, slot, val, slot)
-            return "    s[%d] = s[%d] + %s;" % (slot, slot, val)
-        L.append(accum(0, tref(f.troot)))
+        def accumulate(slot, node, T=T, t_accmul=t_accmul, tref=tref):
+            if node in t_accmul:
+                a, b = (tref(x) for x in T.ops[node][1:])
+                return "    s[%d] = EXMC_GEN_FMA(%s, %s, s[%d]);" % (slot, a, b, slot)
+            return "    s[%d] = s[%d] + %s;" % (slot, slot, tref(node))
+        for i in sorted(t_nodes):
+            if i in t_gone or i in t_accmul:
+                continue
+            op = T.ops[i]
+            e = fused(T, i, t_plan, tref) if i in t_plan else expr(op[0], [tref(x) for x in op[1:]])
+            L.append("    const double t%d = %s;" % (i, e))
+        L.append(accumulate(0, f.troot))
         for j in sorted(f.ext_adj):
-            L.append(accum(acc_of[j], tref(f.ext_adj[j])))
+            L.append(accumulate(acc_of[j], f.ext_adj[j]))
         for p in range(len(f.gather)):
             if f.strip[p] >= 0:
                 L.append("    EXMC_GEN_SH(%d + un) = %s;" % (f.strip[p], tref(f.gat_adj[p])))
+        if f.n < f.npad:
+            L.append("    }")
         L.append("  }")
     L.append("  EXMC_GEN_ALLSUM(s);")
     L.extend(ustmts(n_split, len(g.ops)))
@@ -532,8 +702,7 @@ def generate(g, term_roots, custom_roots, D, G):
         L.append("    const int dim = l + %d;" % (k * G))
         L.append("    double acc = 0.0;")
         if width[k] > 0:
-            L.append("    for (int j = 0; j < %d; j++) acc = acc + EXMC_GEN_SH(it[%d + j * %d + l]);"
-                     % (width[k], ell_base + ell_off[k], G))
+            L.append("    for (int j = 0; j < %d; j++) acc = acc + EXMC_GEN_SH(el[%d + j]);" % (width[k], ell_off[k]))
         sel = "0.0"
         for i in sorted(ug, reverse=True):
             if i // G == k:
@@ -542,8 +711,10 @@ def generate(g, term_roots, custom_roots, D, G):
         L.append("    g[%d] = acc + ugs;" % k)
         L.append("    (void)dim;")
         L.append("  }")
+    L.append("  (void)el; (void)lt;")
     L.append("  return %s + s[0];" % uref(scalar_lp))
     L.append("}")
+    L.append("#endif")
     text = "\n".join(L) + "\n"
     return dict(text=text, data=data, lanes=G, dpl=DPL, lsh=lsh, n_families=len(families),
                 family_sizes=[f.n for f in families], n_scalar_units=len(scalar_units),

@@ -1092,9 +1092,9 @@ static __host__ __device__ __noinline__ double exmc_gen_erf_call(double x) { ret
 #define EXMC_GENL_EXP exmc_gen_exp_call
 #define EXMC_GENL_LOG exmc_gen_log_call
 #define EXMC_GENL_LOG1P exmc_gen_log1p_call
-#else
-#define EXMC_GENL_EXP exmc_exp
-#define EXMC_GENL_LOG exmc_log
+#else   // the general functions with their coefficients pinned in vector registers (same bits)
+#define EXMC_GENL_EXP exmc::Math<true>::exp
+#define EXMC_GENL_LOG exmc::Math<true>::log
 #define EXMC_GENL_LOG1P exmc_log1p
 #endif
 #define EXMC_GENL_ERF exmc_gen_erf_call
@@ -1102,7 +1102,28 @@ static __host__ __device__ __noinline__ double exmc_gen_erf_call(double x) { ret
 #define EXMC_GEN_SH(i) exmc::exmc_dyn_lds[shoff + (i)]
 #define EXMC_GEN_ALLSUM(s) exmc::group_allsum_n<EXMC_GEN_LANES, EXMC_GEN_NS>(s)
 #define EXMC_GEN_FENCE() exmc::wave_lds_fence()
+#define EXMC_GEN_FMA(a, b, c) __builtin_fma(a, b, c)
 #include EXMC_CUSTOM_HEADER
+#ifdef EXMC_GEN_LANES
+// the lane function twice: its tables in global memory, and in an LDS image the NUTS and warmup
+// workgroups stage once per kernel (a lone wave per SIMD would otherwise sit out an L2 round trip
+// per family and leapfrog; ModelDefaults::kLdsDataDoubles). ltoff = the image's offset in doubles.
+#define EXMC_GEN_LANES_SECTION
+#define EXMC_GEN_LANES_NAME exmc_gen_lanes_global
+#define EXMC_GEN_LT(i) lt[i]
+#define EXMC_GEN_IT(i) ((const int*)(lt + EXMC_GEN_IOFF))[i]
+#include EXMC_CUSTOM_HEADER
+#undef EXMC_GEN_LANES_NAME
+#undef EXMC_GEN_LT
+#undef EXMC_GEN_IT
+#undef EXMC_GEN_CTX_DECL
+#define EXMC_GEN_CTX_DECL , int shoff, int ltoff
+#define EXMC_GEN_LANES_NAME exmc_gen_lanes_lds
+#define EXMC_GEN_LT(i) exmc::exmc_dyn_lds[ltoff + (i)]
+#define EXMC_GEN_IT(i) ((const int*)(exmc::exmc_dyn_lds + ltoff + EXMC_GEN_IOFF))[i]
+#include EXMC_CUSTOM_HEADER
+#undef EXMC_GEN_LANES_SECTION
+#endif
 
 namespace exmc {
 
@@ -1142,13 +1163,36 @@ struct Custom<EXMC_GEN_LANES> : ModelDefaults {
   static constexpr int DPL = EXMC_GEN_DPL;
   static_assert(DPL * G >= D, "every dimension has a slot");
   static constexpr bool kVregMath = true;   // the tree's own exp / log (nuts_run)
-  static constexpr bool kPipeWarmup = false;
+  // the two waves of the pipelined warmup never evaluate the model at the same time (the tree wave
+  // only in the step-size searches, while the integrator waits at a barrier): one strip serves both
+  static constexpr bool kPipeWarmup = true;
+  static constexpr int kNutsWavesPerSimd = EXMC_GEN_WAVES_PER_SIMD;
   static constexpr int kExtraLdsDoubles = (64 / G) * EXMC_GEN_LSH;
+  // a short owner list (the strip cells whose sum is this lane's gradient entries) lives in registers
+  static constexpr bool kEllRegs = EXMC_GEN_NELL <= 16;
+  // tables up to 16 KB are staged in LDS by the kernels that run a lone wave per SIMD for long
+  static constexpr bool kLdsTable = EXMC_GEN_NLT <= 2048;
+  static constexpr int kLdsDataDoubles = kLdsTable ? EXMC_GEN_NLT : 0;
   using Consts = CustomConsts;
   struct Lane {
     double* sh;   // the wavefront's scratch (attach_scratch / lane_setup)
+    int xoff;     // the LDS image of the tables (offset in doubles), or -1: read from global memory
+    int ell[kEllRegs ? EXMC_GEN_NELL : 1];
   };
-  __device__ static __forceinline__ void load(const Consts&, int, Lane& ln) { ln.sh = nullptr; }
+  // cooperative (whole workgroup); the caller synchronises afterwards
+  __device__ static __forceinline__ bool stage_data(const Consts& c, double* dst) {
+    for (int i = threadIdx.x; i < EXMC_GEN_NLT; i += blockDim.x) dst[i] = c.lt[i];
+    return true;
+  }
+  __device__ static __forceinline__ void load(const Consts& c, int l, Lane& ln) {
+    ln.sh = nullptr;
+    ln.xoff = -1;
+    if constexpr (kEllRegs) {
+      const int* e = (const int*)c.lt + EXMC_GEN_ELL_OFF + l * EXMC_GEN_NELL;
+#pragma unroll
+      for (int j = 0; j < EXMC_GEN_NELL; j++) ln.ell[j] = e[j];
+    }
+  }
   __device__ static __forceinline__ double logp_grad(const Consts& c, const Lane& ln, int l,
                                                      const double (&q)[DPL], double (&g)[DPL]) {
     const int shoff = (int)(ln.sh - exmc_dyn_lds) + (int)((threadIdx.x & 63) / G) * EXMC_GEN_LSH;
@@ -1156,7 +1200,11 @@ struct Custom<EXMC_GEN_LANES> : ModelDefaults {
     for (int k = 0; k < DPL; k++)
       if (l + k * G < D) exmc_dyn_lds[shoff + l + k * G] = q[k];
     wave_lds_fence();
-    return exmc_gen_lanes(c.lt, l, g, shoff);
+    const int* el = kEllRegs ? ln.ell : ((const int*)c.lt + EXMC_GEN_ELL_OFF + l * EXMC_GEN_NELL);
+    if constexpr (kLdsTable) {
+      if (ln.xoff >= 0) return exmc_gen_lanes_lds(c.lt, el, l, g, shoff, ln.xoff);   // wave-uniform
+    }
+    return exmc_gen_lanes_global(c.lt, el, l, g, shoff);
   }
 };
 #endif

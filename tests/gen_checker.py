@@ -46,7 +46,15 @@ typedef struct { double* sh; int pass; double* S; const double* R; } exmc_gen_ct
     if (ctx->pass == 0) { memcpy(ctx->S + (size_t)l * EXMC_GEN_NS, s, sizeof(double) * EXMC_GEN_NS); return 0.0; } \
     memcpy(s, ctx->R, sizeof(double) * EXMC_GEN_NS); } while (0)
 #define EXMC_GEN_FENCE()
+#define EXMC_GEN_FMA(a, b, c) __builtin_fma(a, b, c)
 #include "%(header)s"
+#ifdef EXMC_GEN_LANES
+#define EXMC_GEN_LANES_SECTION
+#define EXMC_GEN_LANES_NAME exmc_gen_lanes
+#define EXMC_GEN_LT(i) lt[i]
+#define EXMC_GEN_IT(i) ((const int*)(lt + EXMC_GEN_IOFF))[i]
+#include "%(header)s"
+#endif
 int exmc_gen_check_dim(void) { return EXMC_GEN_D; }
 int exmc_gen_check_ndata(void) {
   int n = EXMC_GEN_NDATA;
@@ -75,7 +83,8 @@ double exmc_gen_checkL(const double* data, const double* q, double* g) {
   exmc_gen_ctx ctx = {sh, 0, S, R};
   for (int i = 0; i < EXMC_GEN_LSH; i++) sh[i] = 0.0;
   for (int i = 0; i < EXMC_GEN_D; i++) sh[i] = q[i];
-  for (int l = 0; l < G; l++) (void)exmc_gen_lanes(lt, l, gl, &ctx);
+  const int* ell = (const int*)lt + EXMC_GEN_ELL_OFF;
+  for (int l = 0; l < G; l++) (void)exmc_gen_lanes(lt, ell + l * EXMC_GEN_NELL, l, gl, &ctx);
   for (int k = 0; k < EXMC_GEN_NS; k++) {   /* group_allsum_n: xor butterfly over the G lanes */
     double part[G], nxt[G];
     for (int l = 0; l < G; l++) part[l] = S[l * EXMC_GEN_NS + k];
@@ -87,7 +96,7 @@ double exmc_gen_checkL(const double* data, const double* q, double* g) {
   }
   ctx.pass = 1;
   for (int l = 0; l < G; l++) {
-    const double v = exmc_gen_lanes(lt, l, gl, &ctx);
+    const double v = exmc_gen_lanes(lt, ell + l * EXMC_GEN_NELL, l, gl, &ctx);
     if (l == 0) lp = v;
     for (int k = 0; k < EXMC_GEN_DPL; k++)
       if (l + k * G < EXMC_GEN_D) g[l + k * G] = gl[k];
