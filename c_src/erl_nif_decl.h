@@ -110,6 +110,7 @@ int enif_send(ErlNifEnv* caller_env, const ErlNifPid* to_pid, ErlNifEnv* msg_env
 int enif_get_local_pid(ErlNifEnv*, ERL_NIF_TERM, ErlNifPid* pid);
 int enif_thread_create(char* name, ErlNifTid* tid, void* (*func)(void*), void* args, ErlNifThreadOpts* opts);
 int enif_thread_join(ErlNifTid, void** exit_value);
+int enif_get_tuple(ErlNifEnv*, ERL_NIF_TERM tpl, int* arity, const ERL_NIF_TERM** array);
 ErlNifTid enif_thread_self(void);
 int enif_equal_tids(ErlNifTid tid1, ErlNifTid tid2);
 int enif_keep_resource(void* obj);

@@ -3,6 +3,9 @@
  * SURVEY.md 8b). INTEGRATION.md shows where Exmc.NUTS.Sampler calls them.
  *
  *   model_create/2          Compiler.compile_for_sampling/2 for a built model kind (compiler.ex:46-58)
+ *   model_create_plugin/2   the same for a model GENERATED from its Builder IR (exmc_amd/codegen.py):
+ *                           the plug-in library is dlopen'ed and every later call on the handle goes
+ *                           through that library's own copy of the C ABI
  *   model_set_flat_order/2  PointMap.build's sorted-id layout (point_map.ex:30-60)
  *   logp_grad/3             vag_fn, batched (compiler.ex:131-141)
  *   multi_step/8            multi_step_fn, batched (batched_leapfrog.ex:21-48)
@@ -19,14 +22,62 @@
 #define _POSIX_C_SOURCE 200809L   /* nanosleep */
 #include "exmc_nif_util.h"
 
+#include <dlfcn.h>
 #include <time.h>
 
 static ErlNifResourceType* MODEL_RT;
 static int g_device = 0;
 
+/* The entry points of include/exmc_hip.h this module calls, as a table: the library this shim is
+ * linked against fills one (g_base); a generated model's plug-in library (a build of the same
+ * sources around the generated functor, kind EXMC_MODEL_CUSTOM only) fills another through dlsym.
+ * A handle keeps the table of the library that created it. */
+#define EXMC_NIF_API(X)                                                                                        \
+  X(const char*, last_error, (void))                                                                           \
+  X(int, model_create, (int, int, const double*, int, int, exmc_hip_model**))                                  \
+  X(void, model_destroy, (exmc_hip_model*))                                                                    \
+  X(int, model_dim, (const exmc_hip_model*))                                                                   \
+  X(int, model_set_flat_order, (exmc_hip_model*, const int32_t*, int))                                         \
+  X(int, model_set_dense_mass, (exmc_hip_model*, const double*, const double*, int))                           \
+  X(int, model_clear_dense_mass, (exmc_hip_model*))                                                            \
+  X(int, logp_grad_host, (exmc_hip_model*, const double*, int, int, double*, double*))                         \
+  X(int, multi_step_host, (exmc_hip_model*, const double*, const double*, const double*, double, const double*, \
+                           int, int, int, double*, double*, double*, double*))                                 \
+  X(int, warmup, (exmc_hip_model*, const double*, exmc_hip_opts, exmc_hip_tuning*))                            \
+  X(int, warmup_from, (exmc_hip_model*, const double*, exmc_hip_opts, const exmc_hip_tuning*, exmc_hip_tuning*)) \
+  X(int, warmup_dense, (exmc_hip_model*, const double*, exmc_hip_opts, exmc_hip_tuning*, double*, double*))    \
+  X(int, sample_chains_host, (exmc_hip_model*, const exmc_hip_tuning*, const double*, int, int, int,           \
+                              exmc_hip_opts, exmc_hip_trace, int64_t*, int32_t*))                              \
+  X(int, sample_host, (exmc_hip_model*, const double*, exmc_hip_opts, exmc_hip_trace, exmc_hip_tuning*, int32_t*)) \
+  X(int, stream_begin, (exmc_hip_model*, const double*, exmc_hip_opts, exmc_hip_tuning*))                      \
+  X(int, stream_next_host, (exmc_hip_model*, int, exmc_hip_trace, int32_t*))                                   \
+  X(int, stream_start, (exmc_hip_model*, int, exmc_hip_trace*, const volatile int32_t**))                      \
+  X(int, stream_finish, (exmc_hip_model*, int32_t*))
+
+typedef struct {
+  void* dl;   /* dlopen handle of a plug-in; NULL: the library this shim is linked against */
+#define X(ret, name, args) ret (*name) args;
+  EXMC_NIF_API(X)
+#undef X
+} exmc_api;
+
+static const exmc_api g_base = {
+    NULL,
+#define X(ret, name, args) exmc_hip_##name,
+    EXMC_NIF_API(X)
+#undef X
+};
+
+/* {:exmc_hip_error, code, message} with the message of the library the handle belongs to */
+static ERL_NIF_TERM raise_api(ErlNifEnv* env, const exmc_api* A, int rc) {
+  if (rc == EXMC_ERR_BADARG) return enif_make_badarg(env);
+  return enif_raise_exception(env, tuple3(env, enif_make_atom(env, "exmc_hip_error"), enif_make_int(env, rc),
+                                          enif_make_string(env, A->last_error(), ERL_NIF_LATIN1)));
+}
+
 /* tid / has_tid: the sender thread of the last stream_run (ERTS threads are joinable: it is joined
  * by the next stream_run and by the destructor) */
-typedef struct { exmc_hip_model* m; ErlNifTid tid; int has_tid; } model_res;
+typedef struct { exmc_hip_model* m; const exmc_api* api; ErlNifTid tid; int has_tid; } model_res;
 
 static void join_sender(model_res* r) {
   /* the destructor runs on whichever thread drops the last reference -- possibly the sender
@@ -39,14 +90,26 @@ static void model_dtor(ErlNifEnv* env, void* obj) {
   (void)env;
   model_res* r = (model_res*)obj;
   join_sender(r);
-  if (r->m) exmc_hip_model_destroy(r->m);
+  if (r->m) r->api->model_destroy(r->m);
   r->m = NULL;
+  if (r->api && r->api->dl) {   /* a plug-in's table: the handle was its only user */
+    void* dl = r->api->dl;
+    enif_free((void*)r->api);
+    dlclose(dl);
+  }
+  r->api = NULL;
 }
-static exmc_hip_model* get_model(ErlNifEnv* env, ERL_NIF_TERM t) {
+static model_res* get_res(ErlNifEnv* env, ERL_NIF_TERM t) {
   void* obj;
-  if (!enif_get_resource(env, t, MODEL_RT, &obj)) return NULL;
-  return ((model_res*)obj)->m;
+  if (!enif_get_resource(env, t, MODEL_RT, &obj) || !((model_res*)obj)->m) return NULL;
+  return (model_res*)obj;
 }
+/* every function below starts with: R = the handle, m = its model, A = its library's table */
+#define HANDLE(t)                            \
+  model_res* R = get_res(env, (t));          \
+  exmc_hip_model* m = R ? R->m : NULL;       \
+  const exmc_api* A = R ? R->api : &g_base;  \
+  (void)A
 /* `nil` or an f64 binary of d values */
 static int get_init_q(ErlNifEnv* env, ERL_NIF_TERM t, int d, const double** q) {
   char buf[8];
@@ -58,6 +121,20 @@ static int get_init_q(ErlNifEnv* env, ERL_NIF_TERM t, int d, const double** q) {
   return get_f64_bin(env, t, q, &n) && n == (size_t)d;
 }
 
+static ERL_NIF_TERM make_handle(ErlNifEnv* env, const exmc_api* A, int kind, const double* data, size_t n) {
+  exmc_hip_model* m = NULL;
+  int rc = A->model_create(kind, 0, data, (int)n, g_device, &m);
+  if (rc != EXMC_OK)
+    return tuple2(env, enif_make_atom(env, "error"), enif_make_string(env, A->last_error(), ERL_NIF_LATIN1));
+  model_res* r = (model_res*)enif_alloc_resource(MODEL_RT, sizeof(model_res));
+  r->m = m;
+  r->api = A;
+  r->has_tid = 0;
+  ERL_NIF_TERM ref = enif_make_resource(env, r);
+  enif_release_resource(r);
+  return tuple2(env, enif_make_atom(env, "ok"), ref);
+}
+
 /* model_create(kind, data_bin) -> {:ok, ref} | {:error, message} */
 static ERL_NIF_TERM model_create(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
   int kind;
@@ -66,26 +143,63 @@ static ERL_NIF_TERM model_create(ErlNifEnv* env, int argc, const ERL_NIF_TERM ar
   (void)argc;
   if (!enif_get_int(env, argv[0], &kind) || !get_f64_bin(env, argv[1], &data, &n))
     return enif_make_badarg(env);
-  exmc_hip_model* m = NULL;
-  int rc = exmc_hip_model_create(kind, 0, data, (int)n, g_device, &m);
-  if (rc != EXMC_OK)
-    return tuple2(env, enif_make_atom(env, "error"),
-                  enif_make_string(env, exmc_hip_last_error(), ERL_NIF_LATIN1));
-  model_res* r = (model_res*)enif_alloc_resource(MODEL_RT, sizeof(model_res));
-  r->m = m;
-  r->has_tid = 0;
-  ERL_NIF_TERM ref = enif_make_resource(env, r);
-  enif_release_resource(r);
-  return tuple2(env, enif_make_atom(env, "ok"), ref);
+  return make_handle(env, &g_base, kind, data, n);
+}
+
+/* model_create_plugin(path :: binary, data_bin) -> {:ok, ref} | {:error, message}
+ * `path` names the plug-in library a generated model was compiled into (python -m exmc_amd.codegen
+ * model.json out_dir -> out_dir/libexmc_hip_gen.so; model.json's "data" is data_bin). Its entry
+ * points are bound with dlsym into a table of the handle's own; sampling, streaming, warmup ... are
+ * then the functions above, unchanged. */
+static ERL_NIF_TERM model_create_plugin(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  ErlNifBinary pb;
+  const double* data;
+  size_t n;
+  char path[4096];
+  (void)argc;
+  if (!enif_inspect_binary(env, argv[0], &pb) || pb.size == 0 || pb.size >= sizeof path ||
+      !get_f64_bin(env, argv[1], &data, &n))
+    return enif_make_badarg(env);
+  memcpy(path, pb.data, pb.size);
+  path[pb.size] = 0;
+  void* dl = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+  if (!dl) {
+    const char* e = dlerror();
+    return tuple2(env, enif_make_atom(env, "error"), enif_make_string(env, e ? e : "dlopen failed", ERL_NIF_LATIN1));
+  }
+  exmc_api* api = (exmc_api*)enif_alloc(sizeof(exmc_api));
+  const char* missing = NULL;
+  api->dl = dl;
+#define X(ret, name, args)                                      \
+  *(void**)(&api->name) = dlsym(dl, "exmc_hip_" #name);         \
+  if (!api->name && !missing) missing = "exmc_hip_" #name;
+  EXMC_NIF_API(X)
+#undef X
+  if (missing) {
+    ERL_NIF_TERM err = tuple2(env, enif_make_atom(env, "error"), enif_make_string(env, missing, ERL_NIF_LATIN1));
+    enif_free(api);
+    dlclose(dl);
+    return err;
+  }
+  ERL_NIF_TERM r = make_handle(env, api, EXMC_MODEL_CUSTOM, data, n);
+  int arity;
+  const ERL_NIF_TERM* el;
+  char tag[8];
+  if (enif_get_tuple(env, r, &arity, &el) && enif_get_atom(env, el[0], tag, sizeof tag, ERL_NIF_LATIN1) &&
+      strcmp(tag, "ok") != 0) {   /* no handle took the table over */
+    enif_free(api);
+    dlclose(dl);
+  }
+  return r;
 }
 
 /* model_set_flat_order(ref, perm :: [non_neg_integer]) -> :ok   (perm[r] = kernel dimension of
  * the r-th id of Enum.sort_by(& &1.id), point_map.ex:37) */
 static ERL_NIF_TERM model_set_flat_order(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
-  exmc_hip_model* m = get_model(env, argv[0]);
+  HANDLE(argv[0]);
   unsigned len;
   (void)argc;
-  if (!m || !enif_get_list_length(env, argv[1], &len) || (int)len != exmc_hip_model_dim(m))
+  if (!m || !enif_get_list_length(env, argv[1], &len) || (int)len != A->model_dim(m))
     return enif_make_badarg(env);
   int32_t* perm = (int32_t*)enif_alloc((len ? len : 1) * sizeof(int32_t));
   ERL_NIF_TERM head, tail = argv[1];
@@ -95,32 +209,32 @@ static ERL_NIF_TERM model_set_flat_order(ErlNifEnv* env, int argc, const ERL_NIF
     ok = enif_get_list_cell(env, tail, &head, &tail) && enif_get_int(env, head, &v);
     perm[i] = v;
   }
-  int rc = ok ? exmc_hip_model_set_flat_order(m, perm, (int)len) : EXMC_ERR_BADARG;
+  int rc = ok ? A->model_set_flat_order(m, perm, (int)len) : EXMC_ERR_BADARG;
   enif_free(perm);
-  return rc == EXMC_OK ? enif_make_atom(env, "ok") : raise_hip(env, rc);
+  return rc == EXMC_OK ? enif_make_atom(env, "ok") : raise_api(env, A, rc);
 }
 
 /* logp_grad(ref, q_bin [C][d], n_chains) -> {logp_bin [C], grad_bin [C][d]} */
 static ERL_NIF_TERM logp_grad(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
-  exmc_hip_model* m = get_model(env, argv[0]);
+  HANDLE(argv[0]);
   const double* q;
   size_t n;
   int c;
   (void)argc;
   if (!m || !get_f64_bin(env, argv[1], &q, &n) || !enif_get_int(env, argv[2], &c) || c < 1 ||
-      n != (size_t)c * (size_t)exmc_hip_model_dim(m))
+      n != (size_t)c * (size_t)A->model_dim(m))
     return enif_make_badarg(env);
   ERL_NIF_TERM tl, tg;
   double* lp = new_f64_bin(env, (size_t)c, &tl);
   double* g = new_f64_bin(env, n, &tg);
-  int rc = exmc_hip_logp_grad_host(m, q, c, 0, lp, g);
-  return rc == EXMC_OK ? tuple2(env, tl, tg) : raise_hip(env, rc);
+  int rc = A->logp_grad_host(m, q, c, 0, lp, g);
+  return rc == EXMC_OK ? tuple2(env, tl, tg) : raise_api(env, A, rc);
 }
 
 /* multi_step(ref, q, p, grad :: binary [C][d], eps, inv_mass :: binary [d], n_steps, n_chains)
  *   -> {all_q, all_p, all_logp, all_grad} binaries [C][n][d] / [C][n] */
 static ERL_NIF_TERM multi_step(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
-  exmc_hip_model* m = get_model(env, argv[0]);
+  HANDLE(argv[0]);
   const double *q, *p, *g, *im;
   size_t nq, np, ng, nim;
   double eps;
@@ -131,15 +245,15 @@ static ERL_NIF_TERM multi_step(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv
       !get_f64_bin(env, argv[5], &im, &nim) || !enif_get_int(env, argv[6], &n) ||
       !enif_get_int(env, argv[7], &c) || n < 0 || c < 1)
     return enif_make_badarg(env);
-  const size_t d = (size_t)exmc_hip_model_dim(m);
+  const size_t d = (size_t)A->model_dim(m);
   if (nq != (size_t)c * d || np != nq || ng != nq || nim != d) return enif_make_badarg(env);
   ERL_NIF_TERM t[4];
   double* aq = new_f64_bin(env, (size_t)c * n * d, &t[0]);
   double* ap = new_f64_bin(env, (size_t)c * n * d, &t[1]);
   double* al = new_f64_bin(env, (size_t)c * n, &t[2]);
   double* ag = new_f64_bin(env, (size_t)c * n * d, &t[3]);
-  int rc = exmc_hip_multi_step_host(m, q, p, g, eps, im, n, c, 0, aq, ap, al, ag);
-  return rc == EXMC_OK ? enif_make_tuple_from_array(env, t, 4) : raise_hip(env, rc);
+  int rc = A->multi_step_host(m, q, p, g, eps, im, n, c, 0, aq, ap, al, ag);
+  return rc == EXMC_OK ? enif_make_tuple_from_array(env, t, 4) : raise_api(env, A, rc);
 }
 
 static ERL_NIF_TERM tuning_map(ErlNifEnv* env, const exmc_hip_tuning* tun, int d) {
@@ -164,22 +278,22 @@ static int get_warm_opts(ErlNifEnv* env, const ERL_NIF_TERM argv[], exmc_hip_opt
 /* warmup(ref, init_q | nil, num_warmup, max_tree_depth, target_accept, seed)
  *   -> %{epsilon, inv_mass, warmup_divergences}   (the `tuning` map of sampler.ex:62-71) */
 static ERL_NIF_TERM warmup(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
-  exmc_hip_model* m = get_model(env, argv[0]);
+  HANDLE(argv[0]);
   const double* iq;
   exmc_hip_opts o;
   exmc_hip_tuning tun;
   (void)argc;
-  if (!m || !get_init_q(env, argv[1], exmc_hip_model_dim(m), &iq) || !get_warm_opts(env, argv + 2, &o))
+  if (!m || !get_init_q(env, argv[1], A->model_dim(m), &iq) || !get_warm_opts(env, argv + 2, &o))
     return enif_make_badarg(env);
-  int rc = exmc_hip_warmup(m, iq, o, &tun);
-  return rc == EXMC_OK ? tuning_map(env, &tun, exmc_hip_model_dim(m)) : raise_hip(env, rc);
+  int rc = A->warmup(m, iq, o, &tun);
+  return rc == EXMC_OK ? tuning_map(env, &tun, A->model_dim(m)) : raise_api(env, A, rc);
 }
 
 /* warmup_from(ref, init_q | nil, num_warmup, max_tree_depth, target_accept, seed, prev_epsilon,
  *             prev_inv_mass_bin) -> tuning map: opts[:warm_start] of Sampler.sample
  * (sampler.ex:167-197): the previous run's step size and inverse mass, min(num_warmup, 50) iterations */
 static ERL_NIF_TERM warmup_from(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
-  exmc_hip_model* m = get_model(env, argv[0]);
+  HANDLE(argv[0]);
   const double *iq, *im;
   size_t nim;
   exmc_hip_opts o;
@@ -187,13 +301,13 @@ static ERL_NIF_TERM warmup_from(ErlNifEnv* env, int argc, const ERL_NIF_TERM arg
   (void)argc;
   memset(&prev, 0, sizeof prev);
   if (!m) return enif_make_badarg(env);
-  const int d = exmc_hip_model_dim(m);
+  const int d = A->model_dim(m);
   if (!get_init_q(env, argv[1], d, &iq) || !get_warm_opts(env, argv + 2, &o) ||
       !get_f64(env, argv[6], &prev.epsilon) || !get_f64_bin(env, argv[7], &im, &nim) || nim != (size_t)d)
     return enif_make_badarg(env);
   memcpy(prev.inv_mass, im, (size_t)d * 8);
-  int rc = exmc_hip_warmup_from(m, iq, o, &prev, &tun);
-  return rc == EXMC_OK ? tuning_map(env, &tun, d) : raise_hip(env, rc);
+  int rc = A->warmup_from(m, iq, o, &prev, &tun);
+  return rc == EXMC_OK ? tuning_map(env, &tun, d) : raise_api(env, A, rc);
 }
 
 /* warmup_dense(ref, init_q | nil, num_warmup, max_tree_depth, target_accept, seed, lanes_per_chain)
@@ -201,21 +315,21 @@ static ERL_NIF_TERM warmup_from(ErlNifEnv* env, int argc, const ERL_NIF_TERM arg
  * opts[:dense_mass] (sampler.ex:156, 412-431); the dense mass stays in force on the handle for
  * sample_chains / stream_next until clear_dense_mass */
 static ERL_NIF_TERM warmup_dense(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
-  exmc_hip_model* m = get_model(env, argv[0]);
+  HANDLE(argv[0]);
   const double* iq;
   exmc_hip_opts o;
   exmc_hip_tuning tun;
   (void)argc;
   if (!m) return enif_make_badarg(env);
-  const int d = exmc_hip_model_dim(m);
+  const int d = A->model_dim(m);
   if (!get_init_q(env, argv[1], d, &iq) || !get_warm_opts(env, argv + 2, &o) ||
       !enif_get_int(env, argv[6], &o.lanes_per_chain) || o.lanes_per_chain < 0)
     return enif_make_badarg(env);
   ERL_NIF_TERM tc, tl;
   double* cov = new_f64_bin(env, (size_t)d * d, &tc);
   double* chol = new_f64_bin(env, (size_t)d * d, &tl);
-  int rc = exmc_hip_warmup_dense(m, iq, o, &tun, cov, chol);
-  if (rc != EXMC_OK) return raise_hip(env, rc);
+  int rc = A->warmup_dense(m, iq, o, &tun, cov, chol);
+  if (rc != EXMC_OK) return raise_api(env, A, rc);
   ERL_NIF_TERM map = tuning_map(env, &tun, d);
   map = map_put(env, map, "cov", tc);
   map = map_put(env, map, "chol_cov", tl);
@@ -225,23 +339,23 @@ static ERL_NIF_TERM warmup_dense(ErlNifEnv* env, int argc, const ERL_NIF_TERM ar
 /* set_dense_mass(ref, cov_bin, chol_cov_bin) -> :ok; clear_dense_mass(ref) -> :ok
  * (sample_compiled_tuned with a tuning that carries :chol_cov, sampler.ex:274, 292) */
 static ERL_NIF_TERM set_dense_mass(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
-  exmc_hip_model* m = get_model(env, argv[0]);
+  HANDLE(argv[0]);
   const double *cov, *chol;
   size_t nc, nl;
   (void)argc;
   if (!m) return enif_make_badarg(env);
-  const size_t d = (size_t)exmc_hip_model_dim(m);
+  const size_t d = (size_t)A->model_dim(m);
   if (!get_f64_bin(env, argv[1], &cov, &nc) || !get_f64_bin(env, argv[2], &chol, &nl) || nc != d * d || nl != d * d)
     return enif_make_badarg(env);
-  int rc = exmc_hip_model_set_dense_mass(m, cov, chol, (int)d);
-  return rc == EXMC_OK ? enif_make_atom(env, "ok") : raise_hip(env, rc);
+  int rc = A->model_set_dense_mass(m, cov, chol, (int)d);
+  return rc == EXMC_OK ? enif_make_atom(env, "ok") : raise_api(env, A, rc);
 }
 static ERL_NIF_TERM clear_dense_mass(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
-  exmc_hip_model* m = get_model(env, argv[0]);
+  HANDLE(argv[0]);
   (void)argc;
   if (!m) return enif_make_badarg(env);
-  int rc = exmc_hip_model_clear_dense_mass(m);
-  return rc == EXMC_OK ? enif_make_atom(env, "ok") : raise_hip(env, rc);
+  int rc = A->model_clear_dense_mass(m);
+  return rc == EXMC_OK ? enif_make_atom(env, "ok") : raise_api(env, A, rc);
 }
 
 /* per-draw outputs as binaries: draws [C][S][d] f64; logp, accept_prob, energy [C][S] f64;
@@ -270,7 +384,7 @@ static ERL_NIF_TERM trace_map(ErlNifEnv* env, const trace_bins* b) {
  *               num_samples, max_tree_depth, seed) -> {trace_map, leapfrogs, divergences}
  * chains chain_lo..chain_hi-1 of n_chains (chain i is seeded seed + 7919 i, sampler.ex:1083) */
 static ERL_NIF_TERM sample_chains(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
-  exmc_hip_model* m = get_model(env, argv[0]);
+  HANDLE(argv[0]);
   exmc_hip_tuning tun;
   const double *im, *iq;
   size_t nim;
@@ -281,7 +395,7 @@ static ERL_NIF_TERM sample_chains(ErlNifEnv* env, int argc, const ERL_NIF_TERM a
   memset(&o, 0, sizeof o);
   memset(&tun, 0, sizeof tun);
   if (!m) return enif_make_badarg(env);
-  const int d = exmc_hip_model_dim(m);
+  const int d = A->model_dim(m);
   if (!get_f64(env, argv[1], &tun.epsilon) || !get_f64_bin(env, argv[2], &im, &nim) ||
       nim != (size_t)d || !get_init_q(env, argv[3], d, &iq) || !enif_get_int(env, argv[4], &n_chains) ||
       !enif_get_int(env, argv[5], &lo) || !enif_get_int(env, argv[6], &hi) ||
@@ -295,22 +409,22 @@ static ERL_NIF_TERM sample_chains(ErlNifEnv* env, int argc, const ERL_NIF_TERM a
   new_trace(env, (size_t)(hi - lo) * (size_t)o.num_samples, (size_t)d, &b);
   int64_t lf = 0;
   int32_t dv = 0;
-  int rc = exmc_hip_sample_chains_host(m, &tun, iq, n_chains, lo, hi, o, b.tr, &lf, &dv);
-  if (rc != EXMC_OK) return raise_hip(env, rc);
+  int rc = A->sample_chains_host(m, &tun, iq, n_chains, lo, hi, o, b.tr, &lf, &dv);
+  if (rc != EXMC_OK) return raise_api(env, A, rc);
   return tuple3(env, trace_map(env, &b), enif_make_uint64(env, (ErlNifUInt64)lf), enif_make_int(env, dv));
 }
 
 /* sample(ref, init_q | nil, num_warmup, num_samples, max_tree_depth, target_accept, seed)
  *   -> {trace_map, tuning_map, divergences} */
 static ERL_NIF_TERM sample(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
-  exmc_hip_model* m = get_model(env, argv[0]);
+  HANDLE(argv[0]);
   const double* iq;
   exmc_hip_opts o;
   ErlNifUInt64 seed;
   (void)argc;
   memset(&o, 0, sizeof o);
   if (!m) return enif_make_badarg(env);
-  const int d = exmc_hip_model_dim(m);
+  const int d = A->model_dim(m);
   if (!get_init_q(env, argv[1], d, &iq) || !enif_get_int(env, argv[2], &o.num_warmup) ||
       !enif_get_int(env, argv[3], &o.num_samples) || !enif_get_int(env, argv[4], &o.max_tree_depth) ||
       !get_f64(env, argv[5], &o.target_accept) || !enif_get_uint64(env, argv[6], &seed) ||
@@ -321,36 +435,36 @@ static ERL_NIF_TERM sample(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) 
   new_trace(env, (size_t)o.num_samples, (size_t)d, &b);
   exmc_hip_tuning tun;
   int32_t dv = 0;
-  int rc = exmc_hip_sample_host(m, iq, o, b.tr, &tun, &dv);
-  if (rc != EXMC_OK) return raise_hip(env, rc);
+  int rc = A->sample_host(m, iq, o, b.tr, &tun, &dv);
+  if (rc != EXMC_OK) return raise_api(env, A, rc);
   return tuple3(env, trace_map(env, &b), tuning_map(env, &tun, d), enif_make_int(env, dv));
 }
 
 /* stream_begin(ref, init_q | nil, num_warmup, max_tree_depth, target_accept, seed) -> tuning_map */
 static ERL_NIF_TERM stream_begin(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
-  exmc_hip_model* m = get_model(env, argv[0]);
+  HANDLE(argv[0]);
   const double* iq;
   exmc_hip_opts o;
   exmc_hip_tuning tun;
   (void)argc;
-  if (!m || !get_init_q(env, argv[1], exmc_hip_model_dim(m), &iq) || !get_warm_opts(env, argv + 2, &o))
+  if (!m || !get_init_q(env, argv[1], A->model_dim(m), &iq) || !get_warm_opts(env, argv + 2, &o))
     return enif_make_badarg(env);
-  int rc = exmc_hip_stream_begin(m, iq, o, &tun);
-  return rc == EXMC_OK ? tuning_map(env, &tun, exmc_hip_model_dim(m)) : raise_hip(env, rc);
+  int rc = A->stream_begin(m, iq, o, &tun);
+  return rc == EXMC_OK ? tuning_map(env, &tun, A->model_dim(m)) : raise_api(env, A, rc);
 }
 
 /* stream_next(ref, n_draws) -> {trace_map, divergences}: the next n draws of the resident chain;
  * the caller `send`s {:exmc_sample, i, point_map, step_stat} per row (sampler.ex:1270) */
 static ERL_NIF_TERM stream_next(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
-  exmc_hip_model* m = get_model(env, argv[0]);
+  HANDLE(argv[0]);
   int n;
   (void)argc;
   if (!m || !enif_get_int(env, argv[1], &n) || n < 1) return enif_make_badarg(env);
   trace_bins b;
-  new_trace(env, (size_t)n, (size_t)exmc_hip_model_dim(m), &b);
+  new_trace(env, (size_t)n, (size_t)A->model_dim(m), &b);
   int32_t dv = 0;
-  int rc = exmc_hip_stream_next_host(m, n, b.tr, &dv);
-  if (rc != EXMC_OK) return raise_hip(env, rc);
+  int rc = A->stream_next_host(m, n, b.tr, &dv);
+  if (rc != EXMC_OK) return raise_api(env, A, rc);
   return tuple2(env, trace_map(env, &b), enif_make_int(env, dv));
 }
 
@@ -400,7 +514,7 @@ static void* stream_sender(void* arg) {
     }
   }
   int32_t dv = 0;
-  const int rc = exmc_hip_stream_finish(j->res->m, &dv);
+  const int rc = j->res->api->stream_finish(j->res->m, &dv);
   const int ok = rc == EXMC_OK && sent == j->n;
   enif_send(NULL, &j->pid, env,
             tuple3(env, enif_make_atom(env, ok ? "exmc_done" : "exmc_error"), enif_make_int(env, sent),
@@ -412,29 +526,28 @@ static void* stream_sender(void* arg) {
 }
 
 static ERL_NIF_TERM stream_run(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
-  void* obj;
   int n;
   ErlNifPid pid;
   (void)argc;
-  if (!enif_get_resource(env, argv[0], MODEL_RT, &obj) || !((model_res*)obj)->m ||
-      !enif_get_int(env, argv[1], &n) || n < 1 || !enif_get_local_pid(env, argv[2], &pid))
+  HANDLE(argv[0]);
+  if (!m || !enif_get_int(env, argv[1], &n) || n < 1 || !enif_get_local_pid(env, argv[2], &pid))
     return enif_make_badarg(env);
   stream_job* j = (stream_job*)enif_alloc(sizeof(stream_job));
   if (!j) return enif_make_badarg(env);
-  j->res = (model_res*)obj;
+  j->res = R;
   j->pid = pid;
   j->n = n;
-  j->d = exmc_hip_model_dim(j->res->m);
-  int rc = exmc_hip_stream_start(j->res->m, n, &j->view, &j->progress);
+  j->d = A->model_dim(m);
+  int rc = A->stream_start(m, n, &j->view, &j->progress);
   if (rc != EXMC_OK) {          /* includes: the previous run's sender has not finished yet */
     enif_free(j);
-    return raise_hip(env, rc);
+    return raise_api(env, A, rc);
   }
   join_sender(j->res);          /* the previous sender has called stream_finish: it is ending */
   enif_keep_resource(j->res);   /* the thread's reference */
   if (enif_thread_create((char*)"exmc_hip_stream", &j->res->tid, stream_sender, j, NULL) != 0) {
     int32_t dv;
-    (void)exmc_hip_stream_finish(j->res->m, &dv);
+    (void)A->stream_finish(m, &dv);
     enif_release_resource(j->res);
     enif_free(j);
     return enif_raise_exception(env, enif_make_atom(env, "thread_create_failed"));
@@ -445,6 +558,7 @@ static ERL_NIF_TERM stream_run(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv
 
 static ErlNifFunc nif_funcs[] = {
     {"model_create", 2, model_create, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"model_create_plugin", 2, model_create_plugin, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"model_set_flat_order", 2, model_set_flat_order, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"logp_grad", 3, logp_grad, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"multi_step", 8, multi_step, ERL_NIF_DIRTY_JOB_IO_BOUND},

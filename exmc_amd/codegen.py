@@ -1519,9 +1519,11 @@ def ir_from_json(doc):
     ir = IR()
     if doc.get("data") is not None:
         ir.data(doc["data"])
+    def param(v):      # {"f32": x}: an untyped Nx.tensor(<float>) (class F32)
+        return F32(v["f32"]) if isinstance(v, dict) and set(v) == {"f32"} else v
     for id_, n in doc["nodes"].items():
         if n.get("op") == "rv":
-            ir.rv(id_, n["dist"], n["params"], transform=n.get("transform"))
+            ir.rv(id_, n["dist"], {k: param(v) for k, v in n["params"].items()}, transform=n.get("transform"))
         elif n.get("op") == "obs":
             opts = {k: n[k] for k in ("reduce", "weight", "mask", "censored", "likelihood") if n.get(k) is not None}
             ir.obs(id_, n["target"], n["value"], **opts)
@@ -1542,12 +1544,13 @@ def main(argv=None):
     if len(argv) < 2:
         raise SystemExit("usage: python -m exmc_amd.codegen model.json out_dir [--no-build]")
     doc = json.load(open(argv[0]))
-    gen = generate(ir_from_json(doc), ncp=doc.get("ncp", True), rewrite_passes=doc.get("rewrite", False))
+    gen = generate(ir_from_json(doc), ncp=doc.get("ncp", True), rewrite_passes=doc.get("rewrite", False),
+                   lanes=doc.get("lanes"), waves_per_simd=doc.get("waves_per_simd", 1))
     os.makedirs(argv[1], exist_ok=True)
     with open(os.path.join(argv[1], "exmc_gen_model.h"), "w") as f:
         f.write(gen.header)
     meta = dict(kind=CUSTOM, d=gen.d, var_names=gen.var_names, transforms=gen.transforms,
-                ncp_info=gen.ncp_info, data=gen.data.tolist(), digest=gen.digest)
+                ncp_info=gen.ncp_info, data=gen.data.tolist(), digest=gen.digest, lanes_per_chain=gen.lanes)
     if "--no-build" not in argv:
         shutil.copyfile(build_plugin(gen), os.path.join(argv[1], "libexmc_hip_gen.so"))
         meta["library"] = "libexmc_hip_gen.so"

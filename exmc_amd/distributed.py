@@ -8,7 +8,6 @@ all-reduce of per-parameter ESS sums. This replaces Exmc.NUTS.Distributed's :erp
 (lib/exmc/nuts/distributed.ex:56-101).
 """
 import os
-import tempfile
 
 import numpy as np
 import torch
@@ -130,29 +129,93 @@ def run_shard(engine, spec, num_chains, opts, device, rank, world):
         leapfrogs = int(extra["total_leapfrogs"])
     else:           # more ranks than chains: an empty shard
         raw, leapfrogs = None, 0
-    return dict(rank=rank, lo=lo, hi=hi, raw=raw, leapfrogs=leapfrogs, epsilon=float(tuning["epsilon"]),
-                inv_mass=np.asarray(tuning["inv_mass"], dtype=np.float64))
+    out = dict(rank=rank, lo=lo, hi=hi, raw=raw, leapfrogs=leapfrogs, epsilon=float(tuning["epsilon"]),
+               inv_mass=np.asarray(tuning.get("inv_mass_diag", tuning["inv_mass"]), dtype=np.float64))
+    if tuning.get("chol_cov") is not None:      # opts["dense_mass"]
+        out["cov"], out["chol_cov"] = np.asarray(tuning["cov"]), np.asarray(tuning["chol_cov"])
+    return out
 
 
-def _shard_worker(rank, world, engine_name, spec, num_chains, opts, devices, out_dir):
+_TRACE_KEYS = ("draws", "logp", "tree_depth", "n_steps", "divergent", "accept_prob", "energy")
+
+
+def _gather_shards(local, cmax, dist, device):
+    """All-gather every rank's raw trace arrays ([C_local][S][...], padded to cmax chains) over the
+    process group -- RCCL between GPUs, gloo otherwise -- and return them stacked [world][cmax]...;
+    no file is written and nothing passes through the parent."""
+    import torch
+    out = {}
+    for k in _TRACE_KEYS:
+        a = local[k]
+        pad = np.zeros((cmax,) + a.shape[1:], dtype=a.dtype)
+        pad[:a.shape[0]] = a
+        src = torch.from_numpy(pad).to(device)
+        parts = [torch.empty_like(src) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, src)
+        out[k] = torch.stack(parts, dim=0).cpu().numpy()
+    return out
+
+
+def _shard_worker(rank, world, engine_name, spec, num_chains, opts, devices, port, backend, queue):
     import importlib
+
+    import torch
+    import torch.distributed as dist
     engine = importlib.import_module(engine_name)
-    res = run_shard(engine, spec, num_chains, opts, devices[rank], rank, world)
-    arrays = dict(lo=res["lo"], hi=res["hi"], leapfrogs=res["leapfrogs"], epsilon=res["epsilon"],
-                  inv_mass=res["inv_mass"])
-    if res["raw"] is not None:
-        arrays.update({"raw_" + k: v for k, v in res["raw"].items()})
-    np.savez(os.path.join(out_dir, "shard%d.npz" % rank), **arrays)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    device = torch.device("cpu")
+    if backend == "nccl":
+        torch.cuda.set_device(devices[rank])
+        device = torch.device("cuda", devices[rank])
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        res = run_shard(engine, spec, num_chains, opts, devices[rank], rank, world)
+        S = int(engine._merge_opts(opts)["num_samples"])
+        cmax = max(shard_range(num_chains, r, world)[1] - shard_range(num_chains, r, world)[0] for r in range(world))
+        local = res["raw"]
+        if local is None:           # an empty shard still takes part in the collective
+            local = dict(draws=np.zeros((0, S, spec.d)), logp=np.zeros((0, S)), tree_depth=np.zeros((0, S), np.int32),
+                         n_steps=np.zeros((0, S), np.int32), divergent=np.zeros((0, S), np.int32),
+                         accept_prob=np.zeros((0, S)), energy=np.zeros((0, S)))
+        allraw = _gather_shards({k: np.ascontiguousarray(local[k]) for k in _TRACE_KEYS}, cmax, dist, device)
+        # the shared tuning, cross-checked where it was computed: every rank must have derived the same
+        tun = np.concatenate([[res["epsilon"]], res["inv_mass"].ravel(),
+                              np.asarray(res.get("cov", np.zeros(0)), dtype=np.float64).ravel(),
+                              np.asarray(res.get("chol_cov", np.zeros(0)), dtype=np.float64).ravel()])
+        t = torch.from_numpy(tun).to(device)
+        parts = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(parts, t)
+        same = all(torch.equal(parts[0], p_) for p_ in parts)
+        lf = torch.tensor([float(res["leapfrogs"])], dtype=torch.float64, device=device)
+        dist.all_reduce(lf, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            queue.put(dict(raw=allraw, same_tuning=bool(same), leapfrogs=int(lf.item()), epsilon=res["epsilon"],
+                           inv_mass=res["inv_mass"], cov=res.get("cov"), chol_cov=res.get("chol_cov")))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
 
 
 def sample_chains_sharded(spec, num_chains, opts=None, devices=None, engine="exmc_amd.sampler"):
     """sample_chains over several GPUs of one node: one spawned process per entry of `devices`
-    (started before it touches a GPU; the parent needs none), chain blocks by shard_range, results
-    concatenated in chain order -- so the returned ({name: draws}[], stats[]) equal the
-    single-device sample_chains whatever the number of devices. `engine` names the module that
-    provides compile / warmup / sample_compiled_tuned (the tests substitute the CPU checker)."""
+    (started before it touches a GPU; the parent needs none), chain blocks by shard_range, the
+    finished traces all-gathered over the ranks' process group (RCCL when every rank has a GPU of
+    its own, gloo otherwise -- the CPU tests, or several ranks sharing one GPU) and handed to the
+    parent by rank 0 through a multiprocessing queue: no file is written. The returned
+    ({name: draws}[], stats[]) equal the single-device sample_chains whatever the number of devices.
+    `engine` names the module that provides compile / warmup / sample_compiled_tuned (the tests
+    substitute the CPU checker). A rank that fails takes the call down with it (the reference
+    retries a failed chain on the coordinator, distributed.ex:172-180; a GPU fault is not something
+    to retry blindly)."""
     import importlib
+    import pickle
+    import socket
 
+    import torch
     import torch.multiprocessing as mp
     if num_chains < 1:
         raise ValueError("num_chains must be >= 1")
@@ -161,28 +224,52 @@ def sample_chains_sharded(spec, num_chains, opts=None, devices=None, engine="exm
     if world < 1:
         raise ValueError("devices must name at least one GPU")
     eng = importlib.import_module(engine)
-    with tempfile.TemporaryDirectory(prefix="exmc_shards_") as out_dir:
-        if world == 1:
-            _shard_worker(0, 1, engine, spec, num_chains, opts, devices, out_dir)
-        else:
-            mp.spawn(_shard_worker, args=(world, engine, spec, num_chains, opts, devices, out_dir),
-                     nprocs=world, join=True)
-        shards = [dict(np.load(os.path.join(out_dir, "shard%d.npz" % r))) for r in range(world)]
-    eps = {float(z["epsilon"]) for z in shards}
-    if len(eps) != 1 or any(not np.array_equal(z["inv_mass"], shards[0]["inv_mass"]) for z in shards):
-        raise RuntimeError("ranks disagree on the shared tuning: the warmup is not deterministic")
-    keys = [k[4:] for k in shards[0] if k.startswith("raw_")]
-    filled = [z for z in shards if int(z["hi"]) > int(z["lo"])]
-    raw = {k: np.concatenate([z["raw_" + k] for z in filled], axis=0) for k in keys}
     o = eng._merge_opts(opts)
+    if world == 1:
+        res = run_shard(eng, spec, num_chains, opts, devices[0], 0, 1)
+        raw, total_lf, first = res["raw"], res["leapfrogs"], res
+        shards = [(res["lo"], res["hi"])]
+    else:
+        try:
+            pickle.dumps((spec, opts))
+        except Exception as e:   # e.g. a spec that still holds a Custom distribution's closure
+            raise ValueError("the model spec / opts cannot be sent to the rank processes: %s" % e) from e
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        gpu_each = (engine == "exmc_amd.sampler" and len(set(devices)) == world and
+                    torch.cuda.device_count() >= world)
+        backend = "nccl" if gpu_each else "gloo"
+        ctx = mp.get_context("spawn")
+        queue = ctx.SimpleQueue()
+        procs = mp.spawn(_shard_worker, args=(world, engine, spec, num_chains, opts, devices, port, backend, queue),
+                         nprocs=world, join=False)
+        first = None
+        while first is None:
+            if not queue.empty():
+                first = queue.get()
+            elif procs.join(timeout=0.05):      # every rank has exited (join raises if one failed)
+                if queue.empty():
+                    raise RuntimeError("the rank processes ended without a result")
+        while not procs.join(timeout=0.05):
+            pass
+        if not first["same_tuning"]:
+            raise RuntimeError("ranks disagree on the shared tuning: the warmup is not deterministic")
+        shards = [shard_range(num_chains, r, world) for r in range(world)]
+        raw = {k: np.concatenate([first["raw"][k][r][:hi - lo] for r, (lo, hi) in enumerate(shards)], axis=0)
+               for k in _TRACE_KEYS}
+        total_lf = first["leapfrogs"]
     traces, stats = [], []
     for c in range(num_chains):
         traces.append(eng._build_trace(spec, raw["draws"][c]))
-        stats.append(dict(step_size=float(shards[0]["epsilon"]), inv_mass_diag=shards[0]["inv_mass"].copy(),
-                          divergences=int(raw["divergent"][c].sum()), num_warmup=o["num_warmup"],
-                          num_samples=o["num_samples"], sample_stats=eng.SampleStats(raw, c)))
-    extra = dict(total_leapfrogs=int(sum(int(z["leapfrogs"]) for z in shards)), raw=raw,
-                 shards=[(int(z["lo"]), int(z["hi"])) for z in shards], devices=devices)
+        st = dict(step_size=float(first["epsilon"]), inv_mass_diag=np.array(first["inv_mass"], copy=True),
+                  divergences=int(raw["divergent"][c].sum()), num_warmup=o["num_warmup"],
+                  num_samples=o["num_samples"], sample_stats=eng.SampleStats(raw, c))
+        if first.get("cov") is not None:      # opts["dense_mass"]: as the single-device path returns it
+            st["cov"], st["chol_cov"] = first["cov"], first["chol_cov"]
+        stats.append(st)
+    extra = dict(total_leapfrogs=int(total_lf), raw=raw, shards=[(int(a), int(b)) for a, b in shards],
+                 devices=devices)
     for s_ in stats:
         s_["extra"] = extra
     return traces, stats

@@ -194,6 +194,13 @@ static ERL_NIF_TERM make_seq(int type, const ERL_NIF_TERM arr[], unsigned cnt) {
   return t;
 }
 ERL_NIF_TERM enif_make_tuple_from_array(ErlNifEnv* e, const ERL_NIF_TERM arr[], unsigned cnt) { (void)e; return make_seq(T_TUPLE, arr, cnt); }
+int enif_get_tuple(ErlNifEnv* e, ERL_NIF_TERM tpl, int* arity, const ERL_NIF_TERM** array) {
+  (void)e;
+  if (!T(tpl) || T(tpl)->type != T_TUPLE) return 0;
+  *arity = (int)T(tpl)->n;
+  *array = T(tpl)->items;
+  return 1;
+}
 ERL_NIF_TERM enif_make_list_from_array(ErlNifEnv* e, const ERL_NIF_TERM arr[], unsigned cnt) { (void)e; return make_seq(T_LIST, arr, cnt); }
 ERL_NIF_TERM enif_make_new_map(ErlNifEnv* e) { (void)e; return new_term(T_MAP); }
 int enif_make_map_put(ErlNifEnv* e, ERL_NIF_TERM map_in, ERL_NIF_TERM key, ERL_NIF_TERM value, ERL_NIF_TERM* map_out) {

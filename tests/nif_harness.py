@@ -53,7 +53,7 @@ def build(outdir):
         so = os.path.join(outdir, "lib%s_nif.so" % mod)
         subprocess.check_call(["gcc", "-std=c11", "-O2", "-Wall", "-Wextra", "-Werror", "-fPIC", "-shared",
                                "-o", so, os.path.join(ROOT, "c_src", src), "-L" + LIBDIR, "-lexmc_hip",
-                               "-Wl,-rpath," + LIBDIR, "-Wl,-z,lazy"])
+                               "-Wl,-rpath," + LIBDIR, "-Wl,-z,lazy", "-ldl"])
         shims[mod] = so
     F = C.CDLL(fake, mode=os.RTLD_GLOBAL | os.RTLD_NOW)
     tt = C.c_ulong

@@ -121,3 +121,16 @@ def test_sample_chains_sharded_api_is_independent_of_the_number_of_ranks(world):
     assert np.array_equal(traces[n_chains - 1]["tau"], np.exp(t["draws"][n_chains - 1, :, 1]))
     shards = stats[0]["extra"]["shards"]
     assert shards[0][0] == 0 and shards[-1][1] == n_chains and len(shards) == world
+
+
+def test_sharded_api_refuses_what_it_cannot_send_to_the_ranks():
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from exmc_amd import distributed as xd
+    from exmc_amd import models
+    spec = models.eight_schools()
+    spec.closure = lambda x: x            # e.g. a spec still holding a Custom distribution's closure
+    with pytest.raises(ValueError, match="cannot be sent"):
+        xd.sample_chains_sharded(spec, 4, dict(num_warmup=10, num_samples=5), devices=[0, 1], engine="oracle_engine")
+    with pytest.raises(ValueError):
+        xd.sample_chains_sharded(models.eight_schools(), 0, {}, devices=[0])

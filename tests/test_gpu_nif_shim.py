@@ -208,3 +208,38 @@ def test_hip_native_equals_the_python_mirror(hip, mods):
     assert hn.call("clear_dense_mass", ref) == H.Atom("ok")
     with pytest.raises(H.BadArg):
         hn.call("set_dense_mass", ref, np.zeros(5), np.zeros(5))
+
+
+def test_generated_model_through_the_nif(hip, mods):
+    """HipNative.model_create_plugin/2: a model generated from Builder IR (eight schools as 26 nodes,
+    and sv in the lane layout) reaches the BEAM side -- the plug-in library is dlopen'ed by the shim,
+    warmup / sample_chains / stream_run run through ITS entry points and give what the Python mirror
+    gives through the same library."""
+    from exmc_amd import codegen as cg
+    import gen_models as GM
+    hn = mods["HipNative"]
+    cases = []
+    init = {n: 0.0 for n in ["mu"] + ["theta_%d" % j for j in range(8)]}
+    init["tau"] = 1.0
+    cases.append(cg.compile_ir(cg.eight_schools_ir(), name="gen_eight_schools", default_init=init))
+    ir, ncp, hand, lanes = GM.baseline_pair("sv")
+    cases.append(cg.compile_ir(ir, ncp=ncp, name="gen_sv", default_init=hand.default_init, lanes=lanes))
+    for spec in cases:
+        ok, ref = hn.call("model_create_plugin", spec.lib_path, spec.data)
+        assert ok == H.Atom("ok")
+        nw, ns, nc = (100, 20, 5)
+        q0 = spec.to_unconstrained(spec.default_init)
+        tun = hn.call("warmup", ref, q0, nw, 10, 0.8, 42)
+        comp = sampler.compile(spec)
+        opts = dict(num_warmup=nw, num_samples=ns, seed=42)
+        t2 = sampler.warmup(comp, spec.default_init, opts)
+        assert tun["epsilon"] == t2["epsilon"] and np.array_equal(H.f64(tun["inv_mass"]), t2["inv_mass"])
+        tr, lf, dv = hn.call("sample_chains", ref, tun["epsilon"], H.f64(tun["inv_mass"]), q0, nc, 0, nc, ns, 10, 42)
+        _, _, extra = sampler.sample_compiled_tuned(comp, t2, spec.default_init, opts, num_chains=nc)
+        raw = extra["raw"]
+        assert np.array_equal(H.f64(tr["draws"]).reshape(nc, ns, spec.d), raw["draws"])
+        assert np.array_equal(H.i32(tr["n_steps"]).reshape(nc, ns), raw["n_steps"])
+        assert lf == extra["total_leapfrogs"]
+        # a kind the plug-in does not carry is its own error, through its own last_error
+        bad = hn.call("model_create_plugin", spec.lib_path, np.zeros(spec.data.size + 3))
+        assert bad[0] == H.Atom("error") and "data length" in bad[1]

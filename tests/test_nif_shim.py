@@ -61,7 +61,7 @@ def test_hip_native_entry(mods):
     m = mods["HipNative"]
     assert m.name == "Elixir.Exmc.NUTS.HipNative"
     assert {(n, a) for n, a, _ in m.table()} == {
-        ("model_create", 2), ("model_set_flat_order", 2), ("logp_grad", 3), ("multi_step", 8),
+        ("model_create", 2), ("model_create_plugin", 2), ("model_set_flat_order", 2), ("logp_grad", 3), ("multi_step", 8),
         ("warmup", 6), ("warmup_from", 8), ("warmup_dense", 7), ("set_dense_mass", 3), ("clear_dense_mass", 1),
         ("sample_chains", 10), ("sample", 7), ("stream_begin", 6), ("stream_next", 2), ("stream_run", 3)}
     assert all(flags != 0 for _, _, flags in m.table())      # every call waits on the GPU
@@ -91,6 +91,30 @@ def test_decode_failures_are_badarg(mods):
     hn = mods["HipNative"]
     with pytest.raises(H.BadArg):
         hn.call("model_create", "eight_schools", np.zeros(16))
+
+
+def test_plugin_loading_binds_the_plugins_own_abi(mods):
+    """model_create_plugin dlopens the library a generated model was compiled into and binds its
+    entry points into a table of the handle's own. Without a GPU the plug-in's model_create answers
+    (its own message, no CPU fallback); a library that is not a plug-in and a missing file are errors."""
+    from exmc_amd import _lib, codegen as cg
+    hn = mods["HipNative"]
+    r = hn.call("model_create_plugin", "/nonexistent/libexmc_hip_gen.so", np.zeros(1))
+    assert r[0] == H.Atom("error") and "nonexistent" in r[1]
+    libm = "/lib/x86_64-linux-gnu/libm.so.6"
+    if os.path.exists(libm):
+        r = hn.call("model_create_plugin", libm, np.zeros(1))
+        assert r[0] == H.Atom("error") and r[1].startswith("exmc_hip_")       # the first symbol it lacks
+    with pytest.raises(H.BadArg):
+        hn.call("model_create_plugin", 5, np.zeros(1))
+    gen = cg.generate(cg.eight_schools_ir())
+    so = cg.build_plugin(gen)
+    r = hn.call("model_create_plugin", so, gen.data)
+    if _no_gpu():
+        assert r[0] == H.Atom("error") and "no HIP device" in r[1]
+    else:
+        assert r[0] == H.Atom("ok")
+        assert _lib  # (the GPU suite goes on from here: tests/test_gpu_nif_shim.py)
 
 
 def test_without_a_gpu_the_shims_fail_loudly(mods):

@@ -10,10 +10,11 @@ export TMPDIR=/tmp
 for what in "$@"; do
   echo "== $what $(date +%T)"
   case $what in
-    lanes) python -m pytest tests/test_gpu_codegen_lanes.py -x -q > $out/pytest_lanes.log 2>&1; rc=$?; tail -5 $out/pytest_lanes.log; [ $rc -ne 0 ] && exit $rc ;;
-    stream) python -m pytest tests/test_gpu_parity.py -x -q -k "stream" > $out/pytest_stream.log 2>&1; rc=$?; tail -5 $out/pytest_stream.log; [ $rc -ne 0 ] && exit $rc ;;
-    nif) python -m pytest tests/test_gpu_nif_shim.py -x -q > $out/pytest_nif.log 2>&1; rc=$?; tail -5 $out/pytest_nif.log; [ $rc -ne 0 ] && exit $rc ;;
-    all) python -m pytest tests -m gpu -x -q > $out/pytest.log 2>&1; rc=$?; tail -5 $out/pytest.log; [ $rc -ne 0 ] && exit $rc ;;
+    lanes) python -m pytest tests/test_gpu_codegen_lanes.py -x -q > $out/pytest_lanes.log 2>&1; rc=$?; tail -5 $out/pytest_lanes.log; if [ $rc -ne 0 ]; then exit $rc; fi ;;
+    stream) python -m pytest tests/test_gpu_parity.py -x -q -k "stream" > $out/pytest_stream.log 2>&1; rc=$?; tail -5 $out/pytest_stream.log; if [ $rc -ne 0 ]; then exit $rc; fi ;;
+    shard) python -m pytest tests/test_gpu_sharded_api.py -x -q > $out/pytest_shard.log 2>&1; rc=$?; tail -5 $out/pytest_shard.log; if [ $rc -ne 0 ]; then exit $rc; fi ;;
+    nif) python -m pytest tests/test_gpu_nif_shim.py -x -q > $out/pytest_nif.log 2>&1; rc=$?; tail -5 $out/pytest_nif.log; if [ $rc -ne 0 ]; then exit $rc; fi ;;
+    all) python -m pytest tests -m gpu -x -q > $out/pytest.log 2>&1; rc=$?; tail -5 $out/pytest.log; if [ $rc -ne 0 ]; then exit $rc; fi ;;
     bench) python bench.py > $out/bench.json 2> $out/bench.err || { tail -5 $out/bench.err; exit 1; }; cat $out/bench.json ;;
     prof) rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o run -- python3 bench.py --no-cpu > $out/bench_under_rocprof.json 2> $out/rocprof.err || { tail -5 $out/rocprof.err; exit 1; }
           find $out/prof -name '*kernel_stats.csv' -exec cp {} $out/kernel_stats.csv \; ; rm -rf $out/prof; head -8 $out/kernel_stats.csv ;;
