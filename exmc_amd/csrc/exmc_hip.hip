@@ -471,6 +471,10 @@ int launch_nuts(exmc_hip_model* m, int lanes, int C, int n_draws, int draw_offse
     P.flat = flat_order(m);
     P.progress = progress;
     P.mig = nullptr;
+    {
+      const char* pe = std::getenv("EXMC_HIP_PRIO");   // 0: leave the arbiter's oldest-first order alone
+      P.prio = (pe && pe[0] == '0') ? 0 : 1;
+    }
     if (progress) {
       if constexpr (kStreamKernel<M>) {
         if (timed) HIP_TRY(hipEventRecord(m->ev0, m->stream));
@@ -571,11 +575,12 @@ int finish_timing(exmc_hip_model* m) {
   m->last_ms = ms;
 #ifdef EXMC_XCC_PROBE
   if (const char* path = std::getenv("EXMC_WAVE_PROBE_OUT")) {
-    static std::vector<double> h(4096 * 3);
+    static std::vector<double> h(4096 * 5);
     HIP_TRY(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_wave_probe), h.size() * 8));
     if (FILE* f = std::fopen(path, "w")) {   // rewritten after every timed launch: the last one stays
       std::fprintf(f, "%.3f\n", ms);
-      for (int i = 0; i < 4096; i++) std::fprintf(f, "%d %.0f %.0f %.0f\n", i, h[i * 3], h[i * 3 + 1], h[i * 3 + 2]);
+      for (int i = 0; i < 4096; i++)   // workgroup, placement, shader clocks, leapfrogs, wall start, wall end
+        std::fprintf(f, "%d %.0f %.0f %.0f %.0f %.0f\n", i, h[i * 5], h[i * 5 + 1], h[i * 5 + 2], h[i * 5 + 3], h[i * 5 + 4]);
       std::fclose(f);
     }
   }

@@ -55,7 +55,8 @@
 namespace exmc {
 
 #ifdef EXMC_XCC_PROBE
-__device__ double g_wave_probe[4096 * 3];   // per workgroup of nuts_kernel: placement, clocks, leapfrogs
+__device__ double g_wave_probe[4096 * 5];   // per workgroup of nuts_kernel: placement (xcc, cu, simd), shader
+                                            // clocks, leapfrogs, wall-clock start and end (100 MHz ticks)
 #endif
 
 #if EXMC_PROFILE_SECTIONS
@@ -132,6 +133,7 @@ struct NutsParams {
   double nor_r;
   FlatOrder flat;
   DenseMass dm;   // opts[:dense_mass] in force (lanes_per_chain = 1 only)
+  int prio;       // 1: time-sliced issue priority between the two waves of a SIMD (kNutsWavesPerSimd == 2)
   int* mig;       // chain migration (Model::kMigrate): a zeroed MigBoard, or null
   int* progress;  // kStream launches: where chain 0's count of finished draws is published (host memory)
 };
@@ -225,6 +227,8 @@ struct NutsLane {
                                           // row of M^-1 and column of its Cholesky factor
   LaneDense ld;          // opts[:dense_mass], lane layouts (M::kLaneDense); covp == null: diagonal
   int l;
+  int prio_slot;     // 0 / 1: which of the two waves of its SIMD this is (time-sliced issue priority,
+                     // see nuts_run); -1: the wave has its SIMD to itself
   double* lstk;      // this lane's column of the LDS stack
   double* gstk;      // this lane's column of the global spill stack
   size_t nthreads;
@@ -961,6 +965,18 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
       const int nlev = (Pipe::kOn && depth > 0) ? depth - 1 : depth;
       const int nleaf = 1 << nlev;
       for (int leaf = 0; leaf < nleaf; leaf++) {
+        if constexpr (M::kNutsWavesPerSimd == 2 && !Pipe::kOn) {
+          // Two waves share the SIMD and its arbiter serves the OLDER one first: left alone, the
+          // older wave runs at the speed of a lone wave (sv: 291 leapfrogs/ms), the younger one on
+          // what is left (169), so half the chains end after 52 % of the launch and the other
+          // half then run alone at 64 % of the pair's throughput (profiles/r3_sv_prio). Trading
+          // the priority every 2^16 shader clocks (27 us) makes both progress alike and end together.
+          if (L.prio_slot >= 0) {
+            const bool mine = (((clock64() >> 16) ^ (long long)L.prio_slot) & 1LL) != 0;
+            if (__builtin_amdgcn_readfirstlane(mine ? 1 : 0)) __builtin_amdgcn_s_setprio(3);
+            else __builtin_amdgcn_s_setprio(0);
+          }
+        }
         if constexpr (Pipe::kOn) {
           if (leaf > 0) pipe->sync();   // unit 0 arrived with the doubling's barrier
         }
@@ -1225,6 +1241,7 @@ __device__ __forceinline__ void lane_setup(NutsLane<M, G>& L, const typename M::
   L.zt = zt;
   L.nor_r = nor_r;
   L.alive = true;
+  L.prio_slot = -1;
   M::load(mc, L.l, L.ln);
   if constexpr (M::kExtraLdsDoubles > 0)
     L.ln.sh = lds + (size_t)LDSL * nuts_nslot<M>() * kNutsBlock + kZigLdsBytes / 8;
@@ -1314,6 +1331,9 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock, M::kNutsW
   lane_setup<M, G, LDSL>(L, mc, lds, P.stack, P.inv_mass, P.sqrt_inv_mass, zt, P.nor_r, P.flat, P.dm);
   if constexpr (M::kLdsDataDoubles > 0) L.ln.xoff = xoff;
   L.alive = has_chain;
+  // workgroups i and i + 1024 land on the same SIMD (one wave each, 1024 SIMDs, dispatch in order:
+  // every pair of the 2048-wave sv launch, tools/sv_probe.sh): the second thousand are the younger waves
+  if constexpr (M::kNutsWavesPerSimd == 2 && !kPipe) L.prio_slot = (gridDim.x > 1024 && P.prio) ? (int)((blockIdx.x >> 10) & 1) : -1;
   using Pipe = std::conditional_t<kPipe, PipeBox<DPL>, NoPipe>;
   Pipe pipe;
   if constexpr (kPipe) {
@@ -1396,7 +1416,19 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock, M::kNutsW
     }
   };
 #ifdef EXMC_XCC_PROBE
-  const long long wave_c0 = clock64();
+  const long long wave_c0 = clock64(), wave_w0 = wall_clock64();
+  auto probe_out = [&]() {
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096) {
+      unsigned xcc, hw;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      g_wave_probe[blockIdx.x * 5 + 0] = (double)((xcc & 0xf) * 10000 + ((hw >> 8) & 0xf) * 100 + ((hw >> 13) & 0x7) * 10 + ((hw >> 4) & 0x3));
+      g_wave_probe[blockIdx.x * 5 + 1] = (double)(clock64() - wave_c0);
+      g_wave_probe[blockIdx.x * 5 + 2] = (double)lf_total;
+      g_wave_probe[blockIdx.x * 5 + 3] = (double)wave_w0;
+      g_wave_probe[blockIdx.x * 5 + 4] = (double)wall_clock64();
+    }
+  };
 #endif
   if constexpr (kPipe) {
     nuts_run<M, G, LDSL>(mc, L, st, P.n_draws, P.eps, P.max_depth, sink, &pipe);
@@ -1484,21 +1516,17 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock, M::kNutsW
         atomicAdd(&P.counters[0], lf_total);
         atomicAdd(&P.counters[1], div_total);
       }
+#ifdef EXMC_XCC_PROBE
+      probe_out();
+#endif
       return;
     }
     nuts_run<M, G, LDSL>(mc, L, st, P.n_draws, P.eps, P.max_depth, sink);
   } else {
     nuts_run<M, G, LDSL>(mc, L, st, P.n_draws, P.eps, P.max_depth, sink);
   }
-#ifdef EXMC_XCC_PROBE   // development: per-wave clocks and placement of the sampling kernel
-  if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096) {
-    unsigned xcc, hw;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    g_wave_probe[blockIdx.x * 3 + 0] = (double)((xcc & 0xf) * 1000 + ((hw >> 8) & 0xf) * 10 + ((hw >> 13) & 0x7));
-    g_wave_probe[blockIdx.x * 3 + 1] = (double)(clock64() - wave_c0);
-    g_wave_probe[blockIdx.x * 3 + 2] = (double)lf_total;
-  }
+#ifdef EXMC_XCC_PROBE   // development: per-wave clocks, wall-clock span and placement of the sampling kernel
+  probe_out();
 #endif
 
   if (!has_chain) return;
