@@ -153,10 +153,12 @@ struct NutsParams {
 //   board[2], board[3]    statistics: chains moved, waves that became hosts
 //   board[8 .. 8+16384)   live chains per SIMD, indexed by (XCC_ID, SE, SH, CU, SIMD)
 //   board[16392 + 2 b]    mailbox of workgroup b: chain + 1 (0: empty), draws done
+//   board[16392 + 2 W + b]  (W workgroups) what workgroup b estimates is left of its chain, in
+//                         thousands of leapfrogs + 1 (0: not known yet): its SIMD partner reads it
 constexpr int kMigSimds = 16384;
 constexpr int kMigLive = 8;
 constexpr int kMigMail = kMigLive + kMigSimds;
-__host__ __device__ constexpr size_t mig_board_ints(size_t n_workgroups) { return kMigMail + 2 * n_workgroups; }
+__host__ __device__ constexpr size_t mig_board_ints(size_t n_workgroups) { return kMigMail + 3 * n_workgroups; }
 
 __device__ __forceinline__ int mig_simd_uid() {
   unsigned xcc, hw;
@@ -229,6 +231,7 @@ struct NutsLane {
   int l;
   int prio_slot;     // 0 / 1: which of the two waves of its SIMD this is (time-sliced issue priority,
                      // see nuts_run); -1: the wave has its SIMD to itself
+  int prio_duty;     // sixteenths of the time slot 0 holds the priority (8: even shares)
   double* lstk;      // this lane's column of the LDS stack
   double* gstk;      // this lane's column of the global spill stack
   size_t nthreads;
@@ -969,10 +972,13 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
           // Two waves share the SIMD and its arbiter serves the OLDER one first: left alone, the
           // older wave runs at the speed of a lone wave (sv: 291 leapfrogs/ms), the younger one on
           // what is left (169), so half the chains end after 52 % of the launch and the other
-          // half then run alone at 64 % of the pair's throughput (profiles/r3_sv_prio). Trading
-          // the priority every 2^16 shader clocks (27 us) makes both progress alike and end together.
+          // half then run alone at 64 % of the pair's throughput (profiles/r3_sv_prio). The
+          // priority is traded in sixteenths of a 2^16-clock period (27 us): slot 0 holds it for
+          // prio_duty sixteenths, slot 1 for the rest -- even shares by default, the larger share to
+          // the chain with more left to do where the kernel knows it (nuts_kernel, migration loop).
           if (L.prio_slot >= 0) {
-            const bool mine = (((clock64() >> 16) ^ (long long)L.prio_slot) & 1LL) != 0;
+            const int phase = (int)((clock64() >> 12) & 15);
+            const bool mine = (phase < L.prio_duty) == (L.prio_slot == 0);
             if (__builtin_amdgcn_readfirstlane(mine ? 1 : 0)) __builtin_amdgcn_s_setprio(3);
             else __builtin_amdgcn_s_setprio(0);
           }
@@ -1242,6 +1248,7 @@ __device__ __forceinline__ void lane_setup(NutsLane<M, G>& L, const typename M::
   L.nor_r = nor_r;
   L.alive = true;
   L.prio_slot = -1;
+  L.prio_duty = 8;
   M::load(mc, L.l, L.ln);
   if constexpr (M::kExtraLdsDoubles > 0)
     L.ln.sh = lds + (size_t)LDSL * nuts_nslot<M>() * kNutsBlock + kZigLdsBytes / 8;
@@ -1441,15 +1448,43 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock, M::kNutsW
       int* const mail = board + kMigMail + 2 * (int)blockIdx.x;
       int cur = chain, done = 0;
       if (lane == 0) atomicAdd(live, 1);
+      // what is left of the two chains of this SIMD (workgroups b and b + 1024): the shares of the
+      // issue priority follow it, so that both end together instead of the longer one running on
+      // alone. remaining = leapfrogs per draw so far x draws to go, known to the partner one
+      // transition late; with the pair's rates (291 with the priority, 169 without, of 460) the
+      // share f of slot 0 that makes the rates proportional to rho = left_0 / left_1 is
+      // (291 rho - 169) / (122 (1 + rho)).
+      int* const pair_word = board + kMigMail + 2 * (int)gridDim.x;
+      const int partner = (int)blockIdx.x ^ 1024;
+      const bool paired = L.prio_slot >= 0 && partner < (int)gridDim.x;
+      unsigned long long lf_at_start = 0;
+      int done_at_start = 0;
       for (;;) {
-        // one transition at a time; the two words looked at after it are loaded before it
-        int host_adv = 0, n_live = 0;
+        // one transition at a time; the words looked at after it are loaded before it
+        int host_adv = 0, n_live = 0, partner_left = 0;
         if (lane == 0) {
           host_adv = mig_load(board + 1);
           n_live = mig_load(live);
+          if (paired) partner_left = mig_load(pair_word + partner);
         }
         nuts_run<M, G, LDSL>(mc, L, st, 1, P.eps, P.max_depth, sink);
         done++;
+        if (paired) {
+          const int seen = done - done_at_start;
+          const double per_draw = (seen >= 4) ? (double)(lf_total - lf_at_start) / (double)seen : 0.0;
+          const int my_left = 1 + (int)(per_draw * (double)(P.n_draws - done) * 1.0e-3);
+          if (lane == 0 && seen >= 4) __hip_atomic_store(pair_word + blockIdx.x, my_left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const int pl = __builtin_amdgcn_readfirstlane(partner_left);
+          int duty = 8;
+          if (pl > 0 && seen >= 4) {
+            const double l0 = (L.prio_slot == 0) ? (double)my_left : (double)pl;
+            const double l1 = (L.prio_slot == 0) ? (double)pl : (double)my_left;
+            const double rho = l0 / l1;
+            const double f = (291.0 * rho - 169.0) / (122.0 * (1.0 + rho));
+            duty = (int)(16.0 * fmin(fmax(f, 0.0), 1.0) + 0.5);
+          }
+          L.prio_duty = duty;
+        }
         if (done == P.n_draws) {
           chain_store<M, G>(P.st, C, cur, l, st);
           int last = 0;
@@ -1487,6 +1522,7 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock, M::kNutsW
           }
           chain_load<M, G>(P.st, C, cur, l, st);
           bind(cur, (size_t)P.draw_offset + (size_t)done);
+          L.prio_slot = -1;   // a host has its SIMD to itself
           continue;
         }
         if (__builtin_amdgcn_readfirstlane((host_adv != 0 && n_live >= 2) ? 1 : 0)) {
