@@ -2,6 +2,7 @@
 """Cost of a model's log-density + gradient alone: the B2 multi_step kernel (one leapfrog = one
 logp_grad call plus 3 d flops) over a batch of chains, per model and layout:
     python tools/model_cost.py sv gen_sv logistic gen_logistic radon gen_radon [--steps 64]
+    python tools/model_cost.py logistic:4:32768 logistic:16:32768      (model:lanes:chains)
 Prints ns per leapfrog per chain and leapfrogs/s; under rocprofv3 --pmc SQ_INSTS_VALU ... the
 multi_step_kernel rows give instructions per leapfrog."""
 import ctypes as C
@@ -21,11 +22,12 @@ def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     steps = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else 64
     dev = torch.device("cuda", 0)
-    for name in args:
+    for arg in args:
+        name, *over = arg.split(":")
         spec, _ = bench.make_spec(name)
         comp = sampler.compile(spec)
-        lanes = comp.default_lanes
-        n = bench.DEFAULT_CHAINS_PER_GPU[name]
+        lanes = int(over[0]) if over else comp.default_lanes
+        n = int(over[1]) if len(over) > 1 else bench.DEFAULT_CHAINS_PER_GPU[name]
         d = spec.d
         g = torch.Generator(device=dev).manual_seed(1)
         q0 = torch.tensor(spec.to_unconstrained(spec.default_init), dtype=torch.float64, device=dev)
@@ -47,6 +49,7 @@ def main():
                 ts.append(comp.last_kernel_ms)
         ms = min(ts)
         waves = n * lanes / 64
+        name = arg
         print("%-14s lanes %2d chains %5d (%5d waves): %8.3f ms / %d steps = %7.1f ns per leapfrog-chain, "
               "%.3e leapfrog/s, %.2f us per wave-leapfrog" % (name, lanes, n, waves, ms, steps, ms * 1e6 / steps / n,
                                                               n * steps / (ms * 1e-3), ms * 1e3 / steps / max(1.0, waves / 1024.0) / (1 if waves >= 1024 else 1)))

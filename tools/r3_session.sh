@@ -23,6 +23,8 @@ for what in "$@"; do
     cost) python tools/model_cost.py $COST_MODELS > $out/model_cost.txt 2> $out/model_cost.err || { tail -5 $out/model_cost.err; exit 1; }; cat $out/model_cost.txt ;;
     costpmc) rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD --output-format csv -d $out/costpmc -o run -- python3 tools/model_cost.py $COST_MODELS > $out/model_cost_pmc.txt 2> $out/costpmc.err || { tail -5 $out/costpmc.err; exit 1; }
           python tools/pmc_kernel_table.py $out/costpmc multi_step_kernel | tee $out/model_cost_pmc_table.txt ;;
+    mfma) rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES --output-format csv -d $out/mfmapmc -o run -- python3 tools/model_cost.py $COST_MODELS > $out/mfma_cost.txt 2> $out/mfmapmc.err || { tail -5 $out/mfmapmc.err; exit 1; }
+          cat $out/mfma_cost.txt; python tools/pmc_kernel_table.py $out/mfmapmc multi_step_kernel | tee $out/mfma_pmc_table.txt ;;
     *) echo "unknown step $what"; exit 2 ;;
   esac
 done
