@@ -17,6 +17,9 @@ DEPS = [
     os.path.join(HERE, "csrc", "exmc_models.hpp"),
     os.path.join(HERE, "csrc", "exmc_device.hpp"),
     os.path.join(HERE, "csrc", "exmc_ess.hpp"),
+    os.path.join(HERE, "csrc", "exmc_plugin_part.hip"),
+    os.path.join(HERE, "csrc", "exmc_plugin_kernels.inc"),
+    os.path.join(HERE, "csrc", "exmc_plugin_layouts.inc"),
     os.path.join(ROOT, "include", "exmc_hip.h"),
     os.path.join(ROOT, "include", "exmc_detmath.h"),
     os.path.join(ROOT, "include", "exmc_zig_tables.h"),

@@ -1377,16 +1377,45 @@ def build_plugin(gen, force=False, verbose=False):
         if all(os.path.getmtime(p) <= t for p in _build.DEPS + [hdr]):
             return so
     tmp = "%s.%d.tmp" % (so, os.getpid())       # two processes may build the same model: publish atomically
-    cmd = [_build.hipcc()] + _build.FLAGS + _extra_flags() + ["-DEXMC_ONLY_CUSTOM", '-DEXMC_CUSTOM_HEADER="%s"' % hdr,
-                                              "-o", tmp, _build.SRC]
-    if verbose:
-        print(" ".join(cmd))
+    hipcc = _build.hipcc()
+    defs = ["-DEXMC_ONLY_CUSTOM", '-DEXMC_CUSTOM_HEADER="%s"' % hdr]
+    flags = [f for f in _build.FLAGS if f != "-shared"] + _extra_flags()
+    cwd = os.path.dirname(_build.SRC)
+    objs = []
     try:
-        subprocess.check_call(cmd, cwd=os.path.dirname(_build.SRC))
+        if os.environ.get("EXMC_PLUGIN_ONE_TU") == "1":
+            cmd = [hipcc] + _build.FLAGS + _extra_flags() + defs + ["-o", tmp, _build.SRC]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd, cwd=cwd)
+        else:
+            # the four heavy kernels (sampling, its stream form, the two warmup forms) as translation
+            # units of their own next to the rest of the library, compiled side by side: the plug-in is
+            # ready in the time of its slowest part (the analogue of the EXLA JIT step, jit.ex)
+            part_src = os.path.join(cwd, "exmc_plugin_part.hip")
+            jobs = [([hipcc] + flags + defs + ["-DEXMC_PLUGIN_SPLIT", "-c", "-o", "%s.main.o" % tmp, _build.SRC])]
+            layouts = [k for k, macro in ((1, "EXMC_GEN_ONE_LANE"), (2, "EXMC_GEN_VEC"), (3, "EXMC_GEN_LANES "))
+                       if ("#define " + macro) in gen.header]
+            jobs += [([hipcc] + flags + defs + ["-DEXMC_PLUGIN_PART=%d" % k, "-DEXMC_PLUGIN_LAYOUT=%d" % lay, "-c", "-o",
+                                               "%s.p%d_%d.o" % (tmp, k, lay), part_src])
+                     for k in (3, 4, 1, 2) for lay in layouts]
+            objs = [j[j.index("-o") + 1] for j in jobs]
+            if verbose:
+                for j in jobs:
+                    print(" ".join(j))
+            procs = [subprocess.Popen(j, cwd=cwd) for j in jobs]
+            rcs = [p_.wait() for p_ in procs]
+            if any(rcs):
+                raise subprocess.CalledProcessError(max(rcs), jobs[rcs.index(max(rcs))])
+            link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
+            if verbose:
+                print(" ".join(link))
+            subprocess.check_call(link, cwd=cwd)
         os.replace(tmp, so)
     finally:
-        if os.path.exists(tmp):
-            os.remove(tmp)
+        for f in [tmp] + objs:
+            if os.path.exists(f):
+                os.remove(f)
     return so
 
 

@@ -22,6 +22,14 @@
 
 using namespace exmc;
 
+#ifdef EXMC_PLUGIN_SPLIT
+// a plug-in built in parts (exmc_plugin_part.hip): the four heavy kernels are compiled in translation
+// units of their own, in parallel; here they are only declared
+namespace exmc {
+#include "exmc_plugin_kernels.inc"
+}
+#endif
+
 namespace {
 
 #if EXMC_PROFILE_SECTIONS

@@ -236,6 +236,7 @@ __global__ void __launch_bounds__(kNutsBlock) find_eps_kernel(FindEpsParams P,
   }
 }
 
+#ifndef EXMC_PLUGIN_PART   // the model-independent kernels live in exmc_hip.hip's translation unit only
 // Diagnostics.ess (diagnostics.ex:42-52, 123-167) over a [S][D][C] trace, one lane per (dim, chain)
 // series (lanes sweep chains first, so every load of a wavefront is one coalesced row segment);
 // the per-series routine is exmc_ess.hpp.
@@ -401,5 +402,7 @@ rhat_kernel(const double* draws, int S, int D, int C, double* stats, double* rha
     rhat_out[dim] = __dsqrt_rn(var_hat / w);
   }
 }
+
+#endif  // EXMC_PLUGIN_PART
 
 }  // namespace exmc
