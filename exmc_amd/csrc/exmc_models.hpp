@@ -604,7 +604,9 @@ struct Logistic : ModelDefaults {
 #pragma unroll
       for (int j = 0; j < K; j++) s[1 + j] = __builtin_fma(xr[j], r, s[1 + j]);
     }
-    group_allsum_n<G, D + 1>(s);
+    // (64 lanes: the two cross-row stages of the 22 sums through the LDS crossbar -- with v_readlane each
+    // value passes through eight scalar registers, 176 in flight, which is where the scalar spills came from)
+    group_allsum_n<G, D + 1, (G == 64)>(s);
     double T[DPL];
     bool valid[DPL];
 #pragma unroll
