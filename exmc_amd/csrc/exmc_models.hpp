@@ -334,13 +334,25 @@ __device__ __forceinline__ void lanczos_pair_d(double lz0, double half_log_2pi, 
   double ag1, dag1, ag0, dag0;
   lanczos_sums<MM, G>(term, tdd, lz0, ag1, dag1, ag0, dag0,
                       std::make_integer_sequence<int, 8>{});
+  // The six logarithms in their short form while the wavefront is inside the fast window: every
+  // argument is then positive, finite and normal -- t = x + 6.5 >= 6.5; the caller's two are a
+  // watched scale and a watched degree of freedom times pi; the series sums are watched below and
+  // checked to be positive -- which is the domain of the main path (exmc_log_ge1 is that path plus a
+  // NaN fix-up; its name states the caller it was written for). Same bits as exmc_log there.
+  constexpr bool kFast = std::is_same_v<DV, Div<true>>;
   const double t1 = x1 + 6.5, t0 = x0 + 6.5;
   double la[4] = {t1, t0, extra[0], extra[1]};
-  lane_batch<G, 4>(la, l, [](double v) { return MM::log(v); });
+  if constexpr (kFast) lane_batch<G, 4>(la, l, [](double v) { return MM::log_ge1(v); });
+  else lane_batch<G, 4>(la, l, [](double v) { return MM::log(v); });
   extra[0] = la[2];
   extra[1] = la[3];
   double lb[2] = {ag1, ag0};
-  lane_batch<G, 2>(lb, l, [](double v) { return MM::log(v); });
+  if constexpr (kFast) {
+    dv.ok = dv.ok && (ag1 > 0.0) && (ag0 > 0.0);
+    lane_batch<G, 2>(lb, l, [](double v) { return MM::log_ge1(v); });
+  } else {
+    lane_batch<G, 2>(lb, l, [](double v) { return MM::log(v); });
+  }
   const double xm1 = x1 - 0.5, xm0 = x0 - 0.5;
   dv.watch(xm1); dv.watch(xm0);
   dv.watch(ag1); dv.watch(ag0);
@@ -408,9 +420,10 @@ struct SV : ModelDefaults {
                                                 const double (&q)[DPL], double (&g)[DPL], DV& dv) {
     const double zs_raw = group_bcast_c<G, T % G>(q[T / G]);
     const double zn_raw = group_bcast_c<G, (T + 1) % G>(q[(T + 1) / G]);
+    constexpr bool kFast = std::is_same_v<DV, Div<true>>;
     const double zs = clamp200(zs_raw), zn = clamp200(zn_raw);
     double ez[2] = {zs, zn};
-    lane_batch<G, 2>(ez, l, [](double v) { return MM::exp(v); });
+    lane_batch<G, 2>(ez, l, [](double v) { return MM::exp_pm200(v); });   // clamp200'ed: always in range
     const double sigma = ez[0], nu = ez[1];
     const double ss = fmax(sigma, ln.k[kTiny]);
     const double sdf = fmax(nu, ln.k[kTiny]);
@@ -446,11 +459,16 @@ struct SV : ModelDefaults {
       const double resid = qi - prev;
       dv.template watch_exp_if<-250, 250>(ist, resid);
       const double e = dv(resid, rss);
-      const double z = ln.r[k] * MM::exp(-qi);
+      // the two specials of a slot in their short forms while the wavefront is inside the fast
+      // window (a state below 2^-380 or above 2^7 in magnitude re-evaluates the pass with the
+      // general forms, like an out-of-range quotient; same bits on the domain): exp(-s_t) without
+      // its special-case guards, and log(1 + w) with 1 + w in [1, 2^351) by the watches above
+      dv.template watch_exp_if<-380, 7>(ist, qi);
+      const double z = ln.r[k] * (kFast ? MM::exp_pm200(-qi) : MM::exp(-qi));
       const double zz = z * z;
       dv.template watch_exp_if<-250, 250>(ist, zz);
       const double w = dv(zz, rsdf);
-      const double lg = MM::log(1.0 + w);
+      const double lg = kFast ? MM::log_ge1(1.0 + w) : MM::log(1.0 + w);
       const double wr = dv(w, 1.0 + w);
       P[k] = ist ? (-0.5 * (e * e + cn)) : 0.0;
       E2[k] = ist ? (e * e - 1.0) : 0.0;
@@ -898,8 +916,9 @@ struct Radon : ModelDefaults {
     const double beta = group_bcast_c<G, (J + 4) % G>(q[(J + 4) / G]);
     const double zsa = clamp200(zsa_raw), zsy = clamp200(zsy_raw);
     // the chain-scalar transcendentals as lane-batched evaluations: 2 exps, then the 3 logs
+    constexpr bool kFast = std::is_same_v<DV, Div<true>>;
     double ez[2] = {zsa, zsy};
-    lane_batch<G, 2>(ez, l, [](double v) { return exmc_exp(v); });
+    lane_batch<G, 2>(ez, l, [](double v) { return exmc_exp_pm200(v); });   // clamp200'ed: always in range
     const double sa = ez[0], sy = ez[1];
     const double ssy = fmax(sy, ln.kc[kTiny]);
     dv.template watch_exp_if<-100, 100>(true, ssy);
@@ -911,8 +930,11 @@ struct Radon : ModelDefaults {
     // logp = c_hc - log(1 + z^2), d/dx = -((2z / 2.5) / (1 + z^2))
     const double za = dv(sa, ln.c25), zy = dv(sy, ln.c25);
     const double za2 = za * za, zy2 = zy * zy;
+    // inside the fast window ssy is a watched positive scale and 1 + z^2 lies in [1, e^400]: the main
+    // path of the logarithm alone (same bits)
     double lx[3] = {ssy, 1.0 + za2, 1.0 + zy2};
-    lane_batch<G, 3>(lx, l, [](double v) { return exmc_log(v); });
+    if constexpr (kFast) lane_batch<G, 3>(lx, l, [](double v) { return exmc_log_ge1(v); });
+    else lane_batch<G, 3>(lx, l, [](double v) { return exmc_log(v); });
     const double cn = ln.kc[kLog2Pi] + 2.0 * lx[0];
     const double dsa = -dv(dv(2.0 * za, ln.c25), 1.0 + za2);
     const double dsy = -dv(dv(2.0 * zy, ln.c25), 1.0 + zy2);
