@@ -162,3 +162,70 @@ def test_flatten_rules():
     g.sums.clear()
     assert cl._flatten(g, u, False) == [u]                   # ... is one term of the model,
     assert cl._flatten(g, u, True) == [g.exp(a), g.exp(b), g.exp(c)]   # a reduction inside a closure
+
+
+# ---- randomly drawn models: the lane layout against the one-lane layout (d <= 20) and against
+# central differences (any d), at 16, 32 and 64 lanes per chain ----
+def _random_big_ir(seed):
+    """A hierarchical model with 1-3 plates of random size and kind, hyper-parameters with random
+    transforms, a vector obs and a random walk: d between ~10 and ~150."""
+    rng = np.random.default_rng(1000 + seed)
+    ir = cg.IR()
+    ir.rv("a_loc", "normal", dict(mu=0.3, sigma=2.0))
+    sd = str(rng.choice(["half_cauchy", "half_normal", "exponential"]))
+    sp = {"half_cauchy": dict(scale=2.0), "half_normal": dict(sigma=2.0), "exponential": {"lambda": 0.5}}[sd]
+    ir.rv("b_scale", sd, sp, transform=str(rng.choice(["log", "softplus"])))
+    ir.rv("c_df", "exponential", {"lambda": 0.2}, transform="log")
+    for p in range(int(rng.integers(1, 4))):
+        k = int(rng.integers(3, 45))
+        like = str(rng.choice(["normal", "student_t", "laplace", "bernoulli"]))
+        centred = bool(rng.integers(0, 2))
+        for j in range(k):
+            name = "g%d_%02d" % (p, j)
+            ir.rv(name, "normal", dict(mu="a_loc", sigma=(float(rng.uniform(0.5, 2.0)) if centred else "b_scale")))
+            nobs = int(rng.integers(1, 4))
+            y = rng.normal(size=nobs) * 1.5
+            if like == "normal":
+                ir.rv("y%d_%02d" % (p, j), "normal", dict(mu=name, sigma=float(rng.uniform(0.5, 3.0))))
+            elif like == "student_t":
+                ir.rv("y%d_%02d" % (p, j), "student_t", dict(df="c_df", loc=name, scale="b_scale"))
+            elif like == "laplace":
+                ir.rv("y%d_%02d" % (p, j), "laplace", dict(mu=name, b=float(rng.uniform(0.5, 3.0))))
+            else:
+                ir.rv("q%d_%02d" % (p, j), "normal", dict(mu=name, sigma=1.0), transform="logit")
+                ir.rv("y%d_%02d" % (p, j), "bernoulli", dict(p="q%d_%02d" % (p, j)))
+                y = (rng.uniform(size=nobs) < 0.5).astype(float)
+            ir.obs("o%d_%02d" % (p, j), "y%d_%02d" % (p, j), y if nobs > 1 else float(y[0]))
+    if rng.integers(0, 2):
+        ir.rv("w", "gaussian_random_walk", dict(sigma="b_scale", steps=int(rng.integers(5, 40))))
+    return ir, rng
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_models_in_the_lane_layout(seed):
+    ir, rng = _random_big_ir(seed)
+    lanes = (16, 32, 64)[seed % 3]
+    gen = cg.generate(ir, lanes=lanes)
+    assert gen.lane_layout is not None and gen.lane_layout["n_families"] >= 1
+    q = rng.normal(size=gen.d) * 0.6
+    lp, g = GC.logp_grad(gen, q, lanes=lanes)
+    assert np.isfinite(lp) and np.all(np.isfinite(g))
+    if "EXMC_GEN_ONE_LANE" in gen.header:          # d <= 20: the one-lane form is an independent emission
+        for _ in range(4):
+            q2 = rng.normal(size=gen.d) * 0.8
+            a, ga = GC.logp_grad(gen, q2, 1)
+            b, gb = GC.logp_grad(gen, q2, lanes=lanes)
+            assert abs(a - b) <= 1e-12 * max(1.0, abs(a))
+            np.testing.assert_allclose(ga, gb, rtol=1e-10, atol=1e-10)
+    idx = rng.choice(gen.d, size=min(gen.d, 12), replace=False)
+    for i in idx:
+        e = np.zeros(gen.d)
+        e[i] = 1e-6
+        fd = (GC.logp_grad(gen, q + e, lanes=lanes)[0] - GC.logp_grad(gen, q - e, lanes=lanes)[0]) / 2e-6
+        assert abs(fd - g[i]) <= 2e-5 * max(1.0, abs(g[i]), abs(lp) * 1e-3), (seed, i, fd, g[i])
+    # the two layouts of one model differ in the order of their sums only
+    other = 64 if lanes != 64 else 16
+    gen2 = cg.generate(ir, lanes=other)
+    lp2, g2 = GC.logp_grad(gen2, q, lanes=other)
+    assert abs(lp - lp2) <= 1e-11 * max(1.0, abs(lp))
+    np.testing.assert_allclose(g, g2, rtol=1e-9, atol=1e-9)

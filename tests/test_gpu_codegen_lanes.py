@@ -103,3 +103,41 @@ def test_lane_layout_chain_batches_bit_exact(which, hip):
     assert stats[0]["step_size"] == st.step_size
     for k in ("draws", "logp", "tree_depth", "n_steps", "divergent", "accept_prob", "energy"):
         assert np.array_equal(raw[k], t[k]), k
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_random_models_in_the_lane_layout_bit_exact(seed, hip):
+    """Randomly drawn hierarchical models (tests/test_codegen_lanes.py _random_big_ir: one to three
+    plates of random size and likelihood, random transforms, sometimes a random walk) at 16, 32 and
+    64 lanes per chain: log-density, gradient and a short sample/3 equal the generated text on the
+    CPU bit for bit."""
+    import test_codegen_lanes as TL
+    ir, rng = TL._random_big_ir(seed)
+    lanes = (16, 32, 64)[seed % 3]
+    gen = cg.generate(ir, lanes=lanes)
+    so = cg.build_plugin(gen)
+    init = None
+    spec = cg.GeneratedSpec(gen, so, name="gen_random_lanes_%d" % seed, default_init=init)
+    comp = sampler.compile(spec)
+    om = GC.model(gen, lanes)
+    n = 64
+    q = np.ascontiguousarray(rng.normal(size=(n, gen.d)) * 0.7)
+    q[1] = 40.0
+    q[2] = -40.0
+    lp, g = np.zeros(n), np.zeros((n, gen.d))
+    comp.check(comp.L.exmc_hip_logp_grad_host(comp.h, _dp(q), n, lanes, _dp(lp), _dp(g)))
+    cfg = O.Cfg(1, lanes)
+    for c in range(n):
+        olp, og = om.logp_grad(q[c], cfg)
+        assert olp == lp[c] or (np.isnan(olp) and np.isnan(lp[c])), (seed, c, olp, lp[c])
+        assert np.array_equal(og, g[c], equal_nan=True), (seed, c)
+    q0 = np.ascontiguousarray(rng.normal(size=gen.d) * 0.1)
+    opts = dict(num_warmup=60, num_samples=25, seed=5, lanes_per_chain=lanes)
+    tun = sampler._lib.Tuning()
+    tr, t = sampler._host_trace(1, 25, gen.d)
+    dv = C.c_int32()
+    comp.check(comp.L.exmc_hip_sample_host(comp.h, _dp(q0), sampler._c_opts(sampler._merge_opts(opts)), t,
+                                          C.byref(tun), C.byref(dv)))
+    ot, ost = O.sample(om, init_q=q0, num_warmup=60, num_samples=25, seed=5, cfg=cfg)
+    assert tun.epsilon == ost.step_size
+    assert np.array_equal(tr["draws"][0], ot["draws"]) and np.array_equal(tr["n_steps"][0], ot["n_steps"])
