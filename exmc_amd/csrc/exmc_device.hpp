@@ -522,6 +522,77 @@ struct Math {
   }
 };
 
+// ---- 64-lane sums as a reduce-scatter (one chain per wavefront) ----
+// group_allsum_n<64, N> moves every one of its N values through all six butterfly stages: 6 N
+// exchanges and adds. The sum tree of a value does not care WHICH lane adds a pair, so the first
+// stages can halve the number of values a lane carries instead: at stage xor-m a lane keeps half of
+// its values, sends the other half to lane ^ m (which kept those) and adds what it receives to what
+// it kept; after log2(N) such stages every lane holds one value, partially reduced over its 2^k-lane
+// group, and the remaining stages move that one value. The additions are the butterfly's own --
+// v[l] + v[l ^ 1], then (.)[l] + (.)[l ^ 2], ... -- so every total has the bits group_allsum_n gives
+// it (tools/probe/allsum_rs_probe.hip); quantity k ends up in the lanes with a known code in their
+// low bits. Exchanges: xor 1, 2 by DPP quad_perm, xor 8 by DPP row_ror:8, xor 4 / 16 by ds_swizzle
+// (bit mode), xor 32 by ds_bpermute: for kernels with a second wave on the SIMD to cover the LDS
+// crossbar's round trips, like the kLds form of group_allsum_n.
+template <int CTRL>
+__device__ __forceinline__ double xchg_dpp(double v) { return dpp_move<CTRL>(v); }
+template <int PATTERN>
+__device__ __forceinline__ double xchg_swizzle(double v) {
+  return __hiloint2double(__builtin_amdgcn_ds_swizzle(__double2hiint(v), PATTERN),
+                          __builtin_amdgcn_ds_swizzle(__double2loint(v), PATTERN));
+}
+__device__ __forceinline__ double xchg_xor32(double v) {
+  const int a = (((int)threadIdx.x & 63) ^ 32) << 2;
+  return __hiloint2double(__builtin_amdgcn_ds_bpermute(a, __double2hiint(v)),
+                          __builtin_amdgcn_ds_bpermute(a, __double2loint(v)));
+}
+constexpr int kSwzXor4 = (4 << 10) | 0x1F, kSwzXor16 = (16 << 10) | 0x1F;   // and 0x1f, or 0, xor m
+constexpr int kDppRowRor8 = 0x128;
+
+// one value through the stages xor 4 .. xor 32 (FROM = 4) or xor 8 .. xor 32 (FROM = 8)
+template <int FROM>
+__device__ __forceinline__ double rs64_tail(double z) {
+  if (FROM <= 4) z = z + xchg_swizzle<kSwzXor4>(z);
+  z = z + xchg_dpp<kDppRowRor8>(z);
+  z = z + xchg_swizzle<kSwzXor16>(z);
+  z = z + xchg_xor32(z);
+  return z;
+}
+
+// two sums: lane 0 (and every lane with bit 0 clear) ends with total 0, lane 1 with total 1
+__device__ __forceinline__ double rs64_reduce2(const double (&v)[2]) {
+  const bool b0 = (threadIdx.x & 1) != 0;
+  const double w = (b0 ? v[1] : v[0]) + xchg_dpp<kDppXor1>(b0 ? v[0] : v[1]);
+  return rs64_tail<4>(w + xchg_dpp<kDppXor2>(w));
+}
+// four sums: total 0 in lane 0, 2 in lane 1, 1 in lane 2, 3 in lane 3 (low two bits)
+__device__ __forceinline__ double rs64_reduce4(const double (&v)[4]) {
+  const bool b0 = (threadIdx.x & 1) != 0, b1 = (threadIdx.x & 2) != 0;
+  const double wa = (b0 ? v[2] : v[0]) + xchg_dpp<kDppXor1>(b0 ? v[0] : v[2]);
+  const double wb = (b0 ? v[3] : v[1]) + xchg_dpp<kDppXor1>(b0 ? v[1] : v[3]);
+  const double z = (b1 ? wb : wa) + xchg_dpp<kDppXor2>(b1 ? wa : wb);
+  return rs64_tail<4>(z);
+}
+// six sums: totals 0, 3, 2, 5, 1, 4 in lanes 0 .. 5 (1 and 4 again in lanes 6, 7)
+__device__ __forceinline__ double rs64_reduce6(const double (&v)[6]) {
+  const bool b0 = (threadIdx.x & 1) != 0, b1 = (threadIdx.x & 2) != 0, b2 = (threadIdx.x & 4) != 0;
+  const double w0 = (b0 ? v[3] : v[0]) + xchg_dpp<kDppXor1>(b0 ? v[0] : v[3]);
+  const double w1 = (b0 ? v[4] : v[1]) + xchg_dpp<kDppXor1>(b0 ? v[1] : v[4]);
+  const double w2 = (b0 ? v[5] : v[2]) + xchg_dpp<kDppXor1>(b0 ? v[2] : v[5]);
+  const double x = (b1 ? w2 : w0) + xchg_dpp<kDppXor2>(b1 ? w0 : w2);   // quantities 0 / 3 or 2 / 5
+  const double y = w1 + xchg_dpp<kDppXor2>(w1);                          // quantities 1 / 4
+  const double z = (b2 ? y : x) + xchg_swizzle<kSwzXor4>(b2 ? x : y);
+  return rs64_tail<8>(z);
+}
+// the four totals in every lane (they come back as scalars)
+__device__ __forceinline__ void rs64_allsum4(double (&v)[4]) {
+  const double z = rs64_reduce4(v);
+  v[0] = readlane_f64(z, 0);
+  v[2] = readlane_f64(z, 1);
+  v[1] = readlane_f64(z, 2);
+  v[3] = readlane_f64(z, 3);
+}
+
 // init0 + the sum over the chain's dimensions: lane-partial sum over this lane's valid slots, lane 0
 // seeded with init0, then the butterfly -- or, for a kSeqSum group, init0 + v[dim 0] + v[dim 1] + ...
 template <int G, int DPL, int D = G * DPL, bool kLds = false>
@@ -583,7 +654,13 @@ __device__ __forceinline__ bool uturn(const double (&rho)[DPL], const double (&p
     row_seqsum<D>(s[0], s[1], v * pa[0], v * pb[0]);
   } else {
     uturn_partials<DPL>(rho, pa, pb, im, valid, s[0], s[1]);
-    group_allsum_n<G, 2, kLds>(s);
+    if constexpr (G == 64 && kLds) {
+      // only the signs of the two totals are needed: they sit in lanes 0 and 1
+      const unsigned long long neg = __ballot((rs64_reduce2(s) < 0.0) ? 1 : 0);
+      return (neg & 0x3ULL) != 0;
+    } else {
+      group_allsum_n<G, 2, kLds>(s);
+    }
   }
   return (s[0] < 0.0) || (s[1] < 0.0);
 }
@@ -612,7 +689,15 @@ __device__ __forceinline__ void uturn3(const double (&r1)[DPL], const double (&a
     uturn_partials<DPL>(r1, a1, b1, im, valid, s[0], s[1]);
     uturn_partials<DPL>(r2, a2, b2, im, valid, s[2], s[3]);
     uturn_partials<DPL>(r3, a3, b3, im, valid, s[4], s[5]);
-    group_allsum_n<G, 6, kLds>(s);
+    if constexpr (G == 64 && kLds) {
+      // signs only: totals 0, 3, 2, 5, 1, 4 sit in lanes 0 .. 5 (rs64_reduce6)
+      const unsigned long long neg = __ballot((rs64_reduce6(s) < 0.0) ? 1 : 0);
+      c1 = (neg & ((1ULL << 0) | (1ULL << 4))) != 0;
+      c23 = (neg & ((1ULL << 1) | (1ULL << 2) | (1ULL << 3) | (1ULL << 5))) != 0;
+      return;
+    } else {
+      group_allsum_n<G, 6, kLds>(s);
+    }
   }
   c1 = (s[0] < 0.0) || (s[1] < 0.0);
   c23 = (s[2] < 0.0) || (s[3] < 0.0) || (s[4] < 0.0) || (s[5] < 0.0);

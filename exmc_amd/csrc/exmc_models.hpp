@@ -490,10 +490,27 @@ struct SV : ModelDefaults {
       nxt = (i + 1 < T) ? nxt : 0.0;
       g[k] = g[k] + (de[k] - nxt);
     }
-    const double sp = group_sum_slots<G, DPL, G * DPL, kXRowLds>(P, valid, l, 0.0);
-    const double sl = group_sum_slots<G, DPL, G * DPL, kXRowLds>(LL, valid, l, 0.0);
-    const double se = group_sum_slots<G, DPL, G * DPL, kXRowLds>(E2, valid, l, 0.0);
-    const double sn = group_sum_slots<G, DPL, G * DPL, kXRowLds>(DN, valid, l, 0.0);
+    double sp, sl, se, sn;
+    if constexpr (G == 64 && kXRowLds) {
+      // the four sums as ONE reduce-scatter (exmc_device.hpp rs64_allsum4): the lane partials of
+      // group_sum_slots, then the same xor-butterfly additions with a lane carrying two, then one
+      // value instead of four -- the same totals, bit for bit, for about half the instructions
+      double s4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int k = 0; k < DPL; k++) {
+        s4[0] = valid[k] ? (s4[0] + P[k]) : s4[0];
+        s4[1] = valid[k] ? (s4[1] + LL[k]) : s4[1];
+        s4[2] = valid[k] ? (s4[2] + E2[k]) : s4[2];
+        s4[3] = valid[k] ? (s4[3] + DN[k]) : s4[3];
+      }
+      rs64_allsum4(s4);
+      sp = s4[0]; sl = s4[1]; se = s4[2]; sn = s4[3];
+    } else {
+      sp = group_sum_slots<G, DPL, G * DPL, kXRowLds>(P, valid, l, 0.0);
+      sl = group_sum_slots<G, DPL, G * DPL, kXRowLds>(LL, valid, l, 0.0);
+      se = group_sum_slots<G, DPL, G * DPL, kXRowLds>(E2, valid, l, 0.0);
+      sn = group_sum_slots<G, DPL, G * DPL, kXRowLds>(DN, valid, l, 0.0);
+    }
     const bool in_s = (zs_raw > -200.0) && (zs_raw < 200.0);
     const bool in_n = (zn_raw > -200.0) && (zn_raw < 200.0);
     const double g_s = in_s ? ((se - ln.k[kLamS] * sigma) + 1.0) : 0.0;

@@ -1,0 +1,67 @@
+// The reduce-scatter forms of the 64-lane sums (exmc_device.hpp rs64_reduce2 / 4 / 6, rs64_allsum4)
+// against group_allsum_n<64, N> in both of its spellings, bit for bit, on random doubles of mixed
+// magnitude and sign (so that the order of the additions shows in the last bits), and the lanes the
+// totals end up in.   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -I include -o allsum_rs_probe allsum_rs_probe.hip
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../exmc_amd/csrc/exmc_device.hpp"
+
+using namespace exmc;
+
+__global__ void k(const double* in, double* out) {   // one wave: in [6][64], out [5][6][64]
+  const int l = threadIdx.x;
+  double v[6];
+  for (int j = 0; j < 6; j++) v[j] = in[j * 64 + l];
+  double a[6], b[6];
+  for (int j = 0; j < 6; j++) a[j] = b[j] = v[j];
+  group_allsum_n<64, 6, false>(a);
+  group_allsum_n<64, 6, true>(b);
+  for (int j = 0; j < 6; j++) { out[(0 * 6 + j) * 64 + l] = a[j]; out[(1 * 6 + j) * 64 + l] = b[j]; }
+  out[(2 * 6 + 0) * 64 + l] = rs64_reduce6(v);
+  const double v4[4] = {v[0], v[1], v[2], v[3]};
+  out[(2 * 6 + 1) * 64 + l] = rs64_reduce4(v4);
+  const double v2[2] = {v[0], v[1]};
+  out[(2 * 6 + 2) * 64 + l] = rs64_reduce2(v2);
+  double c[4] = {v[0], v[1], v[2], v[3]};
+  rs64_allsum4(c);
+  for (int j = 0; j < 4; j++) out[(3 * 6 + j) * 64 + l] = c[j];
+}
+
+int main() {
+  double *din, *dout;
+  static double in[6 * 64], out[5 * 6 * 64];
+  hipMalloc(&din, sizeof in);
+  hipMalloc(&dout, sizeof out);
+  long bad = 0;
+  srand(7);
+  for (int trial = 0; trial < 2000; trial++) {
+    for (int i = 0; i < 6 * 64; i++) {
+      const double m = (double)rand() / RAND_MAX - 0.5;
+      const int e = rand() % 40 - 20;
+      in[i] = ldexp(m, e);
+    }
+    hipMemcpy(din, in, sizeof in, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, din, dout);
+    hipMemcpy(out, dout, sizeof out, hipMemcpyDeviceToHost);
+    auto at = [&](int form, int j, int lane) { return out[(form * 6 + j) * 64 + lane]; };
+    auto same = [](double x, double y) { return memcmp(&x, &y, 8) == 0; };
+    static const int lane6[6] = {0, 4, 2, 1, 5, 3};   // total j sits in lane lane6[j]
+    static const int lane4[4] = {0, 2, 1, 3};
+    for (int j = 0; j < 6; j++) {
+      for (int l = 0; l < 64; l++) bad += !same(at(0, j, l), at(1, j, 0));          // the two butterflies, every lane
+      bad += !same(at(2, 0, lane6[j]), at(0, j, 0));
+      bad += !same(at(2, 0, lane6[j] + 8 * (trial % 8)), at(0, j, 0));             // and in the lanes with the same low bits
+    }
+    for (int j = 0; j < 4; j++) {
+      bad += !same(at(2, 1, lane4[j] + 4 * (trial % 16)), at(0, j, 0));
+      for (int l = 0; l < 64; l += 7) bad += !same(at(3, j, l), at(0, j, 0));
+    }
+    for (int j = 0; j < 2; j++) bad += !same(at(2, 2, j + 2 * (trial % 32)), at(0, j, 0));
+  }
+  printf("allsum_rs_probe: 2000 trials of 6 sums over 64 lanes, %ld mismatches\n", bad);
+  return bad != 0;
+}
