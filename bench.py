@@ -78,10 +78,11 @@ def make_spec(name):
             ir = codegen.radon_ir(hand.data[:J], start, hand.data[2 * J + 1:2 * J + 1 + nobs],
                                   hand.data[2 * J + 1 + nobs:], names=cty)
             ncp, lanes = False, 64
-        # radon's 1024 chains are 1024 wavefronts, one per SIMD: no second wave to make room for
-        # (the generated sv and logistic kernels measure faster uncapped too: under the 256-register
-        # cap their model bodies spill inside the leaf loop, profiles/r3_gen; EXMC_GEN_WPS=2 for A/B runs)
-        wps = int(os.environ.get("EXMC_GEN_WPS", "1"))
+        # radon's 1024 chains are 1024 wavefronts, one per SIMD: no second wave to make room for.
+        # sv and logistic launch 2048: compiled for two resident waves per SIMD like their
+        # hand-written kinds (the plug-in sizes its LDS so that eight workgroups fit a CU;
+        # gen_sv 1.9 -> 2.9e8, gen_logistic 1.4 -> 1.7e8 leapfrog/s; EXMC_GEN_WPS=1 / 2 for A/B runs)
+        wps = int(os.environ.get("EXMC_GEN_WPS", "1" if name == "gen_radon" else "2"))
         return codegen.compile_ir(ir, ncp=ncp, name=name, default_init=hand.default_init, lanes=lanes,
                                   waves_per_simd=wps), nbytes
     raise SystemExit("unknown model %s" % name)

@@ -405,9 +405,13 @@ class _Grad:
                    exmc_models.hpp); min likewise; |a|: g, -g or 0 by the sign of a
        Contributions to one node are added in decreasing order of the consumer's index."""
 
-    def __init__(self, g, root):
+    def __init__(self, g, root, const_num_ok=None):
         self.g = g
         self.adj = {root: g.lit(1.0)}
+        # lane layout only: c / b with a constant numerator c that is finite and non-zero (the
+        # callback decides, it knows the per-unit tables) takes d/db = -(y * y) * (1 / c) with 1 / c
+        # folded into the tables -- no second quotient at run time
+        self.const_num_ok = const_num_ok
 
     def _acc(self, node, contrib):
         if self.g.const[node]:
@@ -433,6 +437,13 @@ class _Grad:
             elif op == "neg":
                 self._acc(a[0], g.neg(gy))
             elif op == "div":
+                if (self.const_num_ok is not None and g.const[a[0]] and not g.const[a[1]]
+                        and self.const_num_ok(a[0])):
+                    y2 = g.mul(y, y)
+                    if g.lit_value(a[0]) != 1.0:
+                        y2 = g.mul(y2, g.recip(a[0]))
+                    self._acc(a[1], g.neg(g.mul(gy, y2)))
+                    continue
                 gr = g.mul(gy, g.recip(a[1]))
                 self._acc(a[0], gr)
                 if not g.const[a[1]]:
@@ -503,8 +514,12 @@ def _lgamma(g, x):
     # math.ex:27-52
     t = g.add(x, g.lit(6.5))
     ag = g.lit(_f32(LANCZOS[0]))
+    terms = [ag]
     for i, c in enumerate(LANCZOS[1:]):
-        ag = g.add(ag, g.div(g.lit(_f32(c)), g.add(x, g.lit(float(i)))))
+        terms.append(g.div(g.lit(_f32(c)), g.add(x, g.lit(float(i)))))
+        ag = g.add(ag, terms[-1])
+    if hasattr(g, "sums"):
+        g.sums[ag] = terms          # the lane layout evaluates the series one quotient per lane
     r = g.add(g.lit(HALF_LOG_2PI_F32), g.mul(g.sub(x, g.lit(0.5)), g.log(t)))
     return g.add(g.sub(r, t), g.log(ag))
 

@@ -53,7 +53,7 @@ class _LGraph(cg._Graph):
     in the uniform graph, `red j` (reduced sum j after the butterfly)."""
 
     LEAF_CONST = {"lit": True, "data": True, "q": False, "ext": False, "uc": True, "col": True,
-                  "gat": False, "red": False}
+                  "gat": False, "red": False, "wred": False}
 
     def _node(self, op, *args):
         k = (op,) + args
@@ -67,7 +67,7 @@ class _LGraph(cg._Graph):
         return i
 
 
-_LEAVES = ("lit", "data", "q", "ext", "uc", "col", "gat", "red")
+_LEAVES = ("lit", "data", "q", "ext", "uc", "col", "gat", "red", "wred")
 
 
 def _np_eval(g, nodes, leaf):
@@ -162,11 +162,13 @@ def _flatten(g, root, full):
     return out
 
 
-def _signature(g, root):
+def _signature(g, root, wild=False):
     """(shape, ids): the unit's DAG in post-order with local numbering; shape is what two units of
-    a family share, ids[k] the graph node behind local index k."""
+    a family share, ids[k] the graph node behind local index k. wild: a literal is a per-unit
+    constant like a datum (the coefficients of a series written out term by term)."""
     local, shape, ids = {}, [], []
     stack = [(root, False)]
+    is_wild = (lambda a: g.ops[a][0] == "lit") if wild else (lambda a: False)
     while stack:
         n, done = stack.pop()
         if n in local:
@@ -174,14 +176,22 @@ def _signature(g, root):
         op = g.ops[n]
         if op[0] in ("lit", "q", "data"):
             local[n] = len(shape)
-            shape.append(("lit", op[1]) if op[0] == "lit" else (op[0],))
+            shape.append((("wlit",) if wild else ("lit", op[1])) if op[0] == "lit" else (op[0],))
             ids.append(n)
         elif not done:
             stack.append((n, True))
-            stack.extend((a, False) for a in reversed(op[1:]) if a not in local)
+            stack.extend((a, False) for a in reversed(op[1:]) if a not in local and not is_wild(a))
         else:
+            args = []
+            for a in op[1:]:
+                if is_wild(a):            # every occurrence of a literal is a leaf of its own: the graph
+                    args.append(len(shape))   # shares equal literals, the terms of a series do not
+                    shape.append(("wlit",))
+                    ids.append(a)
+                else:
+                    args.append(local[a])
             local[n] = len(shape)
-            shape.append((op[0],) + tuple(local[a] for a in op[1:]))
+            shape.append((op[0],) + tuple(args))
             ids.append(n)
     return tuple(shape), ids
 
@@ -196,16 +206,21 @@ def _nonzero_const(g, n):
     return math.isfinite(v) and v != 0.0 and math.isfinite(1.0 / v)
 
 
-def _forward_tangents(g, roots):
+def _forward_tangents(g, roots, spread=None):
     """{node: {shared variable index: tangent node}} for every non-constant node the roots need.
-    Local rules mirror codegen._Grad (max / min pass the tangent on strict inequality only)."""
+    Local rules mirror codegen._Grad (max / min pass the tangent on strict inequality only).
+    spread: {sum node: [(input node, node holding d sum / d input)]} for the sums evaluated over the
+    lanes (_uniform_families): their tangent is the chain rule over their inputs."""
+    spread = spread or {}
     need, stack = set(), list(roots)
     while stack:
         n = stack.pop()
         if n in need or g.const[n]:
             continue
         need.add(n)
-        if g.ops[n][0] not in _LEAVES:
+        if n in spread:
+            stack.extend(e for e, _ in spread[n])
+        elif g.ops[n][0] not in _LEAVES:
             stack.extend(g.ops[n][1:])
     zero = g.lit(0.0)
     tan = {}
@@ -228,6 +243,14 @@ def _forward_tangents(g, roots):
             continue
         if k in _LEAVES:
             tan[n] = {}
+            continue
+        if n in spread:
+            r = {}
+            for e, part in spread[n]:
+                for v, x in tan.get(e, {}).items():
+                    term = g.mul(part, x)
+                    r[v] = term if v not in r else g.add(r[v], term)
+            tan[n] = r
             continue
         a = op[1:]
         t = [tan.get(x, {}) for x in a]
@@ -276,6 +299,99 @@ def _forward_tangents(g, roots):
             raise cg.CodegenError("no tangent rule for %s" % k)
         tan[n] = r
     return tan
+
+
+def _uniform_families(g, roots):
+    """Sums of >= MIN_FAMILY like terms in the non-constant graph under `roots` whose terms read
+    shared values and constants only (no variable that differs from term to term); outermost first,
+    and none whose inputs depend on another one's result."""
+    reach, stack = set(), [r for r in roots]
+    while stack:
+        n = stack.pop()
+        if n in reach or g.const[n]:
+            continue
+        reach.add(n)
+        if g.ops[n][0] not in _LEAVES:
+            stack.extend(g.ops[n][1:])
+    found, absorbed = [], set()
+    for V in sorted((n for n in reach if n in g.sums), reverse=True):
+        if V in absorbed:
+            continue
+        terms = g.sums[V]
+        dyn = [t for t in terms if not g.const[t]]
+        if len(dyn) < MIN_FAMILY or len(set(dyn)) != len(dyn):
+            continue
+        sigs = [_signature(g, t, wild=True) for t in dyn]
+        shape = sigs[0][0]
+        if any(sg[0] != shape for sg in sigs[1:]):
+            continue
+        ids = [sg[1] for sg in sigs]
+        uniform = [all(i[k] == ids[0][k] for i in ids) for k in range(len(shape))]
+        if uniform[-1]:
+            continue
+        # the template: from the root down to uniform nodes; a variable of its own per term -> not this kind
+        need, stack, ok = set(), [len(shape) - 1], True
+        while stack:
+            k = stack.pop()
+            if k in need:
+                continue
+            need.add(k)
+            if uniform[k]:
+                continue
+            if shape[k][0] == "q":
+                ok = False
+                break
+            if shape[k][0] not in ("wlit", "data"):
+                stack.extend(shape[k][1:])
+        if not ok:
+            continue
+        f = _Family()
+        f.shape, f.members, f.uniform, f.ids = shape, list(range(len(dyn))), uniform, ids
+        f.out, f.const_part = V, [t for t in terms if g.const[t]]
+        f.inputs = [ids[0][k] for k in sorted(need) if uniform[k] and not g.const[ids[0][k]]]
+        found.append(f)
+        # the partial sums between the terms and the terms' own nodes are no longer evaluated
+        acc = terms[0]
+        for t in terms[1:]:
+            acc = g.key.get(("add", acc, t))
+            if acc is not None:
+                absorbed.add(acc)
+        for i in ids:
+            absorbed.update(i[k] for k in need if not uniform[k])
+    # one level: drop a family whose inputs are computed from another family's sum
+    outs = set(f.out for f in found)
+    memo = {}
+
+    def depends(n):
+        stack = [n]
+        while stack:
+            x = stack[-1]
+            if x in memo:
+                stack.pop()
+                continue
+            if g.const[x] or g.ops[x][0] in _LEAVES:
+                memo[x] = False
+                stack.pop()
+                continue
+            if x in outs:
+                memo[x] = True
+                stack.pop()
+                continue
+            pend = [a for a in g.ops[x][1:] if a not in memo]
+            if pend:
+                stack.extend(pend)
+            else:
+                memo[x] = any(memo[a] for a in g.ops[x][1:])
+                stack.pop()
+        return memo[n]
+    kept = []
+    for f in sorted(found, key=lambda f: f.out):
+        if any(depends(i) for i in f.inputs):
+            outs.discard(f.out)
+            memo.clear()
+            continue
+        kept.append(f)
+    return kept
 
 
 def plan(g, term_roots, custom_roots, D, G):
@@ -338,7 +454,24 @@ def generate(g, term_roots, custom_roots, D, G, waves_per_simd=1):
     b_index = {}
     sh_off = D + 1           # LDS strip: [q (D)] [zero cell] [adjoint strips ...]
     dcols, icols = [], []    # table columns (each NPAD long), in emission order
-    for f in families:
+    def build_template(f):
+        """Twice: the second time the quotients by a denominator whose reciprocal the first pass
+        needed anyway (the adjoint of log b, of another quotient) take that reciprocal too."""
+        nonlocal sh_off
+        build_once(f, frozenset())
+        T = f.T
+        shared = frozenset(k for k, node in f.tmap.items()
+                           if T.key.get(("div", T.lit(1.0), node)) in f.live and not T.const[node])
+        if shared:
+            build_once(f, shared)
+        # LDS strips of the gathered adjoints
+        f.strip = []
+        for p in range(len(f.gather)):
+            f.strip.append(sh_off if f.gat_adj[p] is not None else -1)
+            if f.gat_adj[p] is not None:
+                sh_off += f.npad
+
+    def build_once(f, share_recip):
         n, shape = len(f.members), f.shape
         S = (n + G - 1) // G
         f.n, f.S, f.npad = n, S, S * G
@@ -350,15 +483,42 @@ def generate(g, term_roots, custom_roots, D, G, waves_per_simd=1):
             if k in need:
                 continue
             need.add(k)
-            if not f.uniform[k] and shape[k][0] not in ("lit", "q", "data"):
+            if not f.uniform[k] and shape[k][0] not in ("lit", "wlit", "q", "data"):
                 stack.extend(shape[k][1:])
         T = _LGraph()
         tmap, f.raw_cols, f.gather = {}, [], []     # raw data columns; gathered q indices per unit
+
+        def const_leaf(op, raw=f.raw_cols):
+            if op[0] == "col":
+                return raw[-op[1] - 1]
+            if op[0] == "uc":
+                return np.float64(uc_vals[op[1]])
+            raise cg.CodegenError("unexpected leaf %r in a constant" % (op,))
+
+        def num_ok(node, T=T):
+            """a constant of the template that is finite and non-zero in every unit, and so is 1 / it"""
+            v = np.asarray(_np_eval(T, [node], const_leaf)[node], dtype=np.float64)
+            with np.errstate(all="ignore"):
+                return bool(np.all(np.isfinite(v)) and np.all(v != 0.0) and np.all(np.isfinite(1.0 / v)))
+
+        def quotient(a, b, shared, T=T):
+            """a / b of the template. One reciprocal per distinct denominator serves the value and the
+            adjoint (the lane layout's own contract, like its fused multiply-adds: a * (1 / b) is within
+            an ulp of a / b): by a constant the reciprocal is folded into the tables, by a uniform
+            value it leaves the loop. c / b with a usable constant numerator stays a quotient -- its
+            adjoint is -(y * y) / c and needs no reciprocal at all."""
+            if T.const[b]:
+                return T.mul(a, T.recip(b)) if num_ok(b) else T._node("div", a, b)
+            if T.const[a] and num_ok(a) and not shared:
+                return T._node("div", a, b)
+            return T.mul(a, T.recip(b))
         for k in sorted(need):
             node0 = f.ids[0][k]
             kind = shape[k][0]
             if kind == "lit":
                 tmap[k] = T._node("lit", shape[k][1])
+            elif kind == "wlit" and f.uniform[k]:
+                tmap[k] = T._node("lit", g.ops[node0][1])
             elif f.uniform[k]:
                 if g.const[node0]:
                     tmap[k] = T._node("uc", uc_slot(("node", node0), g_const_value(node0)))
@@ -370,18 +530,21 @@ def generate(g, term_roots, custom_roots, D, G, waves_per_simd=1):
             elif kind == "q":
                 f.gather.append([g.ops[ids[k]][1] for ids in f.ids])
                 tmap[k] = T._node("gat", len(f.gather) - 1)
-            elif kind == "data":
-                vals = [g.data[g.ops[ids[k]][1]] for ids in f.ids]
+            elif kind in ("data", "wlit"):
+                vals = [g.data[g.ops[ids[k]][1]] if kind == "data" else float.fromhex(g.ops[ids[k]][1])
+                        for ids in f.ids]
                 if all(v == vals[0] for v in vals):
                     tmap[k] = T._node("uc", uc_slot(("val", float(vals[0]).hex()), vals[0]))
                 else:
                     f.raw_cols.append(np.asarray(vals, dtype=np.float64))
                     tmap[k] = T._node("col", -len(f.raw_cols))      # raw columns: negative ids
+            elif kind == "div":
+                tmap[k] = quotient(tmap[shape[k][1]], tmap[shape[k][2]], shape[k][2] in share_recip)
             else:
                 tmap[k] = T._node(kind, *[tmap[a] for a in shape[k][1:]])
         f.T, f.troot = T, tmap[root]
         n_fwd = len(T.ops)
-        ad = cg._Grad(T, f.troot)
+        ad = cg._Grad(T, f.troot, const_num_ok=num_ok)
         ad.run(n_fwd)
         f.ext_adj = {}          # boundary index -> adjoint node
         for key, node in list(T.key.items()):
@@ -416,23 +579,41 @@ def generate(g, term_roots, custom_roots, D, G, waves_per_simd=1):
             else:
                 f.col_of[i] = ("col", len(f.cols))
                 f.cols.append(np.array(v))
-        f.live = live
-        # LDS strips of the gathered adjoints, table offsets
-        f.strip = []
-        for p in range(len(f.gather)):
-            f.strip.append(sh_off if f.gat_adj[p] is not None else -1)
-            if f.gat_adj[p] is not None:
-                sh_off += f.npad
+        f.live, f.tmap = live, tmap
+
+    for f in families:
+        build_template(f)
     lsh = sh_off
 
     # ---- the uniform part: scalar units + the boundary nodes, differentiated with the reduced
     # adjoints as seeds (U = scalar_lp + sum_j red_j * b_j) ----
-    n_split = len(g.ops)
     scalar_lp = None
     for t in scalar_units:
         scalar_lp = t if scalar_lp is None else g.add(t, scalar_lp)
     if scalar_lp is None:
         scalar_lp = g.lit(0.0)
+
+    # ---- families INSIDE the uniform part: a sum of like terms of shared values only (the eight
+    # quotients of a Lanczos series, math.ex:27-52) is evaluated one term per lane and reduced in a
+    # butterfly of its own before the family loops, instead of by every lane in full. Per term the
+    # value and its partial derivatives with respect to the term's uniform inputs; the tangent of the
+    # sum is sum_e (reduced partial e) * tangent(e). One level: a sum whose inputs need another
+    # spread sum stays where it is. ----
+    ufams = _uniform_families(g, [scalar_lp] + list(boundary))
+    for f in ufams:
+        build_template(f)
+        if f.gather:
+            raise cg.CodegenError("internal: a uniform family gathered a variable")
+    uf_of = {f.out: f for f in ufams}
+    NW, w_const = 0, {}
+    for f in ufams:
+        f.w0 = NW
+        f.w_of = {j: f.w0 + 1 + k for k, j in enumerate(sorted(f.ext_adj))}
+        NW += 1 + len(f.ext_adj)
+        cpart = np.float64(0.0)
+        for c in f.const_part:                 # folded left to right, added after the reduction
+            cpart = cpart + np.float64(g_const_value(c))
+        f.cpart = float(cpart)
     n_split = len(g.ops)
     # reduced values: s[0] = log-density of the families, s[1 + j] = adjoint of boundary node j
     acc_of = {}
@@ -448,7 +629,8 @@ def generate(g, term_roots, custom_roots, D, G, waves_per_simd=1):
     # computed next to the values instead; what stays live is the Jacobian of the boundary nodes:
     #   d logp / d q_i = d scalar_lp / d q_i + sum_j red_j * d b_j / d q_i
     fwd_roots = [scalar_lp] + list(boundary)
-    tan = _forward_tangents(g, fwd_roots)
+    spread = {f.out: [(boundary[j], g._node("wred", f.w_of[j])) for j in sorted(f.ext_adj)] for f in ufams}
+    tan = _forward_tangents(g, fwd_roots, spread)
     ug = {}
     for i in range(D):
         acc = tan.get(scalar_lp, {}).get(i)
@@ -468,11 +650,21 @@ def generate(g, term_roots, custom_roots, D, G, waves_per_simd=1):
         if i in live:
             continue
         live.add(i)
-        if g.ops[i][0] not in _LEAVES and not g.const[i]:
+        if i in uf_of:
+            stack.extend(uf_of[i].inputs)       # its terms are evaluated by the lanes, not here
+        elif g.ops[i][0] not in _LEAVES and not g.const[i]:
             stack.extend(g.ops[i][1:])
     for i in sorted(live):
         if g.const[i] and g.ops[i][0] != "lit":
             uc_slot(("node", i), g_const_value(i))
+    for f in ufams:
+        if f.const_part:
+            uc_slot(("val", f.cpart.hex()), f.cpart)
+    # nodes that need a spread sum come after its butterfly
+    after_w = set()
+    for i in sorted(live):
+        if i in uf_of or (not g.const[i] and g.ops[i][0] not in _LEAVES and any(a in after_w for a in g.ops[i][1:])):
+            after_w.add(i)
 
     # ---- gather lists of the owner lanes (padded to the widest lane per slot) ----
     contrib = [[] for _ in range(D)]
@@ -502,7 +694,7 @@ def generate(g, term_roots, custom_roots, D, G, waves_per_simd=1):
     # ---- table layout: [uc][double columns][int32 columns (gather indices, owner lists)] ----
     NUC = max(1, len(uc_vals))
     doff = NUC
-    for f in families:
+    for f in families + ufams:
         f.doff = doff                     # row-major: unit u's constants are len(cols) consecutive doubles
         doff += len(f.cols) * f.npad
     ints = []
@@ -516,7 +708,7 @@ def generate(g, term_roots, custom_roots, D, G, waves_per_simd=1):
     if len(ints) % 2:
         ints.append(0)
     dtab = [np.asarray(uc_vals + [0.0] * (NUC - len(uc_vals)), dtype=np.float64)]
-    for f in families:
+    for f in families + ufams:
         if f.cols:
             rows = np.stack(f.cols, axis=1)                       # [n][ncol]
             rows = np.concatenate([rows, np.repeat(rows[:1], f.npad - f.n, axis=0)])
@@ -589,24 +781,66 @@ def generate(g, term_roots, custom_roots, D, G, waves_per_simd=1):
             return lit_text(op[1])
         if op[0] == "red":
             return "s[%d]" % op[1]
+        if op[0] == "wred":
+            return "w[%d]" % op[1]
         if g.const[i]:
             return "EXMC_GEN_LT(%d)" % uc_of[("node", i)]
         return "u%d" % i
 
-    u_nodes = set(i for i in live if not g.const[i] and g.ops[i][0] not in _LEAVES)
+    u_nodes = set(i for i in live if not g.const[i] and g.ops[i][0] not in _LEAVES and i not in uf_of)
     u_pinned = set([scalar_lp] + list(ug.values()) + list(boundary))
     u_plan, u_gone, _ = fuse_plan(g, u_nodes, u_pinned)
 
-    def ustmts(lo, hi):
+    # Chain-scalar transcendentals of the uniform part are the same instruction stream whatever their
+    # argument: the logs (exps, reciprocals) of one dependency level are evaluated together, argument
+    # i by lane i of the group, and broadcast back (exmc_device.hpp lane_batch) -- each value by
+    # exactly the operations of the plain call, so the host checker's loop gives the same bits.
+    batch_names = {"log": "LOG", "exp": "EXP", "log1p": "LOG1P", "rcp": "RCP"}
+    n_batches = [0]
+
+    def batch_kind(i):
+        op = g.ops[i]
+        if op[0] in ("log", "exp", "log1p"):
+            return op[0]
+        if op[0] == "div" and g.lit_value(op[1]) == 1.0:
+            return "rcp"
+        return None
+
+    def ustmts(lo, hi, late=None):
         out = []
-        if lo == 0:     # the shared variables: broadcast reads of the position strip
+        if lo == 0 and not late:     # the shared variables: broadcast reads of the position strip
             out.extend("  const double u%d = EXMC_GEN_SH(%d);" % (i, g.ops[i][1])
                        for i in sorted(live) if g.ops[i][0] == "q")
-        for i in sorted(u_nodes):
-            if lo <= i < hi and i not in u_gone:
-                op = g.ops[i]
-                e = fused(g, i, u_plan, uref) if i in u_plan else expr(op[0], [uref(x) for x in op[1:]])
-                out.append("  const double u%d = %s;" % (i, e))
+        region = [i for i in sorted(u_nodes)
+                  if lo <= i < hi and (late is None or (i in after_w) == late)]
+        level = {}
+        for i in region:
+            lv = max([level.get(a, 0) for a in g.ops[i][1:]] or [0])
+            level[i] = lv + (1 if batch_kind(i) else 0)
+        for lv in range(0, max(level.values(), default=0) + 1):
+            groups = {}
+            for i in region:
+                if level[i] == lv and batch_kind(i):
+                    groups.setdefault(batch_kind(i), []).append(i)
+            for kind in sorted(groups):
+                ids = groups[kind]
+                for c0 in range(0, len(ids), min(G, 16)):
+                    chunk = ids[c0:c0 + min(G, 16)]
+                    args = [uref(g.ops[i][2] if kind == "rcp" else g.ops[i][1]) for i in chunk]
+                    if len(chunk) == 1:
+                        i = chunk[0]
+                        out.append("  const double u%d = %s;" % (i, expr(g.ops[i][0], [uref(x) for x in g.ops[i][1:]])))
+                        continue
+                    b = "b%d" % n_batches[0]
+                    n_batches[0] += 1
+                    out.append("  double %s[%d] = {%s};" % (b, len(chunk), ", ".join(args)))
+                    out.append("  EXMC_GEN_BATCH_%s(%d, %s);" % (batch_names[kind], len(chunk), b))
+                    out.extend("  const double u%d = %s[%d];" % (i, b, j) for j, i in enumerate(chunk))
+            for i in region:
+                if level[i] == lv and not batch_kind(i) and i not in u_gone:
+                    op = g.ops[i]
+                    e = fused(g, i, u_plan, uref) if i in u_plan else expr(op[0], [uref(x) for x in op[1:]])
+                    out.append("  const double u%d = %s;" % (i, e))
         return out
 
     L = []
@@ -622,6 +856,7 @@ def generate(g, term_roots, custom_roots, D, G, waves_per_simd=1):
     L.append("#define EXMC_GEN_DPL %d" % DPL)
     L.append("#define EXMC_GEN_LSH %d" % lsh)
     L.append("#define EXMC_GEN_NS %d" % NS)
+    L.append("#define EXMC_GEN_NW %d   /* sums of the spread part of the uniform terms (0: none) */" % NW)
     L.append("#define EXMC_GEN_NLT %d" % data.size)
     L.append("#define EXMC_GEN_NELL %d   /* ints of a lane's owner list */" % max(1, NELL))
     L.append("#define EXMC_GEN_ELL_OFF %d   /* ... of lane l at ((const int*)lt)[EXMC_GEN_ELL_OFF + l * EXMC_GEN_NELL] */"
@@ -635,11 +870,23 @@ def generate(g, term_roots, custom_roots, D, G, waves_per_simd=1):
     L.append("       * of its index part) defined by the includer: global memory, or an LDS image of it */")
     L.append("EXMC_GEN_FN double EXMC_GEN_LANES_NAME(const double* lt, const int* el, int l, double* g EXMC_GEN_CTX_DECL) {")
     L.append("  EXMC_GEN_SH(%d) = 0.0;" % zero_cell)
-    L.extend(ustmts(0, n_split))
-    L.append("  double s[EXMC_GEN_NS];")
-    L.append("  for (int j = 0; j < EXMC_GEN_NS; j++) s[j] = 0.0;")
-    for fi, f in enumerate(families):
+    def emit_family(f, title, arr, slot_of, tag):
         T = f.T
+        t_nodes = set(i for i in f.live if not T.const[i] and T.ops[i][0] not in _LEAVES)
+        # what does not change from unit to unit (a function of uniform values and uniform constants
+        # only: the reciprocal of a shared scale) is evaluated once, in front of the loop
+        fixed = {}
+        for i in sorted(f.live):
+            op = T.ops[i]
+            if op[0] in ("lit", "uc", "ext"):
+                fixed[i] = True
+            elif op[0] in ("col", "gat"):
+                fixed[i] = False
+            elif i in f.col_of:
+                fixed[i] = f.col_of[i][0] == "uc"
+            else:
+                fixed[i] = all(fixed.get(a, False) for a in op[1:])
+        hoisted = set(i for i in t_nodes if fixed[i])
 
         def tref(i, T=T, f=f):
             op = T.ops[i]
@@ -654,8 +901,16 @@ def generate(g, term_roots, custom_roots, D, G, waves_per_simd=1):
                 return uref(boundary[op[1]])
             if op[0] == "gat":
                 return "v%d" % op[1]
-            return "t%d" % i
-        L.append("  /* family %d: %d units, %d per lane */" % (fi, f.n, f.S))
+            return ("%s_%d" % (tag, i)) if i in hoisted else ("t%d" % i)
+        t_pinned = set([f.troot] + list(f.ext_adj.values()) + [a for a in f.gat_adj if a is not None])
+        t_plan, t_gone, t_accmul = fuse_plan(T, t_nodes, t_pinned)
+        L.append("  /* %s: %d units, %d per lane */" % (title, f.n, f.S))
+        for i in sorted(hoisted):
+            if i in t_gone:
+                continue
+            op = T.ops[i]
+            e = fused(T, i, t_plan, tref) if i in t_plan else expr(op[0], [tref(x) for x in op[1:]])
+            L.append("  const double %s_%d = %s;" % (tag, i, e))
         L.append("  for (int sl = 0; sl < %d; sl++) {" % f.S)
         L.append("    const int un = sl * %d + l;" % G)
         if f.n < f.npad:
@@ -666,9 +921,6 @@ def generate(g, term_roots, custom_roots, D, G, waves_per_simd=1):
             L.append("    const int row = %d + un * %d;" % (f.doff, len(f.cols)))
         for c in range(len(f.cols)):
             L.append("    const double c%d = EXMC_GEN_LT(row + %d);" % (c, c))
-        t_nodes = set(i for i in f.live if not T.const[i] and T.ops[i][0] not in _LEAVES)
-        t_pinned = set([f.troot] + list(f.ext_adj.values()) + [a for a in f.gat_adj if a is not None])
-        t_plan, t_gone, t_accmul = fuse_plan(T, t_nodes, t_pinned)
         n_use = {}
         for x in [f.troot] + list(f.ext_adj.values()):
             n_use[x] = n_use.get(x, 0) + 1
@@ -677,23 +929,45 @@ def generate(g, term_roots, custom_roots, D, G, waves_per_simd=1):
         def accumulate(slot, node, T=T, t_accmul=t_accmul, tref=tref):
             if node in t_accmul:
                 a, b = (tref(x) for x in T.ops[node][1:])
-                return "    s[%d] = EXMC_GEN_FMA(%s, %s, s[%d]);" % (slot, a, b, slot)
-            return "    s[%d] = s[%d] + %s;" % (slot, slot, tref(node))
+                return "    %s[%d] = EXMC_GEN_FMA(%s, %s, %s[%d]);" % (arr, slot, a, b, arr, slot)
+            return "    %s[%d] = %s[%d] + %s;" % (arr, slot, arr, slot, tref(node))
         for i in sorted(t_nodes):
-            if i in t_gone or i in t_accmul:
+            if i in t_gone or i in t_accmul or i in hoisted:
                 continue
             op = T.ops[i]
             e = fused(T, i, t_plan, tref) if i in t_plan else expr(op[0], [tref(x) for x in op[1:]])
             L.append("    const double t%d = %s;" % (i, e))
-        L.append(accumulate(0, f.troot))
+        L.append(accumulate(slot_of[None], f.troot))
         for j in sorted(f.ext_adj):
-            L.append(accumulate(acc_of[j], f.ext_adj[j]))
+            L.append(accumulate(slot_of[j], f.ext_adj[j]))
         for p in range(len(f.gather)):
             if f.strip[p] >= 0:
                 L.append("    EXMC_GEN_SH(%d + un) = %s;" % (f.strip[p], tref(f.gat_adj[p])))
         if f.n < f.npad:
             L.append("    }")
         L.append("  }")
+
+    L.extend(ustmts(0, n_split, late=False))
+    if ufams:
+        L.append("  double w[EXMC_GEN_NW];")
+        L.append("  for (int j = 0; j < EXMC_GEN_NW; j++) w[j] = 0.0;")
+        for fi, f in enumerate(ufams):
+            slots = dict(f.w_of)
+            slots[None] = f.w0
+            emit_family(f, "spread sum %d of the uniform part" % fi, "w", slots, "hw%d" % fi)
+        L.append("  EXMC_GEN_ALLSUM_W(w);")
+        for f in ufams:
+            if f.const_part:
+                L.append("  const double u%d = w[%d] + EXMC_GEN_LT(%d);" % (f.out, f.w0, uc_of[("val", f.cpart.hex())]))
+            else:
+                L.append("  const double u%d = w[%d];" % (f.out, f.w0))
+        L.extend(ustmts(0, n_split, late=True))
+    L.append("  double s[EXMC_GEN_NS];")
+    L.append("  for (int j = 0; j < EXMC_GEN_NS; j++) s[j] = 0.0;")
+    for fi, f in enumerate(families):
+        slots = dict(acc_of)
+        slots[None] = 0
+        emit_family(f, "family %d" % fi, "s", slots, "hf%d" % fi)
     L.append("  EXMC_GEN_ALLSUM(s);")
     L.extend(ustmts(n_split, len(g.ops)))
     L.append("  EXMC_GEN_FENCE();")
@@ -718,4 +992,5 @@ def generate(g, term_roots, custom_roots, D, G, waves_per_simd=1):
     text = "\n".join(L) + "\n"
     return dict(text=text, data=data, lanes=G, dpl=DPL, lsh=lsh, n_families=len(families),
                 family_sizes=[f.n for f in families], n_scalar_units=len(scalar_units),
+                spread_sizes=[f.n for f in ufams], n_spread_sums=NW, n_batches=n_batches[0],
                 n_reduced=NS, n_boundary=len(boundary), gather_width=width)

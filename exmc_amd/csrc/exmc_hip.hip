@@ -201,7 +201,7 @@ int dispatch(exmc_hip_model* m, int lanes, F&& f) {
 #endif
 #ifdef EXMC_GEN_LANES
       if (lanes == EXMC_GEN_LANES)   // several dimensions per lane (codegen_lanes.py)
-        return f(Tag<Custom<EXMC_GEN_LANES>, EXMC_GEN_LANES, (EXMC_GEN_DPL > 1 ? 2 : 6)>{}, m->cu);
+        return f(Tag<Custom<EXMC_GEN_LANES>, EXMC_GEN_LANES, EXMC_GEN_LDSL>{}, m->cu);
 #endif
       break;
 #endif

@@ -1141,7 +1141,14 @@ static __host__ __device__ __noinline__ double exmc_gen_erf_call(double x) { ret
 #define EXMC_GENL_ERF exmc_gen_erf_call
 #define EXMC_GEN_CTX_DECL , int shoff
 #define EXMC_GEN_SH(i) exmc::exmc_dyn_lds[shoff + (i)]
-#define EXMC_GEN_ALLSUM(s) exmc::group_allsum_n<EXMC_GEN_LANES, EXMC_GEN_NS>(s)
+#define EXMC_GEN_XROW (EXMC_GEN_LANES == 64 && EXMC_GEN_WAVES_PER_SIMD == 2)
+#define EXMC_GEN_ALLSUM(s) exmc::group_allsum_n<EXMC_GEN_LANES, EXMC_GEN_NS, EXMC_GEN_XROW>(s)
+#define EXMC_GEN_ALLSUM_W(w) exmc::group_allsum_n<EXMC_GEN_LANES, EXMC_GEN_NW, EXMC_GEN_XROW>(w)
+// n chain-scalar calls as one: argument i on lane i of the group, results broadcast back
+#define EXMC_GEN_BATCH_LOG(n, b) exmc::lane_batch<EXMC_GEN_LANES, n>(b, l, [](double a_) { return EXMC_GENL_LOG(a_); })
+#define EXMC_GEN_BATCH_EXP(n, b) exmc::lane_batch<EXMC_GEN_LANES, n>(b, l, [](double a_) { return EXMC_GENL_EXP(a_); })
+#define EXMC_GEN_BATCH_LOG1P(n, b) exmc::lane_batch<EXMC_GEN_LANES, n>(b, l, [](double a_) { return EXMC_GENL_LOG1P(a_); })
+#define EXMC_GEN_BATCH_RCP(n, b) exmc::lane_batch<EXMC_GEN_LANES, n>(b, l, [](double a_) { return 1.0 / a_; })
 #define EXMC_GEN_FENCE() exmc::wave_lds_fence()
 #define EXMC_GEN_FMA(a, b, c) __builtin_fma(a, b, c)
 #include EXMC_CUSTOM_HEADER
@@ -1164,6 +1171,25 @@ static __host__ __device__ __noinline__ double exmc_gen_erf_call(double x) { ret
 #define EXMC_GEN_IT(i) ((const int*)(exmc::exmc_dyn_lds + ltoff + EXMC_GEN_IOFF))[i]
 #include EXMC_CUSTOM_HEADER
 #undef EXMC_GEN_LANES_SECTION
+#endif
+
+#ifdef EXMC_GEN_LANES
+// LDS of a sampling workgroup of the lane layout: tree-stack levels, the ziggurat tables, the
+// chains' strips and (when it fits) an image of the model's tables. Two waves per SIMD are eight
+// workgroups per CU -- 20 KB each of the 160 KB, or they are not resident together and the launch
+// bound bought nothing (gen_sv: 31.5 KB with two stack levels and the table image = five per CU).
+// A second stack level is worth more than the table image (a wave pair hides the L2 round trips of
+// table reads; stack traffic is on the tree's critical path).
+namespace exmc {
+constexpr int kGenLdsBudget = (EXMC_GEN_WAVES_PER_SIMD == 2) ? 160 * 1024 / 8 : 160 * 1024 / 4;
+constexpr int gen_lds_bytes(int levels, bool table) {
+  return levels * (5 * EXMC_GEN_DPL + 3) * 64 * 8 + 768 * 8 + (64 / EXMC_GEN_LANES) * EXMC_GEN_LSH * 8 +
+         (table ? EXMC_GEN_NLT * 8 : 0);
+}
+constexpr int kGenLdsLevels = (EXMC_GEN_DPL == 1) ? 6 : (gen_lds_bytes(2, false) <= kGenLdsBudget ? 2 : 1);
+constexpr bool kGenLdsTable = EXMC_GEN_NLT <= 2048 && gen_lds_bytes(kGenLdsLevels, true) <= kGenLdsBudget;
+}
+#define EXMC_GEN_LDSL exmc::kGenLdsLevels
 #endif
 
 namespace exmc {
@@ -1208,11 +1234,15 @@ struct Custom<EXMC_GEN_LANES> : ModelDefaults {
   // only in the step-size searches, while the integrator waits at a barrier): one strip serves both
   static constexpr bool kPipeWarmup = true;
   static constexpr int kNutsWavesPerSimd = EXMC_GEN_WAVES_PER_SIMD;
+  // one chain per wave and two waves per SIMD: what the hand-written sv kind runs with -- cross-row
+  // sums through ds_bpermute, chain migration and the time-sliced issue priority (exmc_nuts.hpp)
+  static constexpr bool kXRowLds = (G == 64 && EXMC_GEN_WAVES_PER_SIMD == 2);
+  static constexpr bool kMigrate = (G == 64 && EXMC_GEN_WAVES_PER_SIMD == 2);
   static constexpr int kExtraLdsDoubles = (64 / G) * EXMC_GEN_LSH;
   // a short owner list (the strip cells whose sum is this lane's gradient entries) lives in registers
   static constexpr bool kEllRegs = EXMC_GEN_NELL <= 16;
   // tables up to 16 KB are staged in LDS by the kernels that run a lone wave per SIMD for long
-  static constexpr bool kLdsTable = EXMC_GEN_NLT <= 2048;
+  static constexpr bool kLdsTable = kGenLdsTable;
   static constexpr int kLdsDataDoubles = kLdsTable ? EXMC_GEN_NLT : 0;
   using Consts = CustomConsts;
   struct Lane {

@@ -39,14 +39,24 @@ WRAPPER = """
 /* the lane layout (exmc_amd/codegen_lanes.py) on virtual lanes: every lane runs the function up to
  * the butterfly (pass 0: its partial sums are collected), the sums are added in the order of the
  * device's xor butterfly, every lane runs it again to the end (pass 1) */
-typedef struct { double* sh; int pass; double* S; const double* R; } exmc_gen_ctx;
+typedef struct { double* sh; int pass; double* S; const double* R; double* SW; const double* RW; } exmc_gen_ctx;
 #define EXMC_GEN_CTX_DECL , exmc_gen_ctx* ctx
 #define EXMC_GEN_SH(i) ctx->sh[i]
+/* pass 0 ends at the butterfly of the spread sums of the uniform part (when the model has any),
+ * pass 1 at the butterfly of the families, pass 2 runs to the end */
+#define EXMC_GEN_ALLSUM_W(w) do { \
+    if (ctx->pass == 0) { memcpy(ctx->SW + (size_t)l * EXMC_GEN_NW, w, sizeof(double) * EXMC_GEN_NW); return 0.0; } \
+    memcpy(w, ctx->RW, sizeof(double) * EXMC_GEN_NW); } while (0)
 #define EXMC_GEN_ALLSUM(s) do { \
-    if (ctx->pass == 0) { memcpy(ctx->S + (size_t)l * EXMC_GEN_NS, s, sizeof(double) * EXMC_GEN_NS); return 0.0; } \
+    if (ctx->pass == 1) { memcpy(ctx->S + (size_t)l * EXMC_GEN_NS, s, sizeof(double) * EXMC_GEN_NS); return 0.0; } \
     memcpy(s, ctx->R, sizeof(double) * EXMC_GEN_NS); } while (0)
 #define EXMC_GEN_FENCE()
 #define EXMC_GEN_FMA(a, b, c) __builtin_fma(a, b, c)
+/* lane_batch of exmc_device.hpp: every value by the operations of the plain call */
+#define EXMC_GEN_BATCH_LOG(n, b) do { for (int i_ = 0; i_ < n; i_++) b[i_] = EXMC_GENL_LOG(b[i_]); } while (0)
+#define EXMC_GEN_BATCH_EXP(n, b) do { for (int i_ = 0; i_ < n; i_++) b[i_] = EXMC_GENL_EXP(b[i_]); } while (0)
+#define EXMC_GEN_BATCH_LOG1P(n, b) do { for (int i_ = 0; i_ < n; i_++) b[i_] = EXMC_GENL_LOG1P(b[i_]); } while (0)
+#define EXMC_GEN_BATCH_RCP(n, b) do { for (int i_ = 0; i_ < n; i_++) b[i_] = 1.0 / b[i_]; } while (0)
 #include "%(header)s"
 #ifdef EXMC_GEN_LANES
 #define EXMC_GEN_LANES_SECTION
@@ -80,21 +90,28 @@ double exmc_gen_checkL(const double* data, const double* q, double* g) {
   enum { G = EXMC_GEN_LANES };
   const double* lt = data + EXMC_GEN_LOFF;
   double sh[EXMC_GEN_LSH], S[G * EXMC_GEN_NS], R[EXMC_GEN_NS], gl[EXMC_GEN_DPL], lp = 0.0;
-  exmc_gen_ctx ctx = {sh, 0, S, R};
+  double SW[G * (EXMC_GEN_NW + 1)], RW[EXMC_GEN_NW + 1];
+  exmc_gen_ctx ctx = {sh, 0, S, R, SW, RW};
   for (int i = 0; i < EXMC_GEN_LSH; i++) sh[i] = 0.0;
   for (int i = 0; i < EXMC_GEN_D; i++) sh[i] = q[i];
   const int* ell = (const int*)lt + EXMC_GEN_ELL_OFF;
-  for (int l = 0; l < G; l++) (void)exmc_gen_lanes(lt, ell + l * EXMC_GEN_NELL, l, gl, &ctx);
-  for (int k = 0; k < EXMC_GEN_NS; k++) {   /* group_allsum_n: xor butterfly over the G lanes */
-    double part[G], nxt[G];
-    for (int l = 0; l < G; l++) part[l] = S[l * EXMC_GEN_NS + k];
-    for (int m = 1; m < G; m <<= 1) {
-      for (int l = 0; l < G; l++) nxt[l] = part[l] + part[l ^ m];
-      memcpy(part, nxt, sizeof part);
+  for (int stage = (EXMC_GEN_NW > 0) ? 0 : 1; stage < 2; stage++) {
+    const int n = stage ? EXMC_GEN_NS : EXMC_GEN_NW;
+    double* const from = stage ? S : SW;
+    double* const to = stage ? R : RW;
+    ctx.pass = stage;
+    for (int l = 0; l < G; l++) (void)exmc_gen_lanes(lt, ell + l * EXMC_GEN_NELL, l, gl, &ctx);
+    for (int k = 0; k < n; k++) {   /* group_allsum_n: xor butterfly over the G lanes */
+      double part[G], nxt[G];
+      for (int l = 0; l < G; l++) part[l] = from[l * n + k];
+      for (int m = 1; m < G; m <<= 1) {
+        for (int l = 0; l < G; l++) nxt[l] = part[l] + part[l ^ m];
+        memcpy(part, nxt, sizeof part);
+      }
+      to[k] = part[0];
     }
-    R[k] = part[0];
   }
-  ctx.pass = 1;
+  ctx.pass = 2;
   for (int l = 0; l < G; l++) {
     const double v = exmc_gen_lanes(lt, ell + l * EXMC_GEN_NELL, l, gl, &ctx);
     if (l == 0) lp = v;

@@ -229,3 +229,56 @@ def test_random_models_in_the_lane_layout(seed):
     lp2, g2 = GC.logp_grad(gen2, q, lanes=other)
     assert abs(lp - lp2) <= 1e-11 * max(1.0, abs(lp))
     np.testing.assert_allclose(g, g2, rtol=1e-9, atol=1e-9)
+
+
+def test_uniform_part_is_spread_over_the_lanes_too():
+    """sv's shared part holds two Lanczos series (StudentT's normaliser, math.ex:27-52), six
+    logarithms and their tangents. The series are evaluated one quotient per lane and reduced in a
+    butterfly of their own; the logarithms / reciprocals of one dependency level are evaluated
+    together (lane i takes argument i); a quotient whose denominator's reciprocal the adjoint needs
+    anyway is a product with that reciprocal, and a reciprocal of a shared value leaves the family
+    loop. (The values: test_generated_equals_the_handwritten_oracle_model.)"""
+    sv, _ = _gen("sv")
+    lay = sv.lane_layout
+    assert lay["spread_sizes"] == [8, 8] and lay["n_spread_sums"] == 4 and lay["n_batches"] >= 3
+    text = lay["text"]
+    assert "EXMC_GEN_BATCH_LOG(" in text and "EXMC_GEN_BATCH_RCP(" in text and "EXMC_GEN_ALLSUM_W(w)" in text
+    loop0 = text[text.index("/* family 0"):text.index("/* family 1")]
+    loop1 = text[text.index("/* family 1"):text.index("EXMC_GEN_ALLSUM(s)")]
+    body0 = loop0[loop0.index("for (int sl"):]
+    body1 = loop1[loop1.index("for (int sl"):]
+    assert body0.count(" / ") == 2 and body1.count(" / ") == 0       # were 5 and 2
+    assert loop1[:loop1.index("for (int sl")].count("1.0 / ") == 1   # 1 / sigma, once per leapfrog
+    # radon: the observation loop divides by the shared noise scale -- no quotient left in it
+    rd, _ = _gen("radon")
+    t = rd.lane_layout["text"]
+    obs = t[t.index("/* family 1"):t.index("EXMC_GEN_ALLSUM(s)")]
+    assert obs[obs.index("for (int sl"):].count(" / ") == 0 and rd.lane_layout["spread_sizes"] == []
+
+
+def test_a_spread_sum_does_not_feed_another_one():
+    """One level of spreading: a series whose argument is computed from another series' sum stays in
+    the uniform part (evaluated by every lane), the inner one is spread; both layouts agree."""
+    ir = cg.IR()
+    ir.rv("a", "normal", dict(mu=0.0, sigma=1.0), transform=None)
+    ir.rv("b", "normal", dict(mu=0.0, sigma=1.0), transform=None)
+    for j in range(16):                 # d = 18: the one-lane layout (d <= 20) is the comparison
+        ir.rv("t_%02d" % j, "normal", dict(mu="a", sigma=1.5))
+
+    def lik(o, _x, p):
+        alpha = o.add(o.lit(2.0), o.exp(p["a"]))
+        inner = o.logpdf("gamma", o.lit(1.3), {"alpha": alpha, "beta": o.lit(2.0)})       # lgamma(alpha)
+        alpha2 = o.add(o.lit(3.0), o.exp(o.mul(o.lit(0.01), inner)))
+        outer = o.logpdf("gamma", o.add(o.lit(0.5), o.exp(p["b"])), {"alpha": alpha2, "beta": o.lit(1.0)})
+        return o.add(inner, outer)
+    ir.rv("lik", "custom", dict(logpdf=lik, a="a", b="b"))
+    ir.obs("lik_obs", "lik", 0.0)
+    gen = cg.generate(ir, lanes=16)
+    assert gen.lane_layout["spread_sizes"] == [8]
+    rng = np.random.default_rng(5)
+    for t in range(20):
+        q = rng.normal(size=gen.d) * 0.6
+        lp1, g1 = GC.logp_grad(gen, q, lanes=1)
+        lpl, gl = GC.logp_grad(gen, q, lanes=16)
+        assert abs(lp1 - lpl) <= 1e-12 * max(1.0, abs(lp1)), t
+        assert np.all(np.abs(g1 - gl) <= 1e-11 * np.maximum(1.0, np.abs(g1))), t

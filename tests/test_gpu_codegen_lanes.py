@@ -141,3 +141,30 @@ def test_random_models_in_the_lane_layout_bit_exact(seed, hip):
     ot, ost = O.sample(om, init_q=q0, num_warmup=60, num_samples=25, seed=5, cfg=cfg)
     assert tun.epsilon == ost.step_size
     assert np.array_equal(tr["draws"][0], ot["draws"]) and np.array_equal(tr["n_steps"][0], ot["n_steps"])
+
+
+def test_generated_sv_two_waves_per_simd_bit_exact(hip, monkeypatch):
+    """compile_ir(..., waves_per_simd=2) for a 64-lane model: the sampling kernel is capped at 256
+    registers and runs with what the hand-written sv kind runs with -- cross-row sums through
+    ds_bpermute, chain migration, the time-sliced issue priority. None of it may change a bit: 2048
+    chains (two per SIMD, so all of it is active) equal the one-wave-per-SIMD build and, for a few
+    chains, the checker."""
+    ir, ncp, hand, lanes = GM.baseline_pair("sv")
+    spec1, comp1, om, _, _ = _compiled("sv", hip)
+    spec2 = cg.compile_ir(ir, ncp=ncp, name="gen_sv_wps2", default_init=hand.default_init, lanes=lanes,
+                          waves_per_simd=2)
+    comp2 = sampler.compile(spec2)
+    opts = dict(num_warmup=100, num_samples=40, seed=9)
+    tuning = sampler.warmup(comp1, spec1.default_init, opts)
+    monkeypatch.setenv("EXMC_HIP_MIGRATE", "1")     # (default: launches of 100 draws and more)
+    res = []
+    for comp, spec in ((comp1, spec1), (comp2, spec2)):
+        _, _, extra = sampler.sample_compiled_tuned(comp, tuning, spec.default_init, opts, num_chains=2048)
+        res.append(extra["raw"])
+    for k in ("draws", "n_steps", "tree_depth", "energy", "accept_prob", "divergent", "logp"):
+        assert np.array_equal(res[0][k], res[1][k]), k
+    q0 = spec1.to_unconstrained(spec1.default_init)
+    for c in (0, 1500):
+        t, _ = O.sample_tuned(om, tuning["epsilon"], tuning["inv_mass"], q0, num_samples=40, seed=9 + 7919 * c,
+                              cfg=O.Cfg(1, lanes))
+        assert np.array_equal(t["draws"], res[1]["draws"][c]), c
