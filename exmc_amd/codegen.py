@@ -1408,12 +1408,16 @@ def build_plugin(gen, force=False, verbose=False):
             # units of their own next to the rest of the library, compiled side by side: the plug-in is
             # ready in the time of its slowest part (the analogue of the EXLA JIT step, jit.ex)
             part_src = os.path.join(cwd, "exmc_plugin_part.hip")
-            jobs = [([hipcc] + flags + defs + ["-DEXMC_PLUGIN_SPLIT", "-c", "-o", "%s.main.o" % tmp, _build.SRC])]
+            # (the host pass of every part at -O0: launch code, nothing numeric; a third of a part's time)
+            flags = flags + ["-Xarch_host", "-O0"]
+            common = _build.build_common()
+            jobs = [([hipcc] + flags + defs + ["-DEXMC_PLUGIN_SPLIT", "-DEXMC_COMMON_DECL_ONLY", "-c", "-o",
+                                              "%s.main.o" % tmp, _build.SRC])]
             layouts = [k for k, macro in ((1, "EXMC_GEN_ONE_LANE"), (2, "EXMC_GEN_VEC"), (3, "EXMC_GEN_LANES "))
                        if ("#define " + macro) in gen.header]
             jobs += [([hipcc] + flags + defs + ["-DEXMC_PLUGIN_PART=%d" % k, "-DEXMC_PLUGIN_LAYOUT=%d" % lay, "-c", "-o",
                                                "%s.p%d_%d.o" % (tmp, k, lay), part_src])
-                     for k in (3, 4, 1, 2) for lay in layouts]
+                     for k in (3, 4, 1, 2, 5) for lay in layouts]
             objs = [j[j.index("-o") + 1] for j in jobs]
             if verbose:
                 for j in jobs:
@@ -1422,7 +1426,7 @@ def build_plugin(gen, force=False, verbose=False):
             rcs = [p_.wait() for p_ in procs]
             if any(rcs):
                 raise subprocess.CalledProcessError(max(rcs), jobs[rcs.index(max(rcs))])
-            link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
+            link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs + [common]
             if verbose:
                 print(" ".join(link))
             subprocess.check_call(link, cwd=cwd)

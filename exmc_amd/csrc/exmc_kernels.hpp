@@ -252,7 +252,11 @@ struct EssTailItem {
 
 __global__ void __launch_bounds__(kEssBlock)
 ess_series_kernel(const double* draws, int S, int D, int C, double* ess_out, int* work_count,
-                  EssTailItem* work) {
+                  EssTailItem* work)
+#ifdef EXMC_COMMON_DECL_ONLY
+;   // defined in the prebuilt exmc_common object (exmc_common.hip)
+#else
+{
   const size_t series = (size_t)blockIdx.x * kEssBlock + threadIdx.x;   // dim * C + chain
   const size_t stride = (size_t)D * C;
   if (series >= stride) return;
@@ -269,13 +273,18 @@ ess_series_kernel(const double* draws, int S, int D, int C, double* ess_out, int
     work[slot] = EssTailItem{part.mean, part.var, part.tau, (int)series, part.next_lag};
   }
 }
+#endif
 
 // The rest of a series' lags, a wavefront per series: the centred series in LDS, lane k sums lag
 // l0 + k left to right over i exactly as ess_series does (`acc + c[i] * c[i + lag]`,
 // diagnostics.ex:137-141), 64 lags per sweep; then Geyer's pairs in order (diagnostics.ex:147-167).
 __global__ void __launch_bounds__(64)
 ess_tail_kernel(const double* draws, int S, int D, int C, double* ess_out, const int* work_count,
-                const EssTailItem* work) {
+                const EssTailItem* work)
+#ifdef EXMC_COMMON_DECL_ONLY
+;   // defined in the prebuilt exmc_common object (exmc_common.hip)
+#else
+{
   extern __shared__ double cen[];   // S centred values
   const int lane = threadIdx.x;
   const size_t stride = (size_t)D * C;
@@ -319,6 +328,7 @@ ess_tail_kernel(const double* draws, int S, int D, int C, double* ess_out, const
     }
   }
 }
+#endif
 
 // Diagnostics.ess_bulk (diagnostics.ex:60-72, 186-219), first half: every series is replaced by
 // the normal scores of its ranks -- average rank for ties, (r - 3/8) / (n + 1/4), the reference's
@@ -332,7 +342,11 @@ __device__ __forceinline__ double probit_inner_dev(double p) {
 }
 
 __global__ void __launch_bounds__(256)
-rank_scores_kernel(const double* draws, int S, int D, int C, double* scores) {
+rank_scores_kernel(const double* draws, int S, int D, int C, double* scores)
+#ifdef EXMC_COMMON_DECL_ONLY
+;   // defined in the prebuilt exmc_common object (exmc_common.hip)
+#else
+{
   extern __shared__ double raw[];  // S values
   const size_t series = blockIdx.x;  // dim * C + chain
   const size_t stride = (size_t)D * C;
@@ -353,6 +367,7 @@ rank_scores_kernel(const double* draws, int S, int D, int C, double* scores) {
     z[(size_t)i * stride] = (pr < 0.5) ? -probit_inner_dev(pr) : probit_inner_dev(1.0 - pr);
   }
 }
+#endif
 
 // Diagnostics.rhat (diagnostics.ex:80-115), split R-hat of one dimension per workgroup over a
 // [S][D][C] trace: each chain split at S/2, both halves trimmed to the shorter length; half-chain
@@ -363,7 +378,11 @@ rank_scores_kernel(const double* draws, int S, int D, int C, double* scores) {
 // grid -- with one workgroup per dimension the 328 MB trace of the bench was read by 10 CUs in
 // 8.9 ms --, `phase` 1 is the serial tail of one thread per dimension.
 __global__ void __launch_bounds__(256)
-rhat_kernel(const double* draws, int S, int D, int C, double* stats, double* rhat_out, int phase) {
+rhat_kernel(const double* draws, int S, int D, int C, double* stats, double* rhat_out, int phase)
+#ifdef EXMC_COMMON_DECL_ONLY
+;   // defined in the prebuilt exmc_common object (exmc_common.hip)
+#else
+{
   const int dim = blockIdx.x;
   const int mid = S / 2;
   const int len = mid < (S - mid) ? mid : (S - mid);
@@ -402,6 +421,7 @@ rhat_kernel(const double* draws, int S, int D, int C, double* stats, double* rha
     rhat_out[dim] = __dsqrt_rn(var_hat / w);
   }
 }
+#endif
 
 #endif  // EXMC_PLUGIN_PART
 

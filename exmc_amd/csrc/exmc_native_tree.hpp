@@ -205,7 +205,11 @@ __device__ __forceinline__ void ft_build_subtree(const FtChain& ch, const double
   }
 }
 
-__global__ void __launch_bounds__(64) full_tree_kernel(FullTreeParams P) {
+__global__ void __launch_bounds__(64) full_tree_kernel(FullTreeParams P)
+#ifdef EXMC_COMMON_DECL_ONLY
+;   // defined in the prebuilt exmc_common object (exmc_common.hip)
+#else
+{
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= P.n_chains) return;
   const int d = P.d;
@@ -286,6 +290,7 @@ __global__ void __launch_bounds__(64) full_tree_kernel(FullTreeParams P) {
   P.out_divergent[c] = T.div ? 1 : 0;
   P.out_depth[c] = T.depth;
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // The NIF's incremental interface (lib.rs:37-212, 345-434), batched over chains: a trajectory
@@ -333,7 +338,11 @@ __device__ __forceinline__ FtChain ft_sub_chain(const SubtreeParams& P, int c) {
 }
 
 // build_and_merge_bin (lib.rs:73-112): Xoshiro seeded per call, build_subtree, merge_into_trajectory
-__global__ void __launch_bounds__(64) traj_build_and_merge_kernel(SubtreeParams P) {
+__global__ void __launch_bounds__(64) traj_build_and_merge_kernel(SubtreeParams P)
+#ifdef EXMC_COMMON_DECL_ONLY
+;   // defined in the prebuilt exmc_common object (exmc_common.hip)
+#else
+{
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= P.n_chains) return;
   const int level = P.depth[c];
@@ -389,9 +398,14 @@ __global__ void __launch_bounds__(64) traj_build_and_merge_kernel(SubtreeParams 
   P.T.turn[c] = turning ? 1 : 0;
   P.T.depth[c] += 1;
 }
+#endif
 
 // build_subtree_bin (lib.rs:114-212): the subtree record itself
-__global__ void __launch_bounds__(64) build_subtree_kernel(SubtreeParams P) {
+__global__ void __launch_bounds__(64) build_subtree_kernel(SubtreeParams P)
+#ifdef EXMC_COMMON_DECL_ONLY
+;   // defined in the prebuilt exmc_common object (exmc_common.hip)
+#else
+{
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= P.n_chains) return;
   const int level = P.depth[c];
@@ -419,5 +433,6 @@ __global__ void __launch_bounds__(64) build_subtree_kernel(SubtreeParams P) {
   P.out.div[c] = cur.div ? 1 : 0;
   P.out.turn[c] = cur.turn ? 1 : 0;
 }
+#endif
 
 }  // namespace exmc

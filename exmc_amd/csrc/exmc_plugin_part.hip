@@ -1,8 +1,9 @@
-// exmc_plugin_part.hip — one of the four heavy kernels of a generated model's plug-in library as a
+// exmc_plugin_part.hip — one of the model-dependent kernels of a generated model's plug-in library as a
 // translation unit of its own (exmc_amd/codegen.py build_plugin compiles the parts next to
 // exmc_hip.hip in parallel processes: a plug-in is then ready in about the time of its slowest
 // kernel instead of the sum). EXMC_PLUGIN_PART: 1 nuts_kernel, 2 nuts_kernel (stream form),
-// 3 warmup_kernel (two-wave pipeline), 4 warmup_kernel (one wave). exmc_hip.hip, compiled with
+// 3 warmup_kernel (two-wave pipeline), 4 warmup_kernel (one wave), 5 the auxiliary kernels (vag_fn
+// batches, chain init, step-size search). exmc_hip.hip, compiled with
 // -DEXMC_PLUGIN_SPLIT, declares the same instantiations `extern template` and keeps everything else.
 #include <hip/hip_runtime.h>
 
