@@ -525,9 +525,9 @@ int launch_nuts(exmc_hip_model* m, int lanes, int C, int n_draws, int draw_offse
     }
     if constexpr (M::kPipeNutsLevels > 0) {
       // wave pairs (tree + integrator), fewer stack levels in LDS to make room for the mailbox.
-      // Opt-in (EXMC_HIP_NUTS_PIPE=1): bit-identical, but with the chip already full the pair
-      // executes ~10 % more instructions (mailbox, barriers) than it hides in stalls --
-      // eight_schools 4096 x 1000: 1.81e9 leapfrog/s against 1.90e9 for one wave per SIMD.
+      // Opt-in (EXMC_HIP_NUTS_PIPE=1): bit-identical, but the two waves alternate more than they overlap
+      // (a doubling starts from the decision of the previous one), DESIGN section 5 --
+      // eight_schools 4096 x 1000: 15.3 ms against 14.6 ms for one wave per SIMD.
       const char* pe = std::getenv("EXMC_HIP_NUTS_PIPE");
       if (pe && pe[0] == '1') {
         constexpr int PL = M::kPipeNutsLevels;

@@ -73,7 +73,12 @@ struct EightSchools : ModelDefaults {
   static constexpr int D = 10;
   static constexpr int DPL = (D + G - 1) / G;
   static constexpr bool kVregMath = (DPL <= 2);
-  static constexpr int kPipeNutsLevels = (G == 16) ? 4 : 0;
+  // wave pairs in the sampling kernel: stack levels in LDS such that FOUR workgroups (eight waves:
+  // two per SIMD) fit a CU -- levels x 4 KB + 6 KB of ziggurat tables + the 23 KB mailbox <= 40 KB
+#ifndef EXMC_ES_PIPE_LEVELS
+#define EXMC_ES_PIPE_LEVELS 2
+#endif
+  static constexpr int kPipeNutsLevels = (G == 16) ? EXMC_ES_PIPE_LEVELS : 0;
   using MM = Math<kVregMath>;
   using Consts = EightSchoolsConsts;
   struct Lane {

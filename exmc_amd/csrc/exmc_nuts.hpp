@@ -1350,9 +1350,30 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock, M::kNutsW
     pipe.box = lds + nuts_lds_bytes<M, LDSL>() / 8 + lane;
     pipe.seq = 0;
     pipe.pending = false;
-    if (threadIdx.x >= kNutsBlock) {
+    // The dispatcher puts the two waves of a workgroup on different SIMDs and, with four workgroups
+    // per CU, a tree wave and an integrator wave of different workgroups on (nearly) every SIMD
+    // (1021 of 1023, tools/es_pipe_probe.sh). The tree wave -- the transition's critical path --
+    // takes the issue priority: it runs as if alone on its SIMD, the integrator on what is left.
+    const bool integrator = threadIdx.x >= kNutsBlock;
+#ifdef EXMC_XCC_PROBE
+    if (lane == 0 && 2 * blockIdx.x + (threadIdx.x >> 6) < 4096) {
+      unsigned xcc, hw;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      double* const e = g_wave_probe + (2 * blockIdx.x + (threadIdx.x >> 6)) * 5;
+      e[0] = (double)((xcc & 0xf) * 10000 + ((hw >> 8) & 0xf) * 100 + ((hw >> 13) & 0x7) * 10 + ((hw >> 4) & 0x3));
+      e[1] = integrator ? 1.0 : 0.0;
+      e[3] = (double)wall_clock64();
+    }
+#endif
+    if (P.prio && !integrator) __builtin_amdgcn_s_setprio(3);
+    if (integrator) {
       for (int i = 0; i < P.n_draws; i++)
         if (!pipe_integrate_transition<M, G>(mc, L, pipe)) break;
+#ifdef EXMC_XCC_PROBE
+      if (lane == 0 && 2 * blockIdx.x + (threadIdx.x >> 6) < 4096)
+        g_wave_probe[(2 * blockIdx.x + (threadIdx.x >> 6)) * 5 + 4] = (double)wall_clock64();
+#endif
       return;
     }
   }
@@ -1425,6 +1446,14 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock, M::kNutsW
 #ifdef EXMC_XCC_PROBE
   const long long wave_c0 = clock64(), wave_w0 = wall_clock64();
   auto probe_out = [&]() {
+    if constexpr (kPipe) {   // the pair's entries were opened at the start of the kernel
+      if (lane == 0 && 2 * blockIdx.x + (threadIdx.x >> 6) < 4096) {
+        double* const e = g_wave_probe + (2 * blockIdx.x + (threadIdx.x >> 6)) * 5;
+        e[2] = (double)lf_total;
+        e[4] = (double)wall_clock64();
+      }
+      return;
+    }
     if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096) {
       unsigned xcc, hw;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
