@@ -1418,6 +1418,9 @@ def build_plugin(gen, force=False, verbose=False):
             jobs += [([hipcc] + flags + defs + ["-DEXMC_PLUGIN_PART=%d" % k, "-DEXMC_PLUGIN_LAYOUT=%d" % lay, "-c", "-o",
                                                "%s.p%d_%d.o" % (tmp, k, lay), part_src])
                      for k in (3, 4, 1, 2, 5) for lay in layouts]
+            if 3 in layouts and gen.lanes < 64:     # the one-chain warmup form of the lane layout (CustomSplit)
+                jobs += [([hipcc] + flags + defs + ["-DEXMC_PLUGIN_PART=%d" % k, "-DEXMC_PLUGIN_LAYOUT=3", "-c", "-o",
+                                                   "%s.p%d_3.o" % (tmp, k), part_src]) for k in (6,)]
             objs = [j[j.index("-o") + 1] for j in jobs]
             if verbose:
                 for j in jobs:

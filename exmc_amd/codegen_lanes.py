@@ -870,7 +870,7 @@ def generate(g, term_roots, custom_roots, D, G, waves_per_simd=1):
     L.append("       * of its index part) defined by the includer: global memory, or an LDS image of it */")
     L.append("EXMC_GEN_FN double EXMC_GEN_LANES_NAME(const double* lt, const int* el, int l, double* g EXMC_GEN_CTX_DECL) {")
     L.append("  EXMC_GEN_SH(%d) = 0.0;" % zero_cell)
-    def emit_family(f, title, arr, slot_of, tag):
+    def emit_family(f, title, arr, slot_of, tag, split=False):
         T = f.T
         t_nodes = set(i for i in f.live if not T.const[i] and T.ops[i][0] not in _LEAVES)
         # what does not change from unit to unit (a function of uniform values and uniform constants
@@ -911,7 +911,10 @@ def generate(g, term_roots, custom_roots, D, G, waves_per_simd=1):
             op = T.ops[i]
             e = fused(T, i, t_plan, tref) if i in t_plan else expr(op[0], [tref(x) for x in op[1:]])
             L.append("  const double %s_%d = %s;" % (tag, i, e))
-        L.append("  for (int sl = 0; sl < %d; sl++) {" % f.S)
+        if split:     # the units of a family over the lane groups of the wavefront too (EXMC_GEN_NG > 1:
+            L.append("  for (int sl = EXMC_GEN_G0; sl < %d; sl += EXMC_GEN_NG) {" % f.S)   # one-chain warmup)
+        else:
+            L.append("  for (int sl = 0; sl < %d; sl++) {" % f.S)
         L.append("    const int un = sl * %d + l;" % G)
         if f.n < f.npad:
             L.append("    if (un < %d) {" % f.n)
@@ -967,8 +970,9 @@ def generate(g, term_roots, custom_roots, D, G, waves_per_simd=1):
     for fi, f in enumerate(families):
         slots = dict(acc_of)
         slots[None] = 0
-        emit_family(f, "family %d" % fi, "s", slots, "hf%d" % fi)
+        emit_family(f, "family %d" % fi, "s", slots, "hf%d" % fi, split=True)
     L.append("  EXMC_GEN_ALLSUM(s);")
+    L.append("  EXMC_GEN_XGROUP(s);   /* EXMC_GEN_NG > 1: the groups' sums, group 0 first */")
     L.extend(ustmts(n_split, len(g.ops)))
     L.append("  EXMC_GEN_FENCE();")
     for k in range(DPL):

@@ -118,6 +118,23 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
+// The sums of the 64 / G lane groups of a wavefront, added in group order (group 0 first); every
+// value is uniform inside its group (after the group's butterfly), so a group's value is a
+// v_readlane of its first lane. Every lane of the wavefront ends with the same totals. For a chain
+// whose model terms are spread over all groups of the wavefront (the one-chain warmup of generated
+// lane layouts, exmc_models.hpp CustomSplit).
+template <int G, int N>
+__device__ __forceinline__ void xgroup_sum_n(double (&s)[N]) {
+  static_assert(G == 16 || G == 32, "two or four lane groups per wavefront");
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    double t = readlane_f64(s[k], 0);
+#pragma unroll
+    for (int j = 1; j < 64 / G; j++) t = t + readlane_f64(s[k], j * G);
+    s[k] = t;
+  }
+}
+
 // N independent all-reduce sums over the G-lane group, stage by stage (the N moves of a stage
 // are independent, so their latencies overlap). kLds (G = 64): the two cross-row stages go
 // through the LDS crossbar (ds_bpermute) -- two vector instructions per value instead of the

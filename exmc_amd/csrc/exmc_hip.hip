@@ -188,11 +188,19 @@ struct Tag {
 
 // LDS budget per one-wave workgroup: 4096 chains x G=16 lanes = 1024 workgroups = 4 per CU of
 // 160 KB; sv at 2048 chains x 64 lanes = 8 per CU.
-template <class F>
+// kOneChain: the launches of the shared one-chain warmup (chain init, warmup kernels); a generated
+// lane layout of fewer than 64 lanes per chain has a form of its own for them (lanes = 64: the
+// chain's model terms over the whole wavefront, exmc_models.hpp CustomSplit)
+template <bool kOneChain = false, class F>
 int dispatch(exmc_hip_model* m, int lanes, F&& f) {
   switch (m->kind) {
 #ifdef EXMC_CUSTOM_HEADER
     case EXMC_MODEL_CUSTOM:   // a generated model (exmc_amd/codegen.py)
+#if defined(EXMC_GEN_LANES) && EXMC_GEN_LANES < 64
+      if constexpr (kOneChain) {
+        if (lanes == 64) return f(Tag<CustomSplit, EXMC_GEN_LANES, EXMC_GEN_LDSL>{}, m->cu);
+      }
+#endif
 #ifdef EXMC_GEN_ONE_LANE
       if (lanes == 1) return f(Tag<Custom<1>, 1, EXMC_GEN_LDS_LEVELS>{}, m->cu);   // one lane per chain
 #endif
@@ -305,7 +313,7 @@ int ensure_densep(exmc_hip_model* m, int GD) {
 }
 
 // dispatch for the launches whose mass-dependent operations depend on the dense mode
-template <class F>
+template <bool kOneChain = false, class F>
 int dispatch_mass(exmc_hip_model* m, int lanes, bool dense, F&& f) {
 #if !defined(EXMC_ONLY_CUSTOM) && !defined(EXMC_DEV_ONLY)
   if (dense && m->kind == EXMC_MODEL_EIGHT_SCHOOLS && lanes == 16)
@@ -317,7 +325,7 @@ int dispatch_mass(exmc_hip_model* m, int lanes, bool dense, F&& f) {
   if (dense && m->kind == EXMC_MODEL_LOGISTIC && lanes == 16)
     return f(Tag<LaneDenseModel<Logistic<16>, 16>, 16, 2>{}, m->lg);
 #endif
-  return dispatch(m, lanes, f);
+  return dispatch<kOneChain>(m, lanes, f);
 }
 
 int default_lanes(int kind) {
@@ -402,8 +410,9 @@ const uint64_t* zig_ki(exmc_hip_model* m) { return m->zig.as<uint64_t>(); }
 const double* zig_wi(exmc_hip_model* m) { return m->zig.as<double>() + 256; }
 const double* zig_fi(exmc_hip_model* m) { return m->zig.as<double>() + 512; }
 
+// one_chain: the start of the shared warmup (a generated lane layout may have its one-chain form)
 int launch_init(exmc_hip_model* m, int lanes, int C, int chain_lo, uint64_t seed,
-                const double* init_q_host) {
+                const double* init_q_host, bool one_chain = false) {
   const double* init_dev = nullptr;
   if (init_q_host) {
     double* dst = m->misc.as<double>() + 8;
@@ -419,14 +428,15 @@ int launch_init(exmc_hip_model* m, int lanes, int C, int chain_lo, uint64_t seed
   P.zig_ki = zig_ki(m); P.zig_wi = zig_wi(m); P.zig_fi = zig_fi(m);
   P.nor_r = EXMC_NOR_R;
   P.flat = flat_order(m);
-  return dispatch(m, lanes, [&](auto tag, const auto& mc) {
+  auto launch = [&](auto tag, const auto& mc) {
     using T = decltype(tag);
     const size_t xlds = aux_lds_bytes<typename T::M>();
     hipLaunchKernelGGL((init_chains_kernel<typename T::M, T::G>), grid_for(C, T::G, kBlock),
                        dim3(kBlock), xlds, m->stream, P, mc);
     HIP_TRY(hipGetLastError());
     return (int)EXMC_OK;
-  });
+  };
+  return one_chain ? dispatch<true>(m, lanes, launch) : dispatch(m, lanes, launch);
 }
 
 // the kernels a push-style stream may run: each kind in its default layout
@@ -887,7 +897,7 @@ int run_warmup_device(exmc_hip_model* m, int lanes, exmc_hip_opts o, exmc_hip_tu
   int rc = m->io.ensure(n_out * 8);
   if (rc) return rc;
   P.out = m->io.as<double>();
-  rc = dispatch_mass(m, lanes, dense, [&](auto tag, const auto& mc) {
+  rc = dispatch_mass<true>(m, lanes, dense, [&](auto tag, const auto& mc) {
     using T = decltype(tag);
     using M = typename T::M;
     constexpr int kSpill = (kMaxLevels > T::LDSL) ? (kMaxLevels - T::LDSL) : 1;
@@ -929,7 +939,7 @@ int run_warmup_device(exmc_hip_model* m, int lanes, exmc_hip_opts o, exmc_hip_tu
                       lds_bytes + pipe_lds_doubles<M::DPL>() * 8 <= 160 * 1024;
     if (dense && !M::kLaneDense) lds_bytes += 3 * (size_t)d * d * 8;   // m2, cov, chol behind everything else
     if (lds_bytes > 160 * 1024) return fail(EXMC_ERR_UNSUPPORTED, "dense warmup state does not fit in LDS");
-    if constexpr (!M::kLaneDense && !M::kRowDense) {   // the dense variants have no two-wave form
+    if constexpr (!M::kLaneDense && !M::kRowDense && M::kHasPipeWarmup) {   // the dense variants have no two-wave form
       if (pipe) {
         lds_bytes += pipe_lds_doubles<M::DPL>() * 8;
         if (lds_bytes > 64 * 1024)
@@ -1236,6 +1246,10 @@ int exmc_hip_model_default_warmup_lanes(const exmc_hip_model* m) {
   // logistic: the shared warmup is ONE chain, so its 500 observations are best spread over a whole
   // wavefront (8 per lane instead of 32: 158 -> 62 ms); sampling keeps 16 lanes per chain
   if (m->kind == EXMC_MODEL_LOGISTIC) return 64;
+#if defined(EXMC_GEN_LANES) && EXMC_GEN_LANES < 64
+  // a generated lane layout: the chain's model terms over the whole wavefront (CustomSplit)
+  if (m->kind == EXMC_MODEL_CUSTOM) return 64;
+#endif
   return default_lanes(m->kind);
 }
 int exmc_hip_model_default_dense_lanes(const exmc_hip_model* m) {
@@ -1423,7 +1437,9 @@ int warmup_impl(exmc_hip_model* m, const double* init_q, exmc_hip_opts o, const 
   const int lanes = resolve_lanes(m, o.lanes_per_chain);
   int rc = ensure_state(m, 1);
   if (rc) return rc;
-  rc = launch_init(m, lanes, 1, 0, o.seed, init_q);
+  const char* hw = std::getenv("EXMC_HIP_HOST_WARMUP");
+  const bool host_driven = hw && hw[0] == '1';
+  rc = launch_init(m, lanes, 1, 0, o.seed, init_q, !host_driven);
   if (rc) return rc;
   if (start && o.num_warmup == 0) {   // sampler.ex:195-196: nothing to tune
     *tuning = *start;
@@ -1432,8 +1448,8 @@ int warmup_impl(exmc_hip_model* m, const double* init_q, exmc_hip_opts o, const 
   }
   // EXMC_HIP_HOST_WARMUP=1 keeps the adaptation scalars on the host (one launch per
   // transition); the default runs the whole schedule in one kernel. Both give the same bits.
-  const char* hw = std::getenv("EXMC_HIP_HOST_WARMUP");
-  if (hw && hw[0] == '1') return run_warmup(m, lanes, o, tuning, start);
+  // (The host-driven form runs in sampling layouts only: not in a generated layout's one-chain form.)
+  if (host_driven) return run_warmup(m, lanes, o, tuning, start);
   return run_warmup_device(m, lanes, o, tuning, start);
 }
 }  // namespace

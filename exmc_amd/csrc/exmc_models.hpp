@@ -32,6 +32,7 @@ struct ModelDefaults {
   // tree bookkeeping is a real share of a leaf pass: sv 900 -> 695 ms, radon 194 -> 169 ms,
   // eight_schools ~20 -> ~17 ms; not for logistic, whose pass is nearly all model (158 -> 162 ms)
   static constexpr bool kPipeWarmup = true;
+  static constexpr bool kHasPipeWarmup = true;   // false: the two-wave warmup form is not even built
   // 64-lane sums: the cross-row stages through ds_bpermute instead of v_readlane (exmc_device.hpp
   // group_allsum_n): for kernels bound by vector issue with two waves per SIMD
   static constexpr bool kXRowLds = false;
@@ -1158,10 +1159,40 @@ static __host__ __device__ __noinline__ double exmc_gen_erf_call(double x) { ret
 #define EXMC_GEN_FMA(a, b, c) __builtin_fma(a, b, c)
 #include EXMC_CUSTOM_HEADER
 #ifdef EXMC_GEN_LANES
+// LDS of a sampling workgroup of the lane layout: tree-stack levels, the ziggurat tables, the
+// chains' strips and (when it fits) an image of the model's tables. Two waves per SIMD are eight
+// workgroups per CU -- 20 KB each of the 160 KB, or they are not resident together and the launch
+// bound bought nothing (gen_sv: 31.5 KB with two stack levels and the table image = five per CU).
+// A second stack level is worth more than the table image (a wave pair hides the L2 round trips of
+// table reads; stack traffic is on the tree's critical path).
+#define EXMC_GEN_LDS_BUDGET ((EXMC_GEN_WAVES_PER_SIMD == 2) ? 160 * 1024 / 8 : 160 * 1024 / 4)
+#define EXMC_GEN_LDS_BYTES(levels, table)                                                      \
+  ((levels) * (5 * EXMC_GEN_DPL + 3) * 64 * 8 + 768 * 8 + (64 / EXMC_GEN_LANES) * EXMC_GEN_LSH * 8 + \
+   (table) * EXMC_GEN_NLT * 8)
+#if EXMC_GEN_DPL == 1
+#define EXMC_GEN_LDSL 6
+#elif EXMC_GEN_LDS_BYTES(2, 0) <= EXMC_GEN_LDS_BUDGET
+#define EXMC_GEN_LDSL 2
+#else
+#define EXMC_GEN_LDSL 1
+#endif
+#if EXMC_GEN_NLT <= 2048 && EXMC_GEN_LDS_BYTES(EXMC_GEN_LDSL, 1) <= EXMC_GEN_LDS_BUDGET
+#define EXMC_GEN_TABLE_IN_LDS 1
+#else
+#define EXMC_GEN_TABLE_IN_LDS 0
+#endif
+namespace exmc {
+constexpr bool kGenLdsTable = EXMC_GEN_TABLE_IN_LDS != 0;
+}
+#endif
+#ifdef EXMC_GEN_LANES
 // the lane function twice: its tables in global memory, and in an LDS image the NUTS and warmup
 // workgroups stage once per kernel (a lone wave per SIMD would otherwise sit out an L2 round trip
 // per family and leapfrog; ModelDefaults::kLdsDataDoubles). ltoff = the image's offset in doubles.
 #define EXMC_GEN_LANES_SECTION
+#define EXMC_GEN_G0 0       // a chain's units on its own lane group (sampling: 64 / G chains per wavefront)
+#define EXMC_GEN_NG 1
+#define EXMC_GEN_XGROUP(s)
 #define EXMC_GEN_LANES_NAME exmc_gen_lanes_global
 #define EXMC_GEN_LT(i) lt[i]
 #define EXMC_GEN_IT(i) ((const int*)(lt + EXMC_GEN_IOFF))[i]
@@ -1175,27 +1206,33 @@ static __host__ __device__ __noinline__ double exmc_gen_erf_call(double x) { ret
 #define EXMC_GEN_LT(i) exmc::exmc_dyn_lds[ltoff + (i)]
 #define EXMC_GEN_IT(i) ((const int*)(exmc::exmc_dyn_lds + ltoff + EXMC_GEN_IOFF))[i]
 #include EXMC_CUSTOM_HEADER
+#if EXMC_GEN_LANES < 64
+// a third time for the one-chain warmup of a layout with fewer than 64 lanes per chain: the units of
+// a family over ALL 64 / G lane groups of the wavefront (group g takes the slots g, g + NG, ...), the
+// groups' sums added in group order after each group's butterfly, one set of strips for the wave
+// (CustomSplit below). Tables where the warmup kernel keeps them (kGenLdsTable).
+#undef EXMC_GEN_LANES_NAME
+#undef EXMC_GEN_G0
+#undef EXMC_GEN_NG
+#undef EXMC_GEN_XGROUP
+#define EXMC_GEN_G0 ((int)(threadIdx.x & 63) / EXMC_GEN_LANES)
+#define EXMC_GEN_NG (64 / EXMC_GEN_LANES)
+#define EXMC_GEN_XGROUP(s) exmc::xgroup_sum_n<EXMC_GEN_LANES>(s)
+#if EXMC_GEN_TABLE_IN_LDS
+#define EXMC_GEN_LANES_NAME exmc_gen_lanes_split_lds
+#include EXMC_CUSTOM_HEADER
+#undef EXMC_GEN_LANES_NAME
+#endif
+#undef EXMC_GEN_LT
+#undef EXMC_GEN_IT
+#define EXMC_GEN_LT(i) lt[i]
+#define EXMC_GEN_IT(i) ((const int*)(lt + EXMC_GEN_IOFF))[i]
+#define EXMC_GEN_LANES_NAME exmc_gen_lanes_split_global
+#include EXMC_CUSTOM_HEADER
+#endif
 #undef EXMC_GEN_LANES_SECTION
 #endif
 
-#ifdef EXMC_GEN_LANES
-// LDS of a sampling workgroup of the lane layout: tree-stack levels, the ziggurat tables, the
-// chains' strips and (when it fits) an image of the model's tables. Two waves per SIMD are eight
-// workgroups per CU -- 20 KB each of the 160 KB, or they are not resident together and the launch
-// bound bought nothing (gen_sv: 31.5 KB with two stack levels and the table image = five per CU).
-// A second stack level is worth more than the table image (a wave pair hides the L2 round trips of
-// table reads; stack traffic is on the tree's critical path).
-namespace exmc {
-constexpr int kGenLdsBudget = (EXMC_GEN_WAVES_PER_SIMD == 2) ? 160 * 1024 / 8 : 160 * 1024 / 4;
-constexpr int gen_lds_bytes(int levels, bool table) {
-  return levels * (5 * EXMC_GEN_DPL + 3) * 64 * 8 + 768 * 8 + (64 / EXMC_GEN_LANES) * EXMC_GEN_LSH * 8 +
-         (table ? EXMC_GEN_NLT * 8 : 0);
-}
-constexpr int kGenLdsLevels = (EXMC_GEN_DPL == 1) ? 6 : (gen_lds_bytes(2, false) <= kGenLdsBudget ? 2 : 1);
-constexpr bool kGenLdsTable = EXMC_GEN_NLT <= 2048 && gen_lds_bytes(kGenLdsLevels, true) <= kGenLdsBudget;
-}
-#define EXMC_GEN_LDSL exmc::kGenLdsLevels
-#endif
 
 namespace exmc {
 
@@ -1283,6 +1320,39 @@ struct Custom<EXMC_GEN_LANES> : ModelDefaults {
     return exmc_gen_lanes_global(c.lt, el, l, g, shoff);
   }
 };
+
+#if EXMC_GEN_LANES < 64
+// The same layout for ONE chain on a whole wavefront -- the shared warmup (exmc_hip.hip: warmup
+// lanes 64 for a generated layout of fewer lanes per chain, the default). All 64 / G lane groups
+// carry the chain redundantly (kCoop: they stay in lockstep, group 0 writes) and share group 0's
+// strips; in logp_grad group g evaluates the slots g, g + 64 / G, ... of every family, and the
+// groups' reduced sums are added in group order (exmc_gen_lanes_split). A 500-observation
+// likelihood at 16 lanes per chain: 8 slots per lane instead of 32. The sums differ from the
+// sampling layout's in their order, so this is a layout of its own for the checker too
+// (tests/gen_checker.py model(..., wave_split=True)), like the hand-written logistic kind's 64-lane
+// warmup layout.
+struct CustomSplit : Custom<EXMC_GEN_LANES> {
+  using Base = Custom<EXMC_GEN_LANES>;
+  static constexpr bool kCoop = true;
+  // one wave: where this form pays the pass is nearly all model (like the hand-written logistic
+  // kind, ModelDefaults::kPipeWarmup), and a plug-in build is spared its heaviest kernel
+  static constexpr bool kPipeWarmup = false;
+  static constexpr bool kHasPipeWarmup = false;
+  __device__ static __forceinline__ double logp_grad(const Consts& c, const Lane& ln, int l,
+                                                     const double (&q)[DPL], double (&g)[DPL]) {
+    const int shoff = (int)(ln.sh - exmc_dyn_lds);   // group 0's strips for every group
+#pragma unroll
+    for (int k = 0; k < DPL; k++)
+      if (l + k * G < D) exmc_dyn_lds[shoff + l + k * G] = q[k];   // the same value from every group
+    wave_lds_fence();
+    const int* el = kEllRegs ? ln.ell : ((const int*)c.lt + EXMC_GEN_ELL_OFF + l * EXMC_GEN_NELL);
+#if EXMC_GEN_TABLE_IN_LDS
+    if (ln.xoff >= 0) return exmc_gen_lanes_split_lds(c.lt, el, l, g, shoff, ln.xoff);   // wave-uniform
+#endif
+    return exmc_gen_lanes_split_global(c.lt, el, l, g, shoff, -1);
+  }
+};
+#endif
 #endif
 
 #ifdef EXMC_GEN_VEC

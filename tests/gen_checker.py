@@ -39,7 +39,13 @@ WRAPPER = """
 /* the lane layout (exmc_amd/codegen_lanes.py) on virtual lanes: every lane runs the function up to
  * the butterfly (pass 0: its partial sums are collected), the sums are added in the order of the
  * device's xor butterfly, every lane runs it again to the end (pass 1) */
-typedef struct { double* sh; int pass; double* S; const double* R; double* SW; const double* RW; } exmc_gen_ctx;
+typedef struct { double* sh; int pass; double* S; const double* R; double* SW; const double* RW; int g0, ng; } exmc_gen_ctx;
+/* the one-chain warmup spreads the units of a family over the 64 / G lane groups of the wavefront
+ * (Custom...Split of exmc_models.hpp): group g0 takes the slots g0, g0 + ng, ...; the groups' sums are
+ * added in group order after each group's butterfly (the emulation does that outside the function) */
+#define EXMC_GEN_G0 ctx->g0
+#define EXMC_GEN_NG ctx->ng
+#define EXMC_GEN_XGROUP(s)
 #define EXMC_GEN_CTX_DECL , exmc_gen_ctx* ctx
 #define EXMC_GEN_SH(i) ctx->sh[i]
 /* pass 0 ends at the butterfly of the spread sums of the uniform part (when the model has any),
@@ -86,12 +92,12 @@ double exmc_gen_check(const double* data, const double* q, double* g) {
 #ifdef EXMC_GEN_LANES
 /* Custom<EXMC_GEN_LANES> of exmc_amd/csrc/exmc_models.hpp: dimension i in slot i / G of lane i mod G */
 int exmc_gen_check_lanes(void) { return EXMC_GEN_LANES; }
-double exmc_gen_checkL(const double* data, const double* q, double* g) {
+static double exmc_gen_check_groups(const double* data, const double* q, double* g, int ng) {
   enum { G = EXMC_GEN_LANES };
   const double* lt = data + EXMC_GEN_LOFF;
   double sh[EXMC_GEN_LSH], S[G * EXMC_GEN_NS], R[EXMC_GEN_NS], gl[EXMC_GEN_DPL], lp = 0.0;
   double SW[G * (EXMC_GEN_NW + 1)], RW[EXMC_GEN_NW + 1];
-  exmc_gen_ctx ctx = {sh, 0, S, R, SW, RW};
+  exmc_gen_ctx ctx = {sh, 0, S, R, SW, RW, 0, ng};
   for (int i = 0; i < EXMC_GEN_LSH; i++) sh[i] = 0.0;
   for (int i = 0; i < EXMC_GEN_D; i++) sh[i] = q[i];
   const int* ell = (const int*)lt + EXMC_GEN_ELL_OFF;
@@ -100,18 +106,23 @@ double exmc_gen_checkL(const double* data, const double* q, double* g) {
     double* const from = stage ? S : SW;
     double* const to = stage ? R : RW;
     ctx.pass = stage;
-    for (int l = 0; l < G; l++) (void)exmc_gen_lanes(lt, ell + l * EXMC_GEN_NELL, l, gl, &ctx);
-    for (int k = 0; k < n; k++) {   /* group_allsum_n: xor butterfly over the G lanes */
-      double part[G], nxt[G];
-      for (int l = 0; l < G; l++) part[l] = from[l * n + k];
-      for (int m = 1; m < G; m <<= 1) {
-        for (int l = 0; l < G; l++) nxt[l] = part[l] + part[l ^ m];
-        memcpy(part, nxt, sizeof part);
+    /* the spread sums of the uniform part are not split: every group computes them alike */
+    for (int grp = 0; grp < (stage ? ng : 1); grp++) {
+      ctx.g0 = grp;
+      for (int l = 0; l < G; l++) (void)exmc_gen_lanes(lt, ell + l * EXMC_GEN_NELL, l, gl, &ctx);
+      for (int k = 0; k < n; k++) {   /* group_allsum_n: xor butterfly over the G lanes */
+        double part[G], nxt[G];
+        for (int l = 0; l < G; l++) part[l] = from[l * n + k];
+        for (int m = 1; m < G; m <<= 1) {
+          for (int l = 0; l < G; l++) nxt[l] = part[l] + part[l ^ m];
+          memcpy(part, nxt, sizeof part);
+        }
+        to[k] = grp ? to[k] + part[0] : part[0];   /* xgroup_sum_n: group 0 first */
       }
-      to[k] = part[0];
     }
   }
   ctx.pass = 2;
+  ctx.g0 = 0;   /* every group ends with the same sums and the same strips: group 0's gradient */
   for (int l = 0; l < G; l++) {
     const double v = exmc_gen_lanes(lt, ell + l * EXMC_GEN_NELL, l, gl, &ctx);
     if (l == 0) lp = v;
@@ -119,6 +130,13 @@ double exmc_gen_checkL(const double* data, const double* q, double* g) {
       if (l + k * G < EXMC_GEN_D) g[l + k * G] = gl[k];
   }
   return lp;
+}
+double exmc_gen_checkL(const double* data, const double* q, double* g) {
+  return exmc_gen_check_groups(data, q, g, 1);
+}
+/* the layout of the one-chain warmup: the units over all 64 / G groups of a wavefront */
+double exmc_gen_checkLW(const double* data, const double* q, double* g) {
+  return exmc_gen_check_groups(data, q, g, 64 / EXMC_GEN_LANES);
 }
 #endif
 #ifdef EXMC_GEN_VEC
@@ -175,7 +193,7 @@ def build(gen):
 
 def _lib(gen):
     L = C.CDLL(build(gen))
-    for name in ("exmc_gen_check", "exmc_gen_check16", "exmc_gen_checkL"):
+    for name in ("exmc_gen_check", "exmc_gen_check16", "exmc_gen_checkL", "exmc_gen_checkLW"):
         if hasattr(L, name):
             f = getattr(L, name)
             f.restype = C.c_double
@@ -184,24 +202,28 @@ def _lib(gen):
     return L
 
 
-def model(gen, lanes=None):
+def model(gen, lanes=None, wave_split=False):
     """oracle Model running the generated value+gradient; lanes 1 or 16 (default: the layout the
-    plug-in defaults to). Use with O.Cfg(1, lanes)."""
+    plug-in defaults to). Use with O.Cfg(1, lanes). wave_split: the lane layout as the one-chain
+    warmup runs it (exmc_hip_model_default_warmup_lanes = 64 for a layout of fewer lanes: the units
+    of a family over all lane groups of the wavefront)."""
     lanes = gen.lanes if lanes is None else lanes
     L = _lib(gen)
     assert L.exmc_gen_check_dim() == gen.d and L.exmc_gen_check_ndata() == gen.data.size
     m = O.Model(O.EXO_MODEL_CUSTOM, gen.d, gen.data)
-    fn = C.cast(_entry(gen, L, lanes), C.c_void_p)
+    fn = C.cast(_entry(gen, L, lanes, wave_split), C.c_void_p)
     O.lib().exo_model_set_custom(m.h, fn)
     m.gen_lib = L
     m.lanes = lanes
     return m
 
 
-def _entry(gen, L, lanes):
+def _entry(gen, L, lanes, wave_split=False):
     """The checker function of a layout: one lane, the 16-lane plate layout, or the lane layout."""
     if getattr(gen, "lane_layout", None) is not None and lanes == gen.lane_layout["lanes"]:
-        return L.exmc_gen_checkL
+        return L.exmc_gen_checkLW if wave_split else L.exmc_gen_checkL
+    if wave_split:
+        raise ValueError("only the lane layout has a wave-split warmup form")
     if lanes == 16:
         return L.exmc_gen_check16
     if lanes != 1:
@@ -209,10 +231,10 @@ def _entry(gen, L, lanes):
     return L.exmc_gen_check
 
 
-def logp_grad(gen, q, lanes=1):
+def logp_grad(gen, q, lanes=1, wave_split=False):
     L = _lib(gen)
     q = np.ascontiguousarray(q, dtype=np.float64)
     g = np.zeros(gen.d)
     data = np.ascontiguousarray(gen.data)
-    f = _entry(gen, L, lanes)
+    f = _entry(gen, L, lanes, wave_split)
     return f(O.dptr(data), O.dptr(q), O.dptr(g)), g

@@ -282,3 +282,23 @@ def test_a_spread_sum_does_not_feed_another_one():
         lpl, gl = GC.logp_grad(gen, q, lanes=16)
         assert abs(lp1 - lpl) <= 1e-12 * max(1.0, abs(lp1)), t
         assert np.all(np.abs(g1 - gl) <= 1e-11 * np.maximum(1.0, np.abs(g1))), t
+
+
+@pytest.mark.parametrize("which,lanes", [("logistic", 16), ("sv", 32)])
+def test_one_chain_form_spreads_the_units_over_the_wavefront(which, lanes):
+    """The shared warmup runs ONE chain, so a layout of fewer than 64 lanes per chain has a form in
+    which the 64 / G lane groups of the wavefront share the units of every family (group g takes the
+    slots g, g + 64 / G, ...) and the groups' reduced sums are added in group order: the same
+    density and gradient up to the order of the sums (the checker runs both forms of the same text)."""
+    gen, hand = _gen(which, lanes)
+    assert "sl += EXMC_GEN_NG" in gen.lane_layout["text"] and "EXMC_GEN_XGROUP(s)" in gen.lane_layout["text"]
+    rng = np.random.default_rng(21)
+    differ = 0
+    for t in range(25):
+        q = rng.normal(size=gen.d) * (0.1 if which == "sv" else 0.4)
+        a, ga = GC.logp_grad(gen, q, lanes=lanes)
+        b, gb = GC.logp_grad(gen, q, lanes=lanes, wave_split=True)
+        assert abs(a - b) <= 1e-12 * max(1.0, abs(a)), t
+        assert np.all(np.abs(ga - gb) <= 1e-11 * np.maximum(1.0, np.abs(ga))), t
+        differ += int(a != b or not np.array_equal(ga, gb))
+    assert differ > 0          # a different order of the sums: a layout of its own for the checker

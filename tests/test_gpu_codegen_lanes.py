@@ -94,7 +94,9 @@ def test_lane_layout_chain_batches_bit_exact(which, hip):
     its own LDS strip; sv: one chain per wavefront)."""
     spec, comp, om, _, lanes = _compiled(which, hip)
     nc, nw, ns = (24, 100, 30) if which == "sv" else (70, 120, 60)
-    opts = dict(num_warmup=nw, num_samples=ns, seed=42, init_values=spec.default_init)
+    # (warmup in the sampling layout, as the checker's sample_chains does; the default one-chain
+    # form of a 16-lane layout has its own test below)
+    opts = dict(num_warmup=nw, num_samples=ns, seed=42, init_values=spec.default_init, warmup_lanes=lanes)
     _, stats = sampler.sample_chains_compiled(comp, nc, opts)
     q0 = spec.to_unconstrained(spec.default_init)
     t, st = O.sample_chains(om, nc, init_q=q0, num_warmup=nw, num_samples=ns, seed=42,
@@ -168,3 +170,32 @@ def test_generated_sv_two_waves_per_simd_bit_exact(hip, monkeypatch):
         t, _ = O.sample_tuned(om, tuning["epsilon"], tuning["inv_mass"], q0, num_samples=40, seed=9 + 7919 * c,
                               cfg=O.Cfg(1, lanes))
         assert np.array_equal(t["draws"], res[1]["draws"][c]), c
+
+
+@pytest.mark.parametrize("which", ["logistic", "walk16"])
+def test_one_chain_warmup_form_bit_exact(which, hip):
+    """The shared warmup of a generated layout with fewer than 64 lanes per chain runs the chain on
+    the whole wavefront by default (exmc_hip_model_default_warmup_lanes = 64: CustomSplit, the units
+    of every family over the four lane groups, their sums added in group order). Its tuning equals
+    the checker's in that form (gen_checker.model(..., wave_split=True)), differs from the sampling
+    layout's own warmup, and the chains sampled from it (in the sampling layout) equal the checker."""
+    spec, comp, om, _, lanes = _compiled(which, hip)
+    assert lanes == 16 and comp.default_warmup_lanes == 64
+    oms = GC.model(spec.gen, lanes, wave_split=True)
+    opts = dict(num_warmup=150, num_samples=40, seed=23)
+    tuning = sampler.warmup(comp, spec.default_init, opts)                       # default: the split form
+    q0 = spec.to_unconstrained(spec.default_init)
+    st = O.warmup(oms, q0, num_warmup=150, seed=23, cfg=O.Cfg(1, lanes))
+    assert tuning["epsilon"] == st.step_size
+    assert np.array_equal(tuning["inv_mass"], np.array(st.inv_mass[:spec.d]))
+    plain = sampler.warmup(comp, spec.default_init, dict(opts, warmup_lanes=lanes))
+    st_plain = O.warmup(om, q0, num_warmup=150, seed=23, cfg=O.Cfg(1, lanes))
+    assert plain["epsilon"] == st_plain.step_size
+    assert np.array_equal(plain["inv_mass"], np.array(st_plain.inv_mass[:spec.d]))
+    if which == "logistic":     # (walk16's families have one slot per lane: the other groups add zeros)
+        assert plain["epsilon"] != tuning["epsilon"] or not np.array_equal(plain["inv_mass"], tuning["inv_mass"])
+    _, _, extra = sampler.sample_compiled_tuned(comp, tuning, spec.default_init, opts, num_chains=9)
+    for c in (0, 8):
+        t, _ = O.sample_tuned(om, tuning["epsilon"], tuning["inv_mass"], q0, num_samples=40, seed=23 + 7919 * c,
+                              cfg=O.Cfg(1, lanes))
+        assert np.array_equal(t["draws"], extra["raw"]["draws"][c]), c
