@@ -394,6 +394,42 @@ def _uniform_families(g, roots):
     return kept
 
 
+def _split_by_zero_factors(g, shape, members, sigs):
+    """Units of one shape, split by WHICH of their constant factors are exactly zero (a 0 / 1 datum y
+    in y * log p + (1 - y) * log(1 - p): the units with y = 1 and those with y = 0). In a subfamily
+    such a factor is the same constant for every unit, and the template builder folds 0 * (a provably
+    finite value) away -- each half of a Bernoulli likelihood then evaluates one logarithm, not two.
+    Kept together when a part would have fewer than MIN_FAMILY units or there are more than four."""
+    def costly(k, seen):          # a transcendental or a quotient under shape node k
+        if k in seen:
+            return False
+        seen.add(k)
+        e = shape[k]
+        if e[0] in ("log", "exp", "log1p", "erf", "div"):
+            return True
+        return e[0] not in ("lit", "q", "data") and any(costly(a, seen) for a in e[1:])
+    factors = []
+    for k, e in enumerate(shape):
+        if e[0] != "mul":
+            continue
+        for a, b in ((e[1], e[2]), (e[2], e[1])):
+            node0 = sigs[members[0]][a]
+            if (g.const[node0] and not g.const[sigs[members[0]][b]] and a not in factors
+                    and costly(b, set())):         # (0 * a plain variable saves nothing worth a loop)
+                factors.append(a)
+    if not factors:
+        return [members]
+    leaf = lambda op: np.float64(g.data[op[1]])   # noqa: E731
+    patterns = {}
+    for m in members:
+        nodes = [sigs[m][k] for k in factors]
+        vals = _np_eval(g, nodes, leaf)
+        patterns.setdefault(tuple(bool(vals[n] == 0.0) for n in nodes), []).append(m)
+    if len(patterns) == 1 or len(patterns) > 4 or min(len(v) for v in patterns.values()) < MIN_FAMILY:
+        return [members]
+    return [patterns[p] for p in sorted(patterns, key=lambda p: patterns[p][0])]
+
+
 def plan(g, term_roots, custom_roots, D, G):
     """Units, families and the uniform remainder of the graph `g` whose terms are `term_roots`."""
     units = []
@@ -407,18 +443,19 @@ def plan(g, term_roots, custom_roots, D, G):
         sigs[pos] = ids
         by_shape.setdefault(shape, []).append(pos)
     families, in_family = [], set()
-    for shape, members in by_shape.items():
-        if len(members) < MIN_FAMILY:
+    for shape, all_members in by_shape.items():
+        if len(all_members) < MIN_FAMILY:
             continue
-        first = sigs[members[0]]
-        uniform = [all(sigs[m][k] == first[k] for m in members) for k in range(len(shape))]
-        if uniform[-1]:
-            continue            # the same node n times: n uniform terms
-        f = _Family()
-        f.shape, f.members, f.uniform = shape, members, uniform
-        f.ids = [sigs[m] for m in members]
-        families.append(f)
-        in_family.update(members)
+        for members in _split_by_zero_factors(g, shape, all_members, sigs):
+            first = sigs[members[0]]
+            uniform = [all(sigs[m][k] == first[k] for m in members) for k in range(len(shape))]
+            if uniform[-1]:
+                continue            # the same node n times: n uniform terms
+            f = _Family()
+            f.shape, f.members, f.uniform = shape, members, uniform
+            f.ids = [sigs[m] for m in members]
+            families.append(f)
+            in_family.update(members)
     families.sort(key=lambda f: f.members[0])
     scalar_units = [units[p] for p in range(len(units)) if p not in in_family]
     return families, scalar_units
@@ -512,6 +549,106 @@ def generate(g, term_roots, custom_roots, D, G, waves_per_simd=1):
             if T.const[a] and num_ok(a) and not shared:
                 return T._node("div", a, b)
             return T.mul(a, T.recip(b))
+        cval_memo, bnd_memo = {}, {}
+
+        def cvals(node, T=T):
+            """per-unit values of a constant template node"""
+            if node not in cval_memo:
+                v = np.asarray(_np_eval(T, [node], const_leaf)[node], dtype=np.float64)
+                cval_memo[node] = np.broadcast_to(v, (n,))
+            return cval_memo[node]
+
+        def cval(node, T=T):
+            """the value of a constant template node that is the same for every unit, else None"""
+            if not T.const[node]:
+                return None
+            v = cvals(node)
+            return float(v[0]) if np.all(v == v[0]) else None
+
+        def bounds(node, T=T):
+            """(lo, hi, never NaN) of a template node over all units and all positions: what lets
+            0 * x be folded to 0. Conservative: anything not proven is (-inf, inf, False). fmax / fmin
+            return the other operand for a NaN (IEEE maxNum, the emitted fmax / fmin and v_max_f64)."""
+            if node in bnd_memo:
+                return bnd_memo[node]
+            inf, unknown = math.inf, (-math.inf, math.inf, False)
+            op = T.ops[node]
+            k, r = op[0], unknown
+            if T.const[node]:
+                v = cvals(node)
+                r = (float(np.min(v)), float(np.max(v)), True) if np.all(np.isfinite(v)) else unknown
+            elif k in ("gat", "ext", "q", "red", "wred"):
+                r = unknown
+            else:
+                b = [bounds(a) for a in op[1:]]
+                fin = lambda x: x[2] and math.isfinite(x[0]) and math.isfinite(x[1])   # noqa: E731
+                with np.errstate(all="ignore"):
+                    if k == "neg":
+                        r = (-b[0][1], -b[0][0], b[0][2])
+                    elif k in ("add", "sub") and fin(b[0]) and fin(b[1]):
+                        r = ((b[0][0] + b[1][0], b[0][1] + b[1][1], True) if k == "add"
+                             else (b[0][0] - b[1][1], b[0][1] - b[1][0], True))
+                    elif k == "mul" and fin(b[0]) and fin(b[1]):
+                        c = [x * y for x in b[0][:2] for y in b[1][:2]]
+                        r = (min(c), max(c), True)
+                    elif k == "div" and fin(b[0]) and fin(b[1]) and (b[1][0] > 0.0 or b[1][1] < 0.0):
+                        c = [x / y for x in b[0][:2] for y in b[1][:2]]
+                        r = (min(c), max(c), True)
+                    elif k == "exp" and b[0][2] and b[0][1] < 700.0:
+                        r = (float(np.exp(b[0][0])), float(np.exp(b[0][1])), True)
+                    elif k == "log" and fin(b[0]) and b[0][0] > 0.0:
+                        r = (float(np.log(b[0][0])), float(np.log(b[0][1])), True)
+                    elif k == "log1p" and fin(b[0]) and b[0][0] > -1.0:
+                        r = (float(np.log1p(b[0][0])), float(np.log1p(b[0][1])), True)
+                    elif k == "abs" and b[0][2]:
+                        r = (0.0, max(abs(b[0][0]), abs(b[0][1])), True)
+                    elif k == "erf":
+                        r = (-1.0, 1.0, b[0][2])
+                    elif k in ("max", "min") and (b[0][2] or b[1][2]):
+                        los = [x[0] for x in b if x[2]]
+                        his = [x[1] if x[2] else inf for x in b]
+                        lo_all = [x[0] if x[2] else -inf for x in b]
+                        r = ((max(los), max(his), True) if k == "max" else (min(lo_all), min(x[1] for x in b if x[2]), True))
+                    elif k == "sel_gt":
+                        r = (min(b[2][0], b[3][0]), max(b[2][1], b[3][1]), b[2][2] and b[3][2])
+                if not (r[0] == r[0] and r[1] == r[1]):          # a NaN bound proves nothing
+                    r = unknown
+            bnd_memo[node] = r
+            return r
+
+        def finite(node):
+            lo, hi, ok = bounds(node)
+            return ok and math.isfinite(lo) and math.isfinite(hi)
+
+        def simple(node, T=T):
+            """a constant that is 0, 1 or -1 in every unit as a literal (so that the exact rewrites of
+            the graph's own mul / neg apply to it in the adjoint pass too)"""
+            c = cval(node)
+            return T.lit(c) if c in (0.0, 1.0, -1.0) and T.ops[node][0] != "lit" else node
+
+        def make(kind, a, T=T):
+            """a template node with the rewrites a constant factor or summand allows: 1 * x, x + 0 and
+            0 * x for an x that is finite whatever the position (bounds)."""
+            if kind == "mul":
+                for x, y in ((a[0], a[1]), (a[1], a[0])):
+                    c = cval(x)
+                    if c == 0.0 and finite(y):
+                        return T.lit(0.0)
+                    if c == 1.0:
+                        return y
+                    if c == -1.0:
+                        return T.neg(y)
+            elif kind == "add":
+                if cval(a[0]) == 0.0:
+                    return a[1]
+                if cval(a[1]) == 0.0:
+                    return a[0]
+            elif kind == "sub":
+                if cval(a[1]) == 0.0:
+                    return a[0]
+                if cval(a[0]) == 0.0:
+                    return T.neg(a[1])
+            return simple(T._node(kind, *a))
         for k in sorted(need):
             node0 = f.ids[0][k]
             kind = shape[k][0]
@@ -534,14 +671,15 @@ def generate(g, term_roots, custom_roots, D, G, waves_per_simd=1):
                 vals = [g.data[g.ops[ids[k]][1]] if kind == "data" else float.fromhex(g.ops[ids[k]][1])
                         for ids in f.ids]
                 if all(v == vals[0] for v in vals):
-                    tmap[k] = T._node("uc", uc_slot(("val", float(vals[0]).hex()), vals[0]))
+                    tmap[k] = (T.lit(vals[0]) if vals[0] in (0.0, 1.0, -1.0)
+                               else T._node("uc", uc_slot(("val", float(vals[0]).hex()), vals[0])))
                 else:
                     f.raw_cols.append(np.asarray(vals, dtype=np.float64))
                     tmap[k] = T._node("col", -len(f.raw_cols))      # raw columns: negative ids
             elif kind == "div":
                 tmap[k] = quotient(tmap[shape[k][1]], tmap[shape[k][2]], shape[k][2] in share_recip)
             else:
-                tmap[k] = T._node(kind, *[tmap[a] for a in shape[k][1:]])
+                tmap[k] = make(kind, [tmap[a] for a in shape[k][1:]])
         f.T, f.troot = T, tmap[root]
         n_fwd = len(T.ops)
         ad = cg._Grad(T, f.troot, const_num_ok=num_ok)

@@ -73,7 +73,18 @@ def test_structure_found_in_the_graphs():
     rd, _ = _gen("radon")
     assert rd.lane_layout["family_sizes"] == [88, 919] and rd.lane_layout["n_scalar_units"] == 2
     lg, _ = _gen("logistic")
-    assert lg.lane_layout["family_sizes"] == [21, 500] and lg.lane_layout["n_reduced"] == 22
+    # the 500 observations as two families, by WHICH of y and 1 - y is zero: each half of
+    # y * log p + (1 - y) * log(1 - p) then evaluates one logarithm and one reciprocal (0 * log of a
+    # clipped probability is provably finite and folded away)
+    sizes = lg.lane_layout["family_sizes"]
+    assert sizes[0] == 21 and sum(sizes[1:]) == 500 and len(sizes) == 3 and lg.lane_layout["n_reduced"] == 22
+    text = lg.lane_layout["text"]
+    for fam in ("/* family 1", "/* family 2"):
+        body = text[text.index(fam):]
+        body = body[:body.index("\n  }\n") if "\n  }\n" in body else len(body)]
+        assert body.count("EXMC_GENL_LOG(") == 1 and body.count("1.0 / ") == 2 and body.count("EXMC_GENL_EXP(") == 1
+    # radon's observation loop multiplies the floor indicator with a plain variable: not worth a loop
+    assert rd.lane_layout["family_sizes"] == [88, 919]
     assert lg.lane_layout["dpl"] == 2 and sv.lane_layout["dpl"] == 2 and rd.lane_layout["dpl"] == 2
 
 
