@@ -45,6 +45,9 @@ import numpy as np
 from . import codegen as cg
 
 MIN_FAMILY = 4          # fewer units than this are evaluated by every lane (the uniform part)
+# doubles of table rows / gathered variables fetched ahead per lane (emit_family), by resident waves
+# per SIMD: a lone wave has 512 registers and nobody to hide its latency, a pair 256 each
+PREFETCH_DOUBLES = {1: int(__import__("os").environ.get("EXMC_GEN_PREFETCH", "64")), 2: 24}
 
 
 class _LGraph(cg._Graph):
@@ -1049,19 +1052,55 @@ def generate(g, term_roots, custom_roots, D, G, waves_per_simd=1):
             op = T.ops[i]
             e = fused(T, i, t_plan, tref) if i in t_plan else expr(op[0], [tref(x) for x in op[1:]])
             L.append("  const double %s_%d = %s;" % (tag, i, e))
-        if split:     # the units of a family over the lane groups of the wavefront too (EXMC_GEN_NG > 1:
-            L.append("  for (int sl = EXMC_GEN_G0; sl < %d; sl += EXMC_GEN_NG) {" % f.S)   # one-chain warmup)
+        g0, ng = ("EXMC_GEN_G0", "EXMC_GEN_NG") if split else ("0", "1")   # (the groups of the wavefront
+        nc, ngat = len(f.cols), len(f.gather)                                #  share a family in the one-chain warmup)
+        # A unit's table row and gathered variables are loads the unit's arithmetic waits for, and a
+        # lone wave per SIMD has nothing else to issue meanwhile (radon: 15 slots x ~800 clocks of L2
+        # latency per leapfrog against ~900 vector instructions). Short rows are therefore fetched
+        # for a block of slots at once -- the indices, then the variables, then the arithmetic.
+        B = max(1, min(f.S, PREFETCH_DOUBLES[waves_per_simd] // max(1, nc + ngat)))
+        blocked = B > 1 and (nc + ngat) > 0
+        if blocked:
+            L.append("  for (int jb = 0; %s + jb * %s < %d; jb += %d) {" % (g0, ng, f.S, B))
+            L.append("    int un_[%d];" % B)
+            if nc:
+                L.append("    double c_[%d][%d];" % (B, nc))
+            if ngat:
+                L.append("    int ix_[%d][%d];" % (B, ngat))
+                L.append("    double v_[%d][%d];" % (B, ngat))
+            L.append("    for (int j = 0; j < %d; j++) {" % B)
+            L.append("      const int sl = %s + (jb + j) * %s;" % (g0, ng))
+            L.append("      const int un = sl * %d + l;" % G)
+            L.append("      un_[j] = (sl < %d && un < %d) ? un : -1;" % (f.S, f.n))
+            L.append("      const int uc = un_[j] < 0 ? 0 : un;")
+            for c in range(nc):
+                L.append("      c_[j][%d] = EXMC_GEN_LT(%d + uc * %d + %d);" % (c, f.doff, nc, c))
+            for p in range(ngat):
+                L.append("      ix_[j][%d] = EXMC_GEN_IT(%d + uc);" % (p, f.ioff + p * f.npad))
+            L.append("    }")
+            if ngat:
+                L.append("    for (int j = 0; j < %d; j++) {" % B)
+                for p in range(ngat):
+                    L.append("      v_[j][%d] = EXMC_GEN_SH(ix_[j][%d]);" % (p, p))
+                L.append("    }")
+            L.append("    for (int j = 0; j < %d; j++) {" % B)
+            L.append("    const int un = un_[j];")
+            L.append("    if (un >= 0) {")
+            for p in range(ngat):
+                L.append("    const double v%d = v_[j][%d];" % (p, p))
+            for c in range(nc):
+                L.append("    const double c%d = c_[j][%d];" % (c, c))
         else:
-            L.append("  for (int sl = 0; sl < %d; sl++) {" % f.S)
-        L.append("    const int un = sl * %d + l;" % G)
-        if f.n < f.npad:
-            L.append("    if (un < %d) {" % f.n)
-        for p in range(len(f.gather)):
-            L.append("    const double v%d = EXMC_GEN_SH(EXMC_GEN_IT(%d + un));" % (p, f.ioff + p * f.npad))
-        if f.cols:
-            L.append("    const int row = %d + un * %d;" % (f.doff, len(f.cols)))
-        for c in range(len(f.cols)):
-            L.append("    const double c%d = EXMC_GEN_LT(row + %d);" % (c, c))
+            L.append("  for (int sl = %s; sl < %d; sl += %s) {" % (g0, f.S, ng))
+            L.append("    const int un = sl * %d + l;" % G)
+            if f.n < f.npad:
+                L.append("    if (un < %d) {" % f.n)
+            for p in range(ngat):
+                L.append("    const double v%d = EXMC_GEN_SH(EXMC_GEN_IT(%d + un));" % (p, f.ioff + p * f.npad))
+            if nc:
+                L.append("    const int row = %d + un * %d;" % (f.doff, nc))
+            for c in range(nc):
+                L.append("    const double c%d = EXMC_GEN_LT(row + %d);" % (c, c))
         n_use = {}
         for x in [f.troot] + list(f.ext_adj.values()):
             n_use[x] = n_use.get(x, 0) + 1
@@ -1084,7 +1123,10 @@ def generate(g, term_roots, custom_roots, D, G, waves_per_simd=1):
         for p in range(len(f.gather)):
             if f.strip[p] >= 0:
                 L.append("    EXMC_GEN_SH(%d + un) = %s;" % (f.strip[p], tref(f.gat_adj[p])))
-        if f.n < f.npad:
+        if blocked:
+            L.append("    }")
+            L.append("    }")
+        elif f.n < f.npad:
             L.append("    }")
         L.append("  }")
 

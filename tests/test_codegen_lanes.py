@@ -256,15 +256,17 @@ def test_uniform_part_is_spread_over_the_lanes_too():
     assert "EXMC_GEN_BATCH_LOG(" in text and "EXMC_GEN_BATCH_RCP(" in text and "EXMC_GEN_ALLSUM_W(w)" in text
     loop0 = text[text.index("/* family 0"):text.index("/* family 1")]
     loop1 = text[text.index("/* family 1"):text.index("EXMC_GEN_ALLSUM(s)")]
-    body0 = loop0[loop0.index("for (int sl"):]
-    body1 = loop1[loop1.index("for (int sl"):]
+    body0 = loop0[loop0.index("  for (int "):]
+    body1 = loop1[loop1.index("  for (int "):]
     assert body0.count(" / ") == 2 and body1.count(" / ") == 0       # were 5 and 2
-    assert loop1[:loop1.index("for (int sl")].count("1.0 / ") == 1   # 1 / sigma, once per leapfrog
+    assert loop1[:loop1.index("  for (int ")].count("1.0 / ") == 1   # 1 / sigma, once per leapfrog
+    # short table rows and gathered variables are fetched for a block of slots before the arithmetic
+    assert "for (int jb = 0;" in body0 and "v_[j][0] = EXMC_GEN_SH(ix_[j][0]);" in body0
     # radon: the observation loop divides by the shared noise scale -- no quotient left in it
     rd, _ = _gen("radon")
     t = rd.lane_layout["text"]
     obs = t[t.index("/* family 1"):t.index("EXMC_GEN_ALLSUM(s)")]
-    assert obs[obs.index("for (int sl"):].count(" / ") == 0 and rd.lane_layout["spread_sizes"] == []
+    assert obs[obs.index("  for (int "):].count(" / ") == 0 and rd.lane_layout["spread_sizes"] == []
 
 
 def test_a_spread_sum_does_not_feed_another_one():
@@ -302,7 +304,7 @@ def test_one_chain_form_spreads_the_units_over_the_wavefront(which, lanes):
     slots g, g + 64 / G, ...) and the groups' reduced sums are added in group order: the same
     density and gradient up to the order of the sums (the checker runs both forms of the same text)."""
     gen, hand = _gen(which, lanes)
-    assert "sl += EXMC_GEN_NG" in gen.lane_layout["text"] and "EXMC_GEN_XGROUP(s)" in gen.lane_layout["text"]
+    assert "EXMC_GEN_NG" in gen.lane_layout["text"] and "EXMC_GEN_XGROUP(s)" in gen.lane_layout["text"]
     rng = np.random.default_rng(21)
     differ = 0
     for t in range(25):
