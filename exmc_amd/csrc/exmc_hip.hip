@@ -1090,6 +1090,8 @@ int exmc_hip_model_create(int kind, int d, const double* data, int n_data, int d
       if (!data || n_data < 2 * J + 1 || (n_data - (2 * J + 1)) % 2 != 0) { delete m; return fail(EXMC_ERR_BADARG, "radon needs u[85], start[86], floor[N], y[N]"); }
       const int N = (n_data - (2 * J + 1)) / 2;
       if ((int)data[J] != 0 || (int)data[2 * J] != N) { delete m; return fail(EXMC_ERR_BADARG, "radon county offsets do not cover the observations"); }
+      // the 64-lane layout keeps a lane's observations in registers, 16 slots of 64 (exmc_models.hpp)
+      if (N > 1024) { delete m; return fail(EXMC_ERR_UNSUPPORTED, "the radon kind holds at most 1024 observations"); }
       for (int j = 0; j < J; j++)
         if (data[J + j + 1] < data[J + j]) { delete m; return fail(EXMC_ERR_BADARG, "radon county offsets must be non-decreasing"); }
       m->d = J + 5;
@@ -1158,6 +1160,15 @@ int exmc_hip_model_create(int kind, int d, const double* data, int n_data, int d
         blob[off_yp + n] = data[(size_t)N * K + n];
       }
     }
+    size_t off_cty = 0;
+    if (kind == EXMC_MODEL_RADON) {
+      // the county of every observation, as a double (the 64-lane layout reads it next to y and floor)
+      const int J = 85, N = (n_data - (2 * J + 1)) / 2;
+      off_cty = blob.size();
+      blob.resize(blob.size() + (size_t)N, 0.0);
+      for (int j = 0; j < J; j++)
+        for (int i = (int)data[J + j]; i < (int)data[J + j + 1]; i++) blob[off_cty + i] = (double)j;
+    }
     rc = m->data.ensure(blob.size() * 8);
     if (rc) return bail(rc);
     if (hipMemcpy(m->data.p, blob.data(), blob.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
@@ -1175,6 +1186,7 @@ int exmc_hip_model_create(int kind, int d, const double* data, int n_data, int d
       m->rd.cs = base + J;
       m->rd.fl = base + 2 * J + 1;
       m->rd.y = base + 2 * J + 1 + N;
+      m->rd.cty = base + off_cty;
     }
   }
 #ifdef EXMC_CUSTOM_HEADER

@@ -820,21 +820,26 @@ struct Logistic<4> : ModelDefaults {
 // ------------------------------------------------------------------------------------------
 // hierarchical radon, J = 85 counties (notebooks/09_radon_bhm.livemd "The Radon Model").
 // dims: 0..J-1 alpha_raw_j, J mu_alpha, J+1 gamma_u, J+2 log sigma_alpha, J+3 log sigma_y,
-// J+4 beta. The lane that owns alpha_raw_j walks county j's observations (sorted by county).
-// G = 64: a county's observations are cut into chunks of B = ceil(N / 64). The owner lane walks
-// the first chunk; the chunks after it (only the largest counties have any, at most floor(N / B)
-// <= 64 in total) are numbered county by county and chunk e is walked by lane e as a third work
-// item -- a wave walks at most 3 B observations per leapfrog instead of the largest county
-// (116 of 919 in the bench data). Sums: a chunk from 0.0 in observation
-// order; a county = its chunks in order; the likelihood / floor / z^2 totals = each lane's three
-// work items in order, then the lanes. The CPU checker restates the same rule from the county
-// offsets.
+// J+4 beta; dimension i in slot i / G of lane i % G.
+// G = 64 (the layout that ships): the observations are spread over the lanes whatever their
+// county -- observation i on lane i % 64 in slot i / 64, 15 balanced slots for 919 observations
+// (round 2 walked each county on its owner lane in chunks: 35 lock-step iterations, 43 % of them
+// carrying an observation; round 3's generated radon, which derives this spread from the node
+// list, ran 19 % faster than that kernel). Per leapfrog a lane fetches the y, floor and county of
+// its slots in one batch (held in registers across the kernel they cost more in accumulator-
+// register moves than the loads do), the owner lanes publish their counties' intercepts
+// alpha_j in an LDS strip, every observation reads its county's, and leaves a_i = z_i / sigma_y in
+// a second strip from which the owner lane of a county adds its observations in index order.
+// Sums: the likelihood / floor / z^2 totals = each lane's terms in slot order, then the lanes; a
+// county's sum = its observations in index order from 0.0. The CPU checker restates the same rule.
+// Other G (not dispatched): every county is walked by its owner lane.
 // ------------------------------------------------------------------------------------------
 struct RadonConsts {
   const double* u;      // dev [J]
   const double* cs;     // dev [J+1] county start offsets (as doubles)
   const double* fl;     // dev [N]
   const double* y;      // dev [N]
+  const double* cty;    // dev [N] the county of every observation
   double log2pi32, tiny32;
   double c_mu10;        // log2pi32 + 2*log(10)
   double c_n5;          // log2pi32 + 2*log(5)
@@ -848,65 +853,30 @@ struct Radon : ModelDefaults {
   static constexpr int D = J + 5;
   static constexpr int DPL = (D + G - 1) / G;
   using Consts = RadonConsts;
-  static constexpr int kObsCap = 1024;                 // observations an LDS image can hold
-  static constexpr int kLdsDataDoubles = 2 * kObsCap;  // [floor | y]
-  static constexpr bool kChunks = (G == 64);
+  static constexpr bool kSpread = (G == 64);           // observations over the lanes (see above)
+  static constexpr int kObsCap = 1024;                 // observations the spread layout holds
+  static constexpr int kSlots = kSpread ? kObsCap / 64 : 1;
+  static constexpr int kAlphaOff = kObsCap;            // strip: [a_i (kObsCap)] [alpha_j (J, padded)]
+  static constexpr int kExtraLdsDoubles = kSpread ? kObsCap + 96 : 0;
   struct Lane {
     double u[DPL];
-    int i0[DPL], i1[DPL];   // own counties: the observations this lane walks (kChunks: first chunk)
-    int xi0, xi1, xsrc;     // kChunks: this lane's later chunk [xi0, xi1) and the county it belongs to
-    int xe0[DPL], nx[DPL];  // kChunks: an own county's later chunks sit on lanes xe0 .. xe0 + nx - 1
-    int maxx;               // kChunks: most later chunks of any county
+    int i0[DPL], i1[DPL];   // own counties: their observations [i0, i1)
+    int nobs;
     Recip ten, five, c25;   // prior scales Normal(0, 10), Normal(0, 5), HalfCauchy(2.5)
-    int xoff;               // LDS image of floor / y (offset in doubles), or -1: read from global
+    double* sh;             // kSpread: the wavefront's strips (attach_scratch / lane_setup)
     double kc[6];           // the model's scalar constants as (uniform) vector registers, see SV::Lane::k
   };
   enum { kTiny = 0, kLog2Pi, kHc, kC1, kMu10, kN5 };
-  // cooperative (whole workgroup); the caller synchronises afterwards
-  __device__ static __forceinline__ bool stage_data(const Consts& c, double* dst) {
-    const int N = (int)c.cs[J];
-    if (N >= kObsCap) return false;
-    for (int i = threadIdx.x; i < N; i += blockDim.x) {
-      dst[i] = c.fl[i];
-      dst[kObsCap + i] = c.y[i];
-    }
-    return true;
-  }
   __device__ static __forceinline__ void load(const Consts& c, int l, Lane& ln) {
-    ln.xoff = -1;
-    ln.xi0 = ln.xi1 = ln.xsrc = ln.maxx = 0;
+    ln.sh = nullptr;
+    ln.nobs = (int)c.cs[J];
 #pragma unroll
     for (int k = 0; k < DPL; k++) {
       const int j = l + k * G;
       const bool cty = j < J;
-      ln.xe0[k] = ln.nx[k] = 0;
       ln.u[k] = cty ? c.u[j] : 0.0;
       ln.i0[k] = cty ? (int)c.cs[j] : 0;
       ln.i1[k] = cty ? (int)c.cs[j + 1] : 0;
-    }
-    if constexpr (kChunks) {
-      const int N = (int)c.cs[J];
-      const int B = (N + G - 1) / G;
-      int later = 0;   // later chunks of the counties before j
-      for (int j = 0; j < J; j++) {
-        const int a = (int)c.cs[j], b = (int)c.cs[j + 1];
-        const int nch = (b - a + B - 1) / B;
-        const int nxj = nch > 1 ? nch - 1 : 0;
-#pragma unroll
-        for (int k = 0; k < DPL; k++)
-          if (j == l + k * G) { ln.xe0[k] = later; ln.nx[k] = nxj; }
-        if (l >= later && l < later + nxj) {   // at most floor(N / B) <= 64 later chunks in all
-          const int tt = l - later + 1;
-          ln.xi0 = a + tt * B;
-          ln.xi1 = (a + (tt + 1) * B < b) ? a + (tt + 1) * B : b;
-          ln.xsrc = j;
-        }
-        ln.maxx = nxj > ln.maxx ? nxj : ln.maxx;
-        later += nxj;
-      }
-#pragma unroll
-      for (int k = 0; k < DPL; k++)
-        ln.i1[k] = (ln.i0[k] + B < ln.i1[k]) ? ln.i0[k] + B : ln.i1[k];
     }
     ln.ten = make_recip_literal(10.0);
     ln.five = make_recip_literal(5.0);
@@ -966,72 +936,96 @@ struct Radon : ModelDefaults {
     double s[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // lik, S, S*u, S*alpha_raw, F, Z2 partials
     double T[DPL];
     bool valid[DPL];
-    // observations [i0, i1) against the county intercept alpha, sums from 0.0 in order
-    auto walk = [&](int i0, int i1, double alpha, double& lik, double& sj, double& f, double& z2s) {
-      lik = 0.0; sj = 0.0; f = 0.0; z2s = 0.0;
-      auto obs = [&](double fi, double yi) {
-        const double mean = alpha + beta * fi;
-        const double resid = yi - mean;
-        dv.template watch_exp_if<-250, 250>(true, resid);
-        const double z = dv(resid, rsy);
-        const double a = dv(z, rsy);
-        lik = lik + (-0.5 * (z * z + cn));
-        sj = sj + a;
-        f = f + a * fi;
-        z2s = z2s + (z * z - 1.0);
-      };
-      if (ln.xoff >= 0) {
-        // LDS image, the next observation fetched while this one is used
-        const double* im = exmc_dyn_lds + ln.xoff;
-        int i = i0;
-        double fn = 0.0, yn = 0.0;
-        if (i < i1) { fn = im[i]; yn = im[kObsCap + i]; }
-        for (; i < i1; i++) {
-          const double fi = fn, yi = yn;
-          fn = im[i + 1];            // one past the lane's last observation is still inside the
-          yn = im[kObsCap + i + 1];  // image (N < kObsCap) and never used
-          obs(fi, yi);
-        }
-      } else {
-        for (int i = i0; i < i1; i++) obs(c.fl[i], c.y[i]);
+    // one observation against its county's intercept: -> a = z / sigma_y
+    // (the residuals are watched through the largest and the smallest magnitude a lane has seen:
+    // one check per lane instead of one per observation)
+    double rmax = 1.0, rmin = 1.0;
+    auto obs = [&](double alpha, double fi, double yi, double& lik, double& f, double& z2s) -> double {
+      const double mean = alpha + beta * fi;
+      const double resid = yi - mean;
+      if constexpr (kFast) {
+        const double ar_ = fabs(resid);
+        rmax = fmax(rmax, ar_);
+        rmin = fmin(rmin, ar_);
       }
+      const double z = dv(resid, rsy);
+      const double a = dv(z, rsy);
+      lik = lik + (-0.5 * (z * z + cn));
+      f = f + a * fi;
+      z2s = z2s + (z * z - 1.0);
+      return a;
     };
     double alpha_own[DPL], sj_own[DPL];
 #pragma unroll
     for (int k = 0; k < DPL; k++) {
-      const int j = l + k * G;
-      valid[k] = j < D;
+      valid[k] = (l + k * G) < D;
       alpha_own[k] = (mu + gam * ln.u[k]) + sa * q[k];
-      double lik, f, z2s;
-      walk(ln.i0[k], ln.i1[k], alpha_own[k], lik, sj_own[k], f, z2s);
-      if (kChunks || valid[k]) {
-        s[0] = s[0] + lik;
-        s[4] = s[4] + f;
-        s[5] = s[5] + z2s;
-      }
     }
-    if constexpr (kChunks) {
-      // this lane's later chunk, then the county sums of the counties that have later chunks
-      double alpha_x = 0.0;
+    if constexpr (kSpread) {
+      double* const cell = ln.sh;               // a_i of observation i
+      double* const al = ln.sh + kAlphaOff;     // alpha_j of county j
+#pragma unroll
+      for (int k = 0; k < DPL; k++)
+        if (l + k * G < J) al[l + k * G] = alpha_own[k];
+      wave_lds_fence();
+      // this lane's observations: y, floor and county of all its slots in flight at once (a lone
+      // wave per SIMD has nothing else to issue while a load is out), then the counties' intercepts
+      const int last = ln.nobs - 1;
+      double oy[kSlots], ofl[kSlots], oc[kSlots], av[kSlots];
+#pragma unroll
+      for (int sl = 0; sl < kSlots; sl++) {
+        const int i = sl * 64 + l;
+        const int ic = i < last ? i : last;     // a valid address for an empty slot
+        oy[sl] = c.y[ic];
+        ofl[sl] = c.fl[ic];
+        oc[sl] = c.cty[ic];
+      }
+#pragma unroll
+      for (int sl = 0; sl < kSlots; sl++) av[sl] = al[(int)oc[sl]];
+      double lik = 0.0, f = 0.0, z2s = 0.0;
+      const int nsl = __builtin_amdgcn_readfirstlane((ln.nobs + 63) >> 6);
+#pragma unroll
+      for (int sl = 0; sl < kSlots; sl++) {
+        const int i = sl * 64 + l;
+        if (sl < nsl) {                       // wave-uniform: the empty slots cost nothing
+          if (i < ln.nobs) cell[i] = obs(av[sl], ofl[sl], oy[sl], lik, f, z2s);
+        }
+      }
+      s[0] = lik;
+      s[4] = f;
+      s[5] = z2s;
+      wave_lds_fence();
+      // a county's sum: its cells in index order, four reads in flight at a time
 #pragma unroll
       for (int k = 0; k < DPL; k++) {
-        const double v = __shfl(alpha_own[k], ln.xsrc & 63, 64);
-        alpha_x = ((ln.xsrc >> 6) == k) ? v : alpha_x;
-      }
-      double likx, sjx, fx, z2x;
-      walk(ln.xi0, ln.xi1, alpha_x, likx, sjx, fx, z2x);
-      s[0] = s[0] + likx;
-      s[4] = s[4] + fx;
-      s[5] = s[5] + z2x;
-      const int maxx = __builtin_amdgcn_readfirstlane(ln.maxx);   // the same number on every lane
-      for (int tt = 0; tt < maxx; tt++) {
+        double sj = 0.0;
+        const int i1 = ln.i1[k];
+        for (int i = ln.i0[k]; i < i1; i += 4) {
+          double v[4];
 #pragma unroll
-        for (int k = 0; k < DPL; k++) {
-          const double v = __shfl(sjx, (ln.xe0[k] + tt) & 63, 64);
-          sj_own[k] = (tt < ln.nx[k]) ? (sj_own[k] + v) : sj_own[k];
+          for (int j = 0; j < 4; j++) v[j] = cell[(i + j < i1) ? i + j : i];
+#pragma unroll
+          for (int j = 0; j < 4; j++) sj = (i + j < i1) ? (sj + v[j]) : sj;
+        }
+        sj_own[k] = sj;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < DPL; k++) {
+        double lik = 0.0, f = 0.0, z2s = 0.0, sj = 0.0;
+        for (int i = ln.i0[k]; i < ln.i1[k]; i++) sj = sj + obs(alpha_own[k], c.fl[i], c.y[i], lik, f, z2s);
+        sj_own[k] = sj;
+        if (valid[k]) {
+          s[0] = s[0] + lik;
+          s[4] = s[4] + f;
+          s[5] = s[5] + z2s;
         }
       }
     }
+    // (an infinite residual fails the first watch; a NaN one slips through fmax / fmin -- and makes
+    // the density and the gradient NaN on the short path as on the exact one)
+    dv.template watch_exp_if<-250, 250>(true, rmax);
+    dv.template watch_exp_if<-250, 250>(true, rmin);
 #pragma unroll
     for (int k = 0; k < DPL; k++) {
       const double ar = q[k];

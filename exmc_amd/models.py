@@ -112,11 +112,12 @@ def radon_data(seed=42, n_counties=85, n_obs=919):
 def radon(data=None, sort_counties=True):
     """Hierarchical radon, d = J+5 = 90. Kernel order: the county intercepts alpha_raw_j by
     DESCENDING observation count, then mu_alpha, gamma_u, sigma_alpha, sigma_y, beta (the
-    reference's flat order is the string sort; names carry the original county index). A lane of
-    the 64-lane chain group walks the observations of counties l and l + 64 (with the 21 smallest
-    counties in the second slot), a county larger than ceil(N / 64) observations in chunks spread
-    over the lanes (exmc_models.hpp Radon). sort_counties=False keeps the file order (any order
-    is valid input for the library; the sorted one is the fastest)."""
+    reference's flat order is the string sort; names carry the original county index). In the
+    64-lane layout the observations are spread over the lanes whatever their county (observation i
+    on lane i mod 64) and a county's owner lane adds up its observations' contributions
+    (exmc_models.hpp Radon); at most 1024 observations. sort_counties=False keeps the file order
+    (any order is valid input for the library; with the sorted one the longest owner sums sit in
+    the first dimension slot)."""
     u, start, floor, y = data if data is not None else radon_data()
     J = len(u)
     u, start, floor, y = (np.asarray(u, float), np.asarray(start).astype(int),

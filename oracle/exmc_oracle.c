@@ -577,53 +577,44 @@ static double logp_radon(const exo_model* m, const double* q, double* g, exo_cfg
   double LIK[EXO_MAX_D], S[EXO_MAX_D], SU[EXO_MAX_D], SA[EXO_MAX_D], F[EXO_MAX_D], Z2[EXO_MAX_D];
   double T[EXO_MAX_D];
   for (int j = 0; j < d; j++) LIK[j] = S[j] = SU[j] = SA[j] = F[j] = Z2[j] = T[j] = 0.0;
-  /* 64 lanes per chain: a county's observations are summed in chunks of B = ceil(N / 64)
-   * (each from 0.0 in observation order), a county = its chunks in order. The likelihood, floor
-   * and z^2 totals take every lane's work items in order -- the first chunks of its counties
-   * j = l, l + 64, then the later chunk numbered l (later chunks are numbered county by county)
-   * -- and then the lanes. Other layouts: one chunk per county. */
-  int B = (G == 64) ? (N + 63) / 64 : N + 1;
-  double WL[192], WF[192], WZ[192];   /* work items: [slot * 64 + lane] */
-  for (int w = 0; w < 192; w++) WL[w] = WF[w] = WZ[w] = 0.0;
-  int later = 0;
+  /* 64 lanes per chain (exmc_models.hpp Radon<64>): observation i sits on lane i mod 64 in slot
+   * i / 64 whatever its county, so the likelihood, floor and z^2 totals are each lane's terms in
+   * slot order and then the lanes; a county's sum of a_i = z_i / sigma_y is its observations in
+   * index order from 0.0 (its owner lane adds them up from the wavefront's LDS strip). Other
+   * layouts: the per-county totals over the lanes that own the counties. */
+  double* OL = NULL; double* OF = NULL; double* OZ = NULL;
+  if (G == 64) {
+    OL = (double*)malloc(sizeof(double) * 3 * (size_t)(N > 0 ? N : 1));
+    OF = OL + (N > 0 ? N : 1);
+    OZ = OF + (N > 0 ? N : 1);
+  }
   for (int j = 0; j < J; j++) {
     double ar = q[j];
     double alpha = (mu + gam * u[j]) + sa * ar;
-    double s_county = 0.0, lik_county = 0.0, f_county = 0.0, z2_county = 0.0;
-    int a0 = (int)cs[j], b0 = (int)cs[j + 1];
-    int nch = (b0 - a0 + B - 1) / B;
-    for (int t_ = 0; t_ < (nch > 0 ? nch : 1); t_++) {
-      int i0 = a0 + t_ * B, i1 = (i0 + B < b0) ? i0 + B : b0;
-      double lik = 0.0, s = 0.0, f = 0.0, z2s = 0.0;
-      for (int i = i0; i < i1; i++) {
-        double mean = alpha + beta * fl[i];
-        double z = (y[i] - mean) / ssy;
-        double a = z / ssy;
-        lik = lik + (-0.5 * (z * z + cn));
-        s = s + a;
-        f = f + a * fl[i];
-        z2s = z2s + (z * z - 1.0);
-      }
-      if (t_ == 0) {
-        s_county = s; lik_county = lik; f_county = f; z2_county = z2s;
-        if (G == 64) { WL[j] = lik; WF[j] = f; WZ[j] = z2s; }
-      } else {
-        s_county = s_county + s;
-        WL[128 + later] = lik; WF[128 + later] = f; WZ[128 + later] = z2s;
-        later++;
-      }
+    int i0 = (int)cs[j], i1 = (int)cs[j + 1];
+    double lik = 0.0, s = 0.0, f = 0.0, z2s = 0.0;
+    for (int i = i0; i < i1; i++) {
+      double mean = alpha + beta * fl[i];
+      double z = (y[i] - mean) / ssy;
+      double a = z / ssy;
+      lik = lik + (-0.5 * (z * z + cn));
+      s = s + a;
+      f = f + a * fl[i];
+      z2s = z2s + (z * z - 1.0);
+      if (G == 64) { OL[i] = -0.5 * (z * z + cn); OF[i] = a * fl[i]; OZ[i] = z * z - 1.0; }
     }
-    LIK[j] = lik_county; S[j] = s_county; SU[j] = s_county * u[j]; SA[j] = s_county * ar;
-    F[j] = f_county; Z2[j] = z2_county;
+    LIK[j] = lik; S[j] = s; SU[j] = s * u[j]; SA[j] = s * ar;
+    F[j] = f; Z2[j] = z2s;
     T[j] = -0.5 * (ar * ar + c1);
-    g[j] = (-ar) + s_county * sa;
+    g[j] = (-ar) + s * sa;
   }
-  double lik = (G == 64) ? lane_sum(WL, 192, 64, 0.0) : lane_sum(LIK, d, G, 0.0);
+  double lik = (G == 64) ? lane_sum(OL, N, 64, 0.0) : lane_sum(LIK, d, G, 0.0);
   double ss = lane_sum(S, d, G, 0.0);
   double su = lane_sum(SU, d, G, 0.0);
   double sar = lane_sum(SA, d, G, 0.0);
-  double sf = (G == 64) ? lane_sum(WF, 192, 64, 0.0) : lane_sum(F, d, G, 0.0);
-  double sz2 = (G == 64) ? lane_sum(WZ, 192, 64, 0.0) : lane_sum(Z2, d, G, 0.0);
+  double sf = (G == 64) ? lane_sum(OF, N, 64, 0.0) : lane_sum(F, d, G, 0.0);
+  double sz2 = (G == 64) ? lane_sum(OZ, N, 64, 0.0) : lane_sum(Z2, d, G, 0.0);
+  if (OL) free(OL);
   double zmu = (mu - 0.0) / 10.0, zg = (gam - 0.0) / 5.0, zb = (beta - 0.0) / 5.0;
   T[J] = -0.5 * (zmu * zmu + (LOG_2PI_F32() + 2.0 * log(10.0)));
   T[J + 1] = -0.5 * (zg * zg + (LOG_2PI_F32() + 2.0 * log(5.0)));

@@ -81,8 +81,8 @@ def test_model_logp_grad_bit_exact(hip, name, factory, lane_list):
 
 def _skewed_radon():
     """County sizes like the real radon survey (one county with 116 observations, one with 105,
-    many with 1-3), the large ones LAST in file order: their later chunks and their owner lanes
-    sit in the second dimension slot of the 64-lane layout."""
+    many with 1-3), the large ones LAST in file order: their owner lanes sit in the second dimension
+    slot of the 64-lane layout and add up to 116 cells of the wavefront's strip."""
     rng = np.random.default_rng(17)
     J, N = 85, 919
     sizes = np.concatenate([rng.integers(1, 6, size=J - 6), [14, 25, 46, 52, 105, 116]])
@@ -101,9 +101,10 @@ def _skewed_radon():
 
 @pytest.mark.parametrize("sort_counties", [False, True])
 def test_radon_chunked_counties_bit_exact(hip, sort_counties):
-    """Radon with 64 lanes per chain on survey-like county sizes: counties larger than
-    ceil(N / 64) observations are summed in chunks spread over the lanes; in file order the large
-    counties are owned by the second dimension slot. logp / gradient and whole transitions."""
+    """Radon with 64 lanes per chain on survey-like county sizes: the observations are spread over
+    the lanes whatever their county and a county's owner lane adds its cells in index order (the
+    test keeps its name from the chunked walk of rounds 1-2); in file order the large counties are
+    owned by the second dimension slot. logp / gradient and whole transitions."""
     spec = models.radon(_skewed_radon(), sort_counties=sort_counties)
     comp = sampler.compile(spec)
     om = O.model_for(spec)

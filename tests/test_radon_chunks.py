@@ -1,6 +1,8 @@
-"""CPU: the checker's 64-lane radon order (county observations summed in chunks of ceil(N / 64),
+"""CPU: the checker's 64-lane radon order (observation i on lane i mod 64, the likelihood / floor /
+z^2 totals per lane in slot order and then the lanes; a county's sum in index order --
 exmc_oracle.c logp_radon) against the plain left-to-right order and under a reordering of the
-counties. Sum order changes roundings, never values: everything agrees to ~1e-13 relative."""
+counties. Sum order changes roundings, never values: everything agrees to ~1e-13 relative.
+(The file keeps its name from rounds 1-2, when the 64-lane layout walked counties in chunks.)"""
 import numpy as np
 
 from exmc_amd import models
@@ -26,7 +28,7 @@ def _survey_like(seed=17):
 
 def test_chunked_sums_equal_plain_sums_to_rounding():
     data = _survey_like()
-    assert np.diff(data[1]).max() == 116 and -(-919 // 64) == 15    # 8 chunks for the largest county
+    assert np.diff(data[1]).max() == 116 and -(-919 // 64) == 15    # 15 slots per lane; one county of 116
     for sort_counties in (True, False):
         spec = models.radon(data, sort_counties=sort_counties)
         om = O.model_for(spec)
