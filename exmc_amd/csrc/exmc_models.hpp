@@ -862,6 +862,7 @@ struct Radon : ModelDefaults {
     double u[DPL];
     int i0[DPL], i1[DPL];   // own counties: their observations [i0, i1)
     int nobs;
+    int maxc[DPL];          // kSpread: the largest county of each dimension slot (the same on every lane)
     Recip ten, five, c25;   // prior scales Normal(0, 10), Normal(0, 5), HalfCauchy(2.5)
     double* sh;             // kSpread: the wavefront's strips (attach_scratch / lane_setup)
     double kc[6];           // the model's scalar constants as (uniform) vector registers, see SV::Lane::k
@@ -877,6 +878,15 @@ struct Radon : ModelDefaults {
       ln.u[k] = cty ? c.u[j] : 0.0;
       ln.i0[k] = cty ? (int)c.cs[j] : 0;
       ln.i1[k] = cty ? (int)c.cs[j + 1] : 0;
+      ln.maxc[k] = 0;
+    }
+    if constexpr (kSpread) {
+      for (int j = 0; j < J; j++) {
+        const int nj = (int)c.cs[j + 1] - (int)c.cs[j];
+#pragma unroll
+        for (int k = 0; k < DPL; k++)
+          if (j / G == k) ln.maxc[k] = nj > ln.maxc[k] ? nj : ln.maxc[k];
+      }
     }
     ln.ten = make_recip_literal(10.0);
     ln.five = make_recip_literal(5.0);
@@ -983,11 +993,13 @@ struct Radon : ModelDefaults {
 #pragma unroll
       for (int sl = 0; sl < kSlots; sl++) av[sl] = al[(int)oc[sl]];
       double lik = 0.0, f = 0.0, z2s = 0.0;
-      const int nsl = __builtin_amdgcn_readfirstlane((ln.nobs + 63) >> 6);
+      const int nfull = __builtin_amdgcn_readfirstlane(ln.nobs >> 6);   // slots every lane fills
 #pragma unroll
       for (int sl = 0; sl < kSlots; sl++) {
         const int i = sl * 64 + l;
-        if (sl < nsl) {                       // wave-uniform: the empty slots cost nothing
+        if (sl < nfull) {                     // wave-uniform: no lane mask on the full slots,
+          cell[i] = obs(av[sl], ofl[sl], oy[sl], lik, f, z2s);
+        } else if (sl == nfull) {             // one partly filled slot, and the empty ones cost nothing
           if (i < ln.nobs) cell[i] = obs(av[sl], ofl[sl], oy[sl], lik, f, z2s);
         }
       }
@@ -995,17 +1007,20 @@ struct Radon : ModelDefaults {
       s[4] = f;
       s[5] = z2s;
       wave_lds_fence();
-      // a county's sum: its cells in index order, four reads in flight at a time
+      // a county's sum: its cells in index order, four reads in flight at a time; the loop runs to
+      // the slot's largest county on every lane (a wave-uniform bound: scalar loop control), a lane
+      // past the end of its own county keeps its sum
 #pragma unroll
       for (int k = 0; k < DPL; k++) {
         double sj = 0.0;
-        const int i1 = ln.i1[k];
-        for (int i = ln.i0[k]; i < i1; i += 4) {
+        const int i0 = ln.i0[k], i1 = ln.i1[k];
+        const int nb = __builtin_amdgcn_readfirstlane(ln.maxc[k]);
+        for (int b = 0; b < nb; b += 4) {
           double v[4];
 #pragma unroll
-          for (int j = 0; j < 4; j++) v[j] = cell[(i + j < i1) ? i + j : i];
+          for (int j = 0; j < 4; j++) v[j] = cell[(i0 + b + j < i1) ? i0 + b + j : 0];
 #pragma unroll
-          for (int j = 0; j < 4; j++) sj = (i + j < i1) ? (sj + v[j]) : sj;
+          for (int j = 0; j < 4; j++) sj = (i0 + b + j < i1) ? (sj + v[j]) : sj;
         }
         sj_own[k] = sj;
       }
