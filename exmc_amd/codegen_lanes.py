@@ -30,6 +30,27 @@ and the 500 x 20 logistic regression compile from node lists like every smaller 
   * The uniform part (hyper-priors, everything derived from shared variables, terms that occur
     once) is differentiated as in the one-lane layout, seeded with the reduced adjoints.
 
+What keeps the generated kernels near the hand-written ones (measured there):
+
+  * Families INSIDE the uniform part (_uniform_families): a sum of >= 4 like terms of shared values
+    (the quotients of a Lanczos series) is evaluated one term per lane, value and partials reduced
+    in a butterfly of their own; the tangent of the sum is the chain rule over its inputs.
+  * Batches (ustmts): the chain-scalar exp / log / reciprocals of one dependency level are
+    evaluated together, argument i on lane i, and broadcast back.
+  * Quotients (build_once.quotient): one reciprocal per distinct denominator serves value and
+    adjoint; by a constant it is folded into the tables, by a uniform value it leaves the loop
+    (emit_family hoists what does not change from unit to unit).
+  * Zero factors (_split_by_zero_factors, build_once.make / bounds): units that differ in WHICH of
+    their constant factors are zero form separate families; 0 * x is folded when interval bounds
+    prove x finite (each half of a Bernoulli likelihood evaluates one logarithm).
+  * Fetching ahead (emit_family): short table rows and gathered variables of a block of slots are
+    loaded before the block's arithmetic (a lone wave per SIMD cannot hide the round trips).
+  * One chain on a whole wavefront (EXMC_GEN_G0 / _NG / _XGROUP): for the shared warmup a layout of
+    fewer than 64 lanes per chain spreads the slots of every family over the 64 / G lane groups and
+    adds the groups' sums in group order.
+  * waves_per_simd = 2 (generate): the register cap of two resident waves, with the plug-in's LDS
+    sized so that eight workgroups fit a CU (exmc_models.hpp EXMC_GEN_LDS_*).
+
 Numeric contract: the lane contract of DESIGN.md section 2 -- per lane left to right over its slots,
 then the xor butterfly over the group -- so the sum of a family's terms is NOT the reference's
 left-to-right Nx.sum (nor, for models above 32 nodes, the hash order of an Erlang map, which is not
