@@ -1446,11 +1446,16 @@ int warmup_impl(exmc_hip_model* m, const double* init_q, exmc_hip_opts o, const 
       if (!(start->inv_mass[i] > 0.0)) return fail(EXMC_ERR_BADARG, "warm start needs a positive inverse mass");
   }
   HIP_TRY(hipSetDevice(m->device));
-  const int lanes = resolve_lanes(m, o.lanes_per_chain);
+  int lanes = resolve_lanes(m, o.lanes_per_chain);
   int rc = ensure_state(m, 1);
   if (rc) return rc;
   const char* hw = std::getenv("EXMC_HIP_HOST_WARMUP");
   const bool host_driven = hw && hw[0] == '1';
+#if defined(EXMC_GEN_LANES) && EXMC_GEN_LANES < 64
+  // the host-driven form launches the sampling kernels: a generated layout's one-chain form is not
+  // among them, so it runs in the sampling layout (other bits than the default, the same schedule)
+  if (host_driven && m->kind == EXMC_MODEL_CUSTOM && lanes == 64) lanes = EXMC_GEN_LANES;
+#endif
   rc = launch_init(m, lanes, 1, 0, o.seed, init_q, !host_driven);
   if (rc) return rc;
   if (start && o.num_warmup == 0) {   // sampler.ex:195-196: nothing to tune

@@ -96,7 +96,8 @@ int exmc_hip_device_count(void);
  * (lib/exmc/compiler.ex:46-58): uploads model data, prepares per-model constants.
  * `data`/`n_data` per kind: EIGHT_SCHOOLS y[8],sigma[8]; SIMPLE y[n]; SV r[100];
  * LOGISTIC X[N][20] row-major then y[N]; RADON u[85], county_start[86], floor[N], y[N] with the
- * observations sorted by county. Free variables are in "kernel order" (DESIGN.md section 2). */
+ * observations sorted by county, N <= 1024 (EXMC_ERR_UNSUPPORTED above: the 64-lane layout gives a
+ * lane 16 observation slots). Free variables are in "kernel order" (DESIGN.md section 2). */
 int exmc_hip_model_create(int kind, int d, const double* data, int n_data, int device,
                           exmc_hip_model** out);
 void exmc_hip_model_destroy(exmc_hip_model* m);

@@ -769,3 +769,17 @@ def test_resident_chains_advance_in_pieces_with_migration(hip, monkeypatch):
         assert np.array_equal(out[name][0], out["whole_off"][0]), name
         assert np.array_equal(out[name][1], out["whole_off"][1]) and out[name][2] == out["whole_off"][2], name
     assert out["whole_off"][2] == int(out["whole_off"][1].sum())
+
+
+def test_radon_refuses_more_observations_than_its_lane_layout_holds(hip):
+    """The radon kind's 64-lane layout gives every lane 16 observation slots: 1024 observations are
+    the most it takes, and the library says so instead of walking off its strips."""
+    rng = np.random.default_rng(3)
+    J, N = 85, 1100
+    sizes = np.full(J, N // J)
+    sizes[: N - sizes.sum()] += 1
+    start = np.concatenate([[0], np.cumsum(sizes)])
+    data = (rng.normal(size=J), start, (rng.uniform(size=N) < 0.2).astype(float), rng.normal(size=N))
+    spec = models.radon(data)
+    with pytest.raises(_lib.ExmcHipError, match="1024 observations"):
+        sampler.compile(spec)
