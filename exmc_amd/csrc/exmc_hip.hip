@@ -1446,7 +1446,9 @@ int warmup_impl(exmc_hip_model* m, const double* init_q, exmc_hip_opts o, const 
       if (!(start->inv_mass[i] > 0.0)) return fail(EXMC_ERR_BADARG, "warm start needs a positive inverse mass");
   }
   HIP_TRY(hipSetDevice(m->device));
-  int lanes = resolve_lanes(m, o.lanes_per_chain);
+  // lanes_per_chain = 0: the library's layout for the one-chain warmup (logistic, generated lane
+  // layouts of fewer than 64 lanes: the whole wavefront), not the sampling default
+  int lanes = o.lanes_per_chain > 0 ? o.lanes_per_chain : exmc_hip_model_default_warmup_lanes(m);
   int rc = ensure_state(m, 1);
   if (rc) return rc;
   const char* hw = std::getenv("EXMC_HIP_HOST_WARMUP");
@@ -1617,11 +1619,14 @@ int exmc_hip_sample_warm_host(exmc_hip_model* m, const double* init_q, exmc_hip_
   // exmc_hip_warmup_dense / _model_set_dense_mass belongs to that run's tuning, not to this one
   m->dense_on = false;
   exmc_hip_tuning tun;
+  // one call, one layout: the warmup runs in the layout the draws are sampled in (sample/3 is one
+  // chain from start to end; the shared warmup of sample_chains has a layout of its own)
+  const int lanes = resolve_lanes(m, o.lanes_per_chain);
+  o.lanes_per_chain = lanes;
   // leaves chain 0's state in m->state
   int rc = warm_start ? exmc_hip_warmup_from(m, init_q, o, warm_start, &tun)
                       : exmc_hip_warmup(m, init_q, o, &tun);
   if (rc) return rc;
-  const int lanes = resolve_lanes(m, o.lanes_per_chain);
   rc = upload_tuning(m, tun.inv_mass);
   if (rc) return rc;
   TraceLayout L = trace_layout(o.num_samples, m->d, 1);
@@ -1678,6 +1683,7 @@ int exmc_hip_stream_begin(exmc_hip_model* m, const double* init_q, exmc_hip_opts
   if (check_model(m)) return EXMC_ERR_BADARG;
   m->dense_on = false;   // the diagonal adaptation follows (see exmc_hip_sample_warm_host)
   exmc_hip_tuning tun;
+  o.lanes_per_chain = resolve_lanes(m, o.lanes_per_chain);   // one chain, one layout (as sample/3)
   int rc = exmc_hip_warmup(m, init_q, o, &tun);  // leaves chain 0's state in m->state
   if (rc) return rc;
   rc = upload_tuning(m, tun.inv_mass);

@@ -113,8 +113,10 @@ int exmc_hip_model_set_flat_order(exmc_hip_model* m, const int32_t* perm, int d)
 int exmc_hip_model_dim(const exmc_hip_model* m);
 int exmc_hip_model_default_lanes(const exmc_hip_model* m);
 /* lanes_per_chain that suits the shared one-chain warmup (sampler.ex:1053-1080) when it differs
- * from the sampling layout (logistic: 64). The tuning it returns is layout-independent; chains
- * that continue the warmup chain itself (sample_host, stream) keep one layout for both phases. */
+ * from the sampling layout (logistic: 64; a generated lane layout of fewer than 64 lanes: 64, the
+ * chain's model terms over the whole wavefront). exmc_hip_warmup / _warmup_from with
+ * lanes_per_chain = 0 run in it. The tuning it returns is layout-independent; chains that continue
+ * the warmup chain itself (sample_host, stream) keep one layout for both phases. */
 int exmc_hip_model_default_warmup_lanes(const exmc_hip_model* m);
 /* lanes_per_chain of the layout that carries a dense mass matrix (opts[:dense_mass]) for this
  * model: 1 where a whole chain fits one lane (eight_schools -- 16 also works --, simple, generated
