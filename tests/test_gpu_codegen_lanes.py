@@ -199,3 +199,24 @@ def test_one_chain_warmup_form_bit_exact(which, hip):
         t, _ = O.sample_tuned(om, tuning["epsilon"], tuning["inv_mass"], q0, num_samples=40, seed=23 + 7919 * c,
                               cfg=O.Cfg(1, lanes))
         assert np.array_equal(t["draws"], extra["raw"]["draws"][c]), c
+
+
+def test_one_chain_warmup_form_at_32_lanes_bit_exact(hip):
+    """The same with two lane groups per wavefront: sv compiled at 32 lanes per chain (four
+    dimensions per lane) warms up on the whole wavefront by default and equals the checker's
+    wave-split form; the tuning then drives chains in the 32-lane sampling layout."""
+    ir, ncp, hand, _ = GM.baseline_pair("sv")
+    spec = cg.compile_ir(ir, ncp=ncp, name="gen_sv_32", default_init=hand.default_init, lanes=32)
+    comp = sampler.compile(spec)
+    assert comp.default_lanes == 32 and comp.default_warmup_lanes == 64
+    om, oms = GC.model(spec.gen, 32), GC.model(spec.gen, 32, wave_split=True)
+    opts = dict(num_warmup=80, num_samples=20, seed=31)
+    tuning = sampler.warmup(comp, spec.default_init, opts)
+    q0 = spec.to_unconstrained(spec.default_init)
+    st = O.warmup(oms, q0, num_warmup=80, seed=31, cfg=O.Cfg(1, 32))
+    assert tuning["epsilon"] == st.step_size
+    assert np.array_equal(tuning["inv_mass"], np.array(st.inv_mass[:spec.d]))
+    _, _, extra = sampler.sample_compiled_tuned(comp, tuning, spec.default_init, opts, num_chains=5)
+    t, _ = O.sample_tuned(om, tuning["epsilon"], tuning["inv_mass"], q0, num_samples=20, seed=31 + 7919 * 4,
+                          cfg=O.Cfg(1, 32))
+    assert np.array_equal(t["draws"], extra["raw"]["draws"][4])
