@@ -315,3 +315,43 @@ def test_one_chain_form_spreads_the_units_over_the_wavefront(which, lanes):
         assert np.all(np.abs(ga - gb) <= 1e-11 * np.maximum(1.0, np.abs(ga))), t
         differ += int(a != b or not np.array_equal(ga, gb))
     assert differ > 0          # a different order of the sums: a layout of its own for the checker
+
+
+def test_zero_factor_is_folded_only_when_the_other_factor_is_provably_finite():
+    """y * log p + (1 - y) * log(1 - p) with an UNCLIPPED p = sigmoid(eta): log p can be -inf, and the
+    reference's 0 * -inf is NaN. The observations are still split by their zero factors, but nothing is
+    folded -- both logarithms stay in both halves -- and at an extreme position the lane layout gives
+    the NaN the one-lane layout gives. With the probability clipped (Bernoulli's own logpdf) the fold
+    happens (test_structure_found_in_the_graphs)."""
+    rng = np.random.default_rng(9)
+    n = 12
+    x = rng.normal(size=n)
+    y = (rng.uniform(size=n) < 0.5).astype(float)
+    y[:4] = 1.0
+    y[4:8] = 0.0
+    ir = cg.IR()
+    ir.rv("a", "normal", dict(mu=0.0, sigma=2.0))
+    ir.rv("b", "normal", dict(mu=0.0, sigma=2.0))
+
+    def lik(o, _x, p):
+        terms = []
+        for i in range(n):
+            pr = o.sigmoid(o.add(p["a"], o.mul(p["b"], o.data(x[i]))))
+            terms.append(o.add(o.mul(o.data(y[i]), o.log(pr)),
+                               o.mul(o.data(1.0 - y[i]), o.log(o.sub(o.lit(1.0), pr)))))
+        return o.sum(terms)
+    ir.rv("lik", "custom", dict(logpdf=lik, a="a", b="b"))
+    ir.obs("lik_obs", "lik", 0.0)
+    gen = cg.generate(ir, lanes=16)
+    lay = gen.lane_layout
+    assert len(lay["family_sizes"]) == 2 and sum(lay["family_sizes"]) == n      # split by which factor is zero ...
+    text = lay["text"]
+    halves = (text[text.index("/* family 0"):text.index("/* family 1")],
+              text[text.index("/* family 1"):text.index("EXMC_GEN_ALLSUM(s)")])
+    assert all(h.count("EXMC_GENL_LOG(") == 2 for h in halves)                  # ... nothing folded
+    for q in (np.array([0.3, -0.7]), np.array([800.0, 0.0]), np.array([-800.0, 0.0])):
+        a, ga = GC.logp_grad(gen, q, lanes=1)
+        b, gb = GC.logp_grad(gen, q, lanes=16)
+        assert (np.isnan(a) and np.isnan(b)) or abs(a - b) <= 1e-12 * max(1.0, abs(a)), (q, a, b)
+        assert np.array_equal(np.isnan(ga), np.isnan(gb)), (q, ga, gb)
+    assert np.isnan(GC.logp_grad(gen, np.array([800.0, 0.0]), lanes=16)[0])
