@@ -37,11 +37,10 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def synthetic_sv_returns(seed=42, T=100, sigma=0.15, nu=10.0):
-    """returns simulated with sigma*=0.15, nu*=10 (STANDARD_BENCHMARKS.md:79)."""
-    rng = np.random.default_rng(seed)
-    s = np.cumsum(rng.normal(0, sigma, T))
-    return (np.exp(s) * rng.standard_t(nu, T)).tolist()
+def synthetic_sv_returns():
+    """returns simulated with sigma*=0.15, nu*=10 (STANDARD_BENCHMARKS.md:79) -- the
+    committed series (exmc_amd/data/workloads.npz, digest-pinned), not a fresh draw."""
+    return models.sv_returns()
 
 
 def make_spec(name):
@@ -127,13 +126,17 @@ def issue_roofline(model, chains, steps, lanes, kernel_ms, leapfrogs):
     every = valu + sq["SQ_INSTS_SALU"] + sq["SQ_INSTS_BRANCH"] + sq["SQ_INSTS_LDS"]
     peak = SIMDS * CLOCK_HZ / 4.0 / 1e9
     lone = SIMDS * CLOCK_HZ / 5.2 / 1e9
-    return {"bound": "valu_issue", "achieved": valu / t / 1e9, "peak": peak, "unit": "G wave-instr/s",
-            "frac": valu / t / 1e9 / peak, "kernel": "nuts_kernel",
-            "valu_per_leapfrog": valu / leapfrogs, "f64_arith_share_of_valu": f64 / valu,
-            "instructions_per_leapfrog": every / leapfrogs,
-            "lone_wave_issue": {"achieved": every / t / 1e9, "peak": lone, "frac": every / t / 1e9 / lone,
-                                "note": "all instructions against one issue per 5.2 clocks per SIMD"},
-            "source": e.get("source")}
+    out = {"bound": "valu_issue", "achieved": valu / t / 1e9, "peak": peak, "unit": "G wave-instr/s",
+           "frac": valu / t / 1e9 / peak, "kernel": "nuts_kernel",
+           "valu_per_leapfrog": valu / leapfrogs, "f64_arith_share_of_valu": f64 / valu,
+           "instructions_per_leapfrog": every / leapfrogs,
+           "source": e.get("source")}
+    if chains * lanes <= SIMDS * 64:
+        # the bound of a LONE wave per SIMD; a launch with two waves per SIMD (sv, logistic) issues
+        # past it by design, so the figure is only emitted where it applies
+        out["lone_wave_issue"] = {"achieved": every / t / 1e9, "peak": lone, "frac": every / t / 1e9 / lone,
+                                  "note": "all instructions against one issue per 5.2 clocks per SIMD"}
+    return out
 
 
 def multi_step_roofline(comp, spec, dev, n_chains=262144, n_steps=32, lanes=1, reps=3):
@@ -174,6 +177,144 @@ def multi_step_roofline(comp, spec, dev, n_chains=262144, n_steps=32, lanes=1, r
             "kernel_ms": best, "chains": n_chains, "steps": n_steps, "lanes_per_chain": lanes,
             "leapfrog_steps_per_s": n_chains * n_steps / (best * 1e-3),
             "bytes_per_launch": nbytes}
+
+
+RHAT_ROUTE_TOL = 1e-9
+
+
+def finish_model(*, model, d, K, W, B, adapt, Cper, world, rank, dist, draws, ess, leap_local, div_local,
+                 elapsed_local, kernel_ms, adapt_s, ess_s, ess_ms, epsilon, lanes, warm_lanes,
+                 bytes_per_leapfrog, gather_traces, rhat_fn, dense_mass=False, sync=lambda: None,
+                 traffic=None):
+    """Everything after the timed launch, on whatever device the tensors live (the GPUs of the ranks;
+    CPU tensors over gloo in tests/test_bench_multirank_gloo.py): the max / sum reductions of the
+    ranks' clocks and counters, the ESS sums, both gather routes (the finished [S][d][C] traces;
+    the per-chain half-chain statistics), split R-hat (diagnostics.ex:80-115) by both and the bench
+    line. Every rank makes the same collective calls; returns (line on rank 0 / None, routes_agree).
+
+      draws   [S][d][Cper] this rank's finished trace      ess  [d][Cper] per-chain ESS of it
+      rhat_fn [S][d][C] -> [d] split R-hat of a whole trace (the library's rhat_kernel on the GPU)
+
+    R-hat is computed twice on independent code paths -- rhat_fn on the traces (this rank's shard
+    always; the gathered whole when gather_traces), torch on the gathered half-chain statistics --
+    and the two must agree to RHAT_ROUTE_TOL, else the caller exits non-zero: BENCH_r03.json carried
+    6.58 and 1.19 for one launch and nothing noticed."""
+    S = K * B
+    Ctot = Cper * world
+    dev = draws.device
+    stats = torch.tensor([elapsed_local, float(leap_local), float(div_local)], dtype=torch.float64, device=dev)
+    if dist is not None:
+        mx = stats.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = stats.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        elapsed, leapfrogs, divs = float(mx[0]), float(sm[1]), float(sm[2])
+    else:
+        elapsed, leapfrogs, divs = float(elapsed_local), float(leap_local), float(div_local)
+
+    ess_sum = ess.sum(dim=1)
+    # the sufficient-statistics route is always timed (it is what R-hat needs); sv also runs the
+    # trace all-gather BASELINE.json's config names, and that is the one its ESS/s wall clock counts
+    hm, hv, hn = xd.half_chain_stats(draws)
+    # this rank's shard by both routes: the statistics this rank contributes are checked against
+    # the library's kernel before they travel
+    rhat_local_lib = rhat_fn(draws)
+    rhat_local_stats = xd.split_rhat_from_stats(hm, hv, hn)
+    local_gap = float((rhat_local_lib - rhat_local_stats).abs().max())
+    sync()
+    t0 = time.perf_counter()
+    xd.reduce_sum(ess_sum, dist)
+    gather_stats_s = gather_traces_s = None
+    rhat_traces = None
+    if gather_traces:
+        all_draws = xd.gather_traces(draws, dist)
+        sync()
+        gather_s = gather_traces_s = time.perf_counter() - t0
+        rhat_traces = rhat_local_lib if all_draws is draws else rhat_fn(all_draws)
+        del all_draws
+        t1 = time.perf_counter()
+        ghm, ghv = xd.gather_chain_stats(hm, dist), xd.gather_chain_stats(hv, dist)
+        sync()
+        gather_stats_s = time.perf_counter() - t1
+    else:
+        # the exchange: per-chain sufficient statistics of the finished traces (SURVEY 8e) give
+        # the same split R-hat with ~1 MB per rank on the wire instead of the [S][d][C] draws
+        ghm, ghv = xd.gather_chain_stats(hm, dist), xd.gather_chain_stats(hv, dist)
+        sync()
+        gather_s = gather_stats_s = time.perf_counter() - t0
+        if world == 1:
+            rhat_traces = rhat_local_lib     # one rank holds every chain
+    rhat_stats = xd.split_rhat_from_stats(ghm, ghv, hn)
+    rhat = rhat_traces if rhat_traces is not None else rhat_stats
+    gap = torch.tensor([local_gap, float((rhat - rhat_stats).abs().max())], dtype=torch.float64, device=dev)
+    gap = torch.nan_to_num(gap, nan=float("inf"))
+    xd.reduce_max(gap, dist)
+    ok = bool(float(gap.max()) <= RHAT_ROUTE_TOL)
+    if not ok:
+        log("%s rank %d: split R-hat routes disagree: shard |lib - stats| %.3e, whole |%s - stats| %.3e\n"
+            "  lib   %s\n  stats %s" % (model, rank, float(gap[0]), "traces" if rhat_traces is not None else "stats",
+                                       float(gap[1]), rhat.tolist(), rhat_stats.tolist()))
+        # read the finished trace once more by both routes: values that change between two reads of
+        # the same buffer are a read (or reduction) fault, values that stay are in the data
+        again_lib = rhat_fn(draws)
+        hm2, hv2, _ = xd.half_chain_stats(draws)
+        again_stats = xd.split_rhat_from_stats(hm2, hv2, hn)
+        log("  second evaluation of this rank's shard: lib moved %.3e, stats moved %.3e, |lib - stats| %.3e"
+            % (float((again_lib - rhat_local_lib).abs().max()), float((again_stats - rhat_local_stats).abs().max()),
+               float((again_lib - again_stats).abs().max())))
+    ess_min = float(ess_sum.min())
+    total_s = adapt_s + elapsed + ess_s + gather_s
+    value = leapfrogs / elapsed
+    if rank != 0:
+        return None, ok
+    local_lf = float(leap_local)
+    achieved = bytes_per_leapfrog * local_lf / (kernel_ms * 1e-3) / 1e9
+    out = {
+        "metric": "leapfrog_steps_per_s",
+        "value": value,
+        "unit": "leapfrog_steps/s",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": W,
+        "ms_per_step": elapsed * 1e3 / K,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "%s d=%d, %d chains/GPU (%d total), %d draws/chain (%d steps of %d "
+                               "draws) after one shared %d-iteration warmup, max_tree_depth 10, "
+                               "target_accept 0.8%s"
+                               % (model, d, Cper, Ctot, S, K, B, adapt,
+                                  ", dense mass matrix" if dense_mass else ""),
+                   "draws_per_step": B, "draws_per_chain": S,
+                   "lanes_per_chain": lanes, "warmup_lanes_per_chain": warm_lanes, "seed": 42},
+        "ess_per_s": ess_min / total_s,
+        "ess_min_total": ess_min,
+        "ess_wall_s": {"adaptation": adapt_s, "sampling": elapsed, "ess_kernel": ess_s,
+                       "gather": gather_s},
+        "gather": {"counted": "traces" if gather_traces else "chain_stats",
+                   "traces_s": gather_traces_s, "chain_stats_s": gather_stats_s,
+                   "bytes_per_rank": int(draws.numel() * 8) if gather_traces else int(2 * hm.numel() * 8)},
+        # split R-hat of ALL chains: the library's rhat_kernel on the whole trace where one place
+        # holds it (one rank, or the gathered traces), else the gathered half-chain statistics
+        "rhat_max": float(rhat.max()),
+        "rhat_route": "rhat_kernel(traces)" if rhat_traces is not None else "chain_stats",
+        "rhat_max_from_chain_stats": float(rhat_stats.max()),
+        "rhat_routes_agree": ok,
+        "rhat_routes_max_gap": float(gap.max()),
+        "divergent_transitions": divs,
+        "mean_leapfrogs_per_draw": leapfrogs / (S * Ctot),
+        "step_size": epsilon,
+        "ess_kernel_ms": ess_ms,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": traffic,
+                     "kernel": "nuts_kernel", "launches": 1, "kernel_ms": kernel_ms,
+                     "algorithmic_bytes_per_leapfrog": bytes_per_leapfrog,
+                     "leapfrogs_per_launch": local_lf},
+    }
+    return out, ok
 
 
 def spawn_ranks(n):
@@ -295,12 +436,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    out = run_model(args, args.model, rank, local_rank, world, dev, dist, barrier, primary=True)
+    out, ok = run_model(args, args.model, rank, local_rank, world, dev, dist, barrier, primary=True)
     if args.model == "eight_schools" and not args.no_sv_leg and not args.dense_mass:
         # BASELINE.json's metric names two models: the line the driver records carries the sv(d=102)
         # leg too -- 2048 chains per GPU (16384 over 8), the same 1000-draw protocol, the finished
         # traces all-gathered over RCCL as the config says, its CPU leg on a smaller sample
-        sv = run_model(args, "sv", rank, local_rank, world, dev, dist, barrier, primary=False)
+        sv, ok_sv = run_model(args, "sv", rank, local_rank, world, dev, dist, barrier, primary=False)
+        ok = ok and ok_sv
         if rank == 0:
             out["models"] = {"sv": sv}
     if rank == 0:
@@ -308,10 +450,16 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if not ok:
+        # the line above is printed for the record, but a run whose two R-hat routes disagree is not
+        # a measurement (finish_model): every rank leaves with the same non-zero code
+        log("bench.py: split R-hat routes disagree by more than %.0e -- failing the run" % RHAT_ROUTE_TOL)
+        raise SystemExit(3)
 
 
 def run_model(args, model, rank, local_rank, world, dev, dist, barrier, primary):
-    """One model through the protocol; returns the result object on rank 0 (None elsewhere)."""
+    """One model through the protocol; returns (the result object on rank 0 / None elsewhere,
+    whether the two split R-hat routes agreed -- the same flag on every rank)."""
     spec, bytes_per_leapfrog = make_spec(model)
     gather_traces = args.gather_traces or model in ("sv", "gen_sv")
     K, W, d = args.steps, args.warmup, spec.d
@@ -375,15 +523,6 @@ def run_model(args, model, rank, local_rank, world, dev, dist, barrier, primary)
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = comp.last_kernel_ms                   # HIP events on the library's stream
-    stats = torch.tensor([elapsed, float(leap_local), float(div_local)], dtype=torch.float64, device=dev)
-    if dist is not None:
-        mx = stats.clone()
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        sm = stats.clone()
-        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-        elapsed, leapfrogs, divs = float(mx[0]), float(sm[1]), float(sm[2])
-    else:
-        leapfrogs, divs = float(leap_local), float(div_local)
 
     # --- diagnostics: per-chain Geyer ESS on device, summed over chains; RCCL all-gather of the
     # finished traces for split R-hat (the only collective on the path) ---
@@ -393,86 +532,28 @@ def run_model(args, model, rank, local_rank, world, dev, dist, barrier, primary)
     comp.check(L.exmc_hip_ess(comp.h, draws.data_ptr(), S, d, Cper, ess.data_ptr()))
     ess_s = time.perf_counter() - t0      # the call returns when the kernel has finished
     ess_ms = comp.last_kernel_ms
-    ess_sum = ess.sum(dim=1)
-    # the sufficient-statistics route is always timed (it is what R-hat needs); sv also runs the
-    # trace all-gather BASELINE.json's config names, and that is the one its ESS/s wall clock counts
-    hm, hv, hn = xd.half_chain_stats(draws)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    xd.reduce_sum(ess_sum, dist)
-    gather_stats_s = gather_traces_s = None
-    if gather_traces:
-        all_draws = xd.gather_traces(draws, dist)
-        torch.cuda.synchronize()
-        gather_s = gather_traces_s = time.perf_counter() - t0
-        rhat = xd.split_rhat(all_draws)
-        del all_draws
-        t1 = time.perf_counter()
-        ghm, ghv = xd.gather_chain_stats(hm, dist), xd.gather_chain_stats(hv, dist)
-        torch.cuda.synchronize()
-        gather_stats_s = time.perf_counter() - t1
-        rhat_stats = xd.split_rhat_from_stats(ghm, ghv, hn)
-    else:
-        # the exchange: per-chain sufficient statistics of the finished traces give
-        # the same split R-hat with ~1 MB per rank on the wire instead of the [S][d][C] draws
-        hm, hv = xd.gather_chain_stats(hm, dist), xd.gather_chain_stats(hv, dist)
-        torch.cuda.synchronize()
-        gather_s = gather_stats_s = time.perf_counter() - t0
-        rhat = xd.split_rhat_from_stats(hm, hv, hn)
-        if world == 1:
-            # one GPU holds every chain: Diagnostics.rhat in the reference's summation order on
-            # the device (bit-identical to the checker, tests/test_gpu_diagnostics.py)
-            rk = torch.empty((d,), dtype=torch.float64, device=dev)
-            comp.check(L.exmc_hip_rhat(comp.h, draws.data_ptr(), S, d, Cper, rk.data_ptr()))
-            rhat = rk
-    ess_min = float(ess_sum.min())
-    total_s = adapt_s + elapsed + ess_s + gather_s
-    value = leapfrogs / elapsed
 
+    def rhat_lib(x):
+        """Diagnostics.rhat (diagnostics.ex:80-115) of a [S][d][C] device trace by the library's own
+        rhat_kernel -- the reference's summation order, bit-identical to the checker
+        (tests/test_gpu_diagnostics.py). The library launches on its own stream: whatever torch has
+        queued for x (the all-gather, the permute copy) must have finished first."""
+        x = x.contiguous()
+        rk = torch.empty((x.shape[1],), dtype=torch.float64, device=x.device)
+        torch.cuda.synchronize()
+        comp.check(L.exmc_hip_rhat(comp.h, x.data_ptr(), x.shape[0], x.shape[1], x.shape[2], rk.data_ptr()))
+        return rk
+
+    out, ok = finish_model(model=model, d=d, K=K, W=W, B=B, adapt=args.adapt, Cper=Cper, world=world,
+                           rank=rank, dist=dist, draws=draws, ess=ess, leap_local=leap_local,
+                           div_local=div_local, elapsed_local=elapsed, kernel_ms=kernel_ms,
+                           adapt_s=adapt_s, ess_s=ess_s, ess_ms=ess_ms, epsilon=tuning["epsilon"],
+                           lanes=lanes, warm_lanes=warm_lanes, bytes_per_leapfrog=bytes_per_leapfrog,
+                           gather_traces=gather_traces, rhat_fn=rhat_lib, dense_mass=args.dense_mass,
+                           sync=torch.cuda.synchronize,
+                           traffic=measured_traffic(model, Cper, S, lanes))
     if rank == 0:
-        local_lf = float(leap_local)
-        achieved = bytes_per_leapfrog * local_lf / (kernel_ms * 1e-3) / 1e9
-        out = {
-            "metric": "leapfrog_steps_per_s",
-            "value": value,
-            "unit": "leapfrog_steps/s",
-            "n_gpus": world,
-            "steps": K,
-            "warmup": W,
-            "ms_per_step": elapsed * 1e3 / K,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": "%s d=%d, %d chains/GPU (%d total), %d draws/chain (%d steps of %d "
-                                   "draws) after one shared %d-iteration warmup, max_tree_depth 10, "
-                                   "target_accept 0.8%s"
-                                   % (model, d, Cper, Ctot, S, K, B, args.adapt,
-                                      ", dense mass matrix" if args.dense_mass else ""),
-                       "draws_per_step": B, "draws_per_chain": S,
-                       "lanes_per_chain": lanes, "warmup_lanes_per_chain": warm_lanes, "seed": 42},
-            "ess_per_s": ess_min / total_s,
-            "ess_min_total": ess_min,
-            "ess_wall_s": {"adaptation": adapt_s, "sampling": elapsed, "ess_kernel": ess_s,
-                           "gather": gather_s},
-            "gather": {"counted": "traces" if gather_traces else "chain_stats",
-                       "traces_s": gather_traces_s, "chain_stats_s": gather_stats_s,
-                       "bytes_per_rank": int(draws.numel() * 8) if gather_traces else int(2 * hm.numel() * 8 / world)},
-            "rhat_max": float(rhat.max()),
-            "divergent_transitions": divs,
-            "mean_leapfrogs_per_draw": leapfrogs / (S * Ctot),
-            "step_size": tuning["epsilon"],
-            "ess_kernel_ms": ess_ms,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(model, Cper, S, lanes),
-                         "kernel": "nuts_kernel", "launches": 1, "kernel_ms": kernel_ms,
-                         "algorithmic_bytes_per_leapfrog": bytes_per_leapfrog,
-                         "leapfrogs_per_launch": local_lf},
-        }
-        if gather_traces:
-            out["rhat_max_from_chain_stats"] = float(rhat_stats.max())
+        value, local_lf = out["value"], float(leap_local)
         ri = issue_roofline(model, Cper, S, lanes, kernel_ms, local_lf) if world == 1 else None
         if ri:
             out["roofline_issue"] = ri
@@ -487,9 +568,9 @@ def run_model(args, model, rank, local_rank, world, dev, dist, barrier, primary)
             out["gpu_over_cpu"] = {"leapfrog_steps_per_s": value / cb["value"],
                                    "ess_per_s": out["ess_per_s"] / cb["ess_per_s"]}
         comp.close()
-        return out
+        return out, ok
     comp.close()
-    return None
+    return None, ok
 
 
 if __name__ == "__main__":

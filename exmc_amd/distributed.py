@@ -115,7 +115,8 @@ def split_rhat(draws):
 def run_shard(engine, spec, num_chains, opts, device, rank, world):
     """What one rank does (also the body bench.py's ranks follow): compile on `device`, the
     shared warmup (every rank with the same seed: identical tuning, no broadcast), then chains
-    [lo, hi) of num_chains with seeds seed + 7919 * i. Returns the rank's host traces."""
+    [lo, hi) of num_chains with seeds seed + 7919 * i. Returns the rank's traces: host arrays
+    [C][S][...], or with opts["raw_on_device"] the device buffers themselves ([S][...][C] tensors)."""
     o = dict(opts or {})
     o["device"] = device
     lo, hi = shard_range(num_chains, rank, world)
@@ -139,62 +140,96 @@ def run_shard(engine, spec, num_chains, opts, device, rank, world):
 _TRACE_KEYS = ("draws", "logp", "tree_depth", "n_steps", "divergent", "accept_prob", "energy")
 
 
-def _gather_shards(local, cmax, dist, device):
-    """All-gather every rank's raw trace arrays ([C_local][S][...], padded to cmax chains) over the
-    process group -- RCCL between GPUs, gloo otherwise -- and return them stacked [world][cmax]...;
-    no file is written and nothing passes through the parent."""
+def _gather_shards_to_root(local, cmax, dist, device, rank, world, counts):
+    """Collect every rank's trace arrays on rank 0, one key at a time: `local[k]` is this rank's
+    block in the device layout the kernels write -- torch tensors [S][...][C_local] on `device`, straight
+    from the sampler's buffers (no host round trip before the collective) -- padded to cmax chains,
+    gathered to rank 0 over the process group (RCCL between GPUs; gloo moves host copies), and turned
+    into the host layout [C_total][S][...] there, rank block by rank block. Only rank 0 ever holds more
+    than its own shard, and on the device never more than world x ONE key at a time; the other ranks
+    get None."""
     import torch
-    out = {}
+    out = {} if rank == 0 else None
+    use_host = dist.get_backend() == "gloo"
     for k in _TRACE_KEYS:
         a = local[k]
-        pad = np.zeros((cmax,) + a.shape[1:], dtype=a.dtype)
-        pad[:a.shape[0]] = a
-        src = torch.from_numpy(pad).to(device)
-        parts = [torch.empty_like(src) for _ in range(dist.get_world_size())]
-        dist.all_gather(parts, src)
-        out[k] = torch.stack(parts, dim=0).cpu().numpy()
+        if a.shape[-1] != cmax:
+            pad = torch.zeros(a.shape[:-1] + (cmax,), dtype=a.dtype, device=a.device)
+            pad[..., :a.shape[-1]] = a
+            a = pad
+        src = (a.cpu() if use_host else a).contiguous()
+        parts = [torch.empty_like(src) for _ in range(world)] if rank == 0 else None
+        dist.gather(src, gather_list=parts, dst=0)
+        if rank == 0:
+            blocks = []
+            for r in range(world):
+                h = parts[r][..., :counts[r]].cpu().numpy()          # [S][...][C_r]
+                blocks.append(np.ascontiguousarray(np.moveaxis(h, -1, 0)))   # [C_r][S][...]
+                parts[r] = None                                      # free the device block as we go
+            out[k] = np.concatenate(blocks, axis=0)
+        del src, parts
     return out
 
 
-def _shard_worker(rank, world, engine_name, spec, num_chains, opts, devices, port, backend, queue):
+def _device_layout(raw, device):
+    """Host arrays [C][S][...] (an engine without device buffers: the CPU checker) as tensors in the
+    device layout [S][...][C]."""
+    import torch
+    return {k: torch.from_numpy(np.ascontiguousarray(np.moveaxis(np.asarray(raw[k]), 0, -1))).to(device)
+            for k in _TRACE_KEYS}
+
+
+def _shard_worker(rank, world, engine_name, spec, num_chains, opts, devices, port, backend, queue, received):
     import importlib
 
     import torch
     import torch.distributed as dist
     engine = importlib.import_module(engine_name)
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # the parent holds the rendezvous store on a port it bound itself and still owns
+    store = dist.TCPStore("127.0.0.1", port, world, is_master=False)
     device = torch.device("cpu")
-    if backend == "nccl":
+    on_gpu = engine_name == "exmc_amd.sampler"
+    if on_gpu:
         torch.cuda.set_device(devices[rank])
         device = torch.device("cuda", devices[rank])
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    if backend == "nccl":
+        dist.init_process_group("nccl", store=store, rank=rank, world_size=world, device_id=device)
     else:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.init_process_group("gloo", store=store, rank=rank, world_size=world)
     try:
-        res = run_shard(engine, spec, num_chains, opts, devices[rank], rank, world)
+        o = dict(opts or {})
+        o["device"] = devices[rank]
+        o["raw_on_device"] = on_gpu        # the sampler leaves the finished trace in HBM ([S][...][C])
+        res = run_shard(engine, spec, num_chains, o, devices[rank], rank, world)
         S = int(engine._merge_opts(opts)["num_samples"])
-        cmax = max(shard_range(num_chains, r, world)[1] - shard_range(num_chains, r, world)[0] for r in range(world))
+        counts = [shard_range(num_chains, r, world)[1] - shard_range(num_chains, r, world)[0] for r in range(world)]
+        cmax = max(counts)
         local = res["raw"]
         if local is None:           # an empty shard still takes part in the collective
             local = dict(draws=np.zeros((0, S, spec.d)), logp=np.zeros((0, S)), tree_depth=np.zeros((0, S), np.int32),
                          n_steps=np.zeros((0, S), np.int32), divergent=np.zeros((0, S), np.int32),
                          accept_prob=np.zeros((0, S)), energy=np.zeros((0, S)))
-        allraw = _gather_shards({k: np.ascontiguousarray(local[k]) for k in _TRACE_KEYS}, cmax, dist, device)
+        if not isinstance(local["draws"], torch.Tensor):
+            local = _device_layout(local, device)
+        allraw = _gather_shards_to_root(local, cmax, dist, device, rank, world, counts)
         # the shared tuning, cross-checked where it was computed: every rank must have derived the same
         tun = np.concatenate([[res["epsilon"]], res["inv_mass"].ravel(),
                               np.asarray(res.get("cov", np.zeros(0)), dtype=np.float64).ravel(),
                               np.asarray(res.get("chol_cov", np.zeros(0)), dtype=np.float64).ravel()])
-        t = torch.from_numpy(tun).to(device)
+        t = torch.from_numpy(tun).to(device if backend == "nccl" else "cpu")
         parts = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(parts, t)
         same = all(torch.equal(parts[0], p_) for p_ in parts)
-        lf = torch.tensor([float(res["leapfrogs"])], dtype=torch.float64, device=device)
+        lf = torch.tensor([float(res["leapfrogs"])], dtype=torch.float64, device=t.device)
         dist.all_reduce(lf, op=dist.ReduceOp.SUM)
         if rank == 0:
-            queue.put(dict(raw=allraw, same_tuning=bool(same), leapfrogs=int(lf.item()), epsilon=res["epsilon"],
+            # the traces travel as shared-memory tensors (torch.multiprocessing hands over the
+            # segments, nothing is pickled or written to a file); this process must outlive the hand-over
+            shared = {k: torch.from_numpy(v).share_memory_() for k, v in allraw.items()}
+            queue.put(dict(raw=shared, same_tuning=bool(same), leapfrogs=int(lf.item()), epsilon=res["epsilon"],
                            inv_mass=res["inv_mass"], cov=res.get("cov"), chol_cov=res.get("chol_cov")))
+            received.wait(timeout=600.0)
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -203,19 +238,21 @@ def _shard_worker(rank, world, engine_name, spec, num_chains, opts, devices, por
 def sample_chains_sharded(spec, num_chains, opts=None, devices=None, engine="exmc_amd.sampler"):
     """sample_chains over several GPUs of one node: one spawned process per entry of `devices`
     (started before it touches a GPU; the parent needs none), chain blocks by shard_range, the
-    finished traces all-gathered over the ranks' process group (RCCL when every rank has a GPU of
-    its own, gloo otherwise -- the CPU tests, or several ranks sharing one GPU) and handed to the
-    parent by rank 0 through a multiprocessing queue: no file is written. The returned
-    ({name: draws}[], stats[]) equal the single-device sample_chains whatever the number of devices.
-    `engine` names the module that provides compile / warmup / sample_compiled_tuned (the tests
-    substitute the CPU checker). A rank that fails takes the call down with it (the reference
-    retries a failed chain on the coordinator, distributed.ex:172-180; a GPU fault is not something
-    to retry blindly)."""
+    finished traces gathered from the ranks' device buffers to rank 0 over their process group (RCCL
+    when every rank has a GPU of its own, gloo otherwise -- the CPU tests, or several ranks sharing
+    one GPU) and handed to the parent as shared-memory tensors: no file is written, nothing is
+    pickled. The returned ({name: draws}[], stats[]) equal the single-device sample_chains whatever
+    the number of devices. `engine` names the module that provides compile / warmup /
+    sample_compiled_tuned (the tests substitute the CPU checker). A rank that fails takes the call
+    down with it (the reference retries a failed chain on the coordinator, distributed.ex:172-180; a
+    GPU fault is not something to retry blindly), and so does a rank that neither finishes nor fails
+    within opts["shard_timeout_s"] (default six hours): its process is terminated and the call raises."""
     import importlib
     import pickle
-    import socket
+    import time
 
     import torch
+    import torch.distributed as tdist
     import torch.multiprocessing as mp
     if num_chains < 1:
         raise ValueError("num_chains must be >= 1")
@@ -234,30 +271,46 @@ def sample_chains_sharded(spec, num_chains, opts=None, devices=None, engine="exm
             pickle.dumps((spec, opts))
         except Exception as e:   # e.g. a spec that still holds a Custom distribution's closure
             raise ValueError("the model spec / opts cannot be sent to the rank processes: %s" % e) from e
-        with socket.socket() as so:
-            so.bind(("127.0.0.1", 0))
-            port = so.getsockname()[1]
+        # the rendezvous store lives in this process on a port the kernel picked for it and that stays
+        # bound for the whole call (no bind-then-close window for another process to take)
+        store = tdist.TCPStore("127.0.0.1", 0, world, is_master=True, wait_for_workers=False)
         gpu_each = (engine == "exmc_amd.sampler" and len(set(devices)) == world and
                     torch.cuda.device_count() >= world)
         backend = "nccl" if gpu_each else "gloo"
         ctx = mp.get_context("spawn")
         queue = ctx.SimpleQueue()
-        procs = mp.spawn(_shard_worker, args=(world, engine, spec, num_chains, opts, devices, port, backend, queue),
+        received = ctx.Event()
+        procs = mp.spawn(_shard_worker, args=(world, engine, spec, num_chains, opts, devices, store.port, backend,
+                                              queue, received),
                          nprocs=world, join=False)
+        deadline = time.monotonic() + float(o.get("shard_timeout_s", 6 * 3600.0))
+
+        def expired():
+            if time.monotonic() > deadline:
+                for p_ in procs.processes:
+                    if p_.is_alive():
+                        p_.terminate()
+                raise TimeoutError("sample_chains_sharded: the rank processes did not finish within "
+                                   "shard_timeout_s; they have been terminated")
         first = None
-        while first is None:
-            if not queue.empty():
-                first = queue.get()
-            elif procs.join(timeout=0.05):      # every rank has exited (join raises if one failed)
-                if queue.empty():
-                    raise RuntimeError("the rank processes ended without a result")
+        try:
+            while first is None:
+                if not queue.empty():
+                    first = queue.get()
+                    first["raw"] = {k: v.numpy().copy() for k, v in first["raw"].items()}
+                elif procs.join(timeout=0.05):      # every rank has exited (join raises if one failed)
+                    if queue.empty():
+                        raise RuntimeError("the rank processes ended without a result")
+                expired()
+        finally:
+            received.set()
         while not procs.join(timeout=0.05):
-            pass
+            expired()
+        del store
         if not first["same_tuning"]:
             raise RuntimeError("ranks disagree on the shared tuning: the warmup is not deterministic")
         shards = [shard_range(num_chains, r, world) for r in range(world)]
-        raw = {k: np.concatenate([first["raw"][k][r][:hi - lo] for r, (lo, hi) in enumerate(shards)], axis=0)
-               for k in _TRACE_KEYS}
+        raw = first["raw"]
         total_lf = first["leapfrogs"]
     traces, stats = [], []
     for c in range(num_chains):

@@ -5,6 +5,8 @@ model *kind* plus its data. A ModelSpec carries what Exmc.PointMap carries for t
 variables in kernel order, their transforms (lib/exmc/transform.ex) and the reference's flat
 (alphabetical, point_map.ex:37) order.
 """
+import os
+
 import numpy as np
 
 STD_NORMAL, SIMPLE, EIGHT_SCHOOLS, SV, LOGISTIC, RADON = range(6)
@@ -62,10 +64,55 @@ def simple(y=SIMPLE_Y):
                      {"mu": 2.0, "sigma": 1.0})
 
 
+WORKLOADS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "workloads.npz")
+# sha256 of the arrays' bytes: the benchmark workloads are DATA, committed once.
+# They were drawn with numpy.random.default_rng(42) by the generators below, whose streams numpy does
+# not promise to keep across versions -- a numpy upgrade must not change leapfrogs_per_launch, the
+# tuned step sizes or the key of profiles/pmc_traffic.json. tests/test_workloads_pinned.py checks them.
+WORKLOAD_SHA256 = {
+    "sv_returns": "f26a618726c851925f71c3dcd5904dac163ffde50c37b7abce27c95ef69fbf1a",
+    "logistic_X": "18510110199a0ab7f28508b21a092e5b625229648e34719c04400e4feffbbe5a",
+    "logistic_y": "ae9f41b6fc0248642fc2f0ff932beab0b1c47162d102afcbd1e649ce3d761a6e",
+    "radon_u": "ae11c72c3b8cfc8d02d7ceb59b8f14fc755dd8266875702b809e778a6c943355",
+    "radon_start": "a0e2c5b0c07d935ea59ad70f31321d0b91d9d6c495dc3d6ab0753d7dae899325",
+    "radon_floor": "bdeb12a77e34d2231b9f8dbd9edcd5c11caaac808d17cb7ad2a65223ca93cac5",
+    "radon_y": "e6ec7e7275278656cb54b122c3f6ff6ae5aae1dfbd1ba2346c979414afb6b757",
+}
+_workloads = None
+
+
+def workload(name):
+    """One of the committed benchmark arrays (exmc_amd/data/workloads.npz), digest-checked on load."""
+    global _workloads
+    if _workloads is None:
+        import hashlib
+        z = np.load(WORKLOADS)
+        got = {k: np.ascontiguousarray(z[k]) for k in z.files}
+        for k, want in WORKLOAD_SHA256.items():
+            if hashlib.sha256(got[k].tobytes()).hexdigest() != want:
+                raise ValueError("exmc_amd/data/workloads.npz: array %s does not match its pinned digest" % k)
+        _workloads = got
+    return _workloads[name].copy()
+
+
+def sv_returns(seed=42, T=100, sigma=0.15, nu=10.0):
+    """returns simulated with sigma* = 0.15, nu* = 10 (STANDARD_BENCHMARKS.md:79). The
+    default arguments are the committed benchmark series; anything else is generated (numpy
+    default_rng, not stable across numpy versions)."""
+    if (seed, T, sigma, nu) == (42, 100, 0.15, 10.0):
+        return workload("sv_returns").tolist()
+    rng = np.random.default_rng(seed)
+    s = np.cumsum(rng.normal(0, sigma, T))
+    return (np.exp(s) * rng.standard_t(nu, T)).tolist()
+
+
 def logistic_data(seed=42, n=500, k=20):
     """X iid N(0,1), beta* = 0.5*N(0,1), alpha* = 0.5 (STANDARD_BENCHMARKS.md:77),
     y ~ Bernoulli(sigmoid(alpha* + X beta*)). The reference's generator is not in its
-    repository; this one (numpy default_rng(seed)) is build-defined."""
+    repository; this one is build-defined. The default arguments return the committed benchmark
+    arrays (see WORKLOAD_SHA256); other arguments generate (numpy default_rng(seed))."""
+    if (seed, n, k) == (42, 500, 20):
+        return workload("logistic_X"), workload("logistic_y")
     rng = np.random.default_rng(seed)
     X = rng.normal(size=(n, k))
     beta = 0.5 * rng.normal(size=k)
@@ -92,7 +139,10 @@ def logistic(X=None, y=None):
 def radon_data(seed=42, n_counties=85, n_obs=919):
     """notebooks/09_radon_bhm.livemd: 85 counties, ~919 observations, truth mu_alpha 1.4,
     gamma_u 0.7, sigma_alpha 0.4, sigma_y 0.7, beta -0.7. benchmark/radon_data.exs is absent from
-    the reference repository, so this generator (numpy default_rng(seed)) is build-defined."""
+    the reference repository, so this generator is build-defined. The default arguments return the
+    committed benchmark arrays (see WORKLOAD_SHA256); other arguments generate (numpy default_rng(seed))."""
+    if (seed, n_counties, n_obs) == (42, 85, 919):
+        return workload("radon_u"), workload("radon_start"), workload("radon_floor"), workload("radon_y")
     rng = np.random.default_rng(seed)
     w = rng.gamma(1.5, 1.0, size=n_counties) + 0.15
     counts = np.maximum(2, np.floor(w / w.sum() * n_obs)).astype(int)

@@ -259,7 +259,6 @@ def sample_compiled_tuned(compiled, tuning, init_values=None, opts=None, num_cha
     L = compiled.L
     chain_hi = num_chains if chain_hi is None else chain_hi
     nc = chain_hi - chain_lo
-    t, tr = _host_trace(nc, o["num_samples"], spec.d)
     tun = _tuning_struct(tuning, spec.d)
     _apply_mass(compiled, tuning)
     if tuning.get("chol_cov") is not None and not o.get("lanes_per_chain"):
@@ -267,6 +266,27 @@ def sample_compiled_tuned(compiled, tuning, init_values=None, opts=None, num_cha
     lf = C.c_int64()
     dv = C.c_int32()
     iq = _init_q(spec, init_values)
+    if o.get("raw_on_device"):
+        # the finished trace stays where the kernel wrote it: torch tensors in the device layout
+        # [S][d][C] / [S][C] under extra["raw"] (exmc_hip_sample_chains, caller-owned device buffers);
+        # the sharded fan-out gathers them over RCCL from there (exmc_amd/distributed.py). No
+        # per-chain host traces are built on this path.
+        import torch
+        dev = torch.device("cuda", compiled.device)
+        S = int(o["num_samples"])
+        f64, i32 = torch.float64, torch.int32
+        raw = dict(draws=torch.empty((S, spec.d, nc), dtype=f64, device=dev), logp=torch.empty((S, nc), dtype=f64, device=dev),
+                   tree_depth=torch.empty((S, nc), dtype=i32, device=dev), n_steps=torch.empty((S, nc), dtype=i32, device=dev),
+                   divergent=torch.empty((S, nc), dtype=i32, device=dev), accept_prob=torch.empty((S, nc), dtype=f64, device=dev),
+                   energy=torch.empty((S, nc), dtype=f64, device=dev))
+        trd = _lib.Trace(*[raw[k].data_ptr() for k in ("draws", "logp", "tree_depth", "n_steps", "divergent",
+                                                       "accept_prob", "energy")])
+        compiled.check(L.exmc_hip_sample_chains(compiled.h, C.byref(tun), None if iq is None else _dp(iq),
+                                                num_chains, chain_lo, chain_hi, _c_opts(o), trd, C.byref(lf),
+                                                C.byref(dv)))
+        return None, None, dict(total_leapfrogs=int(lf.value), total_divergences=int(dv.value), raw=raw,
+                                kernel_ms=compiled.last_kernel_ms)
+    t, tr = _host_trace(nc, o["num_samples"], spec.d)
     compiled.check(L.exmc_hip_sample_chains_host(compiled.h, C.byref(tun),
                                              None if iq is None else _dp(iq), num_chains,
                                              chain_lo, chain_hi, _c_opts(o), tr, C.byref(lf),

@@ -134,3 +134,18 @@ def test_sharded_api_refuses_what_it_cannot_send_to_the_ranks():
         xd.sample_chains_sharded(spec, 4, dict(num_warmup=10, num_samples=5), devices=[0, 1], engine="oracle_engine")
     with pytest.raises(ValueError):
         xd.sample_chains_sharded(models.eight_schools(), 0, {}, devices=[0])
+
+
+def test_sharded_api_gives_up_on_ranks_that_hang():
+    """A rank that neither finishes nor fails (here: an engine that sleeps in its warmup) must not
+    hang the caller: past opts["shard_timeout_s"] the rank processes are terminated and the call raises."""
+    import time
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from exmc_amd import distributed as xd
+    from exmc_amd import models
+    t0 = time.monotonic()
+    with pytest.raises(TimeoutError, match="shard_timeout_s"):
+        xd.sample_chains_sharded(models.eight_schools(), 4, dict(num_warmup=10, num_samples=5, shard_timeout_s=4.0),
+                                 devices=[0, 1], engine="hang_engine")
+    assert time.monotonic() - t0 < 60.0
