@@ -114,6 +114,12 @@ int enif_get_tuple(ErlNifEnv*, ERL_NIF_TERM tpl, int* arity, const ERL_NIF_TERM*
 ErlNifTid enif_thread_self(void);
 int enif_equal_tids(ErlNifTid tid1, ErlNifTid tid2);
 int enif_keep_resource(void* obj);
+/* mutexes (erl_nif: enif_mutex_create .. enif_mutex_unlock) */
+typedef struct ErlDrvMutex_ ErlNifMutex;
+ErlNifMutex* enif_mutex_create(char* name);
+void enif_mutex_destroy(ErlNifMutex* mtx);
+void enif_mutex_lock(ErlNifMutex* mtx);
+void enif_mutex_unlock(ErlNifMutex* mtx);
 
 #define ERL_NIF_INIT(NAME, FUNCS, LOAD, RELOAD, UPGRADE, UNLOAD)                              \
   ErlNifEntry* nif_init(void);                                                                \

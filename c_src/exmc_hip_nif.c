@@ -75,15 +75,48 @@ static ERL_NIF_TERM raise_api(ErlNifEnv* env, const exmc_api* A, int rc) {
                                           enif_make_string(env, A->last_error(), ERL_NIF_LATIN1)));
 }
 
-/* tid / has_tid: the sender thread of the last stream_run (ERTS threads are joinable: it is joined
- * by the next stream_run and by the destructor) */
+/* tid / has_tid: the sender thread of the last stream_run. ERTS threads are joinable and must be
+ * joined: by the next stream_run on the handle, by the destructor, or -- when the destructor runs
+ * on the sender itself, which dropped the last reference and cannot join itself -- by the reaper:
+ * the thread leaves its tid in g_reap and whoever calls into this library next (or unloads it)
+ * joins it. tid / has_tid are written and read under g_tid_lock, and the creator holds that lock
+ * across enif_thread_create, so the new thread cannot observe a half-published pair. */
 typedef struct { exmc_hip_model* m; const exmc_api* api; ErlNifTid tid; int has_tid; } model_res;
 
+static ErlNifMutex* g_tid_lock;
+#define EXMC_REAP_MAX 64
+static ErlNifTid g_reap[EXMC_REAP_MAX];
+static int g_reap_n;
+
+/* join the senders that ended on their own last reference (they are past their last use of the
+ * library: the join returns at once) */
+static void reap_senders(void) {
+  for (;;) {
+    ErlNifTid t;
+    enif_mutex_lock(g_tid_lock);
+    const int have = g_reap_n > 0;
+    if (have) t = g_reap[--g_reap_n];
+    enif_mutex_unlock(g_tid_lock);
+    if (!have) return;
+    if (!enif_equal_tids(enif_thread_self(), t)) (void)enif_thread_join(t, NULL);
+    else {                       /* the reaper must not run on a parked thread: put it back and stop */
+      enif_mutex_lock(g_tid_lock);
+      if (g_reap_n < EXMC_REAP_MAX) g_reap[g_reap_n++] = t;
+      enif_mutex_unlock(g_tid_lock);
+      return;
+    }
+  }
+}
+
 static void join_sender(model_res* r) {
-  /* the destructor runs on whichever thread drops the last reference -- possibly the sender
-   * itself, which cannot join itself and ends right after */
-  if (r->has_tid && !enif_equal_tids(enif_thread_self(), r->tid)) (void)enif_thread_join(r->tid, NULL);
+  enif_mutex_lock(g_tid_lock);
+  const int has = r->has_tid;
+  const ErlNifTid t = r->tid;
   r->has_tid = 0;
+  const int self = has && enif_equal_tids(enif_thread_self(), t);
+  if (self && g_reap_n < EXMC_REAP_MAX) g_reap[g_reap_n++] = t;   /* joined by the next caller / at unload */
+  enif_mutex_unlock(g_tid_lock);
+  if (has && !self) (void)enif_thread_join(t, NULL);
 }
 
 static void model_dtor(ErlNifEnv* env, void* obj) {
@@ -123,6 +156,7 @@ static int get_init_q(ErlNifEnv* env, ERL_NIF_TERM t, int d, const double** q) {
 
 static ERL_NIF_TERM make_handle(ErlNifEnv* env, const exmc_api* A, int kind, const double* data, size_t n) {
   exmc_hip_model* m = NULL;
+  reap_senders();
   int rc = A->model_create(kind, 0, data, (int)n, g_device, &m);
   if (rc != EXMC_OK)
     return tuple2(env, enif_make_atom(env, "error"), enif_make_string(env, A->last_error(), ERL_NIF_LATIN1));
@@ -520,6 +554,10 @@ static void* stream_sender(void* arg) {
             tuple3(env, enif_make_atom(env, ok ? "exmc_done" : "exmc_error"), enif_make_int(env, sent),
                    enif_make_int(env, ok ? dv : rc)));
   enif_free_env(env);
+  /* the creator publishes (tid, has_tid) under g_tid_lock right after enif_thread_create: pass
+   * through the lock once so that a destructor running below sees the published pair */
+  enif_mutex_lock(g_tid_lock);
+  enif_mutex_unlock(g_tid_lock);
   enif_release_resource(j->res);
   enif_free(j);
   return NULL;
@@ -544,15 +582,23 @@ static ERL_NIF_TERM stream_run(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv
     return raise_api(env, A, rc);
   }
   join_sender(j->res);          /* the previous sender has called stream_finish: it is ending */
+  reap_senders();
   enif_keep_resource(j->res);   /* the thread's reference */
-  if (enif_thread_create((char*)"exmc_hip_stream", &j->res->tid, stream_sender, j, NULL) != 0) {
+  ErlNifTid tid;
+  enif_mutex_lock(g_tid_lock);
+  const int failed = enif_thread_create((char*)"exmc_hip_stream", &tid, stream_sender, j, NULL) != 0;
+  if (!failed) {
+    j->res->tid = tid;
+    j->res->has_tid = 1;
+  }
+  enif_mutex_unlock(g_tid_lock);
+  if (failed) {
     int32_t dv;
     (void)A->stream_finish(m, &dv);
     enif_release_resource(j->res);
     enif_free(j);
     return enif_raise_exception(env, enif_make_atom(env, "thread_create_failed"));
   }
-  j->res->has_tid = 1;
   return enif_make_atom(env, "ok");   /* the thread frees its job and ends after :exmc_done; it is joined later */
 }
 
@@ -579,8 +625,18 @@ static int on_load(ErlNifEnv* env, void** priv, ERL_NIF_TERM info) {
   (void)info;
   const char* dev = getenv("EXMC_HIP_DEVICE");
   g_device = dev ? atoi(dev) : 0;
+  g_tid_lock = enif_mutex_create((char*)"exmc_hip_tid");
+  g_reap_n = 0;
   MODEL_RT = enif_open_resource_type(env, NULL, "exmc_hip_model", model_dtor, ERL_NIF_RT_CREATE, NULL);
-  return MODEL_RT ? 0 : 1;
+  return (MODEL_RT && g_tid_lock) ? 0 : 1;
 }
 
-ERL_NIF_INIT(Elixir.Exmc.NUTS.HipNative, nif_funcs, on_load, NULL, NULL, NULL)
+static void on_unload(ErlNifEnv* env, void* priv) {
+  (void)env;
+  (void)priv;
+  reap_senders();               /* no sender thread outlives the library's code */
+  if (g_tid_lock) enif_mutex_destroy(g_tid_lock);
+  g_tid_lock = NULL;
+}
+
+ERL_NIF_INIT(Elixir.Exmc.NUTS.HipNative, nif_funcs, on_load, NULL, NULL, on_unload)

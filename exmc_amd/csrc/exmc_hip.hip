@@ -142,6 +142,7 @@ struct exmc_hip_model {
   // resident chains (exmc_hip_chains_init / _advance)
   int res_C = 0, res_lanes = 0, res_max_depth = 10;
   double res_eps = 0.0;
+  int simds = 1024;   // 4 x the device's compute units (MI355X: 256 CUs)
 };
 
 namespace {
@@ -226,7 +227,7 @@ int dispatch(exmc_hip_model* m, int lanes, F&& f) {
 #elif defined(EXMC_DEV_ONLY)
 #if EXMC_DEV_ONLY == EXMC_DEV_SV64
     case EXMC_MODEL_SV:
-      if (lanes == 64) return f(Tag<SV<64>, 64, 2>{}, m->sv);
+      if (lanes == 64) return f(Tag<SV<64>, 64, 3>{}, m->sv);
       break;
 #elif EXMC_DEV_ONLY == EXMC_DEV_RADON64
     case EXMC_MODEL_RADON:
@@ -255,7 +256,7 @@ int dispatch(exmc_hip_model* m, int lanes, F&& f) {
     case EXMC_MODEL_SV:
       switch (lanes) {
         case 32: return f(Tag<SV<32>, 32, 2>{}, m->sv);
-        case 64: return f(Tag<SV<64>, 64, 2>{}, m->sv);
+        case 64: return f(Tag<SV<64>, 64, 3>{}, m->sv);
         default: break;
       }
       break;
@@ -493,10 +494,11 @@ int launch_nuts(exmc_hip_model* m, int lanes, int C, int n_draws, int draw_offse
       const char* pe = std::getenv("EXMC_HIP_PRIO");   // 0: leave the arbiter's oldest-first order alone
       P.prio = (pe && pe[0] == '0') ? 0 : 1;
     }
+    P.simds = m->simds;
     if (progress) {
       if constexpr (kStreamKernel<M>) {
         if (timed) HIP_TRY(hipEventRecord(m->ev0, m->stream));
-        const size_t lds_s = nuts_lds_bytes<M, T::LDSL>();
+        const size_t lds_s = nuts_lds_bytes<M, T::LDSL, M::kNutsZigInLds>();
         hipLaunchKernelGGL((nuts_kernel<M, T::G, T::LDSL, false, true>), grid, dim3(kNutsBlock), lds_s,
                            m->stream, P, mc);
         HIP_TRY(hipGetLastError());
@@ -555,7 +557,7 @@ int launch_nuts(exmc_hip_model* m, int lanes, int C, int n_draws, int draw_offse
       }
     }
     if (timed) HIP_TRY(hipEventRecord(m->ev0, m->stream));
-    const size_t lds_bytes = nuts_lds_bytes<M, T::LDSL>();
+    const size_t lds_bytes = nuts_lds_bytes<M, T::LDSL, M::kNutsZigInLds>();
     if (lds_bytes > 64 * 1024)   // the lane layouts' dense mass keeps M^-1 in LDS
       HIP_TRY(hipFuncSetAttribute((const void*)nuts_kernel<M, T::G, T::LDSL>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -1126,6 +1128,11 @@ int exmc_hip_model_create(int kind, int d, const double* data, int n_data, int d
   if (hipSetDevice(device) != hipSuccess) return bail(fail(EXMC_ERR_HIP, "hipSetDevice failed"));
   if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess)
     return bail(fail(EXMC_ERR_HIP, "hipStreamCreate failed"));
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
+      m->simds = 4 * cus;
+  }
   if (hipEventCreate(&m->ev0) != hipSuccess || hipEventCreate(&m->ev1) != hipSuccess)
     return bail(fail(EXMC_ERR_HIP, "hipEventCreate failed"));
   int rc = m->zig.ensure(768 * 8);
@@ -1721,9 +1728,10 @@ int exmc_hip_stream_next_host(exmc_hip_model* m, int n_draws, exmc_hip_trace tr,
   return download_trace(m, L, n_draws, 1, tr);
 }
 
-int exmc_hip_stream_start(exmc_hip_model* m, int n_draws, exmc_hip_trace* view,
-                          const volatile int32_t** progress) {
-  if (check_model(m)) return EXMC_ERR_BADARG;   // includes: no other stream run in flight
+namespace {
+// the body of exmc_hip_stream_start once the handle is claimed
+int stream_start_claimed(exmc_hip_model* m, int n_draws, exmc_hip_trace* view,
+                         const volatile int32_t** progress) {
   if (m->res_C != 1) return fail(EXMC_ERR_BADARG, "no stream: call exmc_hip_stream_begin");
   if (n_draws < 1 || !view || !progress) return fail(EXMC_ERR_BADARG, "bad arguments");
   if (m->dense_on) return fail(EXMC_ERR_UNSUPPORTED, "a push-style stream runs under the diagonal mass");
@@ -1745,7 +1753,6 @@ int exmc_hip_stream_start(exmc_hip_model* m, int n_draws, exmc_hip_trace* view,
   rc = launch_nuts(m, m->res_lanes, 1, n_draws, 0, m->res_eps, m->res_max_depth,
                    trace_view((char*)dev + 64, L), true, (int*)dev);
   if (rc) return rc;
-  m->stream_in_flight.store(true, std::memory_order_release);
   // with one chain the device layout [draw][dim][chain] is the host layout [draw][dim]
   const TraceDev h = trace_view((char*)m->pin_host + 64, L);
   view->draws = h.draws;
@@ -1757,6 +1764,24 @@ int exmc_hip_stream_start(exmc_hip_model* m, int n_draws, exmc_hip_trace* view,
   view->energy = h.energy;
   *progress = (const volatile int32_t*)m->pin_host;
   return EXMC_OK;
+}
+}  // namespace
+
+int exmc_hip_stream_start(exmc_hip_model* m, int n_draws, exmc_hip_trace* view,
+                          const volatile int32_t** progress) {
+  if (check_handle(m)) return EXMC_ERR_BADARG;
+  // The claim is the compare-and-swap itself: of two callers racing on one handle (two dirty
+  // schedulers of a VM) exactly one goes on, the other is refused before it touches the page-locked
+  // trace or launches anything. Every failure below gives the claim back.
+  bool idle = false;
+  if (!m->stream_in_flight.compare_exchange_strong(idle, true, std::memory_order_acq_rel))
+    return fail(EXMC_ERR_BADARG, "a stream run is in flight on this handle: call exmc_hip_stream_finish first");
+  const int rc = stream_start_claimed(m, n_draws, view, progress);
+  if (rc) {
+    (void)hipStreamSynchronize(m->stream);   // whatever was queued before the failure has drained
+    m->stream_in_flight.store(false, std::memory_order_release);
+  }
+  return rc;
 }
 
 int exmc_hip_stream_finish(exmc_hip_model* m, int32_t* divergences) {

@@ -219,7 +219,7 @@ template <class M, int G>
 __global__ void __launch_bounds__(kNutsBlock) find_eps_kernel(FindEpsParams P,
                                                               typename M::Consts mc) {
   constexpr int DPL = M::DPL;
-  constexpr int NSLOT = 5 * DPL + 3;
+  constexpr int NSLOT = nuts_nslot<M>();
   extern __shared__ double lds[];
   const ZigTables zt = stage_zig_tables<0, NSLOT>(lds, P.zig_ki, P.zig_wi, P.zig_fi);
   const bool writer = threadIdx.x < G;

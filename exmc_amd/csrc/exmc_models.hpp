@@ -51,8 +51,20 @@ struct ModelDefaults {
   // one chain per wave, two waves per SIMD: a chain may move to a SIMD that has run empty while
   // its own SIMD still holds two chains (exmc_nuts.hpp "chain migration")
   static constexpr bool kMigrate = false;
+  // leapfrogs per ms of a wave that shares its SIMD with one other, holding the issue priority and
+  // not holding it (tools/sv_probe.sh): the time-sliced priority of the migration loop gives the
+  // chain with more left to do the larger share by these; equal (unmeasured): even shares
+  static constexpr double kPrioRateWith = 1.0, kPrioRateWithout = 1.0;
   // > 0: the sampling kernel runs as wave pairs too, with this many tree-stack levels in LDS
   static constexpr int kPipeNutsLevels = 0;
+  // false: the sampling kernel reads the ziggurat tables from global memory instead of staging
+  // them in LDS (6 KB per workgroup) -- for a model that draws a momentum once per few hundred
+  // leapfrogs and spends the space on another tree-stack level (exmc_nuts.hpp nuts_lds_data_offset)
+  static constexpr bool kNutsZigInLds = true;
+  // true: tree nodes carry the proposal as (q, logp) only; its gradient is evaluated once more at the
+  // end of the transition (exmc_nuts.hpp nuts_run) -- for deep-tree models, where one more model
+  // evaluation per transition is cheaper than two more doubles in every node
+  static constexpr bool kRegradProposal = false;
 };
 
 // the dynamic LDS of the running kernel (every extern __shared__ array names the same base)
@@ -382,6 +394,13 @@ struct SV : ModelDefaults {
   static constexpr int kNutsWavesPerSimd = (G == 64) ? 2 : 1;
   static constexpr bool kXRowLds = (G == 64);
   static constexpr bool kMigrate = (G == 64);
+  // G = 64: a transition is ~340 leapfrogs and one momentum draw; the 6 KB of the tables buy the
+  // third stack level in LDS (3 x 6.5 KB = 19.5 KB: still eight workgroups per CU), which halves
+  // the visits to the spill stack in global memory (a quarter of the leaves merge or park at level
+  // >= 2, an eighth at level >= 3)
+  static constexpr bool kNutsZigInLds = (G != 64);
+  static constexpr bool kRegradProposal = (G == 64);
+  static constexpr double kPrioRateWith = 291.0, kPrioRateWithout = 169.0;   // profiles/r3_sv_prio
   using Consts = SVConsts;
   struct Lane {
     double r[DPL];

@@ -134,6 +134,7 @@ struct NutsParams {
   FlatOrder flat;
   DenseMass dm;   // opts[:dense_mass] in force (lanes_per_chain = 1 only)
   int prio;       // 1: time-sliced issue priority between the two waves of a SIMD (kNutsWavesPerSimd == 2)
+  int simds;      // SIMDs of the device (4 per compute unit): the pairing below holds for 2 * simds waves
   int* mig;       // chain migration (Model::kMigrate): a zeroed MigBoard, or null
   int* progress;  // kStream launches: where chain 0's count of finished draws is published (host memory)
 };
@@ -174,28 +175,41 @@ constexpr int kMaxLevels = 12;
 constexpr int kNutsBlock = 64;      // one wavefront per workgroup
 constexpr int kZigLdsBytes = 768 * 8;
 
+// doubles per lane of one pending tree node: rho, p_in, p_out, q_prop, g_prop (DPL each), lsw,
+// logp_prop, acc -- without g_prop for a model that recomputes the proposal's gradient at the end of
+// the transition instead of carrying it through every node (M::kRegradProposal)
 template <class M>
-__host__ __device__ constexpr int nuts_nslot() { return 5 * M::DPL + 3; }
+__host__ __device__ constexpr int nuts_nslot() { return (M::kRegradProposal ? 4 : 5) * M::DPL + 3; }
 
 // dynamic LDS of a NUTS workgroup: [tree stack levels < LDSL][ziggurat tables][model scratch]
-// [model data image]
-template <class M, int LDSL>
+// [model data image]. kZig = false: the ziggurat tables stay in global memory (6 KB, L2-resident)
+// -- the sampling kernel of a model that draws its momentum once per few hundred leapfrogs and
+// needs the space for another stack level (M::kNutsZigInLds, sv).
+template <bool kZig>
+__host__ __device__ constexpr size_t nuts_zig_doubles() { return kZig ? kZigLdsBytes / 8 : 0; }
+template <class M, int LDSL, bool kZig = true>
 __host__ __device__ constexpr size_t nuts_lds_data_offset() {   // in doubles
-  return (size_t)LDSL * nuts_nslot<M>() * kNutsBlock + kZigLdsBytes / 8 +
+  return (size_t)LDSL * nuts_nslot<M>() * kNutsBlock + nuts_zig_doubles<kZig>() +
          (size_t)M::kExtraLdsDoubles + (size_t)M::kDenseLdsDoubles;
 }
-template <class M, int LDSL>
+template <class M, int LDSL, bool kZig = true>
 __host__ __device__ constexpr size_t nuts_lds_bytes() {
-  return (nuts_lds_data_offset<M, LDSL>() + (size_t)M::kLdsDataDoubles) * 8;
+  return (nuts_lds_data_offset<M, LDSL, kZig>() + (size_t)M::kLdsDataDoubles) * 8;
+}
+// doubles of global spill stack per workgroup (levels >= LDSL of every lane of one wavefront,
+// contiguous: level, then slot, then lane)
+template <class M, int LDSL>
+__host__ __device__ constexpr size_t nuts_spill_doubles() {
+  return (size_t)((kMaxLevels > LDSL) ? (kMaxLevels - LDSL) : 1) * nuts_nslot<M>() * kNutsBlock;
 }
 
 // Models with kLdsDataDoubles > 0 keep their observations in LDS for the whole kernel
 // (M::stage_data fills the image, Lane::xoff is its offset in doubles or -1): with one wave per
 // SIMD every global load inside logp_grad is an exposed L2 round trip.
-template <class M, int G, int LDSL>
+template <class M, int G, int LDSL, bool kZig = true>
 __device__ __forceinline__ int stage_model_data(const typename M::Consts& mc, double* lds) {
   if constexpr (M::kLdsDataDoubles > 0) {
-    const int off = (int)nuts_lds_data_offset<M, LDSL>();
+    const int off = (int)nuts_lds_data_offset<M, LDSL, kZig>();
     const bool ok = M::stage_data(mc, lds + off);
     __syncthreads();
     return ok ? off : -1;
@@ -233,8 +247,7 @@ struct NutsLane {
                      // see nuts_run); -1: the wave has its SIMD to itself
   int prio_duty;     // sixteenths of the time slot 0 holds the priority (8: even shares)
   double* lstk;      // this lane's column of the LDS stack
-  double* gstk;      // this lane's column of the global spill stack
-  size_t nthreads;
+  double* gstk;      // this lane's column of its workgroup's block of the global spill stack
   ZigTables zt;
   double nor_r;
   bool alive;        // false: a lane group kept only so that wave-cooperative models see all lanes
@@ -358,9 +371,10 @@ struct ChainRegs {
 };
 
 // cooperative: every lane of the workgroup must call this before any lane leaves
-template <int LDSL, int NSLOT>
+template <int LDSL, int NSLOT, bool kZig = true>
 __device__ __forceinline__ ZigTables stage_zig_tables(double* lds, const uint64_t* ki,
                                                       const double* wi, const double* fi) {
+  if constexpr (!kZig) return ZigTables{ki, wi, fi};   // read where they are (see nuts_lds_data_offset)
   double* lz = lds + (size_t)LDSL * NSLOT * kNutsBlock;
   for (int i = threadIdx.x; i < 256; i += kNutsBlock) {
     lz[i] = __longlong_as_double((long long)ki[i]);
@@ -873,13 +887,18 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
                                          int max_depth, Sink&& sink, Pipe* pipe = nullptr,
                                          Idle&& idle = Idle{}) {
   constexpr int DPL = M::DPL;
-  constexpr int NSLOT = 5 * DPL + 3;
+  constexpr int NSLOT = nuts_nslot<M>();
+  // M::kRegradProposal: the proposal travels as (q, logp) only and its gradient is evaluated once
+  // more when the transition is over -- the same function of the same bits, so the same gradient --
+  // instead of riding in every node, every park and every merge's selects (sv: one evaluation per
+  // ~340 leapfrogs against 2 of 13 doubles of every node and 12 vector registers of the leaf loop)
+  constexpr bool kRegrad = M::kRegradProposal;
+  constexpr int kNodeScalars = NSLOT - 3;   // offset of lsw, logp_prop, acc
   using MM = Math<M::kVregMath>;
   const int l = L.l;
   const auto& im = L.im;
   double* lstk = L.lstk;
   double* gstk = L.gstk;
-  const size_t nthreads = L.nthreads;
 
   double q[DPL], p[DPL], g[DPL], qold[DPL], gold[DPL];
   double qL[DPL], pL[DPL], gL[DPL], qR[DPL], pR[DPL], gR[DPL];
@@ -1056,7 +1075,7 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
 #pragma unroll
             for (int k = 0; k < DPL; k++) {
               c_qp[k] = c_div ? qold[k] : q[k];
-              c_gp[k] = c_div ? gold[k] : g[k];
+              if constexpr (!kRegrad) c_gp[k] = c_div ? gold[k] : g[k];
               c_rho[k] = p[k];
               c_pin[k] = p[k];
             }
@@ -1071,10 +1090,10 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
               if (!parked) {
                 double nd[NSLOT];
                 if (lvl < LDSL) node_load<NSLOT>(lstk + (size_t)lvl * NSLOT * kNutsBlock, kNutsBlock, nd);
-                else node_load<NSLOT>(gstk + (size_t)(lvl - LDSL) * NSLOT * nthreads, nthreads, nd);
-                const double a_lsw = nd[5 * DPL + 0];
-                const double a_logpP = nd[5 * DPL + 1];
-                const double a_acc = nd[5 * DPL + 2];
+                else node_load<NSLOT>(gstk + (size_t)(lvl - LDSL) * NSLOT * kNutsBlock, kNutsBlock, nd);
+                const double a_lsw = nd[kNodeScalars + 0];
+                const double a_logpP = nd[kNodeScalars + 1];
+                const double a_acc = nd[kNodeScalars + 2];
 #if EXMC_ABLATE == 2
                 const double lsw = a_lsw + c_lsw;
                 const double u = rng_uniform(trng);
@@ -1087,7 +1106,10 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
                 if (!use_b) {
                   c_logpP = a_logpP;
 #pragma unroll
-                  for (int k = 0; k < DPL; k++) { c_qp[k] = nd[3 * DPL + k]; c_gp[k] = nd[4 * DPL + k]; }
+                  for (int k = 0; k < DPL; k++) {
+                    c_qp[k] = nd[3 * DPL + k];
+                    if constexpr (!kRegrad) c_gp[k] = nd[4 * DPL + k];
+                  }
                 }
                 bool turning = c_div || c_turn;
                 if (!turning) {
@@ -1128,13 +1150,13 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
                   nd[1 * DPL + k] = c_pin[k];
                   nd[2 * DPL + k] = p[k];
                   nd[3 * DPL + k] = c_qp[k];
-                  nd[4 * DPL + k] = c_gp[k];
+                  if constexpr (!kRegrad) nd[4 * DPL + k] = c_gp[k];
                 }
-                nd[5 * DPL + 0] = c_lsw;
-                nd[5 * DPL + 1] = c_logpP;
-                nd[5 * DPL + 2] = c_acc;
+                nd[kNodeScalars + 0] = c_lsw;
+                nd[kNodeScalars + 1] = c_logpP;
+                nd[kNodeScalars + 2] = c_acc;
                 if (lvl < LDSL) node_store<NSLOT>(lstk + (size_t)lvl * NSLOT * kNutsBlock, kNutsBlock, nd);
-                else node_store<NSLOT>(gstk + (size_t)(lvl - LDSL) * NSLOT * nthreads, nthreads, nd);
+                else node_store<NSLOT>(gstk + (size_t)(lvl - LDSL) * NSLOT * kNutsBlock, kNutsBlock, nd);
                 parked = true;
               }
               if (__any(parked ? 0 : 1) == 0) break;   // every live group has parked
@@ -1157,7 +1179,10 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
             if (use_sub) {
               t_logpP = c_logpP;
 #pragma unroll
-              for (int k = 0; k < DPL; k++) { t_qp[k] = c_qp[k]; t_gp[k] = c_gp[k]; }
+              for (int k = 0; k < DPL; k++) {
+                t_qp[k] = c_qp[k];
+                if constexpr (!kRegrad) t_gp[k] = c_gp[k];
+              }
             }
             const bool divg = t_div || c_div;
             bool turning = divg || c_turn;
@@ -1204,6 +1229,11 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
 
     // ---- transition done for every group of the wavefront (sampler.ex:890-925) ----
     if constexpr (Pipe::kOn) pipe->pending = true;   // the integrator wave is drawing the next momentum
+    if constexpr (kRegrad) {
+      // every lane of the wavefront takes part (the model's sums span the lane group); what the
+      // function returns is the proposal's log-density again, already held in t_logpP
+      (void)M::logp_grad(mc, L.ln, l, t_qp, t_gp);
+    }
     if (has) {
       (void)rng_uniform(st.rng);
       st.logp = t_logpP;
@@ -1232,7 +1262,7 @@ __device__ __forceinline__ void rowdense_load(NutsLane<M, G>& L, const double* c
 }
 
 // fill the per-lane constants; inv_mass / sqrt_inv_mass may be null (identity mass)
-template <class M, int G, int LDSL>
+template <class M, int G, int LDSL, bool kZig = true>
 __device__ __forceinline__ void lane_setup(NutsLane<M, G>& L, const typename M::Consts& mc,
                                            double* lds, double* stack, const double* inv_mass,
                                            const double* sqrt_inv_mass, const ZigTables& zt,
@@ -1241,9 +1271,12 @@ __device__ __forceinline__ void lane_setup(NutsLane<M, G>& L, const typename M::
   constexpr int D = M::D, DPL = M::DPL;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   L.l = threadIdx.x & (G - 1);
-  L.nthreads = (size_t)gridDim.x * blockDim.x;
   L.lstk = lds + threadIdx.x;
-  L.gstk = stack + tid;
+  // The spill levels of one wavefront are one contiguous block [level][slot][lane]: a node's
+  // slots are 512 bytes apart, so its loads and stores share one address register and differ in
+  // their immediate offsets (the chain-interleaved layout of rounds 1-3 paid a 64-bit address
+  // computation per slot, 27 of the ~500 instructions of a spilled merge).
+  L.gstk = stack + (size_t)(tid / kNutsBlock) * nuts_spill_doubles<M, LDSL>() + (tid % kNutsBlock);
   L.zt = zt;
   L.nor_r = nor_r;
   L.alive = true;
@@ -1251,7 +1284,7 @@ __device__ __forceinline__ void lane_setup(NutsLane<M, G>& L, const typename M::
   L.prio_duty = 8;
   M::load(mc, L.l, L.ln);
   if constexpr (M::kExtraLdsDoubles > 0)
-    L.ln.sh = lds + (size_t)LDSL * nuts_nslot<M>() * kNutsBlock + kZigLdsBytes / 8;
+    L.ln.sh = lds + (size_t)LDSL * nuts_nslot<M>() * kNutsBlock + nuts_zig_doubles<kZig>();
 #pragma unroll
   for (int k = 0; k < DPL; k++) {
     const int i = L.l + k * G;
@@ -1266,7 +1299,7 @@ __device__ __forceinline__ void lane_setup(NutsLane<M, G>& L, const typename M::
   if constexpr (M::kLaneDense) {
     L.ld.covp = dm.covp;
     L.ld.cholp = dm.cholp;
-    double* dl = lds + (size_t)LDSL * nuts_nslot<M>() * kNutsBlock + kZigLdsBytes / 8 + M::kExtraLdsDoubles;
+    double* dl = lds + (size_t)LDSL * nuts_nslot<M>() * kNutsBlock + nuts_zig_doubles<kZig>() + M::kExtraLdsDoubles;
     L.ld.xs = dl + (size_t)((threadIdx.x & 63) / G) * 3 * D;
     if constexpr (M::kDenseImage) {
       L.ld.covl = dl + (size_t)(64 / G) * 3 * D;
@@ -1323,30 +1356,33 @@ template <class M, int G, int LDSL, bool kPipe = false, bool kStream = false>
 __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock, M::kNutsWavesPerSimd)
     nuts_kernel(NutsParams P, typename M::Consts mc) {
   constexpr int D = M::D, DPL = M::DPL;
-  constexpr int NSLOT = 5 * DPL + 3;
+  constexpr int NSLOT = nuts_nslot<M>();
   extern __shared__ double lds[];
   const int lane = threadIdx.x & 63;
   const int tid = blockIdx.x * kNutsBlock + lane;   // both waves of a pair see the same chains
   const int C = P.n_chains;
   const bool has_chain = (tid / G) < C;
   const int chain = has_chain ? (tid / G) : (C - 1);   // surplus groups shadow the last chain
-  const ZigTables zt = stage_zig_tables<LDSL, NSLOT>(lds, P.zig_ki, P.zig_wi, P.zig_fi);
-  const int xoff = stage_model_data<M, G, LDSL>(mc, lds);
+  constexpr bool kZig = M::kNutsZigInLds || kPipe;
+  const ZigTables zt = stage_zig_tables<LDSL, NSLOT, kZig>(lds, P.zig_ki, P.zig_wi, P.zig_fi);
+  const int xoff = stage_model_data<M, G, LDSL, kZig>(mc, lds);
   if (!M::kCoop && !has_chain) return;
 
   NutsLane<M, G> L;
-  lane_setup<M, G, LDSL>(L, mc, lds, P.stack, P.inv_mass, P.sqrt_inv_mass, zt, P.nor_r, P.flat, P.dm);
+  lane_setup<M, G, LDSL, kZig>(L, mc, lds, P.stack, P.inv_mass, P.sqrt_inv_mass, zt, P.nor_r, P.flat, P.dm);
   if constexpr (M::kLdsDataDoubles > 0) L.ln.xoff = xoff;
   L.alive = has_chain;
-  // workgroups i and i + 1024 land on the same SIMD (one wave each, 1024 SIMDs, dispatch in order:
-  // every pair of the 2048-wave sv launch, tools/sv_probe.sh): the second thousand are the younger waves
-  if constexpr (M::kNutsWavesPerSimd == 2 && !kPipe) L.prio_slot = (gridDim.x > 1024 && P.prio) ? (int)((blockIdx.x >> 10) & 1) : -1;
+  // workgroups i and i + simds land on the same SIMD (one wave each, dispatch in order: every
+  // pair of the 2048-wave sv launch on 1024 SIMDs, tools/sv_probe.sh): the second half are the younger
+  // waves. That is a statement about a launch of exactly two waves per SIMD on a whole device; any
+  // other grid (a partial device, a CU mask, more than two rounds of waves) keeps the arbiter's order.
+  if constexpr (M::kNutsWavesPerSimd == 2 && !kPipe)
+    L.prio_slot = (P.prio && P.simds > 0 && (int)gridDim.x == 2 * P.simds) ? (int)(blockIdx.x >= (unsigned)P.simds) : -1;
   using Pipe = std::conditional_t<kPipe, PipeBox<DPL>, NoPipe>;
   Pipe pipe;
   if constexpr (kPipe) {
     L.lstk = lds + lane;
-    L.gstk = P.stack + tid;
-    L.nthreads = (size_t)gridDim.x * kNutsBlock;
+    L.gstk = P.stack + (size_t)blockIdx.x * nuts_spill_doubles<M, LDSL>() + lane;
     pipe.box = lds + nuts_lds_bytes<M, LDSL>() / 8 + lane;
     pipe.seq = 0;
     pipe.pending = false;
@@ -1484,8 +1520,8 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock, M::kNutsW
       // share f of slot 0 that makes the rates proportional to rho = left_0 / left_1 is
       // (291 rho - 169) / (122 (1 + rho)).
       int* const pair_word = board + kMigMail + 2 * (int)gridDim.x;
-      const int partner = (int)blockIdx.x ^ 1024;
-      const bool paired = L.prio_slot >= 0 && partner < (int)gridDim.x;
+      const int partner = (L.prio_slot == 0) ? (int)blockIdx.x + P.simds : (int)blockIdx.x - P.simds;
+      const bool paired = L.prio_slot >= 0 && partner >= 0 && partner < (int)gridDim.x;
       unsigned long long lf_at_start = 0;
       int done_at_start = 0;
       for (;;) {
@@ -1509,8 +1545,13 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock, M::kNutsW
             const double l0 = (L.prio_slot == 0) ? (double)my_left : (double)pl;
             const double l1 = (L.prio_slot == 0) ? (double)pl : (double)my_left;
             const double rho = l0 / l1;
-            const double f = (291.0 * rho - 169.0) / (122.0 * (1.0 + rho));
-            duty = (int)(16.0 * fmin(fmax(f, 0.0), 1.0) + 0.5);
+            // (the rates of a pair with and without the priority, measured for this model; a model
+            // without measured rates keeps even shares)
+            constexpr double kHi = M::kPrioRateWith, kLo = M::kPrioRateWithout;
+            if constexpr (kHi > kLo) {
+              const double f = (kHi * rho - kLo) / ((kHi - kLo) * (1.0 + rho));
+              duty = (int)(16.0 * fmin(fmax(f, 0.0), 1.0) + 0.5);
+            }
           }
           L.prio_duty = duty;
         }
@@ -1864,7 +1905,7 @@ template <class M, int G, int LDSL, bool kPipe = false>
 __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock)
     warmup_kernel(WarmupParams P, typename M::Consts mc) {
   constexpr int D = M::D, DPL = M::DPL;
-  constexpr int NSLOT = 5 * DPL + 3;
+  constexpr int NSLOT = nuts_nslot<M>();
   extern __shared__ double lds[];
   const ZigTables zt = stage_zig_tables<LDSL, NSLOT>(lds, P.zig_ki, P.zig_wi, P.zig_fi);
   // single workgroup on an otherwise idle chip: keep the model data in LDS when it offers an image
@@ -1895,7 +1936,6 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock)
     // both waves index the stack and the mailbox by their lane, not by threadIdx.x
     L.lstk = lds + lane;
     L.gstk = P.stack + (size_t)blockIdx.x * P.stack_stride + lane;
-    L.nthreads = kNutsBlock;
     pipe.box = lds + lds_used + lane;
     pipe.seq = 0;
     pipe.pending = false;

@@ -159,13 +159,14 @@ def radon_data(seed=42, n_counties=85, n_obs=919):
     return u, start, floor, y
 
 
-def radon(data=None, sort_counties=True):
+def radon(data=None, sort_counties=True, builtin=False):
     """Hierarchical radon, d = J+5 = 90. Kernel order: the county intercepts alpha_raw_j by
     DESCENDING observation count, then mu_alpha, gamma_u, sigma_alpha, sigma_y, beta (the
     reference's flat order is the string sort; names carry the original county index). In the
     64-lane layout the observations are spread over the lanes whatever their county (observation i
     on lane i mod 64) and a county's owner lane adds up its observations' contributions
-    (exmc_models.hpp Radon); at most 1024 observations. sort_counties=False keeps the file order
+    (exmc_models.hpp Radon); at most 1024 observations -- larger data is compiled by the generator into
+    a lane layout of its own (a GeneratedSpec comes back). sort_counties=False keeps the file order
     (any order is valid input for the library; with the sorted one the longest owner sums sit in
     the first dimension slot)."""
     u, start, floor, y = data if data is not None else radon_data()
@@ -181,6 +182,15 @@ def radon(data=None, sort_counties=True):
                                                      "sigma_y", "beta"]
     init = {nm: 0.0 for nm in names}
     init.update(sigma_alpha=1.0, sigma_y=1.0)
+    if len(y) > 1024 and not builtin:   # builtin=True: the kind's own spec whatever the size (the CPU checker takes any)
+        # The built-in kind's 64-lane layout gives a lane 16 observation slots (exmc_hip.h:
+        # EXMC_ERR_UNSUPPORTED above 1024 observations). Larger data goes through the generator: the
+        # same model as Builder nodes (codegen.radon_ir), compiled into a lane layout whose observation
+        # walk is as long as the data needs -- same names, same kernel order, same default init.
+        from . import codegen
+        ir = codegen.radon_ir(u, start, floor, y, names=names[:J])
+        return codegen.compile_ir(ir, ncp=False, name="radon_n%d" % len(y), default_init=init, lanes=64,
+                                  waves_per_simd=1)
     blob = np.concatenate([np.asarray(u, float), np.asarray(start, float), np.asarray(floor, float),
                            np.asarray(y, float)])
     return ModelSpec(RADON, "radon", blob, names, {"sigma_alpha": "log", "sigma_y": "log"}, init)

@@ -266,5 +266,14 @@ int enif_thread_create(char* name, ErlNifTid* tid, void* (*func)(void*), void* a
 int enif_thread_join(ErlNifTid tid, void** exit_value) { return pthread_join((pthread_t)(size_t)tid, exit_value); }
 ErlNifTid enif_thread_self(void) { return (ErlNifTid)(size_t)pthread_self(); }
 int enif_equal_tids(ErlNifTid a, ErlNifTid b) { return pthread_equal((pthread_t)(size_t)a, (pthread_t)(size_t)b); }
+ErlNifMutex* enif_mutex_create(char* name) {
+  (void)name;
+  pthread_mutex_t* m = (pthread_mutex_t*)malloc(sizeof(pthread_mutex_t));
+  pthread_mutex_init(m, NULL);
+  return (ErlNifMutex*)m;
+}
+void enif_mutex_destroy(ErlNifMutex* m) { pthread_mutex_destroy((pthread_mutex_t*)m); free(m); }
+void enif_mutex_lock(ErlNifMutex* m) { pthread_mutex_lock((pthread_mutex_t*)m); }
+void enif_mutex_unlock(ErlNifMutex* m) { pthread_mutex_unlock((pthread_mutex_t*)m); }
 void* enif_alloc(size_t size) { return malloc(size); }
 void enif_free(void* ptr) { free(ptr); }

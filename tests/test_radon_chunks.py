@@ -56,3 +56,26 @@ def test_county_order_is_only_a_relabelling():
     assert abs(la - lb) <= 1e-12 * abs(lb)
     gb_in_a = np.array([gb[b.var_names.index(n)] for n in a.var_names])
     assert np.allclose(ga, gb_in_a, rtol=1e-11, atol=1e-11)
+
+
+def test_more_than_1024_observations_go_through_the_generator():
+    """The built-in radon kind holds at most 1024 observations (16 slots per lane); models.radon
+    routes larger data through the generator (codegen.radon_ir -> a lane layout of its own) instead
+    of refusing it. The generated text equals the hand-written checker model to 1e-12."""
+    import gen_checker as GC
+    import gen_models as GM
+    data = models.radon_data(seed=3, n_counties=85, n_obs=1500)
+    spec = models.radon(data)
+    hand = models.radon(data, builtin=True)
+    assert hasattr(spec, "gen") and spec.d == hand.d == 90
+    assert sorted(spec.var_names) == sorted(hand.var_names) and spec.default_init == hand.default_init
+    om = O.model_for(hand)
+    idx = GM.to_spec_order(spec.gen, hand)
+    rng = np.random.default_rng(8)
+    q0 = hand.to_unconstrained(hand.default_init)
+    for t in range(20):
+        q = q0 + 0.3 * rng.normal(size=hand.d) * (1 + t % 3)
+        lp_o, g_o = om.logp_grad(q, O.Cfg(0, 1))
+        lp_g, g_g = GC.logp_grad(spec.gen, q[idx], lanes=64)
+        assert abs(lp_g - lp_o) <= 1e-12 * max(1.0, abs(lp_o))
+        assert np.all(np.abs(g_g - g_o[idx]) <= 1e-12 * max(1.0, np.max(np.abs(g_o))))
