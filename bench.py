@@ -371,6 +371,14 @@ def cpu_baseline(spec, init, K, n_chains_total, budget_s=15.0, max_chains=None):
             x = np.ascontiguousarray(t["draws"][c, :, i])
             ess[i] += L.exo_ess(O.dptr(x), K)
     ess_min = float(ess.min()) * n / sub
+    # The sample is smaller than the GPU's batch whenever a chain costs about a second (sv), and its
+    # wall clock holds the serial warmup once: per chain that overhead is larger than in a run of
+    # all n_chains_total chains. The same legs scaled to the GPU's chain count (serial warmup once,
+    # chains at the sample's measured rate per thread) give the ratio at EQUAL chains per run.
+    warm_s = max(one - per_chain, 0.0)
+    sample_rate = max(wall - warm_s, 1e-9) / n                       # seconds per chain with `cores` threads busy
+    wall_eq = warm_s + sample_rate * n_chains_total
+    ess_eq = ess_min * n_chains_total / n
     return {
         "value": st.total_leapfrogs / wall,
         "unit": "leapfrog_steps/s",
@@ -382,6 +390,9 @@ def cpu_baseline(spec, init, K, n_chains_total, budget_s=15.0, max_chains=None):
         "ess_per_s": ess_min / wall,
         "chains": n,
         "wall_s": wall,
+        "ess_per_s_at_equal_chains": ess_eq / wall_eq,
+        "equal_chains": {"chains": n_chains_total, "wall_s_extrapolated": wall_eq, "serial_warmup_s": warm_s,
+                         "note": "the sample's per-chain rate scaled to the GPU leg's chain count, serial warmup once"},
     }
 
 
@@ -566,7 +577,8 @@ def run_model(args, model, rank, local_rank, world, dev, dist, barrier, primary)
                               max_chains=None if primary else 256)
             out["cpu_baseline"] = cb
             out["gpu_over_cpu"] = {"leapfrog_steps_per_s": value / cb["value"],
-                                   "ess_per_s": out["ess_per_s"] / cb["ess_per_s"]}
+                                   "ess_per_s": out["ess_per_s"] / cb["ess_per_s"],
+                                   "ess_per_s_at_equal_chains": out["ess_per_s"] / cb["ess_per_s_at_equal_chains"]}
         comp.close()
         return out, ok
     comp.close()

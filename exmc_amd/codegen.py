@@ -47,6 +47,8 @@ import hashlib
 import math
 import os
 import subprocess
+import sys
+import time
 
 import numpy as np
 
@@ -1404,35 +1406,65 @@ def build_plugin(gen, force=False, verbose=False):
                 print(" ".join(cmd))
             subprocess.check_call(cmd, cwd=cwd)
         else:
-            # the four heavy kernels (sampling, its stream form, the two warmup forms) as translation
-            # units of their own next to the rest of the library, compiled side by side: the plug-in is
-            # ready in the time of its slowest part (the analogue of the EXLA JIT step, jit.ex)
+            # The model-dependent kernels (sampling, its stream form, the two warmup forms, the four
+            # auxiliary kernels) are compiled DEVICE-ONLY, one code object per part, side by side; the
+            # rest of the library (host code, the C ABI) is one more unit next to them, compiled with
+            # -DEXMC_PLUGIN_MODULES: it launches those kernels by their device-side names through
+            # hipModuleLaunchKernel from the code objects embedded in the library as data
+            # (exmc_hip.hip "launching the model-dependent kernels"). The plug-in is ready in the time of
+            # its slowest device pass plus a link -- no host pass, no host stubs for the parts (the
+            # analogue of the EXLA JIT step, jit.ex; EXMC_PLUGIN_STUBS=1 builds the round-3 form, every
+            # part a host + device unit launched through its stub).
             part_src = os.path.join(cwd, "exmc_plugin_part.hip")
-            # (the host pass of every part at -O0: launch code, nothing numeric; a third of a part's time)
-            flags = flags + ["-Xarch_host", "-O0"]
+            modules = os.environ.get("EXMC_PLUGIN_STUBS") != "1"
+            host_flags = flags + ["-Xarch_host", "-O0"]   # launch code, nothing numeric
             common = _build.build_common()
-            jobs = [([hipcc] + flags + defs + ["-DEXMC_PLUGIN_SPLIT", "-DEXMC_COMMON_DECL_ONLY", "-c", "-o",
-                                              "%s.main.o" % tmp, _build.SRC])]
+            main_defs = ["-DEXMC_PLUGIN_SPLIT", "-DEXMC_COMMON_DECL_ONLY"] + (["-DEXMC_PLUGIN_MODULES"] if modules else [])
+            jobs = [([hipcc] + host_flags + defs + main_defs + ["-c", "-o", "%s.main.o" % tmp, _build.SRC])]
             layouts = [k for k, macro in ((1, "EXMC_GEN_ONE_LANE"), (2, "EXMC_GEN_VEC"), (3, "EXMC_GEN_LANES "))
                        if ("#define " + macro) in gen.header]
-            jobs += [([hipcc] + flags + defs + ["-DEXMC_PLUGIN_PART=%d" % k, "-DEXMC_PLUGIN_LAYOUT=%d" % lay, "-c", "-o",
-                                               "%s.p%d_%d.o" % (tmp, k, lay), part_src])
-                     for k in (3, 4, 1, 2, 5) for lay in layouts]
+            parts = [(k, lay) for k in (3, 4, 1, 2, 5) for lay in layouts]
             if 3 in layouts and gen.lanes < 64:     # the one-chain warmup form of the lane layout (CustomSplit)
-                jobs += [([hipcc] + flags + defs + ["-DEXMC_PLUGIN_PART=%d" % k, "-DEXMC_PLUGIN_LAYOUT=3", "-c", "-o",
-                                                   "%s.p%d_3.o" % (tmp, k), part_src]) for k in (6,)]
+                parts.append((6, 3))
+            part_flags = ([f for f in flags if f != "-fPIC"] + ["--cuda-device-only"]) if modules else host_flags
+            ext = "hsaco" if modules else "o"
+            jobs += [([hipcc] + part_flags + defs + ["-DEXMC_PLUGIN_PART=%d" % k, "-DEXMC_PLUGIN_LAYOUT=%d" % lay, "-c", "-o",
+                                                    "%s.p%d_%d.%s" % (tmp, k, lay, ext), part_src]) for k, lay in parts]
             objs = [j[j.index("-o") + 1] for j in jobs]
             if verbose:
                 for j in jobs:
                     print(" ".join(j))
+            t_start = time.time()
             procs = [subprocess.Popen(j, cwd=cwd) for j in jobs]
+            if modules:
+                # while the compilers run: the table of embedded code objects, as assembler source
+                blob_s, blob_o = "%s.blobs.S" % tmp, "%s.blobs.o" % tmp
+                with open(blob_s, "w") as f:
+                    f.write('\t.section .rodata.exmc_blobs,"a",@progbits\n')
+                    for i, o in enumerate(objs[1:]):
+                        f.write("\t.balign 4096\nexmc_blob_%d:\n\t.incbin \"%s\"\nexmc_blob_%d_end:\n" % (i, o, i))
+                    f.write('\t.section .data.rel.ro.exmc_blob_table,"aw",@progbits\n\t.balign 8\n'
+                            "\t.globl exmc_blob_table\n\t.type exmc_blob_table,@object\nexmc_blob_table:\n")
+                    for i in range(len(objs) - 1):
+                        f.write("\t.quad exmc_blob_%d\n\t.quad exmc_blob_%d_end\n" % (i, i))
+                    f.write("\t.quad 0\n\t.quad 0\n\t.size exmc_blob_table, .-exmc_blob_table\n"
+                            '\t.section .note.GNU-stack,"",@progbits\n')
             rcs = [p_.wait() for p_ in procs]
             if any(rcs):
                 raise subprocess.CalledProcessError(max(rcs), jobs[rcs.index(max(rcs))])
-            link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs + [common]
+            t_compiled = time.time()
+            link_objs = objs
+            if modules:
+                subprocess.check_call(["gcc", "-c", "-o", blob_o, blob_s], cwd=cwd)   # .incbin reads the code objects now
+                link_objs = [objs[0], blob_o]
+                objs = objs + [blob_s, blob_o]
+            link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + link_objs + [common]
             if verbose:
                 print(" ".join(link))
             subprocess.check_call(link, cwd=cwd)
+            if os.environ.get("EXMC_PLUGIN_TIMING"):
+                print("[exmc plug-in] %d units compiled side by side in %.2f s, link %.2f s" % (
+                    len(jobs), t_compiled - t_start, time.time() - t_compiled), file=sys.stderr)
         os.replace(tmp, so)
     finally:
         for f in [tmp] + objs:

@@ -13,7 +13,9 @@
 #include <cstring>
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/exmc_zig_tables.h"
@@ -96,6 +98,89 @@ struct DevBuf {
   template <class T>
   T* as() const { return (T*)p; }
 };
+
+// ---- launching the model-dependent kernels --------------------------------------------------
+// libexmc_hip.so and one-unit plug-ins: the kernel is an instantiation of this translation unit,
+// launched through its host stub. A plug-in built in parts with -DEXMC_PLUGIN_MODULES (the default
+// of exmc_amd/codegen.py build_plugin since round 4): the model-dependent kernels are compiled
+// DEVICE-ONLY, one code object per part, embedded in the library as data (exmc_blob_table, written
+// by the build next to this unit) and loaded with hipModuleLoadData on first use; a launch looks the
+// kernel up by its device-side mangled name and goes through hipModuleLaunchKernel. No host pass is
+// spent on the parts and no host stub exists for these kernels -- SURVEY section 8 row f3's "IR ->
+// kernel via a run-time compiled code object", with hipcc's device pass in the role of hiprtc.
+#ifdef EXMC_PLUGIN_MODULES
+extern "C" const unsigned char* const exmc_blob_table[];   // start_0, end_0, start_1, end_1, ..., null
+struct ModSet {
+  int device = -1;
+  std::vector<hipModule_t> mods;
+  std::unordered_map<std::string, hipFunction_t> fns;
+};
+std::mutex g_mod_mu;
+std::vector<ModSet*> g_modsets;
+
+// the function `name` of this plug-in's code objects on `device` (the current device of the caller)
+hipError_t mod_function(int device, const char* name, hipFunction_t* out) {
+  std::lock_guard<std::mutex> lock(g_mod_mu);
+  ModSet* ms = nullptr;
+  for (ModSet* x : g_modsets)
+    if (x->device == device) ms = x;
+  if (!ms) {
+    ms = new ModSet;
+    ms->device = device;
+    for (int i = 0; exmc_blob_table[2 * i] != nullptr; i++) {
+      hipModule_t mod = nullptr;
+      const hipError_t e = hipModuleLoadData(&mod, exmc_blob_table[2 * i]);
+      if (e != hipSuccess) {
+        for (hipModule_t m_ : ms->mods) (void)hipModuleUnload(m_);
+        delete ms;
+        return e;
+      }
+      ms->mods.push_back(mod);
+    }
+    g_modsets.push_back(ms);
+  }
+  auto it = ms->fns.find(name);
+  if (it != ms->fns.end()) {
+    *out = it->second;
+    return hipSuccess;
+  }
+  // (a kernel lives in one of the code objects: the lookups in the others fail, and the runtime
+  // remembers the last failure -- it is not the caller's error, whichever way the search ends)
+  hipFunction_t found = nullptr;
+  for (hipModule_t mod : ms->mods) {
+    hipFunction_t f = nullptr;
+    if (hipModuleGetFunction(&f, mod, name) == hipSuccess && f) {
+      found = f;
+      break;
+    }
+  }
+  (void)hipGetLastError();
+  if (!found) return hipErrorInvalidDeviceFunction;
+  ms->fns.emplace(name, found);
+  *out = found;
+  return hipSuccess;
+}
+
+template <class... A>
+hipError_t mod_launch(int device, const char* name, dim3 grid, dim3 block, size_t lds, hipStream_t stream,
+                      A... args) {
+  hipFunction_t f = nullptr;
+  const hipError_t e = mod_function(device, name, &f);
+  if (e != hipSuccess) return e;
+  void* params[] = {(void*)&args...};
+  return hipModuleLaunchKernel(f, grid.x, grid.y, grid.z, block.x, block.y, block.z, (unsigned)lds, stream,
+                               params, nullptr);
+}
+// (the kernel arguments are passed by value exactly as the kernel declares them: every call site
+// hands over the parameter structs themselves)
+#define EXMC_KLAUNCH(dev, kernel, grid, block, lds, stream, ...)   HIP_TRY(mod_launch((dev), __builtin_get_device_side_mangled_name kernel, (grid), (block), (lds), (stream), __VA_ARGS__))
+// dynamic LDS above 64 KB needs no opt-in for a module function on this runtime; a launch that asks
+// for more than the device has fails in hipModuleLaunchKernel
+#define EXMC_KMAXLDS(kernel, bytes)   do {                                } while (0)
+#else
+#define EXMC_KLAUNCH(dev, kernel, grid, block, lds, stream, ...)   hipLaunchKernelGGL(kernel, (grid), (block), (lds), (stream), __VA_ARGS__)
+#define EXMC_KMAXLDS(kernel, bytes)   HIP_TRY(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)))
+#endif
 
 }  // namespace
 
@@ -432,8 +517,8 @@ int launch_init(exmc_hip_model* m, int lanes, int C, int chain_lo, uint64_t seed
   auto launch = [&](auto tag, const auto& mc) {
     using T = decltype(tag);
     const size_t xlds = aux_lds_bytes<typename T::M>();
-    hipLaunchKernelGGL((init_chains_kernel<typename T::M, T::G>), grid_for(C, T::G, kBlock),
-                       dim3(kBlock), xlds, m->stream, P, mc);
+    EXMC_KLAUNCH(m->device, (init_chains_kernel<typename T::M, T::G>), grid_for(C, T::G, kBlock),
+                 dim3(kBlock), xlds, m->stream, P, mc);
     HIP_TRY(hipGetLastError());
     return (int)EXMC_OK;
   };
@@ -499,8 +584,8 @@ int launch_nuts(exmc_hip_model* m, int lanes, int C, int n_draws, int draw_offse
       if constexpr (kStreamKernel<M>) {
         if (timed) HIP_TRY(hipEventRecord(m->ev0, m->stream));
         const size_t lds_s = nuts_lds_bytes<M, T::LDSL, M::kNutsZigInLds>();
-        hipLaunchKernelGGL((nuts_kernel<M, T::G, T::LDSL, false, true>), grid, dim3(kNutsBlock), lds_s,
-                           m->stream, P, mc);
+        EXMC_KLAUNCH(m->device, (nuts_kernel<M, T::G, T::LDSL, false, true>), grid, dim3(kNutsBlock), lds_s,
+                     m->stream, P, mc);
         HIP_TRY(hipGetLastError());
         if (timed) HIP_TRY(hipEventRecord(m->ev1, m->stream));
         return (int)EXMC_OK;
@@ -549,8 +634,8 @@ int launch_nuts(exmc_hip_model* m, int lanes, int C, int n_draws, int draw_offse
         P.stack = m->stack.as<double>();
         if (timed) HIP_TRY(hipEventRecord(m->ev0, m->stream));
         const size_t lds_p = nuts_lds_bytes<M, PL>() + pipe_lds_doubles<M::DPL>() * 8;
-        hipLaunchKernelGGL((nuts_kernel<M, T::G, PL, true>), grid, dim3(2 * kNutsBlock), lds_p,
-                           m->stream, P, mc);
+        EXMC_KLAUNCH(m->device, (nuts_kernel<M, T::G, PL, true>), grid, dim3(2 * kNutsBlock), lds_p,
+                     m->stream, P, mc);
         HIP_TRY(hipGetLastError());
         if (timed) HIP_TRY(hipEventRecord(m->ev1, m->stream));
         return (int)EXMC_OK;
@@ -559,10 +644,9 @@ int launch_nuts(exmc_hip_model* m, int lanes, int C, int n_draws, int draw_offse
     if (timed) HIP_TRY(hipEventRecord(m->ev0, m->stream));
     const size_t lds_bytes = nuts_lds_bytes<M, T::LDSL, M::kNutsZigInLds>();
     if (lds_bytes > 64 * 1024)   // the lane layouts' dense mass keeps M^-1 in LDS
-      HIP_TRY(hipFuncSetAttribute((const void*)nuts_kernel<M, T::G, T::LDSL>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    hipLaunchKernelGGL((nuts_kernel<M, T::G, T::LDSL>), grid, dim3(kNutsBlock), lds_bytes,
-                       m->stream, P, mc);
+      EXMC_KMAXLDS((nuts_kernel<M, T::G, T::LDSL>), lds_bytes);
+    EXMC_KLAUNCH(m->device, (nuts_kernel<M, T::G, T::LDSL>), grid, dim3(kNutsBlock), lds_bytes,
+                 m->stream, P, mc);
     HIP_TRY(hipGetLastError());
     if (timed) HIP_TRY(hipEventRecord(m->ev1, m->stream));
     if (P.mig && std::getenv("EXMC_HIP_MIGRATE_STATS")) {
@@ -784,8 +868,8 @@ int find_eps(exmc_hip_model* m, int lanes, double* eps) {
   int rc = dispatch(m, lanes, [&](auto tag, const auto& mc) {
     using T = decltype(tag);
     const size_t lds_bytes = nuts_lds_bytes<typename T::M, 0>();
-    hipLaunchKernelGGL((find_eps_kernel<typename T::M, T::G>), dim3(1), dim3(kNutsBlock), lds_bytes,
-                       m->stream, P, mc);
+    EXMC_KLAUNCH(m->device, (find_eps_kernel<typename T::M, T::G>), dim3(1), dim3(kNutsBlock), lds_bytes,
+                 m->stream, P, mc);
     HIP_TRY(hipGetLastError());
     return (int)EXMC_OK;
   });
@@ -945,22 +1029,20 @@ int run_warmup_device(exmc_hip_model* m, int lanes, exmc_hip_opts o, exmc_hip_tu
       if (pipe) {
         lds_bytes += pipe_lds_doubles<M::DPL>() * 8;
         if (lds_bytes > 64 * 1024)
-          HIP_TRY(hipFuncSetAttribute((const void*)warmup_kernel<M, T::G, T::LDSL, true>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+          EXMC_KMAXLDS((warmup_kernel<M, T::G, T::LDSL, true>), lds_bytes);
         HIP_TRY(hipEventRecord(m->ev0, m->stream));
-        hipLaunchKernelGGL((warmup_kernel<M, T::G, T::LDSL, true>), dim3(reps), dim3(2 * kNutsBlock),
-                           lds_bytes, m->stream, P, mc);
+        EXMC_KLAUNCH(m->device, (warmup_kernel<M, T::G, T::LDSL, true>), dim3(reps), dim3(2 * kNutsBlock),
+                     lds_bytes, m->stream, P, mc);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(m->ev1, m->stream));
         return (int)EXMC_OK;
       }
     }
     if (lds_bytes > 64 * 1024)
-      HIP_TRY(hipFuncSetAttribute((const void*)warmup_kernel<M, T::G, T::LDSL>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+      EXMC_KMAXLDS((warmup_kernel<M, T::G, T::LDSL>), lds_bytes);
     HIP_TRY(hipEventRecord(m->ev0, m->stream));
-    hipLaunchKernelGGL((warmup_kernel<M, T::G, T::LDSL>), dim3(reps), dim3(kNutsBlock), lds_bytes,
-                       m->stream, P, mc);
+    EXMC_KLAUNCH(m->device, (warmup_kernel<M, T::G, T::LDSL>), dim3(reps), dim3(kNutsBlock), lds_bytes,
+                 m->stream, P, mc);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(m->ev1, m->stream));
     return (int)EXMC_OK;
@@ -1303,8 +1385,8 @@ int exmc_hip_logp_grad_host(exmc_hip_model* m, const double* q, int C, int lanes
   rc = dispatch(m, lanes, [&](auto tag, const auto& mc) {
     using T = decltype(tag);
     const size_t xlds = aux_lds_bytes<typename T::M>();
-    hipLaunchKernelGGL((logp_grad_kernel<typename T::M, T::G>), grid_for(C, T::G, kBlock),
-                       dim3(kBlock), xlds, m->stream, (const double*)dq, C, dl, dg, mc);
+    EXMC_KLAUNCH(m->device, (logp_grad_kernel<typename T::M, T::G>), grid_for(C, T::G, kBlock),
+                 dim3(kBlock), xlds, m->stream, (const double*)dq, (int)C, (double*)dl, (double*)dg, mc);
     HIP_TRY(hipGetLastError());
     return (int)EXMC_OK;
   });
@@ -1343,8 +1425,8 @@ int exmc_hip_multi_step(exmc_hip_model* m, const double* q, const double* p, con
     using T = decltype(tag);
     HIP_TRY(hipEventRecord(m->ev0, m->stream));
     const size_t xlds = aux_lds_bytes<typename T::M>();
-    hipLaunchKernelGGL((multi_step_kernel<typename T::M, T::G>), grid_for(n_chains, T::G, kBlock),
-                       dim3(kBlock), xlds, m->stream, P, mc);
+    EXMC_KLAUNCH(m->device, (multi_step_kernel<typename T::M, T::G>), grid_for(n_chains, T::G, kBlock),
+                 dim3(kBlock), xlds, m->stream, P, mc);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(m->ev1, m->stream));
     return finish_timing(m);

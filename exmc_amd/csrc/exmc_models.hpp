@@ -392,7 +392,10 @@ struct SV : ModelDefaults {
   // one scratch access inside the leaf loop) two are, and the pair issues every ~3.5
   // (4096 chains x 200 draws: 1307 -> 950 ms)
   static constexpr int kNutsWavesPerSimd = (G == 64) ? 2 : 1;
-  static constexpr bool kXRowLds = (G == 64);
+#ifndef EXMC_SV_XROW_LDS
+#define EXMC_SV_XROW_LDS 1
+#endif
+  static constexpr bool kXRowLds = (G == 64) && (EXMC_SV_XROW_LDS != 0);
   static constexpr bool kMigrate = (G == 64);
   // G = 64: a transition is ~340 leapfrogs and one momentum draw; the 6 KB of the tables buy the
   // third stack level in LDS (3 x 6.5 KB = 19.5 KB: still eight workgroups per CU), which halves

@@ -773,13 +773,25 @@ def test_resident_chains_advance_in_pieces_with_migration(hip, monkeypatch):
 
 def test_radon_refuses_more_observations_than_its_lane_layout_holds(hip):
     """The radon kind's 64-lane layout gives every lane 16 observation slots: 1024 observations are
-    the most it takes, and the library says so instead of walking off its strips."""
+    the most it takes, and the library says so instead of walking off its strips. models.radon does
+    not hand it such data: above 1024 observations it returns the generated form of the same model
+    (codegen.radon_ir, a lane layout of its own), which samples bit for bit like its CPU text."""
+    import gen_checker as GC
     rng = np.random.default_rng(3)
     J, N = 85, 1100
     sizes = np.full(J, N // J)
     sizes[: N - sizes.sum()] += 1
     start = np.concatenate([[0], np.cumsum(sizes)])
     data = (rng.normal(size=J), start, (rng.uniform(size=N) < 0.2).astype(float), rng.normal(size=N))
-    spec = models.radon(data)
     with pytest.raises(_lib.ExmcHipError, match="1024 observations"):
-        sampler.compile(spec)
+        sampler.compile(models.radon(data, builtin=True))
+    spec = models.radon(data)
+    assert hasattr(spec, "gen") and spec.d == 90
+    comp = sampler.compile(spec)
+    q = 0.2 * rng.normal(size=(6, spec.d))
+    lp = np.zeros(6)
+    g = np.zeros((6, spec.d))
+    comp.check(comp.L.exmc_hip_logp_grad_host(comp.h, sampler._dp(np.ascontiguousarray(q)), 6, 64, sampler._dp(lp), sampler._dp(g)))
+    for c in range(6):
+        lp_c, g_c = GC.logp_grad(spec.gen, q[c], lanes=64)
+        assert lp[c] == lp_c and np.array_equal(g[c], g_c)
