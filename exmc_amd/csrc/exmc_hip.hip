@@ -316,7 +316,7 @@ int dispatch(exmc_hip_model* m, int lanes, F&& f) {
       break;
 #elif EXMC_DEV_ONLY == EXMC_DEV_RADON64
     case EXMC_MODEL_RADON:
-      if (lanes == 64) return f(Tag<Radon<64>, 64, 2>{}, m->rd);
+      if (lanes == 64) return f(Tag<Radon<64>, 64, 3>{}, m->rd);
       break;
 #elif EXMC_DEV_ONLY == EXMC_DEV_LOGISTIC16
     case EXMC_MODEL_LOGISTIC:
@@ -357,7 +357,7 @@ int dispatch(exmc_hip_model* m, int lanes, F&& f) {
     case EXMC_MODEL_RADON:
       switch (lanes) {
         case 32: return f(Tag<Radon<32>, 32, 2>{}, m->rd);
-        case 64: return f(Tag<Radon<64>, 64, 2>{}, m->rd);
+        case 64: return f(Tag<Radon<64>, 64, 3>{}, m->rd);
         default: break;
       }
       break;
