@@ -457,6 +457,14 @@ def main():
         if rank == 0:
             out["models"] = {"sv": sv}
     if rank == 0:
+        # the batched-leapfrog roofline leg and the CPU checker's legs, after the sampling legs of the line
+        # (see run_model)
+        legs = [out] + list(out.get("models", {}).values())
+        for key in ("_gpu_leg", "_cpu_leg"):
+            for o in legs:
+                leg = o.pop(key, None)
+                if leg is not None:
+                    leg()
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
@@ -565,20 +573,40 @@ def run_model(args, model, rank, local_rank, world, dev, dist, barrier, primary)
                            traffic=measured_traffic(model, Cper, S, lanes))
     if rank == 0:
         value, local_lf = out["value"], float(leap_local)
+        if model == "eight_schools":
+            # the HBM fraction of this kernel has a ceiling that is not HBM
+            out["roofline"]["note"] = ("issue-bound, not HBM-bound: chain state never leaves registers / LDS (counter traffic = the "
+                                       "trace write); 4096 chains x 16 lanes are one wave per SIMD, which issues at 0.88 of a lone "
+                                       "wave's rate; 0.40 of HBM peak would need <= 61 instructions per leapfrog, the kernel "
+                                       "executes 198 (DESIGN.md section 5)")
         ri = issue_roofline(model, Cper, S, lanes, kernel_ms, local_lf) if world == 1 else None
         if ri:
             out["roofline_issue"] = ri
         if world == 1 and model == "eight_schools" and not args.no_multi_step:
-            # the B2 batched-leapfrog contract at a batch that fills the chip (not the timed path)
-            out["roofline_multi_step"] = multi_step_roofline(comp, spec, dev)
+            # the B2 batched-leapfrog contract at a batch that fills the chip (not the timed path). It runs
+            # after every sampling leg of the line: its 2 GB of buffers, allocated and freed between the
+            # two models' legs, made the sv launch that followed 6 % slower in two runs of three (1693 /
+            # 1697 / 1602 ms against 1593-1605 without it, tools/r4_sv_variance.sh, profiles/r4_driver_cmd)
+            def multi_step_leg():
+                c2 = sampler.compile(spec, {"device": local_rank})
+                try:
+                    out["roofline_multi_step"] = multi_step_roofline(c2, spec, dev)
+                finally:
+                    c2.close()
+                    torch.cuda.empty_cache()
+            out["_gpu_leg"] = multi_step_leg
         if world == 1 and not args.no_cpu:
-            # the second model's CPU leg is bounded tighter (sv: about one second per chain per core)
-            cb = cpu_baseline(spec, init, S, Ctot, budget_s=15.0 if primary else 8.0,
-                              max_chains=None if primary else 256)
-            out["cpu_baseline"] = cb
-            out["gpu_over_cpu"] = {"leapfrog_steps_per_s": value / cb["value"],
-                                   "ess_per_s": out["ess_per_s"] / cb["ess_per_s"],
-                                   "ess_per_s_at_equal_chains": out["ess_per_s"] / cb["ess_per_s_at_equal_chains"]}
+            # The CPU legs run after EVERY GPU leg of the line (main calls these): nothing host-side
+            # sits between the two models' GPU legs
+            def cpu_leg():
+                # the second model's CPU leg is bounded tighter (sv: about one second per chain per core)
+                cb = cpu_baseline(spec, init, S, Ctot, budget_s=15.0 if primary else 8.0,
+                                  max_chains=None if primary else 256)
+                out["cpu_baseline"] = cb
+                out["gpu_over_cpu"] = {"leapfrog_steps_per_s": value / cb["value"],
+                                       "ess_per_s": out["ess_per_s"] / cb["ess_per_s"],
+                                       "ess_per_s_at_equal_chains": out["ess_per_s"] / cb["ess_per_s_at_equal_chains"]}
+            out["_cpu_leg"] = cpu_leg
         comp.close()
         return out, ok
     comp.close()
