@@ -9,7 +9,11 @@ untimed steps are taken on throw-away chains, the chains are initialised again, 
 (one launch of the NUTS kernel, one trace of K * draws-per-step rows) are timed between
 barrier + synchronize pairs. value = useful leapfrogs (sum of n_steps, tree.ex:1612) per second
 over all GPUs; ESS/s (adaptation + sampling + the ESS kernel + the gather), the roofline of the
-NUTS kernel and the CPU checker's numbers ride along.
+NUTS kernel and the CPU checker's numbers ride along. Order of the default run: the eight_schools
+sampling leg, the sv sampling leg (BASELINE.json's metric names both), then -- after every sampling leg
+-- the batched-leapfrog roofline leg and the CPU checker's legs (profiles/r4_driver_cmd/README.md says
+why the order matters). Split R-hat is computed on two independent routes that must agree to 1e-9,
+or every rank exits with code 3 (finish_model).
 
     python bench.py --gpus N --steps K --warmup W      (N > 1 without a launcher: spawns the ranks)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
