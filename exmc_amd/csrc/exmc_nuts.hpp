@@ -156,10 +156,14 @@ struct NutsParams {
 //   board[16392 + 2 b]    mailbox of workgroup b: chain + 1 (0: empty), draws done
 //   board[16392 + 2 W + b]  (W workgroups) what workgroup b estimates is left of its chain, in
 //                         thousands of leapfrogs + 1 (0: not known yet): its SIMD partner reads it
+//   board[16392 + 3 W + 2 u + s]  the occupants of SIMD u: the workgroup that arrived there s-th
+//                         (s = 0, 1), + 1 (0: nobody yet) -- how a wave finds its SIMD partner
 constexpr int kMigSimds = 16384;
 constexpr int kMigLive = 8;
 constexpr int kMigMail = kMigLive + kMigSimds;
-__host__ __device__ constexpr size_t mig_board_ints(size_t n_workgroups) { return kMigMail + 3 * n_workgroups; }
+__host__ __device__ constexpr size_t mig_board_ints(size_t n_workgroups) {
+  return kMigMail + 3 * n_workgroups + 2 * (size_t)kMigSimds;
+}
 
 __device__ __forceinline__ int mig_simd_uid() {
   unsigned xcc, hw;
@@ -1372,10 +1376,11 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock, M::kNutsW
   lane_setup<M, G, LDSL, kZig>(L, mc, lds, P.stack, P.inv_mass, P.sqrt_inv_mass, zt, P.nor_r, P.flat, P.dm);
   if constexpr (M::kLdsDataDoubles > 0) L.ln.xoff = xoff;
   L.alive = has_chain;
-  // workgroups i and i + simds land on the same SIMD (one wave each, dispatch in order: every
-  // pair of the 2048-wave sv launch on 1024 SIMDs, tools/sv_probe.sh): the second half are the younger
-  // waves. That is a statement about a launch of exactly two waves per SIMD on a whole device; any
-  // other grid (a partial device, a CU mask, more than two rounds of waves) keeps the arbiter's order.
+  // workgroups i and i + simds USUALLY land on the same SIMD (one wave each, dispatch in order:
+  // tools/sv_probe.sh), the second half being the younger waves: good enough for the even shares of
+  // launches without a migration board (short launches, logistic); the migration loop below finds
+  // the real partner instead (tools/r4_sv_pairs.sh). Any grid other than exactly two waves per SIMD of
+  // the whole device keeps the arbiter's order.
   if constexpr (M::kNutsWavesPerSimd == 2 && !kPipe)
     L.prio_slot = (P.prio && P.simds > 0 && (int)gridDim.x == 2 * P.simds) ? (int)(blockIdx.x >= (unsigned)P.simds) : -1;
   using Pipe = std::conditional_t<kPipe, PipeBox<DPL>, NoPipe>;
@@ -1509,19 +1514,47 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock, M::kNutsW
     if (P.mig != nullptr && P.n_draws > 0) {
       // chain migration (see MigBoard above); everything here is wave-uniform
       int* const board = P.mig;
-      int* const live = board + kMigLive + mig_simd_uid();
+      const int simd_uid = mig_simd_uid();
+      int* const live = board + kMigLive + simd_uid;
       int* const mail = board + kMigMail + 2 * (int)blockIdx.x;
       int cur = chain, done = 0;
-      if (lane == 0) atomicAdd(live, 1);
-      // what is left of the two chains of this SIMD (workgroups b and b + 1024): the shares of the
-      // issue priority follow it, so that both end together instead of the longer one running on
-      // alone. remaining = leapfrogs per draw so far x draws to go, known to the partner one
-      // transition late; with the pair's rates (291 with the priority, 169 without, of 460) the
-      // share f of slot 0 that makes the rates proportional to rho = left_0 / left_1 is
-      // (291 rho - 169) / (122 (1 + rho)).
+      // Who shares this SIMD is found out, not assumed. In a launch of exactly two waves per SIMD the
+      // dispatcher USUALLY puts workgroups b and b + simds on one SIMD (1024 pairs of 1024 in 31 of 32
+      // probed launches) -- and sometimes does not (25 of 1024, tools/r4_sv_pairs.sh), and then a
+      // priority schedule negotiated between strangers costs the launch 3 to 7 %: the slow state of
+      // round 3's and round 4's driver-command runs. So every wave enters itself in its SIMD's
+      // occupant list in arrival order; the first to arrive is slot 0 (it is the older wave, the one
+      // the arbiter prefers when priorities are equal), and the partner is whoever holds the other slot.
+      int arrival = 0;
+      if (lane == 0) arrival = atomicAdd(live, 1);
+      arrival = __builtin_amdgcn_readfirstlane(arrival);
+      int* const occupants = board + kMigMail + 3 * (int)gridDim.x + 2 * simd_uid;
+      const bool two_per_simd = P.prio && P.simds > 0 && (int)gridDim.x == 2 * P.simds;
+      const bool listed = two_per_simd && arrival < 2;
+      int partner = -1;
+      if (listed) {
+        if (lane == 0) __hip_atomic_store(occupants + arrival, (int)blockIdx.x + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the other occupant enters itself within microseconds of this one (all waves of the launch are
+        // dispatched at once); a wave that is alone on its SIMD gives up after ~0.3 ms
+        int o = 0;
+        for (int spin = 0; spin < 256 && o == 0; spin++) {
+          if (lane == 0) o = mig_load(occupants + (1 - arrival));
+          o = __builtin_amdgcn_readfirstlane(o);
+          if (o == 0) __builtin_amdgcn_s_sleep(32);
+        }
+        partner = o - 1;
+      }
+      // slot 0 is the OLDER wave of the two -- the one dispatched first, the lower workgroup index:
+      // the arbiter prefers it whenever the two priorities are equal (around every change of the time
+      // slice), and the measured rates the shares are computed from are those of that wave
+      L.prio_slot = (partner >= 0) ? (((int)blockIdx.x < partner) ? 0 : 1) : -1;
+      // what is left of the two chains of this SIMD: the shares of the issue priority follow it, so
+      // that both end together instead of the longer one running on alone. remaining = leapfrogs per
+      // draw so far x draws to go, known to the partner one transition late; with the pair's rates
+      // (sv: 291 with the priority, 169 without, of 460) the share f of slot 0 that makes the rates
+      // proportional to rho = left_0 / left_1 is (291 rho - 169) / (122 (1 + rho)).
       int* const pair_word = board + kMigMail + 2 * (int)gridDim.x;
-      const int partner = (L.prio_slot == 0) ? (int)blockIdx.x + P.simds : (int)blockIdx.x - P.simds;
-      const bool paired = L.prio_slot >= 0 && partner >= 0 && partner < (int)gridDim.x;
+      const bool paired = L.prio_slot >= 0;
       unsigned long long lf_at_start = 0;
       int done_at_start = 0;
       for (;;) {

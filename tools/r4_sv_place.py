@@ -42,6 +42,11 @@ def case(mode):
         bench.multi_step_roofline(comp0, spec0, dev)
         if mode == "msleg":
             comp0.close()
+    elif mode == "svms":
+        # a batched-leapfrog launch of sv's own kernel (sv-only development builds have no other kind)
+        comp0 = sampler.compile(spec, {"device": 0})
+        bench.multi_step_roofline(comp0, spec, dev, n_chains=8192, n_steps=8, lanes=64)
+        comp0.close()
     elif mode != "none":
         bufs = [torch.empty((32, 10, 262144), dtype=torch.float64, device=dev) for _ in range(3)]
         bufs.append(torch.empty((32, 262144), dtype=torch.float64, device=dev))
