@@ -222,6 +222,23 @@ __device__ __forceinline__ int stage_model_data(const typename M::Consts& mc, do
   }
 }
 
+// the LDS levels of the stack through pointers that SAY they are LDS: where the level is a run-time
+// value (eight_schools: one loop over all levels) the compiler otherwise merges the LDS and the global
+// branch into one generic pointer and emits flat_load / flat_store for both -- a flat access to LDS
+// goes through the vector-memory path and both wait counters
+typedef __attribute__((address_space(3))) double lds_f64;
+template <int N>
+__device__ __forceinline__ void node_load_lds(const double* base, size_t stride, double (&nd)[N]) {
+  const lds_f64* b = (const lds_f64*)base;
+#pragma unroll
+  for (int s = 0; s < N; s++) nd[s] = b[(size_t)s * stride];
+}
+template <int N>
+__device__ __forceinline__ void node_store_lds(double* base, size_t stride, const double (&nd)[N]) {
+  lds_f64* b = (lds_f64*)base;
+#pragma unroll
+  for (int s = 0; s < N; s++) b[(size_t)s * stride] = nd[s];
+}
 template <int N>
 __device__ __forceinline__ void node_load(const double* base, size_t stride, double (&nd)[N]) {
 #pragma unroll
@@ -1093,7 +1110,7 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
             if ((leaf >> lvl) & 1) {
               if (!parked) {
                 double nd[NSLOT];
-                if (lvl < LDSL) node_load<NSLOT>(lstk + (size_t)lvl * NSLOT * kNutsBlock, kNutsBlock, nd);
+                if (lvl < LDSL) node_load_lds<NSLOT>(lstk + (size_t)lvl * NSLOT * kNutsBlock, kNutsBlock, nd);
                 else node_load<NSLOT>(gstk + (size_t)(lvl - LDSL) * NSLOT * kNutsBlock, kNutsBlock, nd);
                 const double a_lsw = nd[kNodeScalars + 0];
                 const double a_logpP = nd[kNodeScalars + 1];
@@ -1159,7 +1176,7 @@ __device__ __forceinline__ void nuts_run(const typename M::Consts& mc, const Nut
                 nd[kNodeScalars + 0] = c_lsw;
                 nd[kNodeScalars + 1] = c_logpP;
                 nd[kNodeScalars + 2] = c_acc;
-                if (lvl < LDSL) node_store<NSLOT>(lstk + (size_t)lvl * NSLOT * kNutsBlock, kNutsBlock, nd);
+                if (lvl < LDSL) node_store_lds<NSLOT>(lstk + (size_t)lvl * NSLOT * kNutsBlock, kNutsBlock, nd);
                 else node_store<NSLOT>(gstk + (size_t)(lvl - LDSL) * NSLOT * kNutsBlock, kNutsBlock, nd);
                 parked = true;
               }

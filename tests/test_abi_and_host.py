@@ -129,3 +129,28 @@ def test_sampler_option_defaults_match_reference():
     # a dense tuning (d x d covariance) contributes its diagonal to the struct (sampler.ex:236-240)
     t = sampler._tuning_struct({"epsilon": 0.1, "inv_mass": np.diag([1.0, 2.0, 3.0]) + 0.1}, 3)
     assert [t.inv_mass[i] for i in range(3)] == [1.1, 2.1, 3.1]
+
+
+def test_plugin_carries_its_kernels_as_code_objects_not_host_stubs():
+    """A generated model's plug-in (exmc_amd/codegen.py build_plugin, round 4): the model-dependent
+    kernels are compiled device-only, embedded as code objects behind `exmc_blob_table` and launched by
+    name through hipModuleLaunchKernel -- so the library has the table, gfx950 code objects behind it,
+    every C-ABI entry point, and NO host stub of a model-dependent kernel (the model-independent
+    kernels of exmc_common.o keep theirs)."""
+    import subprocess
+    from exmc_amd import _lib, codegen
+    so = codegen.build_plugin(codegen.generate(codegen.simple_ir()))
+    syms = subprocess.run(["nm", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    assert " exmc_blob_table" in syms
+    stubs = [ln for ln in syms.splitlines() if "__device_stub__" in ln]
+    assert stubs and all(any(k in ln for k in ("ess_", "rhat_kernel", "rank_scores", "full_tree", "subtree", "traj_build"))
+                         for ln in stubs), stubs
+    for k in ("nuts_kernel", "warmup_kernel", "multi_step_kernel", "logp_grad_kernel", "init_chains_kernel", "find_eps_kernel"):
+        assert not any(k in ln for ln in stubs), k
+    blob = open(so, "rb").read()
+    assert blob.count(b"amdgcn-amd-amdhsa--gfx950") >= 5          # one code object per part (+ the host unit's own)
+    for k in (b"nuts_kernel", b"warmup_kernel", b"find_eps_kernel"):
+        assert k in blob                                          # the kernels' device-side names, looked up at launch
+    P = _lib.bind(so)
+    for name in _lib.EXPORTS:
+        getattr(P, name)
