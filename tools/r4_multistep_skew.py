@@ -66,5 +66,21 @@ def main():
         torch.cuda.empty_cache()
 
 
+def by_chain_count():
+    """The row pitch of the [n][d][C] outputs is C * 8 bytes: 2 MB at C = 262144, so the thirty streams a wavefront writes
+    per step are congruent modulo 2 MB. Other chain counts, separate torch tensors."""
+    dev = torch.device("cuda", 0)
+    spec, _ = bench.make_spec("eight_schools")
+    comp = sampler.compile(spec, {"device": 0})
+    for n_chains in (262144, 262144 + 64, 262144 + 1024, 254 * 1024, 264 * 1024, 249856 + 192, 262144):
+        for rep in range(2):
+            r = bench.multi_step_roofline(comp, spec, dev, n_chains=n_chains, reps=5)
+            print("chains %7d (pitch %% 2 MB = %7d B): %.3f ms, %.1f %% of 8 TB/s" % (n_chains, (n_chains * 8) % (2 << 20), r["kernel_ms"], 100 * r["frac"]), flush=True)
+        torch.cuda.empty_cache()
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "chains":
+        by_chain_count()
+    else:
+        main()
