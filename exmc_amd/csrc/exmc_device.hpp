@@ -135,6 +135,49 @@ __device__ __forceinline__ void xgroup_sum_n(double (&s)[N]) {
   }
 }
 
+// ---- cross-row exchanges without the LDS crossbar (gfx950) ----
+// v_permlane16_swap_b32 / v_permlane32_swap_b32 (CDNA4) swap the odd 16-lane rows of one register
+// with the even rows of another / the upper half of one with the lower half of another, in the
+// vector ALU. Fed two copies of a value v they leave (a, b) with a + b = v[l] + v[l ^ 16] (resp.
+// l ^ 32) in EVERY lane -- in half the lanes as own + partner, in the other half as partner + own,
+// which are the same bits: the butterfly stage of group_allsum_n and of the reduce-scatter below
+// without the round trip through LDS (two swaps, one move and the add per stage and value, against
+// two ds_bpermute and the add; a tenth of the latency, which is what a wave that has the issue
+// priority -- or its SIMD to itself -- waits for). EXMC_XROW_PERMLANE=0 builds the LDS forms.
+#ifndef EXMC_XROW_PERMLANE
+#define EXMC_XROW_PERMLANE 1
+#endif
+__device__ __forceinline__ double sum_xor16(double v) {
+#if EXMC_XROW_PERMLANE
+  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __hiloint2double((int)rh[0], (int)rl[0]) + __hiloint2double((int)rh[1], (int)rl[1]);
+#else
+  const int a = (((int)threadIdx.x & 63) ^ 16) << 2;
+  return v + __hiloint2double(__builtin_amdgcn_ds_bpermute(a, __double2hiint(v)),
+                              __builtin_amdgcn_ds_bpermute(a, __double2loint(v)));
+#endif
+}
+__device__ __forceinline__ double sum_xor32(double v) {
+#if EXMC_XROW_PERMLANE
+  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double((int)rh[0], (int)rl[0]) + __hiloint2double((int)rh[1], (int)rl[1]);
+#else
+  const int a = (((int)threadIdx.x & 63) ^ 32) << 2;
+  return v + __hiloint2double(__builtin_amdgcn_ds_bpermute(a, __double2hiint(v)),
+                              __builtin_amdgcn_ds_bpermute(a, __double2loint(v)));
+#endif
+}
+// lane l <- lane l ^ 4: two masked DPP moves per dword (row_shr:4 into the banks whose lanes have
+// bit 2 set, row_shl:4 into the others) instead of a ds_swizzle
+__device__ __forceinline__ int xor4_b32(int x) {
+  int t = __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xA, false);   // row_shr:4 -> lanes 4-7, 12-15
+  return __builtin_amdgcn_update_dpp(t, x, 0x104, 0xF, 0x5, false);    // row_shl:4 -> lanes 0-3, 8-11
+}
+
 // N independent all-reduce sums over the G-lane group, stage by stage (the N moves of a stage
 // are independent, so their latencies overlap). kLds (G = 64): the two cross-row stages go
 // through the LDS crossbar (ds_bpermute) -- two vector instructions per value instead of the
@@ -159,22 +202,25 @@ __device__ __forceinline__ void group_allsum_n(double (&v)[N]) {
 #pragma unroll
     for (int j = 0; j < N; j++) v[j] = v[j] + dpp_move<kDppRowMirror>(v[j]);
   }
+#if EXMC_XROW_PERMLANE
+  // the cross-row stages in the vector ALU (sum_xor16 / sum_xor32 above), whatever kLds says: rows
+  // (0, 1) and (2, 3) first, then the halves -- (r0 + r1) + (r2 + r3) in every lane, the expression
+  // the v_readlane form and the LDS form both compute
+  if (G >= 32) {
+#pragma unroll
+    for (int j = 0; j < N; j++) v[j] = sum_xor16(v[j]);
+  }
+  if (G == 64) {
+#pragma unroll
+    for (int j = 0; j < N; j++) v[j] = sum_xor32(v[j]);
+  }
+#else
   if constexpr (G == 64 && kLds) {
     // v + v[l ^ 16], then + v[l ^ 32]: the same butterfly
-    const int lane = threadIdx.x & 63;
-    const int a16 = (lane ^ 16) << 2, a32 = (lane ^ 32) << 2;
 #pragma unroll
-    for (int j = 0; j < N; j++) {
-      int lo = __double2loint(v[j]), hi = __double2hiint(v[j]);
-      const double o = __hiloint2double(__builtin_amdgcn_ds_bpermute(a16, hi), __builtin_amdgcn_ds_bpermute(a16, lo));
-      v[j] = v[j] + o;
-    }
+    for (int j = 0; j < N; j++) v[j] = sum_xor16(v[j]);
 #pragma unroll
-    for (int j = 0; j < N; j++) {
-      int lo = __double2loint(v[j]), hi = __double2hiint(v[j]);
-      const double o = __hiloint2double(__builtin_amdgcn_ds_bpermute(a32, hi), __builtin_amdgcn_ds_bpermute(a32, lo));
-      v[j] = v[j] + o;
-    }
+    for (int j = 0; j < N; j++) v[j] = sum_xor32(v[j]);
     return;
   }
   if (G >= 32) {
@@ -188,6 +234,7 @@ __device__ __forceinline__ void group_allsum_n(double (&v)[N]) {
       else v[j] = h0 + h1;                        // == half + (half ^ 1)
     }
   }
+#endif
 }
 
 template <int G, bool kLds = false>
@@ -558,6 +605,13 @@ __device__ __forceinline__ double xchg_swizzle(double v) {
   return __hiloint2double(__builtin_amdgcn_ds_swizzle(__double2hiint(v), PATTERN),
                           __builtin_amdgcn_ds_swizzle(__double2loint(v), PATTERN));
 }
+__device__ __forceinline__ double xchg_xor4(double v) {   // lane l <- lane l ^ 4
+#if EXMC_XROW_PERMLANE
+  return __hiloint2double(xor4_b32(__double2hiint(v)), xor4_b32(__double2loint(v)));
+#else
+  return xchg_swizzle<(4 << 10) | 0x1F>(v);
+#endif
+}
 __device__ __forceinline__ double xchg_xor32(double v) {
   const int a = (((int)threadIdx.x & 63) ^ 32) << 2;
   return __hiloint2double(__builtin_amdgcn_ds_bpermute(a, __double2hiint(v)),
@@ -569,10 +623,10 @@ constexpr int kDppRowRor8 = 0x128;
 // one value through the stages xor 4 .. xor 32 (FROM = 4) or xor 8 .. xor 32 (FROM = 8)
 template <int FROM>
 __device__ __forceinline__ double rs64_tail(double z) {
-  if (FROM <= 4) z = z + xchg_swizzle<kSwzXor4>(z);
+  if (FROM <= 4) z = z + xchg_xor4(z);
   z = z + xchg_dpp<kDppRowRor8>(z);
-  z = z + xchg_swizzle<kSwzXor16>(z);
-  z = z + xchg_xor32(z);
+  z = sum_xor16(z);
+  z = sum_xor32(z);
   return z;
 }
 
@@ -598,7 +652,7 @@ __device__ __forceinline__ double rs64_reduce6(const double (&v)[6]) {
   const double w2 = (b0 ? v[5] : v[2]) + xchg_dpp<kDppXor1>(b0 ? v[2] : v[5]);
   const double x = (b1 ? w2 : w0) + xchg_dpp<kDppXor2>(b1 ? w0 : w2);   // quantities 0 / 3 or 2 / 5
   const double y = w1 + xchg_dpp<kDppXor2>(w1);                          // quantities 1 / 4
-  const double z = (b2 ? y : x) + xchg_swizzle<kSwzXor4>(b2 ? x : y);
+  const double z = (b2 ? y : x) + xchg_xor4(b2 ? x : y);
   return rs64_tail<8>(z);
 }
 // the four totals in every lane (they come back as scalars)
