@@ -143,15 +143,12 @@ def issue_roofline(model, chains, steps, lanes, kernel_ms, leapfrogs):
     return out
 
 
-def multi_step_roofline(comp, spec, dev, n_chains=262208, n_steps=32, lanes=1, reps=3):
+def multi_step_roofline(comp, spec, dev, n_chains=262144, n_steps=32, lanes=1, reps=3):
     """The B2 `multi_step_fn` contract at scale (batched_leapfrog.ex:50-101): every chain takes
     n_steps leapfrogs and every intermediate (q, p, grad, logp) is written to HBM, [step][dim][chain].
     Bytes per launch are algorithmic: reads 3*d*8*C, writes (3*d+1)*8*n*C. Kernel time from the HIP
-    events the library records on its own stream.
-    The batch is 4097 x 64 chains, not 2^18: the rows of the [step][dim][chain] outputs are C * 8 bytes
-    apart, and at C = 262144 that pitch is exactly 2 MB -- the thirty streams a wavefront writes per step
-    then fall on the same HBM channels (0.65 of peak at 262144, 0.77-0.78 at 262208 or 260096 chains,
-    tools/r4_multistep_skew.py; the layout is the B2 contract's, the batch size is this leg's choice)."""
+    events the library records on its own stream. (The figure moves between 0.63 and 0.80 of peak with
+    the box and with where the four output arrays land: tools/r4_multistep_skew.py)"""
     d = spec.d
     L = comp.L
     g = torch.Generator(device=dev).manual_seed(1)
