@@ -1029,7 +1029,7 @@ struct Radon : ModelDefaults {
       s[4] = f;
       s[5] = z2s;
       wave_lds_fence();
-      // a county's sum: its cells in index order, four reads in flight at a time; the loop runs to
+      // a county's sum: its cells in index order, several reads in flight at a time; the loop runs to
       // the slot's largest county on every lane (a wave-uniform bound: scalar loop control), a lane
       // past the end of its own county keeps its sum
 #pragma unroll
@@ -1037,12 +1037,18 @@ struct Radon : ModelDefaults {
         double sj = 0.0;
         const int i0 = ln.i0[k], i1 = ln.i1[k];
         const int nb = __builtin_amdgcn_readfirstlane(ln.maxc[k]);
-        for (int b = 0; b < nb; b += 4) {
-          double v[4];
+        // (kAhead reads in flight: a wave that has its SIMD to itself waits out every LDS round trip,
+        // and the additions behind them are one dependent chain in index order whatever the batch)
+#ifndef EXMC_RADON_AHEAD
+#define EXMC_RADON_AHEAD 8
+#endif
+        constexpr int kAhead = EXMC_RADON_AHEAD;
+        for (int b = 0; b < nb; b += kAhead) {
+          double v[kAhead];
 #pragma unroll
-          for (int j = 0; j < 4; j++) v[j] = cell[(i0 + b + j < i1) ? i0 + b + j : 0];
+          for (int j = 0; j < kAhead; j++) v[j] = cell[(i0 + b + j < i1) ? i0 + b + j : 0];
 #pragma unroll
-          for (int j = 0; j < 4; j++) sj = (i0 + b + j < i1) ? (sj + v[j]) : sj;
+          for (int j = 0; j < kAhead; j++) sj = (i0 + b + j < i1) ? (sj + v[j]) : sj;
         }
         sj_own[k] = sj;
       }
