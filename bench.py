@@ -186,11 +186,36 @@ def multi_step_roofline(comp, spec, dev, n_chains=262144, n_steps=32, lanes=1, r
 
 RHAT_ROUTE_TOL = 1e-9
 
+# What the reference itself publishes for these models (1 chain, 1000 + 1000,
+# 5-seed medians, CPU of unstated make, EXLA-JIT'd gradients): quoted beside cpu_baseline, which is
+# this repository's C port of the same sampler on the GPU box's host cores -- not eXMC on the BEAM.
+REFERENCE_PUBLISHED = {
+    "eight_schools": {"ess_per_s": 12.0, "pymc_ess_per_s": 5.0, "source": "README.md:44",
+                      "note": "centered parameterisation (STANDARD_BENCHMARKS.md:30); this line runs the non-centered "
+                              "posteriordb variant BASELINE.json names"},
+    "logistic": {"ess_per_s": 69.0, "pymc_ess_per_s": 336.0, "source": "README.md:46",
+                 "wall_s_per_run": "14-16 (STANDARD_BENCHMARKS.md:185-187)"},
+    "sv": {"ess_per_s": 1.0, "pymc_ess_per_s": 1.0, "source": "README.md:47",
+           "note": "ratio 1.20x; 83-95 s per run, median min-ESS 52 (STANDARD_BENCHMARKS.md:171-175)"},
+    "radon": None,   # no published number (notebooks/09_radon_bhm.livemd prints wall time at run time)
+}
+F64_PEAK_TFLOPS = 78.6     # 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz: vector FMA = matrix f64 peak
+
+
+def reference_published(model):
+    base = model[4:] if model.startswith("gen_") else model
+    r = REFERENCE_PUBLISHED.get(base)
+    if r is None:
+        return {"ess_per_s": None, "note": "the reference publishes no number for this model (BASELINE.md section 1)"}
+    return dict(r, protocol="1 chain, 1000 warmup + 1000 draws, 5-seed median, min-over-parameters ESS / wall s; "
+                            "eXMC on the BEAM with EXLA-JIT'd gradients, CPU, hardware unstated",
+                comparable="no: different hardware, one chain, and not the implementation cpu_baseline times")
+
 
 def finish_model(*, model, d, K, W, B, adapt, Cper, world, rank, dist, draws, ess, leap_local, div_local,
                  elapsed_local, kernel_ms, adapt_s, ess_s, ess_ms, epsilon, lanes, warm_lanes,
                  bytes_per_leapfrog, gather_traces, rhat_fn, dense_mass=False, sync=lambda: None,
-                 traffic=None):
+                 traffic=None, force=False, ess_bulk=None, ess_bulk_s=None):
     """Everything after the timed launch, on whatever device the tensors live (the GPUs of the ranks;
     CPU tensors over gloo in tests/test_bench_multirank_gloo.py): the max / sum reductions of the
     ranks' clocks and counters, the ESS sums, both gather routes (the finished [S][d][C] traces;
@@ -203,7 +228,12 @@ def finish_model(*, model, d, K, W, B, adapt, Cper, world, rank, dist, draws, es
     R-hat is computed twice on independent code paths -- rhat_fn on the traces (this rank's shard
     always; the gathered whole when gather_traces), torch on the gathered half-chain statistics --
     and the two must agree to RHAT_ROUTE_TOL, else the caller exits non-zero: BENCH_r03.json carried
-    6.58 and 1.19 for one launch and nothing noticed."""
+    6.58 and 1.19 for one launch and nothing noticed.
+
+    force: make every collective even in a process group of ONE rank (`--force-dist`,
+    tests/test_gpu_rccl_one_rank.py: the RCCL calls executed on the real device of a one-GPU box; the
+    line must equal the dist=None line). ess_bulk: [d][Cper] rank-normalised bulk ESS
+    (diagnostics.ex:60-72) with its wall clock, or None."""
     S = K * B
     Ctot = Cper * world
     dev = draws.device
@@ -228,23 +258,27 @@ def finish_model(*, model, d, K, W, B, adapt, Cper, world, rank, dist, draws, es
     local_gap = float((rhat_local_lib - rhat_local_stats).abs().max())
     sync()
     t0 = time.perf_counter()
-    xd.reduce_sum(ess_sum, dist)
+    xd.reduce_sum(ess_sum, dist, force)
+    ess_bulk_sum = None
+    if ess_bulk is not None:
+        ess_bulk_sum = ess_bulk.sum(dim=1)
+        xd.reduce_sum(ess_bulk_sum, dist, force)
     gather_stats_s = gather_traces_s = None
     rhat_traces = None
     if gather_traces:
-        all_draws = xd.gather_traces(draws, dist)
+        all_draws = xd.gather_traces(draws, dist, force)
         sync()
         gather_s = gather_traces_s = time.perf_counter() - t0
         rhat_traces = rhat_local_lib if all_draws is draws else rhat_fn(all_draws)
         del all_draws
         t1 = time.perf_counter()
-        ghm, ghv = xd.gather_chain_stats(hm, dist), xd.gather_chain_stats(hv, dist)
+        ghm, ghv = xd.gather_chain_stats(hm, dist, force), xd.gather_chain_stats(hv, dist, force)
         sync()
         gather_stats_s = time.perf_counter() - t1
     else:
         # the exchange: per-chain sufficient statistics of the finished traces give
         # the same split R-hat with ~1 MB per rank on the wire instead of the [S][d][C] draws
-        ghm, ghv = xd.gather_chain_stats(hm, dist), xd.gather_chain_stats(hv, dist)
+        ghm, ghv = xd.gather_chain_stats(hm, dist, force), xd.gather_chain_stats(hv, dist, force)
         sync()
         gather_s = gather_stats_s = time.perf_counter() - t0
         if world == 1:
@@ -253,7 +287,7 @@ def finish_model(*, model, d, K, W, B, adapt, Cper, world, rank, dist, draws, es
     rhat = rhat_traces if rhat_traces is not None else rhat_stats
     gap = torch.tensor([local_gap, float((rhat - rhat_stats).abs().max())], dtype=torch.float64, device=dev)
     gap = torch.nan_to_num(gap, nan=float("inf"))
-    xd.reduce_max(gap, dist)
+    xd.reduce_max(gap, dist, force)
     ok = bool(float(gap.max()) <= RHAT_ROUTE_TOL)
     if not ok:
         log("%s rank %d: split R-hat routes disagree: shard |lib - stats| %.3e, whole |%s - stats| %.3e\n"
@@ -319,6 +353,16 @@ def finish_model(*, model, d, K, W, B, adapt, Cper, world, rank, dist, draws, es
                      "algorithmic_bytes_per_leapfrog": bytes_per_leapfrog,
                      "leapfrogs_per_launch": local_lf},
     }
+    if ess_bulk_sum is not None:
+        # Diagnostics.ess_bulk (diagnostics.ex:60-72): the same minimum over parameters on the
+        # rank-normalised traces, with ITS kernels' wall clock in place of the Geyer kernel's
+        bulk_min = float(ess_bulk_sum.min())
+        out["ess_bulk_min_total"] = bulk_min
+        out["ess_bulk_per_s"] = bulk_min / (adapt_s + elapsed + ess_bulk_s + gather_s)
+        out["ess_wall_s"]["ess_bulk_kernels"] = ess_bulk_s
+    if force:
+        out["collectives"] = {"forced": True, "backend": dist.get_backend() if dist is not None else None,
+                              "world": world}
     return out, ok
 
 
@@ -427,6 +471,12 @@ def main():
                          "per-chain half-chain statistics (sv does by default: BASELINE.json's config)")
     ap.add_argument("--no-sv-leg", action="store_true",
                     help="default run only: skip the sv(d=102) leg that rides on the eight_schools line")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="default run only: skip the logistic and radon legs (BASELINE configs 3 and 5)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="--gpus 1 only: create a ONE-rank nccl (RCCL) process group on the device and make "
+                         "every collective of the multi-GPU path anyway (all_reduce, all_gather_into_tensor, "
+                         "all_gather, barrier); the line must equal the ordinary one")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -445,6 +495,11 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    elif args.force_dist:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        store = dist.TCPStore("127.0.0.1", 0, 1, is_master=True, wait_for_workers=False)
+        dist.init_process_group("nccl", store=store, rank=0, world_size=1, device_id=dev)
 
     def barrier():
         torch.cuda.synchronize()
@@ -461,6 +516,14 @@ def main():
         ok = ok and ok_sv
         if rank == 0:
             out["models"] = {"sv": sv}
+    if args.model == "eight_schools" and not args.no_extra_legs and not args.dense_mass:
+        # BASELINE configs 3 and 5 in the same record: logistic 8192 and radon 1024 chains per GPU (their
+        # GPU legs are a few hundred milliseconds each; their CPU legs are bounded to a few seconds)
+        for extra in ("logistic", "radon"):
+            eo, ok_e = run_model(args, extra, rank, local_rank, world, dev, dist, barrier, primary=False)
+            ok = ok and ok_e
+            if rank == 0:
+                out.setdefault("models", {})[extra] = eo
     if rank == 0:
         # the batched-leapfrog roofline leg and the CPU checker's legs, after the sampling legs of the line
         # (see run_model)
@@ -556,6 +619,13 @@ def run_model(args, model, rank, local_rank, world, dev, dist, barrier, primary)
     comp.check(L.exmc_hip_ess(comp.h, draws.data_ptr(), S, d, Cper, ess.data_ptr()))
     ess_s = time.perf_counter() - t0      # the call returns when the kernel has finished
     ess_ms = comp.last_kernel_ms
+    # Diagnostics.ess_bulk (diagnostics.ex:60-72): rank-normalise (rank_scores_kernel) into a second
+    # trace, then the same ESS kernels on it -- BASELINE.md section 2 asks for ESS/s by both
+    essb = torch.empty((d, Cper), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    comp.check(L.exmc_hip_ess_bulk(comp.h, draws.data_ptr(), S, d, Cper, essb.data_ptr()))
+    ess_bulk_s = time.perf_counter() - t0
 
     def rhat_lib(x):
         """Diagnostics.rhat (diagnostics.ex:80-115) of a [S][d][C] device trace by the library's own
@@ -575,7 +645,9 @@ def run_model(args, model, rank, local_rank, world, dev, dist, barrier, primary)
                            lanes=lanes, warm_lanes=warm_lanes, bytes_per_leapfrog=bytes_per_leapfrog,
                            gather_traces=gather_traces, rhat_fn=rhat_lib, dense_mass=args.dense_mass,
                            sync=torch.cuda.synchronize,
-                           traffic=measured_traffic(model, Cper, S, lanes))
+                           traffic=measured_traffic(model, Cper, S, lanes),
+                           force=bool(getattr(args, "force_dist", False)) and world == 1,
+                           ess_bulk=essb, ess_bulk_s=ess_bulk_s)
     if rank == 0:
         value, local_lf = out["value"], float(leap_local)
         if model == "eight_schools":
@@ -587,6 +659,18 @@ def run_model(args, model, rank, local_rank, world, dev, dist, barrier, primary)
         ri = issue_roofline(model, Cper, S, lanes, kernel_ms, local_lf) if world == 1 else None
         if ri:
             out["roofline_issue"] = ri
+        out["reference_published"] = reference_published(model)
+        if model in ("logistic", "gen_logistic"):
+            # "MFMA utilisation instead of HBM fraction for the logistic logp kernel".
+            # The two contractions of a leapfrog (X beta and X^T r over N x (K + 1)) are 2 * 2 * N * (K + 1)
+            # flops; the f64 matrix peak equals the vector FMA peak on this chip, and the kernel runs them
+            # on the vector pipe (the per-observation exp / quotient / log bind it)
+            n_obs = int(getattr(spec, "n_obs", 500))
+            flop = 4.0 * n_obs * spec.d
+            tf = flop * local_lf / (kernel_ms * 1e-3) / 1e12
+            out["roofline_f64"] = {"bound": "f64_flops", "achieved": tf, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": tf / F64_PEAK_TFLOPS, "flop_per_leapfrog": flop,
+                                   "note": "contraction flops only (2 * 2 * N * (K + 1)); the specials are not counted"}
         if world == 1 and model == "eight_schools" and not args.no_multi_step:
             # the B2 batched-leapfrog contract at a batch that fills the chip (not the timed path). It runs
             # after every sampling leg of the line: its 2 GB of buffers, allocated and freed between the
@@ -605,8 +689,10 @@ def run_model(args, model, rank, local_rank, world, dev, dist, barrier, primary)
             # sits between the two models' GPU legs
             def cpu_leg():
                 # the second model's CPU leg is bounded tighter (sv: about one second per chain per core)
-                cb = cpu_baseline(spec, init, S, Ctot, budget_s=15.0 if primary else 8.0,
-                                  max_chains=None if primary else 256)
+                # (logistic, radon: a chain is ~1 s of one core; their legs stay within ~6 s each so that the
+                # whole default command stays under a minute)
+                budget = 15.0 if primary else (8.0 if model == "sv" else 3.0)
+                cb = cpu_baseline(spec, init, S, Ctot, budget_s=budget, max_chains=None if primary else 256)
                 out["cpu_baseline"] = cb
                 out["gpu_over_cpu"] = {"leapfrog_steps_per_s": value / cb["value"],
                                        "ess_per_s": out["ess_per_s"] / cb["ess_per_s"],

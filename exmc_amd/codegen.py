@@ -1372,10 +1372,21 @@ def _extra_flags():
     return os.environ.get("EXMC_GEN_EXTRA_FLAGS", "").split()
 
 
+def _build_form():
+    """How build_plugin links the model-dependent kernels: device-only code objects launched through
+    hipModuleLaunchKernel (the default), host stubs (EXMC_PLUGIN_STUBS=1), or one translation unit
+    (EXMC_PLUGIN_ONE_TU=1). Part of the cache tag: a library of one form is never handed out for another."""
+    if os.environ.get("EXMC_PLUGIN_ONE_TU") == "1":
+        return "onetu"
+    return "stubs" if os.environ.get("EXMC_PLUGIN_STUBS") == "1" else "modules"
+
+
 def plugin_paths(gen):
     tag = gen.digest
     if _extra_flags():
         tag += "_" + hashlib.sha256(" ".join(_extra_flags()).encode()).hexdigest()[:8]
+    if _build_form() != "modules":
+        tag += "_" + _build_form()
     d = os.path.join(GEN_DIR, tag)
     return d, os.path.join(d, "exmc_gen_model.h"), os.path.join(d, "libexmc_hip_gen.so")
 
@@ -1435,17 +1446,20 @@ def build_plugin(gen, force=False, verbose=False):
                 for j in jobs:
                     print(" ".join(j))
             t_start = time.time()
+            part_objs = objs[1:]
+            if modules:
+                blob_s, blob_o = "%s.blobs.S" % tmp, "%s.blobs.o" % tmp
+                objs = objs + [blob_s, blob_o]      # on the clean-up list before anything can fail
             procs = [subprocess.Popen(j, cwd=cwd) for j in jobs]
             if modules:
                 # while the compilers run: the table of embedded code objects, as assembler source
-                blob_s, blob_o = "%s.blobs.S" % tmp, "%s.blobs.o" % tmp
                 with open(blob_s, "w") as f:
                     f.write('\t.section .rodata.exmc_blobs,"a",@progbits\n')
-                    for i, o in enumerate(objs[1:]):
+                    for i, o in enumerate(part_objs):
                         f.write("\t.balign 4096\nexmc_blob_%d:\n\t.incbin \"%s\"\nexmc_blob_%d_end:\n" % (i, o, i))
                     f.write('\t.section .data.rel.ro.exmc_blob_table,"aw",@progbits\n\t.balign 8\n'
                             "\t.globl exmc_blob_table\n\t.type exmc_blob_table,@object\nexmc_blob_table:\n")
-                    for i in range(len(objs) - 1):
+                    for i in range(len(part_objs)):
                         f.write("\t.quad exmc_blob_%d\n\t.quad exmc_blob_%d_end\n" % (i, i))
                     f.write("\t.quad 0\n\t.quad 0\n\t.size exmc_blob_table, .-exmc_blob_table\n"
                             '\t.section .note.GNU-stack,"",@progbits\n')
@@ -1455,9 +1469,13 @@ def build_plugin(gen, force=False, verbose=False):
             t_compiled = time.time()
             link_objs = objs
             if modules:
-                subprocess.check_call(["gcc", "-c", "-o", blob_o, blob_s], cwd=cwd)   # .incbin reads the code objects now
+                # a kernel the host unit can launch but no part defines used to be a link error; in this
+                # form it would be hipErrorInvalidDeviceFunction at that kernel's first launch
+                _check_module_kernels(objs[0], part_objs, common)
+                # (.incbin reads the code objects now; assembled by the compiler driver already in use:
+                # no second toolchain in the JIT path)
+                subprocess.check_call([hipcc, "-x", "assembler", "-c", "-o", blob_o, blob_s], cwd=cwd)
                 link_objs = [objs[0], blob_o]
-                objs = objs + [blob_s, blob_o]
             link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + link_objs + [common]
             if verbose:
                 print(" ".join(link))
@@ -1471,6 +1489,60 @@ def build_plugin(gen, force=False, verbose=False):
             if os.path.exists(f):
                 os.remove(f)
     return so
+
+
+def _elf_symbol_names(path):
+    """Names in the symbol tables of a little-endian ELF64 file (no tool needed)."""
+    import struct
+    b = open(path, "rb").read()
+    if b[:24] == b"__CLANG_OFFLOAD_BUNDLE__":      # what --cuda-device-only -c writes: the code object inside
+        n, = struct.unpack_from("<Q", b, 24)
+        at, names = 32, set()
+        for _ in range(n):
+            off, size, tl = struct.unpack_from("<QQQ", b, at)
+            triple = b[at + 24:at + 24 + tl]
+            at += 24 + tl
+            if size and triple.startswith(b"hip"):
+                names |= _elf_symbols(b[off:off + size], path)
+        return names
+    return _elf_symbols(b, path)
+
+
+def _elf_symbols(b, path):
+    import struct
+    if b[:4] != b"\x7fELF" or b[4] != 2:
+        raise RuntimeError("%s is not an ELF64 object" % path)
+    shoff, = struct.unpack_from("<Q", b, 0x28)
+    shentsize, shnum = struct.unpack_from("<HH", b, 0x3A)
+    secs = [struct.unpack_from("<IIQQQQIIQQ", b, shoff + i * shentsize) for i in range(shnum)]
+    names = set()
+    for sh in secs:
+        if sh[1] not in (2, 11):          # SHT_SYMTAB, SHT_DYNSYM
+            continue
+        off, size, link, entsize = sh[4], sh[5], sh[6], sh[9] or 24
+        stroff = secs[link][4]
+        for i in range(size // entsize):
+            st_name, = struct.unpack_from("<I", b, off + i * entsize)
+            if st_name:
+                end = b.index(b"\0", stroff + st_name)
+                names.add(b[stroff + st_name:end].decode("ascii", "replace"))
+    return names
+
+
+def _check_module_kernels(host_obj, part_objs, common_obj):
+    """Every device-side kernel name the host unit carries (the operands of its EXMC_KLAUNCH calls,
+    stored as strings) must be defined by one of the parts' code objects -- or, for the
+    model-independent kernels it launches through their host stubs, by the prebuilt common object."""
+    import re
+    wanted = set(m.decode() for m in re.findall(rb"_ZN4exmc\d+\w*kernel\w*", open(host_obj, "rb").read()))
+    have = set()
+    for o in list(part_objs) + [common_obj]:
+        have |= _elf_symbol_names(o)
+    missing = sorted(n for n in wanted if n not in have)
+    if missing:
+        raise RuntimeError("plug-in build: the host unit can launch %d kernel(s) that no part defines "
+                           "(exmc_plugin_kernels.inc out of step with exmc_hip.hip?):\n  %s"
+                           % (len(missing), "\n  ".join(missing)))
 
 
 def inverse_stick_breaking(x):

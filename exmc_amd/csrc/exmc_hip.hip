@@ -597,7 +597,7 @@ int launch_nuts(exmc_hip_model* m, int lanes, int C, int n_draws, int draw_offse
       // worth it when the launch puts two chains on a SIMD (more waves than the 1024 SIMDs) and
       // runs long enough to have a tail; EXMC_HIP_MIGRATE=0 / 1 forces it off / on
       const char* me = std::getenv("EXMC_HIP_MIGRATE");
-      const bool on = me ? (me[0] == '1') : ((int)grid.x > 1024 && n_draws >= 100);
+      const bool on = me ? (me[0] == '1') : ((int)grid.x > (m->simds > 0 ? m->simds : 1024) && n_draws >= 100);
       if (on) {
         const size_t nb = mig_board_ints(grid.x) * sizeof(int);
         rc = m->migboard.ensure(nb);
@@ -635,6 +635,33 @@ int launch_nuts(exmc_hip_model* m, int lanes, int C, int n_draws, int draw_offse
         if (timed) HIP_TRY(hipEventRecord(m->ev0, m->stream));
         const size_t lds_p = nuts_lds_bytes<M, PL>() + pipe_lds_doubles<M::DPL>() * 8;
         EXMC_KLAUNCH(m->device, (nuts_kernel<M, T::G, PL, true>), grid, dim3(2 * kNutsBlock), lds_p,
+                     m->stream, P, mc);
+        HIP_TRY(hipGetLastError());
+        if (timed) HIP_TRY(hipEventRecord(m->ev1, m->stream));
+        return (int)EXMC_OK;
+      }
+    }
+    if constexpr (M::kWgWaves > 0 && !M::kLaneDense && !M::kRowDense) {
+      // Workgroups of kWgWaves wavefronts around one LDS image of the model's data (exmc_nuts.hpp
+      // nuts_kernel_wg). Worth it as soon as some SIMD has to hold two wavefronts anyway (more waves
+      // than SIMDs); below that every wavefront has a SIMD to itself in the one-wave form and a
+      // workgroup per compute unit would leave units idle. EXMC_HIP_NUTS_WG=0 / 1 forces either form.
+      constexpr int W = M::kWgWaves, WL = M::kWgLdsLevels;
+      const char* we = std::getenv("EXMC_HIP_NUTS_WG");
+      const size_t waves = grid.x;
+      const bool on = we ? (we[0] == '1') : ((int)waves > (m->simds > 0 ? m->simds : 1024));
+      if (on && !m->dense_on && M::wg_ok(mc)) {
+        const dim3 wgrid((unsigned)((waves + W - 1) / W));
+        const size_t wthreads = (size_t)wgrid.x * W * kNutsBlock;
+        constexpr int kSpillW = (kMaxLevels > WL) ? (kMaxLevels - WL) : 1;
+        rc = m->stack.ensure((size_t)kSpillW * nuts_nslot<M>() * wthreads * 8);
+        if (rc) return rc;
+        P.stack = m->stack.as<double>();
+        const size_t lds_w = nuts_wg_lds_bytes<M, WL, W>();
+        static_assert(nuts_wg_lds_bytes<M, WL, W>() <= 160 * 1024, "one workgroup per compute unit");
+        EXMC_KMAXLDS((nuts_kernel_wg<M, T::G, WL, W>), lds_w);
+        if (timed) HIP_TRY(hipEventRecord(m->ev0, m->stream));
+        EXMC_KLAUNCH(m->device, (nuts_kernel_wg<M, T::G, WL, W>), wgrid, dim3(W * kNutsBlock), lds_w,
                      m->stream, P, mc);
         HIP_TRY(hipGetLastError());
         if (timed) HIP_TRY(hipEventRecord(m->ev1, m->stream));

@@ -65,10 +65,20 @@ struct ModelDefaults {
   // end of the transition (exmc_nuts.hpp nuts_run) -- for deep-tree models, where one more model
   // evaluation per transition is cheaper than two more doubles in every node
   static constexpr bool kRegradProposal = false;
+  // > 0: the sampling kernel also exists as workgroups of this many wavefronts that share one LDS
+  // image of the model's data (stage / kStageDoubles), with kWgLdsLevels tree-stack levels per
+  // wavefront in LDS (exmc_nuts.hpp nuts_kernel_wg); wg_ok(consts): the data fit the image
+  static constexpr int kWgWaves = 0;
+  static constexpr int kWgLdsLevels = 1;
+  template <class C>
+  __host__ __device__ static bool wg_ok(const C&) { return false; }
 };
 
 // the dynamic LDS of the running kernel (every extern __shared__ array names the same base)
 extern __shared__ double exmc_dyn_lds[];
+// two doubles of LDS behind a pointer that says so: ds_read_b128 of a 16-byte aligned pair
+typedef double exmc_v2d __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) exmc_v2d lds_v2d;
 
 // ------------------------------------------------------------------------------------------
 // eight_schools, non-centered (benchmark/posteriordb/validate_posteriordb.exs:246-324).
@@ -398,7 +408,8 @@ struct SV : ModelDefaults {
   static constexpr bool kXRowLds = (G == 64) && (EXMC_SV_XROW_LDS != 0);
   static constexpr bool kMigrate = (G == 64);
   // G = 64: a transition is ~340 leapfrogs and one momentum draw; the 6 KB of the tables buy the
-  // third stack level in LDS (3 x 6.5 KB = 19.5 KB: still eight workgroups per CU), which halves
+  // third stack level in LDS (nodes of 11 doubles since kRegradProposal: 3 x 5.5 KB = 16.5 KB, still
+  // eight workgroups per CU), which halves
   // the visits to the spill stack in global memory (a quarter of the leaves merge or park at level
   // >= 2, an eighth at level >= 3)
   static constexpr bool kNutsZigInLds = (G != 64);
@@ -582,19 +593,34 @@ struct Logistic : ModelDefaults {
   static constexpr int D = K + 1;
   static constexpr int DPL = (D + G - 1) / G;
   using Consts = LogisticConsts;
-  // LDS image of X and y for single-workgroup kernels (the adaptation warmup): with one wave on
-  // the whole chip every row of X is otherwise an exposed L2 round trip, 32 times per leapfrog
+  // LDS image of X and y: row n = x[n][0..19], y[n], one pad double. 22 doubles = 176 bytes, so
+  // every row is 16-byte aligned (ds_read_b128) and sixteen consecutive rows start 44 dwords apart:
+  // in sixteen different groups of four banks, the 16-lane groups of a b128 read are conflict-free.
+  // Rows N..kObsCap-1 are zero. For single-workgroup kernels (the adaptation warmup: with one wave
+  // on the whole chip every row of X is otherwise an exposed L2 round trip, 32 times per leapfrog)
+  // and for the sampling kernel in its workgroup form (kWgWaves, exmc_nuts.hpp nuts_kernel_wg).
   static constexpr int kObsCap = 512;
-  static constexpr int kRowStride = K + 1;   // 21 doubles: rows 16 apart fall in different LDS banks
-  static constexpr int kStageDoubles = kObsCap * kRowStride + kObsCap;
+  static constexpr int kRowStride = K + 2;
+  static constexpr int kStageDoubles = kObsCap * kRowStride;
+  // G = 16: the sampling kernel as workgroups of eight wavefronts (two per SIMD, one workgroup per
+  // compute unit) that share ONE image: 8192 chains x 16 lanes are exactly 256 such workgroups.
+  // 88 KB of image + 6 KB of ziggurat tables leave one tree-stack level per wavefront in LDS
+  // (8 x 6.5 KB); a 7-leapfrog tree parks one node per transition on level 1 (L2-resident).
+  static constexpr int kWgWaves = (G == 16) ? 8 : 0;
+  static constexpr int kWgLdsLevels = 1;
+  __host__ __device__ static bool wg_ok(const Consts& c) { return c.N <= kObsCap; }
   struct Lane {
-    const double* xs;   // LDS image [N][kRowStride] then y, or null (rows stream from L2)
+    const double* xs;   // LDS image, or null (rows stream from L2)
   };
   __device__ static __forceinline__ void load(const Consts&, int, Lane& ln) { ln.xs = nullptr; }
   // cooperative (whole workgroup); the caller synchronises afterwards and guarantees N <= kObsCap
   __device__ static __forceinline__ void stage(const Consts& c, double* dst) {
-    for (int i = threadIdx.x; i < c.N * K; i += blockDim.x) dst[(i / K) * kRowStride + i % K] = c.X[i];
-    for (int i = threadIdx.x; i < c.N; i += blockDim.x) dst[kObsCap * kRowStride + i] = c.y[i];
+    for (int i = threadIdx.x; i < kStageDoubles; i += blockDim.x) {
+      const int n = i / kRowStride, j = i % kRowStride;
+      double v = 0.0;
+      if (n < c.N) v = (j < K) ? c.X[(size_t)n * K + j] : ((j == K) ? c.y[n] : 0.0);
+      dst[i] = v;
+    }
   }
 
   // every lane needs the whole coefficient vector: dim i lives in slot i / G of lane i % G
@@ -607,14 +633,147 @@ struct Logistic : ModelDefaults {
   __device__ static __forceinline__ double logp_grad(const Consts& c, const Lane& ln, int l,
                                                      const double (&q)[DPL], double (&g)[DPL]) {
     // the short forms (below) where the kernel has registers for the two copies of the pass: the
-    // one-chain-per-wave layout of the shared warmup (61.8 -> 54.2 ms); at 16 lanes per chain the
-    // sampling kernel is capped at 256 registers and measured 1 % slower with them
+    // one-chain-per-wave layout of the shared warmup (61.8 -> 54.2 ms). The 16-lane sampling layout
+    // decides per observation step instead (eval_row16)
     if constexpr (G == 64) {
       return with_fast_div([&](auto& dv) -> double { return eval(c, ln, l, q, g, dv); });
+    } else if constexpr (G == 16) {
+      return eval_row16(c, ln, l, q, g);
     } else {
       Div<false> exact;
       return eval(c, ln, l, q, g, exact);
     }
+  }
+
+  // ---- the 16-lane layout: a chain is one DPP row (round 5) ----
+  // Same operations in the same order as eval() below (the numeric contract of logp_logistic in the
+  // checker is untouched); what differs is how they are issued:
+  //  * the linear predictor reads the coefficients where they live -- dimension i in lane i % 16,
+  //    slot i / 16 of the chain's row -- through v_fmac_f64_dpp row_newbcast: eta = fma(beta_j[lane],
+  //    x_j, eta) is one instruction per feature and no lane keeps a copy of all 21 coefficients
+  //    (42 registers, and the 42 DPP moves that filled them every leapfrog);
+  //  * the three specials of an observation in their short forms (exp without its guards, the
+  //    quotient through the refined reciprocal, log of a clipped probability: the main path alone)
+  //    with the polynomial coefficients in scalar registers (exmc_detmath.h, _s cores), decided PER
+  //    STEP of sixteen observations: a wavefront whose predictors all lie in [-200, 200] takes the
+  //    short forms, otherwise that step alone takes the general ones. Same bits on the domain;
+  //  * every lane runs every step (the row's DPP reads need their source lanes active); a lane
+  //    whose observation index is past N reads a zero row and adds r = 0 and ll = 0, which leave
+  //    the (never negative-zero) partial sums as they are.
+  __device__ static __forceinline__ double eta_row16(double q0, double q1, const double (&x)[K]) {
+    static_assert(G != 16 || (K == 20 && DPL == 2), "dims 0..15 in slot 0, 16..20 in slot 1");
+    double e = 0.0;
+    const double one = seq_one();
+    __asm__("s_nop 1\n\t"
+            "v_fmac_f64_dpp %[e], %[q0], %[one] row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %[e], %[q0], %[x0] row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %[e], %[q0], %[x1] row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %[e], %[q0], %[x2] row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %[e], %[q0], %[x3] row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %[e], %[q0], %[x4] row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %[e], %[q0], %[x5] row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %[e], %[q0], %[x6] row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %[e], %[q0], %[x7] row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %[e], %[q0], %[x8] row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %[e], %[q0], %[x9] row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %[e], %[q0], %[x10] row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %[e], %[q0], %[x11] row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %[e], %[q0], %[x12] row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %[e], %[q0], %[x13] row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %[e], %[q0], %[x14] row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %[e], %[q1], %[x15] row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %[e], %[q1], %[x16] row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %[e], %[q1], %[x17] row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %[e], %[q1], %[x18] row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %[e], %[q1], %[x19] row_newbcast:4 row_mask:0xf bank_mask:0xf"
+            : [e] "+v"(e)
+            : [q0] "v"(q0), [q1] "v"(q1), [one] "v"(one), [x0] "v"(x[0]), [x1] "v"(x[1]),
+              [x2] "v"(x[2]), [x3] "v"(x[3]), [x4] "v"(x[4]), [x5] "v"(x[5]), [x6] "v"(x[6]),
+              [x7] "v"(x[7]), [x8] "v"(x[8]), [x9] "v"(x[9]), [x10] "v"(x[10]), [x11] "v"(x[11]),
+              [x12] "v"(x[12]), [x13] "v"(x[13]), [x14] "v"(x[14]), [x15] "v"(x[K > 15 ? 15 : 0]),
+              [x16] "v"(x[K > 16 ? 16 : 0]), [x17] "v"(x[K > 17 ? 17 : 0]),
+              [x18] "v"(x[K > 18 ? 18 : 0]), [x19] "v"(x[K > 19 ? 19 : 0]));
+    return e;
+  }
+
+  // one step: observations it * 16 + l of the row's sixteen lanes
+  template <bool kStaged>
+  __device__ static __forceinline__ void step_row16(const Consts& c, const lds_v2d* img, int l, int it,
+                                                    double q0, double q1, double (&s)[D + 1]) {
+    constexpr double kLo = (double)1.0e-7f, kHi = 1.0 - (double)1.0e-7f;   // = Consts::lo, hi
+    const int n = l + (it << 4);
+    const bool live = n < c.N;
+    double xr[K], yn;
+    if constexpr (kStaged) {
+      const lds_v2d* const row = img + n * (kRowStride / 2);
+#pragma unroll
+      for (int j = 0; j < K / 2; j++) {
+        const exmc_v2d v = row[j];
+        xr[2 * j] = v[0];
+        xr[2 * j + 1] = v[1];
+      }
+      yn = row[K / 2][0];
+    } else {
+      const int nr = live ? n : (c.N - 1);
+      const double* x = c.X + (size_t)nr * K;
+#pragma unroll
+      for (int j = 0; j < K; j++) xr[j] = x[j];
+      yn = c.y[nr];
+    }
+    const double eta = eta_row16(q0, q1, xr);
+    double p, ll;
+    const bool inr = fabs(eta) <= 200.0;   // false for a NaN
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!inr) == 0, 1)) {
+      const double u = 1.0 + exmc_exp_pm200_s(-eta);   // [1, e^200 + 1): inside the division window
+      p = exmc_div_core(1.0, u, exmc_rcp_refined(u));
+      const double pc = fmin(fmax(p, kLo), kHi);
+      ll = exmc_log_normal_s((yn == 1.0) ? pc : (1.0 - pc));   // [1e-7, 1 - 1e-7]: normal, positive
+    } else {
+      p = 1.0 / (1.0 + exmc_exp(-eta));
+      const double pc = fmin(fmax(p, kLo), kHi);
+      ll = exmc_log((yn == 1.0) ? pc : (1.0 - pc));
+    }
+    const double r = (live && p > kLo && p < kHi) ? (yn - p) : 0.0;
+    s[D] = s[D] + (live ? ll : 0.0);
+    s[0] = __builtin_fma(1.0, r, s[0]);
+#pragma unroll
+    for (int j = 0; j < K; j++) s[1 + j] = __builtin_fma(xr[j], r, s[1 + j]);
+  }
+
+  // kImage: the caller guarantees the LDS image (the workgroup form of the sampling kernel)
+  __device__ static __forceinline__ double logp_grad_staged(const Consts& c, const Lane& ln, int l,
+                                                            const double (&q)[DPL], double (&g)[DPL]) {
+    return eval_row16<true>(c, ln, l, q, g);
+  }
+  template <bool kImage = false>
+  __device__ static __forceinline__ double eval_row16(const Consts& c, const Lane& ln, int l,
+                                                      const double (&q)[DPL], double (&g)[DPL]) {
+    double s[D + 1];   // s[0..D-1] gradient partials, s[D] likelihood partial
+#pragma unroll
+    for (int j = 0; j <= D; j++) s[j] = 0.0;
+    const int steps = (c.N + 15) >> 4;
+    const double q0 = q[0], q1 = q[DPL > 1 ? 1 : 0];
+    if (kImage || ln.xs != nullptr) {   // wave-uniform
+      const lds_v2d* const img = (const lds_v2d*)ln.xs;
+      for (int it = 0; it < steps; it++) step_row16<true>(c, img, l, it, q0, q1, s);
+    } else {
+      for (int it = 0; it < steps; it++) step_row16<false>(c, nullptr, l, it, q0, q1, s);
+    }
+    group_allsum_n<G, D + 1>(s);
+    double T[DPL];
+    bool valid[DPL];
+#pragma unroll
+    for (int k = 0; k < DPL; k++) {
+      const int i = l + k * G;
+      valid[k] = i < D;
+      double gi = 0.0;
+#pragma unroll
+      for (int j = 0; j < D; j++) gi = (i == j) ? s[j] : gi;
+      const double z = (q[k] - 0.0) / 10.0;
+      T[k] = -0.5 * (z * z + c.c10);
+      g[k] = valid[k] ? ((-(z / 10.0)) + gi) : 0.0;
+    }
+    return group_sum_slots<G, DPL>(T, valid, l, s[D]);
   }
 
   // The three per-observation specials in their short forms while every linear predictor of the
@@ -640,7 +799,7 @@ struct Logistic : ModelDefaults {
         const double* x = exmc_dyn_lds + xoff + n * kRowStride;
 #pragma unroll
         for (int j = 0; j < K; j++) xr[j] = x[j];
-        yn = exmc_dyn_lds[xoff + kObsCap * kRowStride + n];
+        yn = x[K];
       } else {
         const double* x = c.X + (size_t)n * K;
 #pragma unroll

@@ -193,8 +193,10 @@ template <bool kZig>
 __host__ __device__ constexpr size_t nuts_zig_doubles() { return kZig ? kZigLdsBytes / 8 : 0; }
 template <class M, int LDSL, bool kZig = true>
 __host__ __device__ constexpr size_t nuts_lds_data_offset() {   // in doubles
-  return (size_t)LDSL * nuts_nslot<M>() * kNutsBlock + nuts_zig_doubles<kZig>() +
-         (size_t)M::kExtraLdsDoubles + (size_t)M::kDenseLdsDoubles;
+  // (an even count: what follows -- a model's data image, the warmup's staged image -- is read in
+  // 16-byte pairs)
+  return ((size_t)LDSL * nuts_nslot<M>() * kNutsBlock + nuts_zig_doubles<kZig>() +
+          (size_t)M::kExtraLdsDoubles + (size_t)M::kDenseLdsDoubles + 1) & ~(size_t)1;
 }
 template <class M, int LDSL, bool kZig = true>
 __host__ __device__ constexpr size_t nuts_lds_bytes() {
@@ -1571,10 +1573,11 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock, M::kNutsW
       // (sv: 291 with the priority, 169 without, of 460) the share f of slot 0 that makes the rates
       // proportional to rho = left_0 / left_1 is (291 rho - 169) / (122 (1 + rho)).
       int* const pair_word = board + kMigMail + 2 * (int)gridDim.x;
-      const bool paired = L.prio_slot >= 0;
       unsigned long long lf_at_start = 0;
       int done_at_start = 0;
       for (;;) {
+        // (a wave that became a host has its SIMD to itself: prio_slot -1 from then on)
+        const bool paired = L.prio_slot >= 0;
         // one transition at a time; the words looked at after it are loaded before it
         int host_adv = 0, n_live = 0, partner_left = 0;
         if (lane == 0) {
@@ -1686,6 +1689,100 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock, M::kNutsW
 #endif
 
   if (!has_chain) return;
+  chain_store<M, G>(P.st, C, chain, l, st);
+  if (l == 0 && P.counters) {
+    atomicAdd(&P.counters[0], lf_total);
+    atomicAdd(&P.counters[1], div_total);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// The sampling kernel as workgroups of W wavefronts that share ONE LDS image of the model's data
+// (M::kWgWaves, M::stage / kStageDoubles; logistic at 16 lanes per chain: its 500 x 20 design
+// matrix, which every wavefront otherwise streams from L2 at every leapfrog). Every wavefront is
+// the one-wave kernel on its own slice of LDS -- W tree stacks of LDSL levels, then the ziggurat
+// tables and the image once -- and after the staging barrier no wavefront waits for another.
+//   LDS: [wave 0 stack][wave 1 stack] ... [ziggurat tables][image]
+// Diagonal mass, no stream, no migration (the kinds that have those keep nuts_kernel).
+// ------------------------------------------------------------------------------------------
+template <class M, int LDSL, int W>
+__host__ __device__ constexpr size_t nuts_wg_image_offset() {   // in doubles; even
+  return (size_t)W * LDSL * nuts_nslot<M>() * kNutsBlock + kZigLdsBytes / 8;
+}
+template <class M, int LDSL, int W>
+__host__ __device__ constexpr size_t nuts_wg_lds_bytes() {
+  return (nuts_wg_image_offset<M, LDSL, W>() + (size_t)M::kStageDoubles) * 8;
+}
+
+// the model as the workgroup form evaluates it: always from the image
+template <class B>
+struct WgModel : B {
+  __device__ static __forceinline__ double logp_grad(const typename B::Consts& c, const typename B::Lane& ln,
+                                                     int l, const double (&q)[B::DPL], double (&g)[B::DPL]) {
+    return B::logp_grad_staged(c, ln, l, q, g);
+  }
+};
+
+template <class B, int G, int LDSL, int W>
+__global__ void __launch_bounds__(W * kNutsBlock) nuts_kernel_wg(NutsParams P, typename B::Consts mc) {
+  using M = WgModel<B>;
+  constexpr int D = M::D, DPL = M::DPL;
+  constexpr int NSLOT = nuts_nslot<M>();
+  static_assert(M::kStageDoubles > 0 && !M::kCoop && M::kLdsDataDoubles == 0 && M::kExtraLdsDoubles == 0,
+                "a model with a stage()-filled image and nothing else in LDS");
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tid = blockIdx.x * (W * kNutsBlock) + threadIdx.x;
+  const int C = P.n_chains;
+  const bool has_chain = (tid / G) < C;
+  const int chain = has_chain ? (tid / G) : (C - 1);
+  // cooperative part: the tables and the image, once per workgroup
+  double* const lz = lds + (size_t)W * LDSL * NSLOT * kNutsBlock;
+  for (int i = threadIdx.x; i < 256; i += W * kNutsBlock) {
+    lz[i] = __longlong_as_double((long long)P.zig_ki[i]);
+    lz[256 + i] = P.zig_wi[i];
+    lz[512 + i] = P.zig_fi[i];
+  }
+  double* const image = lds + nuts_wg_image_offset<M, LDSL, W>();
+  M::stage(mc, image);
+  __syncthreads();
+  if (!has_chain) return;
+
+  NutsLane<M, G> L;
+  const ZigTables zt{(const uint64_t*)lz, lz + 256, lz + 512};
+  lane_setup<M, G, LDSL>(L, mc, lds, P.stack, P.inv_mass, P.sqrt_inv_mass, zt, P.nor_r, P.flat, P.dm);
+  L.lstk = lds + (size_t)wave * LDSL * NSLOT * kNutsBlock + lane;   // this wavefront's stack
+  L.ln.xs = image;
+  // two waves per SIMD by construction (W = 8 on four SIMDs); which two share one is the
+  // dispatcher's choice, so the priority is left to the arbiter
+  L.prio_slot = -1;
+  ChainRegs<DPL> st;
+  chain_load<M, G>(P.st, C, chain, L.l, st);
+
+  unsigned long long lf_total = 0, div_total = 0;
+  const int l = L.l;
+  const bool own = (l == 0);
+  // (the trace addresses are computed per draw: a draw of this kernel is tens of thousands of
+  // instructions, and cursors held across them would only be spilled)
+  auto sink = [&](int draw, const double (&sq)[DPL], double slogp, int depth, int t_n, bool t_div,
+                  double t_acc, double jlp0) {
+    const size_t row = (size_t)P.draw_offset + (size_t)draw;
+#pragma unroll
+    for (int k = 0; k < DPL; k++)
+      if (L.valid[k] && P.tr.draws) P.tr.draws[(row * D + (l + k * G)) * C + chain] = sq[k];
+    if (own) {
+      const size_t at = row * C + chain;
+      if (P.tr.logp) P.tr.logp[at] = slogp;
+      if (P.tr.tree_depth) P.tr.tree_depth[at] = depth;
+      if (P.tr.n_steps) P.tr.n_steps[at] = t_n;
+      if (P.tr.divergent) P.tr.divergent[at] = t_div ? 1 : 0;
+      if (P.tr.accept_prob) P.tr.accept_prob[at] = (t_n > 0) ? (t_acc / (double)t_n) : 0.0;
+      if (P.tr.energy) P.tr.energy[at] = -jlp0;
+    }
+    lf_total += (unsigned long long)t_n;
+    div_total += t_div ? 1u : 0u;
+  };
+  nuts_run<M, G, LDSL>(mc, L, st, P.n_draws, P.eps, P.max_depth, sink);
   chain_store<M, G>(P.st, C, chain, l, st);
   if (l == 0 && P.counters) {
     atomicAdd(&P.counters[0], lf_total);

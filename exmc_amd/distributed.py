@@ -21,10 +21,17 @@ def shard_range(n_chains_total, rank, world):
     return lo, hi
 
 
-def gather_traces(draws_local, dist=None):
+def _skip(dist, force):
+    """No collective to make: no process group, or a group of one rank (unless `force`: a one-rank
+    group still executes every collective on the real backend -- how the RCCL calls are exercised on
+    a one-GPU box, tests/test_gpu_rccl_one_rank.py, `bench.py --force-dist`)."""
+    return dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force)
+
+
+def gather_traces(draws_local, dist=None, force=False):
     """All-gather [S][D][C_local] trace blocks into [S][D][C_total] in chain order.
     Every rank must hold the same C_local (pad the last shard otherwise)."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if _skip(dist, force):
         return draws_local
     world = dist.get_world_size()
     S, D, Cl = draws_local.shape
@@ -40,14 +47,14 @@ def gather_traces(draws_local, dist=None):
     return gathered.permute(1, 2, 0, 3).reshape(S, D, world * Cl)
 
 
-def reduce_sum(t, dist=None):
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+def reduce_sum(t, dist=None, force=False):
+    if not _skip(dist, force):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
 
 
-def reduce_max(t, dist=None):
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+def reduce_max(t, dist=None, force=False):
+    if not _skip(dist, force):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return t
 
@@ -64,10 +71,10 @@ def half_chain_stats(draws):
     return means, variances, n
 
 
-def gather_chain_stats(stat_local, dist=None):
+def gather_chain_stats(stat_local, dist=None, force=False):
     """All-gather [2][D][C_local] per-chain statistics into [2][D][C_total] in chain order: a few
     hundred KB instead of the [S][D][C] traces (2.6 GB per rank at 8 x 4096 x 1000 x 10)."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if _skip(dist, force):
         return stat_local
     world = dist.get_world_size()
     src = stat_local.contiguous()
@@ -285,28 +292,46 @@ def sample_chains_sharded(spec, num_chains, opts=None, devices=None, engine="exm
                          nprocs=world, join=False)
         deadline = time.monotonic() + float(o.get("shard_timeout_s", 6 * 3600.0))
 
+        def stop_ranks():
+            """End the rank processes (never re-exec): SIGTERM, a short join, SIGKILL for whatever is
+            left -- a rank blocked in a driver call or a collective can sit out the first signal -- and
+            a last join so that no child stays unreaped."""
+            alive = [p_ for p_ in procs.processes if p_.is_alive()]
+            for p_ in alive:
+                p_.terminate()
+            for p_ in alive:
+                p_.join(timeout=5.0)
+            for p_ in alive:
+                if p_.is_alive():
+                    p_.kill()
+            for p_ in alive:
+                p_.join(timeout=5.0)
+
         def expired():
             if time.monotonic() > deadline:
-                for p_ in procs.processes:
-                    if p_.is_alive():
-                        p_.terminate()
+                stop_ranks()
                 raise TimeoutError("sample_chains_sharded: the rank processes did not finish within "
                                    "shard_timeout_s; they have been terminated")
         first = None
         try:
-            while first is None:
-                if not queue.empty():
-                    first = queue.get()
-                    first["raw"] = {k: v.numpy().copy() for k, v in first["raw"].items()}
-                elif procs.join(timeout=0.05):      # every rank has exited (join raises if one failed)
-                    if queue.empty():
-                        raise RuntimeError("the rank processes ended without a result")
+            try:
+                while first is None:
+                    if not queue.empty():
+                        first = queue.get()
+                        first["raw"] = {k: v.numpy().copy() for k, v in first["raw"].items()}
+                    elif procs.join(timeout=0.05):      # every rank has exited (join raises if one failed)
+                        if queue.empty():
+                            raise RuntimeError("the rank processes ended without a result")
+                    expired()
+            finally:
+                received.set()
+            while not procs.join(timeout=0.05):
                 expired()
+        except BaseException:
+            stop_ranks()     # a failed rank (join raised) must not leave its peers holding their GPUs
+            raise
         finally:
-            received.set()
-        while not procs.join(timeout=0.05):
-            expired()
-        del store
+            del store        # the rendezvous store goes with the call, whichever way it ends
         if not first["same_tuning"]:
             raise RuntimeError("ranks disagree on the shared tuning: the warmup is not deterministic")
         shards = [shard_range(num_chains, r, world) for r in range(world)]

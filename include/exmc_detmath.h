@@ -157,12 +157,61 @@ static __device__ __forceinline__ void exmc_log_core_v(double w, double* u1_out,
   *u1_out = u1;
   *u2_out = u2;
 }
+/* Third spelling: the same chains with the coefficients in SCALAR registers (a VOP3 instruction of
+ * gfx950 reads one scalar operand: every Horner step acc*r + C is one v_fma_f64 with C scalar; the
+ * first step of a chain has two constants, so one of them rides in a vector register). For kernels
+ * that have neither the ~40 vector registers of the _v form nor issue slots for the v_mov of the
+ * compiler's form (the 16-lane logistic sampling kernel: 256 registers, two waves per SIMD). */
+static __device__ __forceinline__ void exmc_exp_core_s(double kf, double x, double* r_out, double* p_out) {
+  double p, r;
+  __asm__("v_fma_f64 %1, %2, %4, %3\n\t"
+          "v_fma_f64 %1, %2, %5, %1\n\t"
+          "v_fma_f64 %0, %1, %6, %7\n\t"
+          "v_fma_f64 %0, %0, %1, %8\n\t"
+          "v_fma_f64 %0, %0, %1, %9\n\t"
+          "v_fma_f64 %0, %0, %1, %10\n\t"
+          "v_fma_f64 %0, %0, %1, %11\n\t"
+          "v_fma_f64 %0, %0, %1, %12\n\t"
+          "v_fma_f64 %0, %0, %1, %13\n\t"
+          "v_fma_f64 %0, %0, %1, %14\n\t"
+          "v_fma_f64 %0, %0, %1, %15\n\t"
+          "v_fma_f64 %0, %0, %1, %16"
+          : "=&v"(p), "=&v"(r)
+          : "v"(kf), "v"(x), "s"(-0x1.62e42fefa39efp-1), "s"(-0x1.abc9e3b39803fp-56),
+            "s"(0x1.6124613a86d09p-33), "v"(0x1.1eed8eff8d898p-29), "s"(0x1.ae64567f544e4p-26),
+            "s"(0x1.27e4fb7789f5cp-22), "s"(0x1.71de3a556c734p-19), "s"(0x1.a01a01a01a01ap-16),
+            "s"(0x1.a01a01a01a01ap-13), "s"(0x1.6c16c16c16c17p-10), "s"(0x1.1111111111111p-7),
+            "s"(0x1.5555555555555p-5), "s"(0x1.5555555555555p-3));
+  *r_out = r;
+  *p_out = p;
+}
+static __device__ __forceinline__ void exmc_log_core_s(double w, double* u1_out, double* u2_out) {
+  double u1, u2;
+  __asm__("v_fma_f64 %0, %2, %3, %4\n\t"
+          "v_fma_f64 %1, %2, %6, %7\n\t"
+          "v_fma_f64 %0, %2, %0, %5\n\t"
+          "v_fma_f64 %1, %2, %1, %8\n\t"
+          "v_fma_f64 %1, %2, %1, %9"
+          : "=&v"(u1), "=&v"(u2)
+          : "v"(w), "s"(1.531383769920937332e-01), "v"(2.222219843214978396e-01),
+            "s"(3.999999999940941908e-01), "s"(1.479819860511658591e-01),
+            "v"(1.818357216161805012e-01), "s"(2.857142874366239149e-01),
+            "s"(6.666666666666735130e-01));
+  *u1_out = u1;
+  *u2_out = u2;
+}
 #elif defined(__HIPCC__)
 /* host pass of hipcc: the names must exist; the bodies are the portable ones */
 static __device__ __forceinline__ void exmc_exp_core_v(double kf, double x, double* r_out, double* p_out) {
   exmc_exp_core(kf, x, r_out, p_out);
 }
 static __device__ __forceinline__ void exmc_log_core_v(double w, double* u1_out, double* u2_out) {
+  exmc_log_core(w, u1_out, u2_out);
+}
+static __device__ __forceinline__ void exmc_exp_core_s(double kf, double x, double* r_out, double* p_out) {
+  exmc_exp_core(kf, x, r_out, p_out);
+}
+static __device__ __forceinline__ void exmc_log_core_s(double w, double* u1_out, double* u2_out) {
   exmc_log_core(w, u1_out, u2_out);
 }
 #endif
@@ -349,6 +398,13 @@ static __device__ __forceinline__ double exmc_exp_v(double x) { EXMC_EXP_BODY(ex
 static __device__ __forceinline__ double exmc_log_v(double x) { EXMC_LOG_BODY(exmc_log_core_v) }
 #define EXMC_RHD static __device__ __forceinline__
 EXMC_RANGE_FUNCS(_v, exmc_exp_core_v, exmc_log_core_v)
+EXMC_RANGE_FUNCS(_s, exmc_exp_core_s, exmc_log_core_s)
+/* log of a NORMAL positive x (the caller proves x is neither zero, subnormal, infinite nor NaN): the
+ * main path alone, e.g. a probability clipped into [1e-7, 1 - 1e-7] */
+static __device__ __forceinline__ double exmc_log_normal_s(double x) {
+  EXMC_LOG_MAIN(exmc_log_core_s, x, res)
+  return res;
+}
 #undef EXMC_RHD
 #endif
 

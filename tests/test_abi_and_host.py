@@ -154,3 +154,41 @@ def test_plugin_carries_its_kernels_as_code_objects_not_host_stubs():
     P = _lib.bind(so)
     for name in _lib.EXPORTS:
         getattr(P, name)
+
+
+def test_plugin_build_form_is_part_of_the_cache_tag_and_missing_kernels_fail_the_build(tmp_path, monkeypatch):
+    """(a) the library of one build form (code objects / host stubs / one unit) must never be
+    handed out for another -- the form is in the cache tag; (b) a kernel the host unit can launch but
+    no part defines is a BUILD error, as the link error it used to be, not a launch-time one."""
+    import re
+    import subprocess
+    from exmc_amd import build as _build
+    from exmc_amd import codegen
+    gen = codegen.generate(codegen.simple_ir())
+    monkeypatch.delenv("EXMC_PLUGIN_STUBS", raising=False)
+    monkeypatch.delenv("EXMC_PLUGIN_ONE_TU", raising=False)
+    d_mod = codegen.plugin_paths(gen)[0]
+    monkeypatch.setenv("EXMC_PLUGIN_STUBS", "1")
+    d_stub = codegen.plugin_paths(gen)[0]
+    monkeypatch.setenv("EXMC_PLUGIN_ONE_TU", "1")
+    d_one = codegen.plugin_paths(gen)[0]
+    assert len({d_mod, d_stub, d_one}) == 3
+    monkeypatch.delenv("EXMC_PLUGIN_STUBS")
+    monkeypatch.delenv("EXMC_PLUGIN_ONE_TU")
+    # (b) a host object that names a kernel nobody defines
+    src = tmp_path / "h.c"
+    src.write_text('const char* a = "_ZN4exmc11nuts_kernelINS_6CustomILi1EEELi1ELi2ELb0ELb0EEEvNS_10NutsParamsENT_6ConstsE";\n'
+                   'const char* b = "_ZN4exmc13bogus_kernel_that_no_part_definesEv";\n')
+    host = tmp_path / "h.o"
+    subprocess.check_call(["gcc", "-c", "-o", str(host), str(src)])
+    part = tmp_path / "p.o"
+    psrc = tmp_path / "p.c"
+    psrc.write_text("void _ZN4exmc11nuts_kernelINS_6CustomILi1EEELi1ELi2ELb0ELb0EEEvNS_10NutsParamsENT_6ConstsE(void) {}\n")
+    subprocess.check_call(["gcc", "-c", "-o", str(part), str(psrc)])
+    common = _build.build_common()
+    with pytest.raises(RuntimeError, match="bogus_kernel_that_no_part_defines"):
+        codegen._check_module_kernels(str(host), [str(part)], common)
+    host2 = tmp_path / "h2.o"
+    src.write_text(re.sub(r"const char\* b.*\n", "", src.read_text()))
+    subprocess.check_call(["gcc", "-c", "-o", str(host2), str(src)])
+    codegen._check_module_kernels(str(host2), [str(part)], common)     # every name defined: no error
