@@ -488,6 +488,13 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device is visible (no CPU fallback)")
+    # The contract is ONE JSON line on stdout. Libraries write there too -- RCCL prints a five-line
+    # version banner to stdout when the first communicator is created (seen the first time any nccl
+    # branch of this file ran: profiles/r5_rccl) -- so from here on file descriptor 1 IS stderr, and
+    # the line goes out through a private duplicate of the real stdout.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -533,7 +540,7 @@ def main():
                 leg = o.pop(key, None)
                 if leg is not None:
                     leg()
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -49,6 +49,8 @@ static int g_device = 0;
   X(int, sample_chains_host, (exmc_hip_model*, const exmc_hip_tuning*, const double*, int, int, int,           \
                               exmc_hip_opts, exmc_hip_trace, int64_t*, int32_t*))                              \
   X(int, sample_host, (exmc_hip_model*, const double*, exmc_hip_opts, exmc_hip_trace, exmc_hip_tuning*, int32_t*)) \
+  X(int, sample_independent_host, (exmc_hip_model*, const double*, int, int, int, exmc_hip_opts, exmc_hip_trace, \
+                                   double*, int64_t*, int32_t*))                                               \
   X(int, stream_begin, (exmc_hip_model*, const double*, exmc_hip_opts, exmc_hip_tuning*))                      \
   X(int, stream_next_host, (exmc_hip_model*, int, exmc_hip_trace, int32_t*))                                   \
   X(int, stream_start, (exmc_hip_model*, int, exmc_hip_trace*, const volatile int32_t**))                      \
@@ -84,24 +86,28 @@ static ERL_NIF_TERM raise_api(ErlNifEnv* env, const exmc_api* A, int rc) {
 typedef struct { exmc_hip_model* m; const exmc_api* api; ErlNifTid tid; int has_tid; } model_res;
 
 static ErlNifMutex* g_tid_lock;
-#define EXMC_REAP_MAX 64
-static ErlNifTid g_reap[EXMC_REAP_MAX];
-static int g_reap_n;
+/* senders that ended on their own last reference, waiting to be joined: a list under g_tid_lock
+ * (no bound: every such thread is joined, as ERTS requires) */
+typedef struct reap_node { ErlNifTid tid; struct reap_node* next; } reap_node;
+static reap_node* g_reap;
 
-/* join the senders that ended on their own last reference (they are past their last use of the
- * library: the join returns at once) */
+/* Join the parked senders. A parked sender may still be inside its handle's destructor (model
+ * destruction frees device memory and destroys a stream), so a join here can wait for that to end:
+ * every caller is a dirty IO-bound NIF or the unload hook, never a normal scheduler. */
 static void reap_senders(void) {
   for (;;) {
-    ErlNifTid t;
     enif_mutex_lock(g_tid_lock);
-    const int have = g_reap_n > 0;
-    if (have) t = g_reap[--g_reap_n];
+    reap_node* n = g_reap;
+    if (n) g_reap = n->next;
     enif_mutex_unlock(g_tid_lock);
-    if (!have) return;
-    if (!enif_equal_tids(enif_thread_self(), t)) (void)enif_thread_join(t, NULL);
-    else {                       /* the reaper must not run on a parked thread: put it back and stop */
+    if (!n) return;
+    if (!enif_equal_tids(enif_thread_self(), n->tid)) {
+      (void)enif_thread_join(n->tid, NULL);
+      enif_free(n);
+    } else {                     /* the reaper must not run on a parked thread: put it back and stop */
       enif_mutex_lock(g_tid_lock);
-      if (g_reap_n < EXMC_REAP_MAX) g_reap[g_reap_n++] = t;
+      n->next = g_reap;
+      g_reap = n;
       enif_mutex_unlock(g_tid_lock);
       return;
     }
@@ -109,13 +115,21 @@ static void reap_senders(void) {
 }
 
 static void join_sender(model_res* r) {
+  /* (the node is allocated before the lock is taken: nothing allocates under g_tid_lock) */
+  reap_node* n = (reap_node*)enif_alloc(sizeof(reap_node));
   enif_mutex_lock(g_tid_lock);
   const int has = r->has_tid;
   const ErlNifTid t = r->tid;
   r->has_tid = 0;
   const int self = has && enif_equal_tids(enif_thread_self(), t);
-  if (self && g_reap_n < EXMC_REAP_MAX) g_reap[g_reap_n++] = t;   /* joined by the next caller / at unload */
+  if (self && n) {               /* joined by the next caller / at unload */
+    n->tid = t;
+    n->next = g_reap;
+    g_reap = n;
+    n = NULL;
+  }
   enif_mutex_unlock(g_tid_lock);
+  if (n) enif_free(n);
   if (has && !self) (void)enif_thread_join(t, NULL);
 }
 
@@ -448,6 +462,43 @@ static ERL_NIF_TERM sample_chains(ErlNifEnv* env, int argc, const ERL_NIF_TERM a
   return tuple3(env, trace_map(env, &b), enif_make_uint64(env, (ErlNifUInt64)lf), enif_make_int(env, dv));
 }
 
+/* sample_independent(ref, init_q | nil, n_chains, chain_lo, chain_hi, num_warmup, num_samples,
+ *                    max_tree_depth, target_accept, seed)
+ *   -> {trace_map, tuning_bin, leapfrogs, divergences}
+ * sample_chains(ir, n, vectorized: false) -- sample_chains_parallel, sampler.ex:1139-1176: chains
+ * [chain_lo, chain_hi) of n_chains, chain i = sample/3 with seed + 7919 i (its own adaptation, then its
+ * draws), all in one launch. tuning_bin: per chain 3 + d doubles -- final step size, warmup
+ * divergences, warmup leapfrogs, inv_mass (kernel order); leapfrogs / divergences: sampling phase. */
+static ERL_NIF_TERM sample_independent(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  HANDLE(argv[0]);
+  const double* iq;
+  int n_chains, lo, hi;
+  ErlNifUInt64 seed;
+  exmc_hip_opts o;
+  (void)argc;
+  memset(&o, 0, sizeof o);
+  if (!m) return enif_make_badarg(env);
+  const int d = A->model_dim(m);
+  if (!get_init_q(env, argv[1], d, &iq) || !enif_get_int(env, argv[2], &n_chains) ||
+      !enif_get_int(env, argv[3], &lo) || !enif_get_int(env, argv[4], &hi) ||
+      !enif_get_int(env, argv[5], &o.num_warmup) || !enif_get_int(env, argv[6], &o.num_samples) ||
+      !enif_get_int(env, argv[7], &o.max_tree_depth) || !get_f64(env, argv[8], &o.target_accept) ||
+      !enif_get_uint64(env, argv[9], &seed) || lo < 0 || hi <= lo || hi > n_chains || o.num_samples < 1 ||
+      o.num_warmup < 0)
+    return enif_make_badarg(env);
+  o.seed = seed;
+  const size_t C = (size_t)(hi - lo);
+  trace_bins b;
+  new_trace(env, C * (size_t)o.num_samples, (size_t)d, &b);
+  ERL_NIF_TERM tune_term;
+  double* tune = (double*)enif_make_new_binary(env, C * (size_t)(3 + d) * 8, &tune_term);
+  int64_t lf = 0;
+  int32_t dv = 0;
+  int rc = A->sample_independent_host(m, iq, n_chains, lo, hi, o, b.tr, tune, &lf, &dv);
+  if (rc != EXMC_OK) return raise_api(env, A, rc);
+  return tuple4(env, trace_map(env, &b), tune_term, enif_make_uint64(env, (ErlNifUInt64)lf), enif_make_int(env, dv));
+}
+
 /* sample(ref, init_q | nil, num_warmup, num_samples, max_tree_depth, target_accept, seed)
  *   -> {trace_map, tuning_map, divergences} */
 static ERL_NIF_TERM sample(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
@@ -527,7 +578,9 @@ static void* stream_sender(void* arg) {
   int sent = 0;
   long idle_naps = 0;
   while (sent < j->n) {
-    const int ready = *j->progress;          /* rows [0, ready) are final */
+    /* rows [0, ready) are final: the device publishes the count with a system-scope release after
+     * the rows' stores; the acquire keeps this thread's reads of the rows behind the count */
+    const int ready = __atomic_load_n((const int32_t*)j->progress, __ATOMIC_ACQUIRE);
     if (ready <= sent) {
       if (++idle_naps > 6000000L) break;     /* ten minutes without a draw: give up, report below */
       nanosleep(&nap, NULL);
@@ -615,6 +668,7 @@ static ErlNifFunc nif_funcs[] = {
     {"clear_dense_mass", 1, clear_dense_mass, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"sample_chains", 10, sample_chains, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"sample", 7, sample, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"sample_independent", 10, sample_independent, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"stream_begin", 6, stream_begin, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"stream_next", 2, stream_next, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"stream_run", 3, stream_run, ERL_NIF_DIRTY_JOB_IO_BOUND},
@@ -626,7 +680,7 @@ static int on_load(ErlNifEnv* env, void** priv, ERL_NIF_TERM info) {
   const char* dev = getenv("EXMC_HIP_DEVICE");
   g_device = dev ? atoi(dev) : 0;
   g_tid_lock = enif_mutex_create((char*)"exmc_hip_tid");
-  g_reap_n = 0;
+  g_reap = NULL;
   MODEL_RT = enif_open_resource_type(env, NULL, "exmc_hip_model", model_dtor, ERL_NIF_RT_CREATE, NULL);
   return (MODEL_RT && g_tid_lock) ? 0 : 1;
 }

@@ -89,6 +89,11 @@ static __attribute__((unused)) ERL_NIF_TERM tuple3(ErlNifEnv* env, ERL_NIF_TERM 
   ERL_NIF_TERM v[3] = {a, b, c};
   return enif_make_tuple_from_array(env, v, 3);
 }
+static __attribute__((unused)) ERL_NIF_TERM tuple4(ErlNifEnv* env, ERL_NIF_TERM a, ERL_NIF_TERM b, ERL_NIF_TERM c,
+                                                   ERL_NIF_TERM d) {
+  ERL_NIF_TERM v[4] = {a, b, c, d};
+  return enif_make_tuple_from_array(env, v, 4);
+}
 /* a failed library call: raise {:exmc_hip_error, code, message} (Rustler turns a NifResult::Err
  * into a raised term the same way) */
 static __attribute__((unused)) ERL_NIF_TERM raise_hip(ErlNifEnv* env, int rc) {

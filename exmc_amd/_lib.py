@@ -25,6 +25,7 @@ EXPORTS = [
     "exmc_hip_model_set_flat_order", "exmc_hip_warmup_from", "exmc_hip_sample_warm_host",
     "exmc_hip_warmup_dense", "exmc_hip_model_set_dense_mass", "exmc_hip_model_clear_dense_mass",
     "exmc_hip_sample_dense_host",
+    "exmc_hip_sample_independent", "exmc_hip_sample_independent_host",
 ]
 
 
@@ -123,6 +124,9 @@ def bind(path):
     L.exmc_hip_build_subtree_host.argtypes = [
         C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, C.c_int, dp, dp, ip, ip, up,
         dp, dp, dp, dp, dp, dp, dp, dp, dp, dp, ip, ip, dp, ip, ip, dp]
+    L.exmc_hip_sample_independent.argtypes = [vp, dp, C.c_int, C.c_int, C.c_int, Opts, Trace, dp,
+                                              C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
+    L.exmc_hip_sample_independent_host.argtypes = L.exmc_hip_sample_independent.argtypes
     L.exmc_hip_ess.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
     L.exmc_hip_rhat.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
     L.exmc_hip_ess_bulk.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]

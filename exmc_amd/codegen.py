@@ -1434,7 +1434,7 @@ def build_plugin(gen, force=False, verbose=False):
             jobs = [([hipcc] + host_flags + defs + main_defs + ["-c", "-o", "%s.main.o" % tmp, _build.SRC])]
             layouts = [k for k, macro in ((1, "EXMC_GEN_ONE_LANE"), (2, "EXMC_GEN_VEC"), (3, "EXMC_GEN_LANES "))
                        if ("#define " + macro) in gen.header]
-            parts = [(k, lay) for k in (3, 4, 1, 2, 5) for lay in layouts]
+            parts = [(k, lay) for k in (3, 4, 7, 1, 2, 5) for lay in layouts]
             if 3 in layouts and gen.lanes < 64:     # the one-chain warmup form of the lane layout (CustomSplit)
                 parts.append((6, 3))
             part_flags = ([f for f in flags if f != "-fPIC"] + ["--cuda-device-only"]) if modules else host_flags

@@ -1099,6 +1099,72 @@ int run_warmup_device(exmc_hip_model* m, int lanes, exmc_hip_opts o, exmc_hip_tu
   return EXMC_OK;
 }
 
+// sample_chains(..., vectorized: false): the kinds' default layouts carry the independent-adaptation
+// kernel (exmc_nuts.hpp indep_kernel), like the stream form
+template <class M> inline constexpr bool kIndepKernel = kStreamKernel<M>;
+#if defined(EXMC_DEV_ES16_ONLY)
+template <> inline constexpr bool kIndepKernel<EightSchools<16>> = true;
+#elif defined(EXMC_DEV_ONLY)
+#if EXMC_DEV_ONLY == EXMC_DEV_SV64
+template <> inline constexpr bool kIndepKernel<SV<64>> = true;
+#elif EXMC_DEV_ONLY == EXMC_DEV_RADON64
+template <> inline constexpr bool kIndepKernel<Radon<64>> = true;
+#elif EXMC_DEV_ONLY == EXMC_DEV_LOGISTIC16
+template <> inline constexpr bool kIndepKernel<Logistic<16>> = true;
+#endif
+#endif
+
+// one launch: every chain of [chain_lo, chain_hi) adapts and samples on its own (indep_kernel)
+int launch_independent(exmc_hip_model* m, int lanes, int C, exmc_hip_opts o, TraceDev tr, double* tune_dev) {
+  if (o.max_tree_depth < 1 || o.max_tree_depth > kMaxLevels)
+    return fail(EXMC_ERR_BADARG, "max_tree_depth out of range");
+  const int W = o.num_warmup;
+  IndepParams P;
+  P.st = state_view(m, C);
+  P.n_chains = C;
+  P.num_warmup = W;
+  P.num_samples = o.num_samples;
+  P.max_depth = o.max_tree_depth;
+  P.target_accept = o.target_accept;
+  P.log_half = std::log(0.5);
+  P.init_buffer = (75 < W / 3) ? 75 : W / 3;
+  P.adapt_end = W - 50;
+  auto wins = build_windows(P.init_buffer, P.adapt_end, 25);
+  if (wins.size() > 32) return fail(EXMC_ERR_BADARG, "num_warmup needs more than 32 windows");
+  P.n_windows = (int)wins.size();
+  for (int k = 0; k < 32; k++) {
+    P.win_start[k] = k < P.n_windows ? wins[k].first : -1;
+    P.win_end[k] = k < P.n_windows ? wins[k].second : -1;
+  }
+  P.tr = tr;
+  P.tune_out = tune_dev;
+  P.counters = (unsigned long long*)(m->misc.as<double>() + 1);
+  P.zig_ki = zig_ki(m); P.zig_wi = zig_wi(m); P.zig_fi = zig_fi(m);
+  P.nor_r = EXMC_NOR_R;
+  P.flat = flat_order(m);
+  return dispatch(m, lanes, [&](auto tag, const auto& mc) {
+    using T = decltype(tag);
+    using M = typename T::M;
+    if constexpr (kIndepKernel<M>) {
+      dim3 grid = grid_for(C, T::G, kNutsBlock);
+      const size_t nthreads = (size_t)grid.x * kNutsBlock;
+      constexpr int kSpill = (kMaxLevels > T::LDSL) ? (kMaxLevels - T::LDSL) : 1;
+      int rc = m->stack.ensure((size_t)kSpill * nuts_nslot<M>() * nthreads * 8);
+      if (rc) return rc;
+      P.stack = m->stack.as<double>();
+      const size_t lds_bytes = nuts_lds_bytes<M, T::LDSL>();
+      if (lds_bytes > 64 * 1024) EXMC_KMAXLDS((indep_kernel<M, T::G, T::LDSL>), lds_bytes);
+      HIP_TRY(hipEventRecord(m->ev0, m->stream));
+      EXMC_KLAUNCH(m->device, (indep_kernel<M, T::G, T::LDSL>), grid, dim3(kNutsBlock), lds_bytes, m->stream, P, mc);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipEventRecord(m->ev1, m->stream));
+      return (int)EXMC_OK;
+    } else {
+      return fail(EXMC_ERR_UNSUPPORTED, "independent adaptation runs in the model kind's default layout");
+    }
+  });
+}
+
 // Every entry point that touches the handle's buffers, stream or counters goes through here. While
 // a push-style stream run is in flight (exmc_hip_stream_start .. _finish) the launch is writing the
 // page-locked trace and owns ev0 / ev1 and the counters: everything else is refused until
@@ -1761,6 +1827,59 @@ int exmc_hip_sample_warm_host(exmc_hip_model* m, const double* init_q, exmc_hip_
   if (divergences) *divergences = div + tun.warmup_divergences;  // stats.divergences, sampler.ex:245
   if (tuning_out) *tuning_out = tun;
   return download_trace(m, L, o.num_samples, 1, tr);
+}
+
+int exmc_hip_sample_independent(exmc_hip_model* m, const double* init_q, int n_chains, int chain_lo,
+                                int chain_hi, exmc_hip_opts o, exmc_hip_trace tr, double* tuning_host,
+                                int64_t* total_leapfrogs, int32_t* total_divergences) {
+  if (check_model(m)) return EXMC_ERR_BADARG;
+  if (n_chains < 1 || chain_lo < 0 || chain_hi > n_chains || chain_hi <= chain_lo || o.num_samples < 0 ||
+      o.num_warmup < 0)
+    return fail(EXMC_ERR_BADARG, "bad arguments");
+  HIP_TRY(hipSetDevice(m->device));
+  m->dense_on = false;   // every chain runs the diagonal adaptation itself
+  const int C = chain_hi - chain_lo, d = m->d;
+  const int lanes = resolve_lanes(m, o.lanes_per_chain);
+  int rc = ensure_state(m, C);
+  if (rc) return rc;
+  rc = launch_init(m, lanes, C, chain_lo, o.seed, init_q);   // chain i: seed + 7919 i, as sample/3 seeds chain 0
+  if (rc) return rc;
+  const size_t n_tune = (size_t)C * (3 + d);
+  rc = m->io.ensure(n_tune * 8);
+  if (rc) return rc;
+  rc = reset_counters(m);
+  if (rc) return rc;
+  TraceDev t;
+  t.draws = tr.draws; t.logp = tr.logp; t.tree_depth = tr.tree_depth; t.n_steps = tr.n_steps;
+  t.divergent = tr.divergent; t.accept_prob = tr.accept_prob; t.energy = tr.energy;
+  rc = launch_independent(m, lanes, C, o, t, m->io.as<double>());
+  if (rc) return rc;
+  rc = finish_timing(m);
+  if (rc) return rc;
+  m->res_C = 0;   // the chains ran with tunings of their own: nothing chains_advance could continue
+  if (tuning_host)
+    HIP_TRY(hipMemcpy(tuning_host, m->io.p, n_tune * 8, hipMemcpyDeviceToHost));
+  return read_counters(m, total_leapfrogs, total_divergences);
+}
+
+int exmc_hip_sample_independent_host(exmc_hip_model* m, const double* init_q, int n_chains, int chain_lo,
+                                     int chain_hi, exmc_hip_opts o, exmc_hip_trace tr, double* tuning_host,
+                                     int64_t* total_leapfrogs, int32_t* total_divergences) {
+  if (check_model(m)) return EXMC_ERR_BADARG;
+  if (chain_hi <= chain_lo || o.num_samples < 1) return fail(EXMC_ERR_BADARG, "bad arguments");
+  HIP_TRY(hipSetDevice(m->device));
+  const int C = chain_hi - chain_lo;
+  TraceLayout L = trace_layout(o.num_samples, m->d, C);
+  int rc = m->trace.ensure(L.total);
+  if (rc) return rc;
+  TraceDev t = trace_view(m->trace.p, L);
+  exmc_hip_trace dv;
+  dv.draws = t.draws; dv.logp = t.logp; dv.tree_depth = t.tree_depth; dv.n_steps = t.n_steps;
+  dv.divergent = t.divergent; dv.accept_prob = t.accept_prob; dv.energy = t.energy;
+  rc = exmc_hip_sample_independent(m, init_q, n_chains, chain_lo, chain_hi, o, dv, tuning_host,
+                                   total_leapfrogs, total_divergences);
+  if (rc) return rc;
+  return download_trace(m, L, o.num_samples, C, tr);
 }
 
 int exmc_hip_sample_dense_host(exmc_hip_model* m, const double* init_q, exmc_hip_opts o,

@@ -2364,4 +2364,177 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock)
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// sample_chains(ir, n, vectorized: false) -- sample_chains_parallel, sampler.ex:1139-1176: every
+// chain is Sampler.sample/3 with seed base + 7919 i: its OWN adaptation (step-size search, dual
+// averaging, Welford windows, sampler.ex:537-762) and then its draws, continuing from the adapted
+// position with the same generator. One launch: every lane group of the grid is one such chain
+// from its first warmup transition to its last draw. The adaptation state of a chain (dual
+// averaging, window moments, step size, inverse mass) is per-lane data, so the groups of a
+// wavefront adapt side by side; the window schedule is the same for all of them (it depends on
+// num_warmup alone), which keeps the phase boundaries wave-uniform, and nuts_run walks their
+// trees in lock step as the sampling kernel does. Each chain executes the operations of the
+// one-chain warmup_kernel followed by those of nuts_kernel on its own registers: every output equals
+// the checker's sample(seed = base + 7919 i) bit for bit. Diagonal mass, one-wave form.
+// ------------------------------------------------------------------------------------------
+struct IndepParams {
+  ChainState st;            // C chains, initialised by init_chains_kernel (seed base + 7919 i)
+  int n_chains;
+  int num_warmup, num_samples, max_depth;
+  double target_accept, log_half;
+  int init_buffer, adapt_end, n_windows;
+  int win_start[32], win_end[32];
+  double* stack;
+  TraceDev tr;              // [S][D][C] / [S][C]
+  double* tune_out;         // [C][3 + D]: final step size, warmup divergences, warmup leapfrogs, inv_mass[D]
+  unsigned long long* counters;   // [0] leapfrogs, [1] divergent transitions of the SAMPLING phase
+  const uint64_t* zig_ki;
+  const double* zig_wi;
+  const double* zig_fi;
+  double nor_r;
+  FlatOrder flat;
+};
+
+template <class M, int G, int LDSL>
+__global__ void __launch_bounds__(kNutsBlock) indep_kernel(IndepParams P, typename M::Consts mc) {
+  constexpr int D = M::D, DPL = M::DPL;
+  constexpr int NSLOT = nuts_nslot<M>();
+  static_assert(!M::kCoop, "wave-cooperative models evaluate every group at the same point of the same chain");
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x & 63;
+  const int tid = blockIdx.x * kNutsBlock + lane;
+  const int C = P.n_chains;
+  const bool has_chain = (tid / G) < C;
+  const int chain = has_chain ? (tid / G) : (C - 1);
+  const ZigTables zt = stage_zig_tables<LDSL, NSLOT>(lds, P.zig_ki, P.zig_wi, P.zig_fi);
+  const int xoff = stage_model_data<M, G, LDSL>(mc, lds);
+  if (!has_chain) return;
+
+  NutsLane<M, G> L;
+  lane_setup<M, G, LDSL>(L, mc, lds, P.stack, nullptr, nullptr, zt, P.nor_r, P.flat);   // identity mass
+  if constexpr (M::kLdsDataDoubles > 0) L.ln.xoff = xoff;
+  ChainRegs<DPL> st;
+  chain_load<M, G>(P.st, C, chain, L.l, st);
+  const int l = L.l;
+
+  // ---- adaptation (the diagonal path of warmup_kernel, per lane group) ----
+  double accept = 0.0;
+  bool diverged = false;
+  unsigned long long w_leapfrogs = 0;
+  int w_divergences = 0;
+  auto wsink = [&](int, const double (&)[DPL], double, int, int t_n, bool t_div, double t_acc, double) {
+    accept = (t_n > 0) ? (t_acc / (double)t_n) : 0.0;
+    diverged = t_div;
+    w_leapfrogs += (unsigned long long)t_n;
+  };
+  const int W = P.num_warmup;
+  double eps = find_eps_dev<M, G>(mc, L, st, P.log_half);
+  double eps_final = eps;
+  if (W > 0) {
+    const bool has_windows = P.adapt_end > P.init_buffer;
+    const int n_iter = has_windows ? W : P.init_buffer;
+    DualAvgDev da;
+    da.init(eps, P.target_accept);
+    int win = 0;
+    bool in_window = false;
+    int wn = 0;
+    double wmean[DPL], wm2[DPL];
+#pragma unroll
+    for (int k = 0; k < DPL; k++) wmean[k] = wm2[k] = 0.0;
+    for (int i = 0; i < n_iter; i++) {
+      if (has_windows) {
+        if (win < P.n_windows && i == P.win_start[win]) {
+          if (win == 0) eps = exmc_exp(da.log_epsilon);   // sampler.ex:578
+          wn = 0;
+#pragma unroll
+          for (int k = 0; k < DPL; k++) wmean[k] = wm2[k] = 0.0;
+          da.init(eps, P.target_accept);
+          in_window = true;
+        }
+        if (i == P.adapt_end) da.init(eps, P.target_accept);   // Phase III (sampler.ex:601)
+      }
+      // sampler.ex:709: depth cap 8 for absolute warmup index < 200, Phase II only
+      const int cap = (in_window && i < 200) ? (P.max_depth < 8 ? P.max_depth : 8) : P.max_depth;
+      auto idle = [&]() { da.prepare(); };
+      nuts_run<M, G, LDSL>(mc, L, st, 1, exmc_exp(da.log_epsilon), cap, wsink, (NoPipe*)nullptr, idle);
+      w_divergences += diverged ? 1 : 0;
+      da.update(accept);
+      if (in_window) {
+        if (!diverged) {   // mass_matrix.ex:40-54
+          const int nn = wn + 1;
+#pragma unroll
+          for (int k = 0; k < DPL; k++) {
+            const double delta = st.q[k] - wmean[k];
+            const double nm = wmean[k] + delta / ((double)nn * 1.0);
+            const double d2 = st.q[k] - nm;
+            wm2[k] = wm2[k] + delta * d2;
+            wmean[k] = nm;
+          }
+          wn = nn;
+        }
+        if (i + 1 == P.win_end[win]) {
+          // mass_matrix.ex:77-97, then re-search the step size (sampler.ex:747-756)
+          if (wn < 3) {
+#pragma unroll
+            for (int k = 0; k < DPL; k++) L.im[k] = 1.0;
+          } else {
+            const double alpha = 5.0 / (wn + 5.0);
+#pragma unroll
+            for (int k = 0; k < DPL; k++) {
+              double var = wm2[k] / ((double)(wn - 1) * 1.0);
+              var = fmax(var, 1.0e-6);
+              L.im[k] = L.valid[k] ? ((1.0 - alpha) * var + alpha * 1.0e-3) : 1.0;
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < DPL; k++) L.sim[k] = __dsqrt_rn(L.im[k]);
+          eps = find_eps_dev<M, G>(mc, L, st, P.log_half);
+          win++;
+          in_window = false;
+        }
+      }
+    }
+    eps_final = exmc_exp(da.log_epsilon_bar);
+  }
+  double* const to = P.tune_out + (size_t)chain * (3 + D);
+  if (l == 0) {
+    to[0] = eps_final;
+    to[1] = (double)w_divergences;
+    to[2] = (double)w_leapfrogs;
+  }
+#pragma unroll
+  for (int k = 0; k < DPL; k++) {
+    const int i = l + k * G;
+    if (i < D) to[3 + i] = L.im[k];
+  }
+
+  // ---- the chain's draws (sample_from_compiled: the same chain goes on, sampler.ex:199-257) ----
+  unsigned long long lf_total = 0, div_total = 0;
+  const bool own = (l == 0);
+  auto sink = [&](int draw, const double (&sq)[DPL], double slogp, int depth, int t_n, bool t_div,
+                  double t_acc, double jlp0) {
+    const size_t row = (size_t)draw;
+#pragma unroll
+    for (int k = 0; k < DPL; k++)
+      if (L.valid[k] && P.tr.draws) P.tr.draws[(row * D + (l + k * G)) * C + chain] = sq[k];
+    if (own) {
+      const size_t at = row * C + chain;
+      if (P.tr.logp) P.tr.logp[at] = slogp;
+      if (P.tr.tree_depth) P.tr.tree_depth[at] = depth;
+      if (P.tr.n_steps) P.tr.n_steps[at] = t_n;
+      if (P.tr.divergent) P.tr.divergent[at] = t_div ? 1 : 0;
+      if (P.tr.accept_prob) P.tr.accept_prob[at] = (t_n > 0) ? (t_acc / (double)t_n) : 0.0;
+      if (P.tr.energy) P.tr.energy[at] = -jlp0;
+    }
+    lf_total += (unsigned long long)t_n;
+    div_total += t_div ? 1u : 0u;
+  };
+  nuts_run<M, G, LDSL>(mc, L, st, P.num_samples, eps_final, P.max_depth, sink);
+  chain_store<M, G>(P.st, C, chain, l, st);
+  if (l == 0 && P.counters) {
+    atomicAdd(&P.counters[0], lf_total);
+    atomicAdd(&P.counters[1], div_total);
+  }
+}
+
 }  // namespace exmc

@@ -317,12 +317,62 @@ def sample_chains_compiled(compiled, num_chains, opts=None):
     return traces, stats
 
 
+def sample_chains_independent_compiled(compiled, num_chains, opts=None, chain_lo=0, chain_hi=None):
+    """sample_chains_parallel (sampler.ex:1139-1176) -- `sample_chains(ir, n, vectorized: false)`:
+    chain i is Sampler.sample/3 with seed + 7919 i, its own adaptation and then its draws. On the
+    GPU all chains of [chain_lo, chain_hi) run as ONE launch, every lane group a chain from its first
+    warmup transition to its last draw (exmc_hip_sample_independent_host). Each chain's stats carry
+    its own step size, inverse mass and warmup divergences, as the reference's per-chain stats do."""
+    if num_chains < 1:
+        raise ValueError("num_chains must be >= 1")
+    o = _merge_opts(opts)
+    if o.get("dense_mass") or o.get("warm_start"):
+        raise ValueError("vectorized: false runs the diagonal cold-start adaptation per chain "
+                         "(dense_mass / warm_start: use sample/3 per chain)")
+    spec = compiled.spec
+    L = compiled.L
+    chain_hi = num_chains if chain_hi is None else chain_hi
+    nc = chain_hi - chain_lo
+    iq = _init_q(spec, o.get("init_values") or {})
+    lf, dv = C.c_int64(), C.c_int32()
+    tune = np.zeros((nc, 3 + spec.d))
+    t, tr = _host_trace(nc, o["num_samples"], spec.d)
+    compiled.check(L.exmc_hip_sample_independent_host(compiled.h, None if iq is None else _dp(iq), num_chains,
+                                                      chain_lo, chain_hi, _c_opts(o), tr, _dp(tune),
+                                                      C.byref(lf), C.byref(dv)))
+    traces, stats = [], []
+    extra = dict(total_leapfrogs=int(lf.value), total_divergences=int(dv.value), raw=t,
+                 kernel_ms=compiled.last_kernel_ms, tuning=tune,
+                 warmup_leapfrogs=int(tune[:, 2].sum()))
+    for c in range(nc):
+        traces.append(_build_trace(spec, t["draws"][c]))
+        # stats.divergences counts warmup + sampling (sampler.ex:245)
+        stats.append(dict(step_size=float(tune[c, 0]), inv_mass_diag=np.array(tune[c, 3:]),
+                          divergences=int(t["divergent"][c].sum()) + int(tune[c, 1]),
+                          num_warmup=o["num_warmup"], num_samples=o["num_samples"],
+                          sample_stats=SampleStats(t, c), extra=extra))
+    return traces, stats
+
+
 def sample_chains(ir, num_chains, opts=None):
-    """Exmc.NUTS.Sampler.sample_chains/3. With opts["devices"] = [0, 1, ...] the chains are sharded
-    over those GPUs, one process each (exmc_amd.distributed.sample_chains_sharded, the analogue of
-    Exmc.NUTS.Distributed.sample_chains/2); the result does not depend on the number of devices."""
+    """Exmc.NUTS.Sampler.sample_chains/3. opts["vectorized"] (default: num_chains > 1, sampler.ex:993)
+    chooses between the shared warmup (one adaptation, every chain with its tuning) and
+    sample_chains_parallel (False: every chain adapts on its own, sample_chains_independent_compiled).
+    With opts["devices"] = [0, 1, ...] the chains are sharded over those GPUs, one process each
+    (exmc_amd.distributed.sample_chains_sharded, the analogue of Exmc.NUTS.Distributed.sample_chains/2);
+    the result does not depend on the number of devices. A rank process that fails or hangs takes a
+    sharded call down with it (distributed.sample_chains_sharded; the reference retries a failed chain
+    on the coordinator, distributed.ex:172-180 -- a GPU fault is not retried blindly)."""
     opts = opts or {}
     devices = opts.get("devices")
+    vectorized = opts.get("vectorized", num_chains > 1)
+    if not (vectorized and num_chains > 1):
+        if devices is not None and len(devices) > 1:
+            raise ValueError("vectorized: false is a single-device mode here (shard the chain range yourself: "
+                             "sample_chains_independent_compiled(..., chain_lo, chain_hi))")
+        o1 = dict(opts, device=devices[0]) if devices else opts
+        compiled = ir if isinstance(ir, Compiled) else Compiled(ir, device=o1.get("device", 0))
+        return sample_chains_independent_compiled(compiled, num_chains, o1)
     if devices is not None and len(devices) > 1:
         if isinstance(ir, Compiled):
             ir = ir.spec

@@ -217,6 +217,25 @@ int exmc_hip_sample_warm_host(exmc_hip_model* m, const double* init_q, exmc_hip_
                               const exmc_hip_tuning* warm_start, exmc_hip_trace trace,
                               exmc_hip_tuning* tuning_out, int32_t* divergences);
 
+/* Exmc.NUTS.Sampler.sample_chains(ir, n, vectorized: false) -- sample_chains_parallel
+ * (sampler.ex:992-1000, 1139-1176): chain i of n_chains is Sampler.sample/3 with seed + 7919*i,
+ * i.e. it runs its OWN adaptation (step-size search, dual averaging, Welford windows) and then its
+ * num_samples draws from the adapted position with the same generator. One launch for chains
+ * [chain_lo, chain_hi): every lane group of the grid is one chain from its first warmup transition
+ * to its last draw (exmc_nuts.hpp indep_kernel). Trace as exmc_hip_sample_chains (_host: the
+ * reference's [chain][draw][dim]); tuning_host (may be NULL) receives, per chain of the shard,
+ * 3 + d doubles: final step size, warmup divergences, warmup leapfrogs, inv_mass[d] (kernel order).
+ * total_leapfrogs / total_divergences count the sampling phase. Diagonal mass, the kind's default
+ * layout (EXMC_ERR_UNSUPPORTED otherwise). */
+int exmc_hip_sample_independent(exmc_hip_model* m, const double* init_q, int n_chains, int chain_lo,
+                                int chain_hi, exmc_hip_opts opts, exmc_hip_trace trace_dev,
+                                double* tuning_host, int64_t* total_leapfrogs,
+                                int32_t* total_divergences);
+int exmc_hip_sample_independent_host(exmc_hip_model* m, const double* init_q, int n_chains,
+                                     int chain_lo, int chain_hi, exmc_hip_opts opts,
+                                     exmc_hip_trace trace_host, double* tuning_host,
+                                     int64_t* total_leapfrogs, int32_t* total_divergences);
+
 /* Exmc.Diagnostics.rhat (lib/exmc/diagnostics.ex:80-115): split R-hat per dimension across the
  * n_chains chains of a device trace [draw][dim][chain] (n_draws >= 4): rhat_dev [dim]. */
 int exmc_hip_rhat(exmc_hip_model* m, const double* draws_dev, int n_draws, int d, int n_chains,

@@ -25,8 +25,12 @@ typedef struct {
   void* obj;             /* resource */
 } term;
 
-static term* g_terms;
-static size_t g_n, g_cap;
+/* the table is chunked so that a term's address never moves: a sender thread (enif_send) and the
+ * harness thread may create terms at the same time (tools/sanitize_cpu.sh runs both under TSan) */
+#define FK_CHUNK 1024
+#define FK_MAX_CHUNKS 8192
+static term* g_chunks[FK_MAX_CHUNKS];
+static size_t g_n;
 static ERL_NIF_TERM g_exception;   /* 0 = none */
 static int g_badarg;
 
@@ -36,12 +40,12 @@ static struct enif_environment_t g_env;
 struct enif_resource_type_t { ErlNifResourceDtor* dtor; char name[64]; };
 typedef struct { struct enif_resource_type_t* type; int refc; } res_hdr;
 
-/* terms made by a sender thread (enif_send) share the table: one lock around its growth; the
- * harness does not touch terms while a sender runs (fk_mailbox_wait only counts) */
+/* one lock around the table's growth and the mailbox */
 static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
 static ERL_NIF_TERM* g_mail;
 static size_t g_mail_n, g_mail_cap;
 
+static term* slot(size_t i) { return &g_chunks[i / FK_CHUNK][i % FK_CHUNK]; }
 static ERL_NIF_TERM new_term_locked(int type);
 static ERL_NIF_TERM new_term(int type) {
   pthread_mutex_lock(&g_lock);
@@ -50,21 +54,25 @@ static ERL_NIF_TERM new_term(int type) {
   return t;
 }
 static ERL_NIF_TERM new_term_locked(int type) {
-  if (g_n + 1 >= g_cap) {
-    g_cap = g_cap ? 2 * g_cap : 1024;
-    g_terms = (term*)realloc(g_terms, g_cap * sizeof(term));
-  }
-  if (g_n == 0) { memset(&g_terms[0], 0, sizeof(term)); g_n = 1; }   /* term 0 = invalid */
-  memset(&g_terms[g_n], 0, sizeof(term));
-  g_terms[g_n].type = type;
+  if (g_n == 0) g_n = 1;   /* term 0 = invalid */
+  if (g_n / FK_CHUNK >= FK_MAX_CHUNKS) { fprintf(stderr, "fake_erl_nif: term table full\n"); abort(); }
+  if (!g_chunks[g_n / FK_CHUNK]) g_chunks[g_n / FK_CHUNK] = (term*)calloc(FK_CHUNK, sizeof(term));
+  memset(slot(g_n), 0, sizeof(term));
+  slot(g_n)->type = type;
   return (ERL_NIF_TERM)g_n++;
 }
-static term* T(ERL_NIF_TERM t) { return (t > 0 && t < g_n) ? &g_terms[t] : NULL; }
+static size_t table_len(void) {
+  pthread_mutex_lock(&g_lock);
+  const size_t n = g_n;
+  pthread_mutex_unlock(&g_lock);
+  return n;
+}
+static term* T(ERL_NIF_TERM t) { return (t > 0 && t < table_len()) ? slot(t) : NULL; }
 
 /* ---- harness API (called from Python through ctypes) ---- */
 void fk_reset(void) {
   for (size_t i = 1; i < g_n; i++) {
-    term* t = &g_terms[i];
+    term* t = slot(i);
     free(t->s);
     if (t->type == T_BIN) free(t->data);
     free(t->items);
@@ -74,6 +82,15 @@ void fk_reset(void) {
   g_exception = 0;
   g_badarg = 0;
   g_mail_n = 0;
+}
+/* the harness's own reference to a resource term goes away (a variable going out of scope on the BEAM) */
+void fk_drop_resource_term(ERL_NIF_TERM t) {
+  term* x = T(t);
+  if (x && x->type == T_RES && x->obj) {
+    void* obj = x->obj;
+    x->obj = NULL;
+    enif_release_resource(obj);
+  }
 }
 /* the mailbox of the one fake process: messages in arrival order */
 size_t fk_mailbox_len(void) {
@@ -230,12 +247,12 @@ void* enif_alloc_resource(ErlNifResourceType* type, size_t size) {
 }
 void enif_release_resource(void* obj) {
   res_hdr* h = (res_hdr*)obj - 1;
-  if (--h->refc == 0) { if (h->type->dtor) h->type->dtor(&g_env, obj); free(h); }
+  if (__atomic_sub_fetch(&h->refc, 1, __ATOMIC_ACQ_REL) == 0) { if (h->type->dtor) h->type->dtor(&g_env, obj); free(h); }
 }
 ERL_NIF_TERM enif_make_resource(ErlNifEnv* e, void* obj) {
-  (void)e; ERL_NIF_TERM t = new_term(T_RES); T(t)->obj = obj; ((res_hdr*)obj - 1)->refc++; return t;
+  (void)e; ERL_NIF_TERM t = new_term(T_RES); T(t)->obj = obj; __atomic_add_fetch(&((res_hdr*)obj - 1)->refc, 1, __ATOMIC_RELAXED); return t;
 }
-int enif_keep_resource(void* obj) { ((res_hdr*)obj - 1)->refc++; return 1; }
+int enif_keep_resource(void* obj) { __atomic_add_fetch(&((res_hdr*)obj - 1)->refc, 1, __ATOMIC_RELAXED); return 1; }
 ErlNifEnv* enif_alloc_env(void) { return (ErlNifEnv*)calloc(1, sizeof(struct enif_environment_t)); }
 void enif_free_env(ErlNifEnv* e) { free(e); }
 void enif_clear_env(ErlNifEnv* e) { (void)e; }   /* nothing is collected before fk_reset */
