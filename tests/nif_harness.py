@@ -46,13 +46,17 @@ def build(outdir):
     if outdir in _cache:
         return _cache[outdir]
     fake = os.path.join(outdir, "libfake_erl_nif.so")
-    subprocess.check_call(["gcc", "-std=gnu11", "-O1", "-Wall", "-Wextra", "-fPIC", "-shared", "-pthread", "-o", fake,
-                           os.path.join(ROOT, "tests", "host", "fake_erl_nif.c")])
+    # EXMC_SANITIZE=address,undefined (tools/sanitize_cpu.sh, with libasan preloaded into the interpreter):
+    # the shims and the term table are built with the sanitizers
+    san = os.environ.get("EXMC_SANITIZE")
+    sflags = ["-fsanitize=" + san, "-fno-omit-frame-pointer", "-g"] if san else []
+    subprocess.check_call(["gcc", "-std=gnu11", "-O1", "-Wall", "-Wextra", "-fPIC", "-shared", "-pthread"] + sflags +
+                          ["-o", fake, os.path.join(ROOT, "tests", "host", "fake_erl_nif.c")])
     shims = {}
     for mod, src in (("NativeTree", "exmc_native_tree_nif.c"), ("HipNative", "exmc_hip_nif.c")):
         so = os.path.join(outdir, "lib%s_nif.so" % mod)
-        subprocess.check_call(["gcc", "-std=c11", "-O2", "-Wall", "-Wextra", "-Werror", "-fPIC", "-shared",
-                               "-o", so, os.path.join(ROOT, "c_src", src), "-L" + LIBDIR, "-lexmc_hip",
+        subprocess.check_call(["gcc", "-std=c11", "-O2", "-Wall", "-Wextra", "-Werror", "-fPIC", "-shared"] + sflags +
+                              ["-o", so, os.path.join(ROOT, "c_src", src), "-L" + LIBDIR, "-lexmc_hip",
                                "-Wl,-rpath," + LIBDIR, "-Wl,-z,lazy", "-ldl"])
         shims[mod] = so
     F = C.CDLL(fake, mode=os.RTLD_GLOBAL | os.RTLD_NOW)

@@ -9,7 +9,8 @@ import subprocess
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(ROOT, "oracle", "build", "libexmc_oracle.so")
+# EXMC_ORACLE_LIB: another build of the same checker (tools/sanitize_cpu.sh: -fsanitize=address,undefined)
+LIB_PATH = os.environ.get("EXMC_ORACLE_LIB") or os.path.join(ROOT, "oracle", "build", "libexmc_oracle.so")
 
 MAX_D = 256
 STD_NORMAL, SIMPLE, EIGHT_SCHOOLS, SV, LOGISTIC, RADON = range(6)
