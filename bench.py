@@ -473,6 +473,10 @@ def main():
                     help="default run only: skip the sv(d=102) leg that rides on the eight_schools line")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="default run only: skip the logistic and radon legs (BASELINE configs 3 and 5)")
+    ap.add_argument("--independent-warmup", action="store_true",
+                    help="sample_chains(ir, n, vectorized: false), sampler.ex:1139-1176: every chain runs its OWN "
+                         "adaptation and then its draws, all chains in one launch (exmc_hip_sample_independent); "
+                         "the timed region is that launch, adaptation included. Not the default protocol.")
     ap.add_argument("--force-dist", action="store_true",
                     help="--gpus 1 only: create a ONE-rank nccl (RCCL) process group on the device and make "
                          "every collective of the multi-GPU path anyway (all_reduce, all_gather_into_tensor, "
@@ -573,6 +577,9 @@ def run_model(args, model, rank, local_rank, world, dev, dist, barrier, primary)
     init = spec.default_init
     L = comp.L
 
+    if getattr(args, "independent_warmup", False):
+        return run_model_independent(args, model, spec, comp, opts, lanes, bytes_per_leapfrog, gather_traces,
+                                     rank, world, dev, dist, barrier, Cper)
     # --- shared adaptation warmup: every rank runs it with the same seed (deterministic, so no
     # broadcast is needed) ---
     # (a 2-iteration throwaway call first, untimed like the W warmup steps of the sampling region:
@@ -709,6 +716,80 @@ def run_model(args, model, rank, local_rank, world, dev, dist, barrier, primary)
         return out, ok
     comp.close()
     return None, ok
+
+
+def run_model_independent(args, model, spec, comp, opts, lanes, bytes_per_leapfrog, gather_traces, rank, world,
+                          dev, dist, barrier, Cper):
+    """`--independent-warmup`: sample_chains_parallel (sampler.ex:1139-1176) as ONE launch per rank --
+    chain i = sample/3 with seed 42 + 7919 i: its own step-size search, dual averaging and Welford
+    windows, then its draws from the adapted position. The timed region is the whole launch; `value`
+    counts every leapfrog of it (warmup and sampling), ESS/s has no separate adaptation term."""
+    K, W, d = args.steps, args.warmup, spec.d
+    B = args.draws_per_step
+    S = K * B
+    Ctot = Cper * world
+    L = comp.L
+    lo, hi = rank * Cper, (rank + 1) * Cper
+    draws = torch.empty((S, d, Cper), dtype=torch.float64, device=dev)
+    n_steps = torch.empty((S, Cper), dtype=torch.int32, device=dev)
+    diverg = torch.empty((S, Cper), dtype=torch.int32, device=dev)
+    tr = _lib.Trace(draws.data_ptr(), None, None, n_steps.data_ptr(), diverg.data_ptr(), None, None)
+    tune = np.zeros((Cper, 3 + d))
+    tp = tune.ctypes.data_as(C.POINTER(C.c_double))
+    lf, dv = C.c_int64(), C.c_int32()
+    init = spec.default_init
+    iq = np.ascontiguousarray(spec.to_unconstrained(init))
+    iqp = iq.ctypes.data_as(C.POINTER(C.c_double))
+    if W > 0:   # a throw-away launch pays for the code object and the first touch of the buffers
+        o2 = sampler._c_opts(dict(opts, num_warmup=2, num_samples=min(S, 2)))
+        comp.check(L.exmc_hip_sample_independent(comp.h, iqp, Ctot, lo, hi, o2, tr, tp, C.byref(lf), C.byref(dv)))
+    barrier()
+    t0 = time.perf_counter()
+    comp.check(L.exmc_hip_sample_independent(comp.h, iqp, Ctot, lo, hi, sampler._c_opts(opts), tr, tp,
+                                             C.byref(lf), C.byref(dv)))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = comp.last_kernel_ms
+    warm_lf = int(tune[:, 2].sum())
+    ess = torch.empty((d, Cper), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    comp.check(L.exmc_hip_ess(comp.h, draws.data_ptr(), S, d, Cper, ess.data_ptr()))
+    ess_s = time.perf_counter() - t0
+    ess_ms = comp.last_kernel_ms
+    essb = torch.empty((d, Cper), dtype=torch.float64, device=dev)
+    t0 = time.perf_counter()
+    comp.check(L.exmc_hip_ess_bulk(comp.h, draws.data_ptr(), S, d, Cper, essb.data_ptr()))
+    ess_bulk_s = time.perf_counter() - t0
+
+    def rhat_lib(x):
+        x = x.contiguous()
+        rk = torch.empty((x.shape[1],), dtype=torch.float64, device=x.device)
+        torch.cuda.synchronize()
+        comp.check(L.exmc_hip_rhat(comp.h, x.data_ptr(), x.shape[0], x.shape[1], x.shape[2], rk.data_ptr()))
+        return rk
+    eps = np.sort(tune[:, 0])
+    out, ok = finish_model(model=model, d=d, K=K, W=W, B=B, adapt=args.adapt, Cper=Cper, world=world, rank=rank,
+                           dist=dist, draws=draws, ess=ess, leap_local=lf.value + warm_lf, div_local=dv.value,
+                           elapsed_local=elapsed, kernel_ms=kernel_ms, adapt_s=0.0, ess_s=ess_s, ess_ms=ess_ms,
+                           epsilon=float(eps[len(eps) // 2]), lanes=lanes, warm_lanes=lanes,
+                           bytes_per_leapfrog=bytes_per_leapfrog, gather_traces=gather_traces, rhat_fn=rhat_lib,
+                           sync=torch.cuda.synchronize, ess_bulk=essb, ess_bulk_s=ess_bulk_s)
+    if rank == 0:
+        out["config"]["workload"] = out["config"]["workload"].replace(
+            "after one shared %d-iteration warmup" % args.adapt,
+            "each after its OWN %d-iteration warmup (vectorized: false), one launch" % args.adapt)
+        out["independent_warmup"] = {
+            "sampling_leapfrogs": int(lf.value), "warmup_leapfrogs": warm_lf,
+            "warmup_divergences": int(tune[:, 1].sum()),
+            "step_size_min_median_max": [float(eps[0]), float(eps[len(eps) // 2]), float(eps[-1])],
+            "note": "value and roofline count the leapfrogs of both phases; ess_wall_s.adaptation is 0 because the "
+                    "adaptation is inside the timed launch"}
+        out["reference_published"] = reference_published(model)
+        if world == 1:
+            out["mean_leapfrogs_per_draw"] = lf.value / float(S * Ctot)   # the draws' own trees
+    comp.close()
+    return (out if rank == 0 else None), ok
 
 
 if __name__ == "__main__":

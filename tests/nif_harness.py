@@ -43,8 +43,10 @@ _cache = {}
 
 
 def build(outdir):
-    if outdir in _cache:
-        return _cache[outdir]
+    # ONE term table per process: the fake runtime is loaded RTLD_GLOBAL (the shims resolve their
+    # enif_* calls against it), so a second copy would split the state between two libraries
+    if _cache:
+        return next(iter(_cache.values()))
     fake = os.path.join(outdir, "libfake_erl_nif.so")
     # EXMC_SANITIZE=address,undefined (tools/sanitize_cpu.sh, with libasan preloaded into the interpreter):
     # the shims and the term table are built with the sanitizers
