@@ -79,6 +79,7 @@ extern __shared__ double exmc_dyn_lds[];
 // two doubles of LDS behind a pointer that says so: ds_read_b128 of a 16-byte aligned pair
 typedef double exmc_v2d __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) exmc_v2d lds_v2d;
+typedef __attribute__((address_space(3))) double lds_f64_m;
 
 // ------------------------------------------------------------------------------------------
 // eight_schools, non-centered (benchmark/posteriordb/validate_posteriordb.exs:246-324).
@@ -583,6 +584,12 @@ struct LogisticConsts {
   int Npad;            // N rounded up to a multiple of 16
 };
 
+// 1: the next step's row is read into a second buffer before this step's arithmetic. Measured on
+// the workgroup form (profiles/r5_lg_wg/ab_row_ahead.log): 156.0 against 155.2 ms -- the second wave
+// of the SIMD already covers the LDS round trip, the kernel is bound by vector issue. Off.
+#ifndef EXMC_LG_ROW_AHEAD
+#define EXMC_LG_ROW_AHEAD 0
+#endif
 template <int G>
 struct Logistic : ModelDefaults {
   static constexpr bool kPipeWarmup = false;
@@ -696,48 +703,99 @@ struct Logistic : ModelDefaults {
     return e;
   }
 
-  // one step: observations it * 16 + l of the row's sixteen lanes
+  // a row of the design matrix and its response, as a step holds them
+  struct Row {
+    double x[K], y;
+  };
   template <bool kStaged>
-  __device__ static __forceinline__ void step_row16(const Consts& c, const lds_v2d* img, int l, int it,
-                                                    double q0, double q1, double (&s)[D + 1]) {
-    constexpr double kLo = (double)1.0e-7f, kHi = 1.0 - (double)1.0e-7f;   // = Consts::lo, hi
-    const int n = l + (it << 4);
-    const bool live = n < c.N;
-    double xr[K], yn;
+  __device__ static __forceinline__ void load_row(const Consts& c, const lds_v2d* img, int n, bool live, Row& r) {
     if constexpr (kStaged) {
       const lds_v2d* const row = img + n * (kRowStride / 2);
 #pragma unroll
       for (int j = 0; j < K / 2; j++) {
         const exmc_v2d v = row[j];
-        xr[2 * j] = v[0];
-        xr[2 * j + 1] = v[1];
+        r.x[2 * j] = v[0];
+        r.x[2 * j + 1] = v[1];
       }
-      yn = row[K / 2][0];
+      // (8 bytes, not the pair with the pad: a dead half would be a register the allocator hands to
+      // something else while the read is still in flight -- a wait in front of that something)
+      r.y = *(const lds_f64_m*)(row + K / 2);
     } else {
       const int nr = live ? n : (c.N - 1);
       const double* x = c.X + (size_t)nr * K;
 #pragma unroll
-      for (int j = 0; j < K; j++) xr[j] = x[j];
-      yn = c.y[nr];
+      for (int j = 0; j < K; j++) r.x[j] = x[j];
+      r.y = c.y[nr];
     }
-    const double eta = eta_row16(q0, q1, xr);
+  }
+  // one step: observations it * 16 + l of the row's sixteen lanes, from the row already in registers.
+  // kTail: the last, partly filled step (N mod 16 lanes carry an observation): `live` masks the two
+  // contributions; the full steps carry no mask at all.
+  template <bool kTail>
+  __device__ static __forceinline__ void step_row16(const Row& row, bool live, double q0, double q1,
+                                                    double (&s)[D + 1]) {
+    constexpr double kLo = (double)1.0e-7f, kHi = 1.0 - (double)1.0e-7f;   // = Consts::lo, hi
+    const double yn = row.y;
+    const double eta = eta_row16(q0, q1, row.x);
     double p, ll;
     const bool inr = fabs(eta) <= 200.0;   // false for a NaN
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(!inr) == 0, 1)) {
       const double u = 1.0 + exmc_exp_pm200_s(-eta);   // [1, e^200 + 1): inside the division window
       p = exmc_div_core(1.0, u, exmc_rcp_refined(u));
       const double pc = fmin(fmax(p, kLo), kHi);
-      ll = exmc_log_normal_s((yn == 1.0) ? pc : (1.0 - pc));   // [1e-7, 1 - 1e-7]: normal, positive
+      // y = 1: pc, y = 0: 1 - pc, as ONE fma(pc, 2y - 1, 1 - y): pc * 1 + 0 and pc * (-1) + 1 are the
+      // two values exactly (a compare and two selects less); [1e-7, 1 - 1e-7]: normal, positive
+      const double sgn = __builtin_fma(yn, 2.0, -1.0), off = 1.0 - yn;
+      ll = exmc_log_normal_s(__builtin_fma(pc, sgn, off));
     } else {
       p = 1.0 / (1.0 + exmc_exp(-eta));
       const double pc = fmin(fmax(p, kLo), kHi);
       ll = exmc_log((yn == 1.0) ? pc : (1.0 - pc));
     }
-    const double r = (live && p > kLo && p < kHi) ? (yn - p) : 0.0;
-    s[D] = s[D] + (live ? ll : 0.0);
+    const bool in = p > kLo && p < kHi;
+    const double r = (kTail ? (live && in) : in) ? (yn - p) : 0.0;
+    s[D] = s[D] + ((!kTail || live) ? ll : 0.0);
     s[0] = __builtin_fma(1.0, r, s[0]);
 #pragma unroll
-    for (int j = 0; j < K; j++) s[1 + j] = __builtin_fma(xr[j], r, s[1 + j]);
+    for (int j = 0; j < K; j++) s[1 + j] = __builtin_fma(row.x[j], r, s[1 + j]);
+  }
+  // all steps of a pass; kAhead: the next step's row is requested before this step's arithmetic (the
+  // LDS image: a ds_read_b128 burst whose latency the specials cover; from L2 the second row buffer
+  // costs more in registers than the wait it hides)
+  template <bool kStaged, bool kAhead>
+  __device__ static __forceinline__ void steps_row16(const Consts& c, const lds_v2d* img, int l, double q0,
+                                                     double q1, double (&s)[D + 1]) {
+    const int steps = (c.N + 15) >> 4;
+    if constexpr (kAhead) {
+      // two row buffers taking turns (a rotating copy would be 21 register moves per step)
+      Row a, b;
+      load_row<kStaged>(c, img, l, l < c.N, a);
+      for (int it = 0; it < steps; it += 2) {
+        const int n = l + (it << 4);
+        const bool two = it + 1 < steps;                 // wave-uniform
+        const int nb = two ? n + 16 : n;
+        load_row<kStaged>(c, img, nb, nb < c.N, b);
+        step_row16<true>(a, n < c.N, q0, q1, s);
+        if (two) {
+          const int na = (it + 2 < steps) ? n + 32 : n;
+          load_row<kStaged>(c, img, na, na < c.N, a);
+          step_row16<true>(b, nb < c.N, q0, q1, s);
+        }
+      }
+    } else {
+      const int full = c.N >> 4;                           // steps in which every lane has an observation
+      int n = l;
+      for (int it = 0; it < full; it++, n += 16) {
+        Row cur;
+        load_row<kStaged>(c, img, n, true, cur);
+        step_row16<false>(cur, true, q0, q1, s);
+      }
+      if (full < steps) {                                  // wave-uniform
+        Row cur;
+        load_row<kStaged>(c, img, n, n < c.N, cur);
+        step_row16<true>(cur, n < c.N, q0, q1, s);
+      }
+    }
   }
 
   // kImage: the caller guarantees the LDS image (the workgroup form of the sampling kernel)
@@ -751,13 +809,11 @@ struct Logistic : ModelDefaults {
     double s[D + 1];   // s[0..D-1] gradient partials, s[D] likelihood partial
 #pragma unroll
     for (int j = 0; j <= D; j++) s[j] = 0.0;
-    const int steps = (c.N + 15) >> 4;
     const double q0 = q[0], q1 = q[DPL > 1 ? 1 : 0];
     if (kImage || ln.xs != nullptr) {   // wave-uniform
-      const lds_v2d* const img = (const lds_v2d*)ln.xs;
-      for (int it = 0; it < steps; it++) step_row16<true>(c, img, l, it, q0, q1, s);
+      steps_row16<true, EXMC_LG_ROW_AHEAD != 0>(c, (const lds_v2d*)ln.xs, l, q0, q1, s);
     } else {
-      for (int it = 0; it < steps; it++) step_row16<false>(c, nullptr, l, it, q0, q1, s);
+      steps_row16<false, false>(c, nullptr, l, q0, q1, s);
     }
     group_allsum_n<G, D + 1>(s);
     double T[DPL];
@@ -1131,19 +1187,25 @@ struct Radon : ModelDefaults {
     // (the residuals are watched through the largest and the smallest magnitude a lane has seen:
     // one check per lane instead of one per observation)
     double rmax = 1.0, rmin = 1.0;
+    // Round 5: the unit arithmetic of the generated radon (codegen_lanes.py), which measured 6 % faster
+    // with it: fused multiply-adds, and the two quotients by sigma_y as products with ONE correctly
+    // rounded reciprocal per leapfrog (1 / sigma_y by the IEEE division, so the checker reproduces it
+    // as 1.0 / ssy) -- 12 operations per observation instead of 18. Inside the 1e-12 tolerance to the
+    // reference's own arithmetic (tests/test_oracle_sampler.py); restated in the checker's logp_radon.
+    const double rinv = dv(1.0, rsy);
     auto obs = [&](double alpha, double fi, double yi, double& lik, double& f, double& z2s) -> double {
-      const double mean = alpha + beta * fi;
+      const double mean = __builtin_fma(beta, fi, alpha);
       const double resid = yi - mean;
       if constexpr (kFast) {
         const double ar_ = fabs(resid);
         rmax = fmax(rmax, ar_);
         rmin = fmin(rmin, ar_);
       }
-      const double z = dv(resid, rsy);
-      const double a = dv(z, rsy);
-      lik = lik + (-0.5 * (z * z + cn));
-      f = f + a * fi;
-      z2s = z2s + (z * z - 1.0);
+      const double z = resid * rinv;
+      const double a = z * rinv;
+      lik = __builtin_fma(-0.5, __builtin_fma(z, z, cn), lik);
+      f = __builtin_fma(a, fi, f);
+      z2s = z2s + __builtin_fma(z, z, -1.0);
       return a;
     };
     double alpha_own[DPL], sj_own[DPL];

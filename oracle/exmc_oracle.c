@@ -574,6 +574,7 @@ static double logp_radon(const exo_model* m, const double* q, double* g, exo_cfg
   double ssy = fmax(sy, TINY_F32());
   double cn = LOG_2PI_F32() + 2.0 * exo_log(ssy, mm);
   double c1 = LOG_2PI_F32() + 2.0 * 0.0;
+  double rinv = 1.0 / ssy;   /* deterministic mode: the one reciprocal of a leapfrog */
   double LIK[EXO_MAX_D], S[EXO_MAX_D], SU[EXO_MAX_D], SA[EXO_MAX_D], F[EXO_MAX_D], Z2[EXO_MAX_D];
   double T[EXO_MAX_D];
   for (int j = 0; j < d; j++) LIK[j] = S[j] = SU[j] = SA[j] = F[j] = Z2[j] = T[j] = 0.0;
@@ -594,6 +595,23 @@ static double logp_radon(const exo_model* m, const double* q, double* g, exo_cfg
     int i0 = (int)cs[j], i1 = (int)cs[j + 1];
     double lik = 0.0, s = 0.0, f = 0.0, z2s = 0.0;
     for (int i = i0; i < i1; i++) {
+      if (mm) {
+        /* deterministic mode = the kernels' unit arithmetic since round 5 (exmc_models.hpp Radon::eval,
+         * taken from the generated radon): fused multiply-adds and the two quotients by sigma_y as
+         * products with one correctly rounded reciprocal. 64 lanes: the three totals are accumulated
+         * per lane in slot order (below), so only the per-observation values are kept here. */
+        double mean = __builtin_fma(beta, fl[i], alpha);
+        double z = (y[i] - mean) * rinv;
+        double a = z * rinv;
+        double t = __builtin_fma(z, z, cn);
+        double zz1 = __builtin_fma(z, z, -1.0);
+        lik = __builtin_fma(-0.5, t, lik);
+        s = s + a;
+        f = __builtin_fma(a, fl[i], f);
+        z2s = z2s + zz1;
+        if (G == 64) { OL[i] = t; OF[i] = a; OZ[i] = zz1; }
+        continue;
+      }
       double mean = alpha + beta * fl[i];
       double z = (y[i] - mean) / ssy;
       double a = z / ssy;
@@ -608,12 +626,31 @@ static double logp_radon(const exo_model* m, const double* q, double* g, exo_cfg
     T[j] = -0.5 * (ar * ar + c1);
     g[j] = (-ar) + s * sa;
   }
-  double lik = (G == 64) ? lane_sum(OL, N, 64, 0.0) : lane_sum(LIK, d, G, 0.0);
+  double lik, sf, sz2;
+  if (G == 64 && mm) {
+    /* lane l, slots in order: lik = fma(-0.5, t_i, lik), f = fma(a_i, floor_i, f), z2s = z2s + (z_i^2 - 1);
+     * then the butterfly over the 64 lanes */
+    double PL[64], PF[64], PZ[64];
+    for (int l = 0; l < 64; l++) {
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+      for (int i = l; i < N; i += 64) {
+        a0 = __builtin_fma(-0.5, OL[i], a0);
+        a1 = __builtin_fma(OF[i], fl[i], a1);
+        a2 = a2 + OZ[i];
+      }
+      PL[l] = a0; PF[l] = a1; PZ[l] = a2;
+    }
+    lik = lane_sum(PL, 64, 64, 0.0);
+    sf = lane_sum(PF, 64, 64, 0.0);
+    sz2 = lane_sum(PZ, 64, 64, 0.0);
+  } else {
+    lik = (G == 64) ? lane_sum(OL, N, 64, 0.0) : lane_sum(LIK, d, G, 0.0);
+    sf = (G == 64) ? lane_sum(OF, N, 64, 0.0) : lane_sum(F, d, G, 0.0);
+    sz2 = (G == 64) ? lane_sum(OZ, N, 64, 0.0) : lane_sum(Z2, d, G, 0.0);
+  }
   double ss = lane_sum(S, d, G, 0.0);
   double su = lane_sum(SU, d, G, 0.0);
   double sar = lane_sum(SA, d, G, 0.0);
-  double sf = (G == 64) ? lane_sum(OF, N, 64, 0.0) : lane_sum(F, d, G, 0.0);
-  double sz2 = (G == 64) ? lane_sum(OZ, N, 64, 0.0) : lane_sum(Z2, d, G, 0.0);
   if (OL) free(OL);
   double zmu = (mu - 0.0) / 10.0, zg = (gam - 0.0) / 5.0, zb = (beta - 0.0) / 5.0;
   T[J] = -0.5 * (zmu * zmu + (LOG_2PI_F32() + 2.0 * log(10.0)));
