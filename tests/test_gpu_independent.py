@@ -95,3 +95,30 @@ def test_logistic_and_radon_chains_adapt_independently():
     kernel) and radon (64 lanes, observations in LDS), small protocols."""
     _check(models.logistic(), 6, 16, 80, 30, 3)
     _check(models.radon(), 3, 64, 80, 30, 3)
+
+
+def test_generated_models_adapt_independently():
+    """A plug-in carries the kernel too (its part 7): eight schools written as Builder nodes, one lane
+    per chain (64 chains of a wavefront adapt side by side) and in the 16-lane plate layout, against
+    the generated text compiled for the host."""
+    import gen_checker as GC
+    from exmc_amd import codegen
+    gen = codegen.generate(codegen.eight_schools_ir())
+    init = {n: 0.0 for n in ["mu"] + ["theta_%d" % j for j in range(8)]}
+    init["tau"] = 1.0
+    spec = codegen.compile_ir(codegen.eight_schools_ir(), default_init=init)
+    for lanes, n_chains in ((1, 70), (16, 6)):
+        comp = sampler.compile(spec)
+        try:
+            opts = dict(num_warmup=100, num_samples=40, seed=21, lanes_per_chain=lanes, vectorized=False)
+            _, stats = sampler.sample_chains_independent_compiled(comp, n_chains, opts)
+        finally:
+            comp.close()
+        om = GC.model(gen, lanes)
+        raw = stats[0]["extra"]["raw"]
+        for c in range(n_chains):
+            t, st = O.sample(om, num_warmup=100, num_samples=40, seed=21 + 7919 * c, cfg=O.Cfg(1, lanes))
+            assert stats[c]["step_size"] == st.step_size, (lanes, c)
+            assert np.array_equal(stats[c]["inv_mass_diag"], np.array(st.inv_mass[:spec.d])), (lanes, c)
+            for key in ("draws", "tree_depth", "n_steps", "divergent", "logp", "accept_prob", "energy"):
+                assert np.array_equal(raw[key][c], t[key]), (lanes, c, key)
