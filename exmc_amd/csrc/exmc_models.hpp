@@ -1096,6 +1096,7 @@ struct Radon : ModelDefaults {
   static constexpr int kObsCap = 1024;                 // observations the spread layout holds
   static constexpr int kSlots = kSpread ? kObsCap / 64 : 1;
   static constexpr int kAlphaOff = kObsCap;            // strip: [a_i (kObsCap)] [alpha_j (J, padded)]
+  static constexpr int kZeroCell = kObsCap + 95;       // the last pad cell of the strip holds 0.0
   static constexpr int kExtraLdsDoubles = kSpread ? kObsCap + 96 : 0;
   struct Lane {
     double u[DPL];
@@ -1151,6 +1152,23 @@ struct Radon : ModelDefaults {
   template <class DV>
   __device__ static __forceinline__ double eval(const Consts& c, const Lane& ln, int l,
                                                 const double (&q)[DPL], double (&g)[DPL], DV& dv) {
+    // this lane's observations (64 lanes: y, floor and county of all its slots) are requested FIRST: the
+    // addresses depend on nothing computed here, and a wave that has its SIMD to itself sits out every
+    // L2 round trip it starts late -- this one now runs beside the five transcendentals below
+    // (round 5; same values, same bits)
+    [[maybe_unused]] double oy[kSlots], ofl[kSlots], oc[kSlots];
+    if constexpr (kSpread) {
+      const int last = ln.nobs - 1;
+#pragma unroll
+      for (int sl = 0; sl < kSlots; sl++) {
+        const int i = sl * 64 + l;
+        const int ic = i < last ? i : last;     // a valid address for an empty slot
+        oy[sl] = c.y[ic];
+        ofl[sl] = c.fl[ic];
+        oc[sl] = c.cty[ic];
+      }
+      __builtin_amdgcn_sched_barrier(0);   // the scheduler would sink the loads back towards their uses
+    }
     const double mu = group_bcast_c<G, J % G>(q[J / G]);
     const double gam = group_bcast_c<G, (J + 1) % G>(q[(J + 1) / G]);
     const double zsa_raw = group_bcast_c<G, (J + 2) % G>(q[(J + 2) / G]);
@@ -1186,9 +1204,8 @@ struct Radon : ModelDefaults {
     double T[DPL];
     bool valid[DPL];
     // one observation against its county's intercept: -> a = z / sigma_y
-    // (the residuals are watched through the largest and the smallest magnitude a lane has seen:
-    // one check per lane instead of one per observation)
-    double rmax = 1.0, rmin = 1.0;
+    // (rounds 2-4 watched the residuals' magnitudes for the short division; since round 5 z and a are
+    // PRODUCTS with the reciprocal of sigma_y, exact for any operand, so nothing is left to watch)
     // Round 5: the unit arithmetic of the generated radon (codegen_lanes.py), which measured 6 % faster
     // with it: fused multiply-adds, and the two quotients by sigma_y as products with ONE correctly
     // rounded reciprocal per leapfrog (1 / sigma_y by the IEEE division, so the checker reproduces it
@@ -1198,11 +1215,6 @@ struct Radon : ModelDefaults {
     auto obs = [&](double alpha, double fi, double yi, double& lik, double& f, double& z2s) -> double {
       const double mean = __builtin_fma(beta, fi, alpha);
       const double resid = yi - mean;
-      if constexpr (kFast) {
-        const double ar_ = fabs(resid);
-        rmax = fmax(rmax, ar_);
-        rmin = fmin(rmin, ar_);
-      }
       const double z = resid * rinv;
       const double a = z * rinv;
       lik = __builtin_fma(-0.5, __builtin_fma(z, z, cn), lik);
@@ -1222,19 +1234,10 @@ struct Radon : ModelDefaults {
 #pragma unroll
       for (int k = 0; k < DPL; k++)
         if (l + k * G < J) al[l + k * G] = alpha_own[k];
+      if (l == 0) al[kZeroCell - kAlphaOff] = 0.0;   // what a lane past the end of its county adds (below)
       wave_lds_fence();
-      // this lane's observations: y, floor and county of all its slots in flight at once (a lone
-      // wave per SIMD has nothing else to issue while a load is out), then the counties' intercepts
-      const int last = ln.nobs - 1;
-      double oy[kSlots], ofl[kSlots], oc[kSlots], av[kSlots];
-#pragma unroll
-      for (int sl = 0; sl < kSlots; sl++) {
-        const int i = sl * 64 + l;
-        const int ic = i < last ? i : last;     // a valid address for an empty slot
-        oy[sl] = c.y[ic];
-        ofl[sl] = c.fl[ic];
-        oc[sl] = c.cty[ic];
-      }
+      // (this lane's observations were requested at the top) the counties' intercepts
+      double av[kSlots];
 #pragma unroll
       for (int sl = 0; sl < kSlots; sl++) av[sl] = al[(int)oc[sl]];
       double lik = 0.0, f = 0.0, z2s = 0.0;
@@ -1266,12 +1269,15 @@ struct Radon : ModelDefaults {
 #define EXMC_RADON_AHEAD 8
 #endif
         constexpr int kAhead = EXMC_RADON_AHEAD;
+        // (a lane past the end of its own county reads the strip's zero cell: sj + 0.0 is sj -- the sum
+        // starts at +0.0 and a sum of doubles is never -0.0 unless every term is -- so the addition
+        // needs no mask: two selects per cell less, same bits)
         for (int b = 0; b < nb; b += kAhead) {
           double v[kAhead];
 #pragma unroll
-          for (int j = 0; j < kAhead; j++) v[j] = cell[(i0 + b + j < i1) ? i0 + b + j : 0];
+          for (int j = 0; j < kAhead; j++) v[j] = cell[(i0 + b + j < i1) ? i0 + b + j : kZeroCell];
 #pragma unroll
-          for (int j = 0; j < kAhead; j++) sj = (i0 + b + j < i1) ? (sj + v[j]) : sj;
+          for (int j = 0; j < kAhead; j++) sj = sj + v[j];
         }
         sj_own[k] = sj;
       }
@@ -1288,10 +1294,6 @@ struct Radon : ModelDefaults {
         }
       }
     }
-    // (an infinite residual fails the first watch; a NaN one slips through fmax / fmin -- and makes
-    // the density and the gradient NaN on the short path as on the exact one)
-    dv.template watch_exp_if<-250, 250>(true, rmax);
-    dv.template watch_exp_if<-250, 250>(true, rmin);
 #pragma unroll
     for (int k = 0; k < DPL; k++) {
       const double ar = q[k];
