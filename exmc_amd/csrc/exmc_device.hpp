@@ -664,6 +664,17 @@ __device__ __forceinline__ void rs64_allsum4(double (&v)[4]) {
   v[3] = readlane_f64(z, 3);
 }
 
+// the six totals in every lane (rs64_reduce6 leaves totals 0, 3, 2, 5, 1, 4 in lanes 0 .. 5)
+__device__ __forceinline__ void rs64_allsum6(double (&v)[6]) {
+  const double z = rs64_reduce6(v);
+  v[0] = readlane_f64(z, 0);
+  v[3] = readlane_f64(z, 1);
+  v[2] = readlane_f64(z, 2);
+  v[5] = readlane_f64(z, 3);
+  v[1] = readlane_f64(z, 4);
+  v[4] = readlane_f64(z, 5);
+}
+
 // init0 + the sum over the chain's dimensions: lane-partial sum over this lane's valid slots, lane 0
 // seeded with init0, then the butterfly -- or, for a kSeqSum group, init0 + v[dim 0] + v[dim 1] + ...
 template <int G, int DPL, int D = G * DPL, bool kLds = false>

@@ -1306,7 +1306,10 @@ struct Radon : ModelDefaults {
       T[k] = -0.5 * (ar * ar + ln.kc[kC1]);
       g[k] = (-ar) + sj * sa;
     }
-    group_allsum_n<G, 6>(s);
+    // 64 lanes: the six totals as a reduce-scatter (exmc_device.hpp rs64_reduce6: the butterfly's own
+    // additions, half its instructions) and six scalar broadcasts -- the same bits
+    if constexpr (G == 64) rs64_allsum6(s);
+    else group_allsum_n<G, 6>(s);
     const double zmu = dv(mu - 0.0, ln.ten), zg = dv(gam - 0.0, ln.five), zb = dv(beta - 0.0, ln.five);
     const bool in_a = (zsa_raw > -200.0) && (zsa_raw < 200.0);
     const bool in_y = (zsy_raw > -200.0) && (zsy_raw < 200.0);
