@@ -2166,8 +2166,17 @@ int exmc_hip_ess_bulk(exmc_hip_model* m, const double* draws_dev, int n_draws, i
     HIP_TRY(hipFuncSetAttribute((const void*)rank_scores_kernel,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   HIP_TRY(hipEventRecord(m->ev0, m->stream));
-  hipLaunchKernelGGL(rank_scores_kernel, dim3((unsigned)series), dim3(256), lds, m->stream,
-                     draws_dev, n_draws, d, n_chains, m->scores.as<double>());
+  int P = 2;
+  while (P < n_draws) P <<= 1;
+  const char* re = std::getenv("EXMC_HIP_RANK_SORT");   // 0: the counting kernel (A/B runs, tests)
+  if (P <= kRankSortMaxP && !(re && re[0] == '0')) {
+    // ranks by sorting the series in LDS (exmc_kernels.hpp rank_scores_sort_kernel)
+    hipLaunchKernelGGL(rank_scores_sort_kernel, dim3((unsigned)series), dim3(256), (size_t)P * 12, m->stream,
+                       draws_dev, n_draws, P, d, n_chains, m->scores.as<double>());
+  } else {
+    hipLaunchKernelGGL(rank_scores_kernel, dim3((unsigned)series), dim3(256), lds, m->stream,
+                       draws_dev, n_draws, d, n_chains, m->scores.as<double>());
+  }
   HIP_TRY(hipGetLastError());
   rc = launch_ess(m, (const double*)m->scores.as<double>(), n_draws, d, n_chains, ess_dev);
   if (rc) return rc;

@@ -36,3 +36,45 @@ def test_ess_bulk_kernel_bit_exact(hip, S, D, Cn):
             series = np.ascontiguousarray(x[:, dim, c])
             assert L.exo_ess_bulk_mode(O.dptr(series), S, 1) == out[dim, c], (dim, c)
             assert abs(L.exo_ess_bulk(O.dptr(series), S) - out[dim, c]) <= 1e-9 * S
+
+
+@pytest.mark.parametrize("S", [4, 5, 64, 1000, 1024, 1025, 4096, 4097])
+def test_ranks_by_sorting_equal_ranks_by_counting(hip, monkeypatch, S):
+    """Round 5: the ranks come from a bitonic sort of the series in LDS (rank_scores_sort_kernel) where
+    they used to be counted (S comparisons per element). Ranks are integers: both kernels, and the
+    checker, must give the same bits -- on ties, a constant series, signed zeros, infinities, a series
+    that holds a NaN (ranked by the counting rule), at sizes on both sides of every power of two and of
+    the sort's capacity (4096, above it the counting kernel runs)."""
+    comp = sampler.compile(models.eight_schools())
+    rng = np.random.default_rng(S)
+    D, Cn = 2, 6
+    x = rng.normal(size=(S, D, Cn))
+    x[:, 0, 1] = 3.25                                   # constant
+    x[:, 0, 2] = np.round(x[:, 0, 2] * 2.0) / 2.0       # heavy ties
+    x[::3, 0, 3] = 0.0
+    x[1::3, 0, 3] = -0.0                                # -0.0 == +0.0: one tie group
+    x[0, 0, 4] = np.inf
+    x[S - 1, 0, 4] = -np.inf
+    if S > 4:
+        x[2, 0, 4] = np.inf
+    x[S // 2, 1, 0] = np.nan                            # a NaN: every comparison with it is false
+    dev = torch.device("cuda:0")
+    xd = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    outs = []
+    for mode in (None, "0"):
+        if mode is None:
+            monkeypatch.delenv("EXMC_HIP_RANK_SORT", raising=False)
+        else:
+            monkeypatch.setenv("EXMC_HIP_RANK_SORT", mode)
+        out = torch.empty((D, Cn), dtype=torch.float64, device=dev)
+        _lib.check(hip.exmc_hip_ess_bulk(comp.h, xd.data_ptr(), S, D, Cn, out.data_ptr()))
+        torch.cuda.synchronize()
+        outs.append(out.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1], equal_nan=True)
+    L = O.lib()
+    for dim in range(D):
+        for c in range(Cn):
+            series = np.ascontiguousarray(x[:, dim, c])
+            want = L.exo_ess_bulk_mode(O.dptr(series), S, 1)
+            got = outs[0][dim, c]
+            assert want == got or (np.isnan(want) and np.isnan(got)), (S, dim, c, want, got)
