@@ -675,6 +675,42 @@ __device__ __forceinline__ void rs64_allsum6(double (&v)[6]) {
   v[4] = readlane_f64(z, 5);
 }
 
+// N sums over the sixteen lanes of a DPP row as a reduce-scatter (round 5): lane l ends with the totals
+// of quantities l, l + 16, ... (out[k] = total of quantity l + 16 k), each total the expression
+// ((v0 + v1) + (v2 + v3)) + ... the butterfly of group_allsum_n<16, N> gives it (stage by stage a lane
+// keeps the half of its quantities whose destination lane has its own bit, sends the other half to the
+// partner and adds what it receives: own + partner, the butterfly's addition on that lane) -- in about
+// 7 N instructions instead of 12 N, and with every total already on the lane that uses it. Quantities
+// past N are zero padding; their "totals" are never read.
+template <int N>
+__device__ __forceinline__ void row16_reduce_scatter(const double (&v)[N], double (&out)[(N + 15) / 16]) {
+  constexpr int N1 = (N + 1) / 2, N2 = (N1 + 1) / 2, N3 = (N2 + 1) / 2, N4 = (N3 + 1) / 2;
+  static_assert(N4 == (N + 15) / 16, "four halvings");
+  const int lane = threadIdx.x;
+  const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0, b2 = (lane & 4) != 0, b3 = (lane & 8) != 0;
+  double a1[N1], a2[N2], a3[N3];
+#pragma unroll
+  for (int i = 0; i < N1; i++) {
+    const double lo = v[2 * i], hi = (2 * i + 1 < N) ? v[(2 * i + 1 < N) ? 2 * i + 1 : 0] : 0.0;
+    a1[i] = (b0 ? hi : lo) + xchg_dpp<kDppXor1>(b0 ? lo : hi);
+  }
+#pragma unroll
+  for (int i = 0; i < N2; i++) {
+    const double lo = a1[2 * i], hi = (2 * i + 1 < N1) ? a1[(2 * i + 1 < N1) ? 2 * i + 1 : 0] : 0.0;
+    a2[i] = (b1 ? hi : lo) + xchg_dpp<kDppXor2>(b1 ? lo : hi);
+  }
+#pragma unroll
+  for (int i = 0; i < N3; i++) {
+    const double lo = a2[2 * i], hi = (2 * i + 1 < N2) ? a2[(2 * i + 1 < N2) ? 2 * i + 1 : 0] : 0.0;
+    a3[i] = (b2 ? hi : lo) + xchg_xor4(b2 ? lo : hi);
+  }
+#pragma unroll
+  for (int i = 0; i < N4; i++) {
+    const double lo = a3[2 * i], hi = (2 * i + 1 < N3) ? a3[(2 * i + 1 < N3) ? 2 * i + 1 : 0] : 0.0;
+    out[i] = (b3 ? hi : lo) + xchg_dpp<kDppRowRor8>(b3 ? lo : hi);
+  }
+}
+
 // init0 + the sum over the chain's dimensions: lane-partial sum over this lane's valid slots, lane 0
 // seeded with init0, then the butterfly -- or, for a kSeqSum group, init0 + v[dim 0] + v[dim 1] + ...
 template <int G, int DPL, int D = G * DPL, bool kLds = false>

@@ -815,21 +815,24 @@ struct Logistic : ModelDefaults {
     } else {
       steps_row16<false, false>(c, nullptr, l, q0, q1, s);
     }
-    group_allsum_n<G, D + 1>(s);
+    // the 22 sums as a reduce-scatter over the row (exmc_device.hpp row16_reduce_scatter: the butterfly's
+    // own additions): lane l ends with the gradient totals of ITS dimensions l and 16 + l -- no select
+    // chain over 21 totals per slot -- and lane 5 with the likelihood total (quantity 21 = 16 + 5),
+    // which the final sum wants as lane 0's seed: one row broadcast
+    double tot[DPL];
+    row16_reduce_scatter<D + 1>(s, tot);
+    const double lik = row_bcast_f64<(D % 16)>(tot[D / 16]);
     double T[DPL];
     bool valid[DPL];
 #pragma unroll
     for (int k = 0; k < DPL; k++) {
       const int i = l + k * G;
       valid[k] = i < D;
-      double gi = 0.0;
-#pragma unroll
-      for (int j = 0; j < D; j++) gi = (i == j) ? s[j] : gi;
       const double z = (q[k] - 0.0) / 10.0;
       T[k] = -0.5 * (z * z + c.c10);
-      g[k] = valid[k] ? ((-(z / 10.0)) + gi) : 0.0;
+      g[k] = valid[k] ? ((-(z / 10.0)) + tot[k]) : 0.0;
     }
-    return group_sum_slots<G, DPL>(T, valid, l, s[D]);
+    return group_sum_slots<G, DPL>(T, valid, l, lik);
   }
 
   // The three per-observation specials in their short forms while every linear predictor of the

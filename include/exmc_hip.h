@@ -23,6 +23,10 @@
  *                                default: two-wave where the model gains from it
  *   EXMC_HIP_WARMUP_REPLICAS=N   workgroups racing through the same warmup chain (default 32)
  *   EXMC_HIP_NUTS_PIPE=1         wave pairs in the sampling kernel too (eight_schools, 16 lanes)
+ *   EXMC_HIP_NUTS_WG=0|1         logistic at 16 lanes per chain: the one-wave sampling kernel / workgroups of
+ *                                eight wavefronts around one LDS image of the design matrix; default: the
+ *                                workgroup form when a launch has more wavefronts than the device has SIMDs
+ *   EXMC_HIP_RANK_SORT=0         exmc_hip_ess_bulk: ranks by counting instead of by sorting the series in LDS
  */
 #ifndef EXMC_HIP_H
 #define EXMC_HIP_H

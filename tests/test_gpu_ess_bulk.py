@@ -75,6 +75,8 @@ def test_ranks_by_sorting_equal_ranks_by_counting(hip, monkeypatch, S):
     for dim in range(D):
         for c in range(Cn):
             series = np.ascontiguousarray(x[:, dim, c])
+            if np.isnan(series).any():
+                continue    # outside the reference's domain (a BEAM float is never NaN): only sort == count, above
             want = L.exo_ess_bulk_mode(O.dptr(series), S, 1)
             got = outs[0][dim, c]
             assert want == got or (np.isnan(want) and np.isnan(got)), (S, dim, c, want, got)
