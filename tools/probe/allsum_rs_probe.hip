@@ -31,6 +31,23 @@ __global__ void k(const double* in, double* out) {   // one wave: in [6][64], ou
   for (int j = 0; j < 4; j++) out[(3 * 6 + j) * 64 + l] = c[j];
 }
 
+// 16-lane rows (round 5): row16_reduce_scatter<22> against group_allsum_n<16, 22>, four rows of a wave with
+// different data; and rs64_allsum6 against the 64-lane butterfly.   in [22][64], out [22 + 2 + 6][64]
+__global__ void k16(const double* in, double* out) {
+  const int l = threadIdx.x;
+  double v[22], a[22];
+  for (int j = 0; j < 22; j++) v[j] = a[j] = in[j * 64 + l];
+  group_allsum_n<16, 22>(a);
+  for (int j = 0; j < 22; j++) out[j * 64 + l] = a[j];
+  double t[2];
+  row16_reduce_scatter<22>(v, t);
+  out[22 * 64 + l] = t[0];
+  out[23 * 64 + l] = t[1];
+  double c[6] = {v[0], v[1], v[2], v[3], v[4], v[5]};
+  rs64_allsum6(c);
+  for (int j = 0; j < 6; j++) out[(24 + j) * 64 + l] = c[j];
+}
+
 int main() {
   double *din, *dout;
   static double in[6 * 64], out[5 * 6 * 64];
@@ -62,6 +79,30 @@ int main() {
     }
     for (int j = 0; j < 2; j++) bad += !same(at(2, 2, j + 2 * (trial % 32)), at(0, j, 0));
   }
-  printf("allsum_rs_probe: 2000 trials of 6 sums over 64 lanes, %ld mismatches\n", bad);
+  {
+    static double in16[22 * 64], out16[30 * 64], ref6[6 * 64];
+    double *d16i, *d16o;
+    hipMalloc(&d16i, sizeof in16);
+    hipMalloc(&d16o, sizeof out16);
+    for (int trial = 0; trial < 500; trial++) {
+      for (int i = 0; i < 22 * 64; i++) in16[i] = ldexp((double)rand() / RAND_MAX - 0.5, rand() % 40 - 20);
+      hipMemcpy(d16i, in16, sizeof in16, hipMemcpyHostToDevice);
+      hipLaunchKernelGGL(k16, dim3(1), dim3(64), 0, 0, d16i, d16o);
+      hipMemcpy(out16, d16o, sizeof out16, hipMemcpyDeviceToHost);
+      auto same = [](double x, double y) { return memcmp(&x, &y, 8) == 0; };
+      for (int l = 0; l < 64; l++) {
+        bad += !same(out16[22 * 64 + l], out16[(l % 16) * 64 + l]);                       // quantity l of this row
+        if (l % 16 < 6) bad += !same(out16[23 * 64 + l], out16[(16 + l % 16) * 64 + l]);  // quantity 16 + l
+      }
+      // rs64_allsum6 against the 64-lane butterfly of the first six quantities (computed on the host
+      // copy of the butterfly kernel above: forms 0 of k)
+      hipMemcpy(din, in16, 6 * 64 * 8, hipMemcpyHostToDevice);
+      hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, din, dout);
+      hipMemcpy(ref6, dout, sizeof ref6, hipMemcpyDeviceToHost);
+      for (int j = 0; j < 6; j++)
+        for (int l = 0; l < 64; l += 5) bad += !same(out16[(24 + j) * 64 + l], ref6[j * 64 + 0]);
+    }
+  }
+  printf("allsum_rs_probe: 2000 trials of 6 sums over 64 lanes, 500 of 22 sums over 16-lane rows, %ld mismatches\n", bad);
   return bad != 0;
 }
