@@ -70,6 +70,7 @@ struct ModelDefaults {
   // wavefront in LDS (exmc_nuts.hpp nuts_kernel_wg); wg_ok(consts): the data fit the image
   static constexpr int kWgWaves = 0;
   static constexpr int kWgLdsLevels = 1;
+  static constexpr int kWgImageDoubles = 0;   // the image's size; wg_stage fills it, wg_attach points a lane at it
   template <class C>
   __host__ __device__ static bool wg_ok(const C&) { return false; }
 };
@@ -616,9 +617,12 @@ struct Logistic : ModelDefaults {
   static constexpr int kWgWaves = (G == 16) ? 8 : 0;
   static constexpr int kWgLdsLevels = 1;
   __host__ __device__ static bool wg_ok(const Consts& c) { return c.N <= kObsCap; }
+  static constexpr int kWgImageDoubles = (G == 16) ? kStageDoubles : 0;
   struct Lane {
     const double* xs;   // LDS image, or null (rows stream from L2)
   };
+  __device__ static __forceinline__ void wg_stage(const Consts& c, double* image) { stage(c, image); }
+  __device__ static __forceinline__ void wg_attach(Lane& ln, double* image, int) { ln.xs = image; }
   __device__ static __forceinline__ void load(const Consts&, int, Lane& ln) { ln.xs = nullptr; }
   // cooperative (whole workgroup); the caller synchronises afterwards and guarantees N <= kObsCap
   __device__ static __forceinline__ void stage(const Consts& c, double* dst) {
@@ -1449,6 +1453,11 @@ static __host__ __device__ __noinline__ double exmc_gen_erf_call(double x) { ret
 #else
 #define EXMC_GEN_TABLE_IN_LDS 0
 #endif
+// (Round 5 measured the workgroup form of the sampling kernel -- eight wavefronts around ONE LDS image of
+// the tables, exmc_nuts.hpp nuts_kernel_wg -- for the generated 500 x 20 logistic regression, whose
+// 86 KB of tables do not fit beside a one-wave workgroup: 267.9 against 269.5 ms, bit-identical. The
+// generated pass waits on its LDS strips and fences, not on its table reads, so the form is not built
+// for generated layouts: no ninth translation unit in every plug-in for it.)
 namespace exmc {
 constexpr bool kGenLdsTable = EXMC_GEN_TABLE_IN_LDS != 0;
 }

@@ -1698,23 +1698,29 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock, M::kNutsW
 
 // ------------------------------------------------------------------------------------------
 // The sampling kernel as workgroups of W wavefronts that share ONE LDS image of the model's data
-// (M::kWgWaves, M::stage / kStageDoubles; logistic at 16 lanes per chain: its 500 x 20 design
-// matrix, which every wavefront otherwise streams from L2 at every leapfrog). Every wavefront is
-// the one-wave kernel on its own slice of LDS -- W tree stacks of LDSL levels, then the ziggurat
-// tables and the image once -- and after the staging barrier no wavefront waits for another.
-//   LDS: [wave 0 stack][wave 1 stack] ... [ziggurat tables][image]
+// (M::kWgWaves, M::wg_stage / wg_attach / kWgImageDoubles; logistic at 16 lanes per chain: its
+// 500 x 20 design matrix, which every wavefront otherwise streams from L2 at every leapfrog; a
+// generated lane layout: its tables). Every wavefront is the one-wave kernel on its own slice of LDS
+// -- W tree stacks of LDSL levels, the ziggurat tables once, W strips of model scratch
+// (kExtraLdsDoubles), the image once -- and after the staging barrier no wavefront waits for another.
+//   LDS: [wave 0 stack][wave 1 stack] ... [ziggurat tables][wave 0 scratch] ... [image]
 // Diagonal mass, no stream, no migration (the kinds that have those keep nuts_kernel).
 // ------------------------------------------------------------------------------------------
 template <class M, int LDSL, int W>
-__host__ __device__ constexpr size_t nuts_wg_image_offset() {   // in doubles; even
+__host__ __device__ constexpr size_t nuts_wg_extra_offset() {   // in doubles: the wavefronts' model scratch
   return (size_t)W * LDSL * nuts_nslot<M>() * kNutsBlock + kZigLdsBytes / 8;
 }
 template <class M, int LDSL, int W>
+__host__ __device__ constexpr size_t nuts_wg_image_offset() {   // in doubles; even
+  return (nuts_wg_extra_offset<M, LDSL, W>() + (size_t)W * M::kExtraLdsDoubles + 1) & ~(size_t)1;
+}
+template <class M, int LDSL, int W>
 __host__ __device__ constexpr size_t nuts_wg_lds_bytes() {
-  return (nuts_wg_image_offset<M, LDSL, W>() + (size_t)M::kStageDoubles) * 8;
+  return (nuts_wg_image_offset<M, LDSL, W>() + (size_t)M::kWgImageDoubles) * 8;
 }
 
-// the model as the workgroup form evaluates it: always from the image
+// the model as the workgroup form evaluates it: always from the image (wg_attach has pointed the lane
+// at it), through the model's own entry for that case -- the compiler keeps one copy of the pass
 template <class B>
 struct WgModel : B {
   __device__ static __forceinline__ double logp_grad(const typename B::Consts& c, const typename B::Lane& ln,
@@ -1728,8 +1734,7 @@ __global__ void __launch_bounds__(W * kNutsBlock) nuts_kernel_wg(NutsParams P, t
   using M = WgModel<B>;
   constexpr int D = M::D, DPL = M::DPL;
   constexpr int NSLOT = nuts_nslot<M>();
-  static_assert(M::kStageDoubles > 0 && !M::kCoop && M::kLdsDataDoubles == 0 && M::kExtraLdsDoubles == 0,
-                "a model with a stage()-filled image and nothing else in LDS");
+  static_assert(M::kWgImageDoubles > 0 && !M::kCoop, "a model with an image for the workgroup form (wg_stage / wg_attach)");
   extern __shared__ double lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tid = blockIdx.x * (W * kNutsBlock) + threadIdx.x;
@@ -1744,7 +1749,7 @@ __global__ void __launch_bounds__(W * kNutsBlock) nuts_kernel_wg(NutsParams P, t
     lz[512 + i] = P.zig_fi[i];
   }
   double* const image = lds + nuts_wg_image_offset<M, LDSL, W>();
-  M::stage(mc, image);
+  M::wg_stage(mc, image);
   __syncthreads();
   if (!has_chain) return;
 
@@ -1752,7 +1757,9 @@ __global__ void __launch_bounds__(W * kNutsBlock) nuts_kernel_wg(NutsParams P, t
   const ZigTables zt{(const uint64_t*)lz, lz + 256, lz + 512};
   lane_setup<M, G, LDSL>(L, mc, lds, P.stack, P.inv_mass, P.sqrt_inv_mass, zt, P.nor_r, P.flat, P.dm);
   L.lstk = lds + (size_t)wave * LDSL * NSLOT * kNutsBlock + lane;   // this wavefront's stack
-  L.ln.xs = image;
+  if constexpr (M::kExtraLdsDoubles > 0)                             // ... and its model scratch
+    L.ln.sh = lds + nuts_wg_extra_offset<M, LDSL, W>() + (size_t)wave * M::kExtraLdsDoubles;
+  M::wg_attach(L.ln, image, (int)nuts_wg_image_offset<M, LDSL, W>());
   // two waves per SIMD by construction (W = 8 on four SIMDs); which two share one is the
   // dispatcher's choice, so the priority is left to the arbiter
   L.prio_slot = -1;
