@@ -39,9 +39,13 @@ def _rank_inputs(rank, world):
     draws = torch.from_numpy(np.ascontiguousarray(t["draws"].transpose(1, 2, 0)))
     L = O.lib()
     ess = np.zeros((10, cper))
+    essb = np.zeros((10, cper))
     for c in range(cper):
         for i in range(10):
-            ess[i, c] = L.exo_ess(O.dptr(np.ascontiguousarray(t["draws"][c, :, i])), S)
+            series = np.ascontiguousarray(t["draws"][c, :, i])
+            ess[i, c] = L.exo_ess(O.dptr(series), S)
+            essb[i, c] = L.exo_ess_bulk(O.dptr(series), S)
+    _rank_inputs.bulk = torch.from_numpy(essb)     # rides beside the Geyer ESS (finish_model's ess_bulk)
     return draws, torch.from_numpy(ess), int(st.total_leapfrogs), int(t["divergent"].sum()), float(st.step_size)
 
 
@@ -69,7 +73,8 @@ def _line(rank, world, dist_mod, gather_traces, break_route=False):
                               world=world, rank=rank, dist=dist_mod, draws=draws, ess=ess, leap_local=lf,
                               div_local=dv, elapsed_local=0.5 + 0.125 * rank, kernel_ms=400.0, adapt_s=0.25,
                               ess_s=0.0625, ess_ms=60.0, epsilon=eps, lanes=16, warm_lanes=16,
-                              bytes_per_leapfrog=488, gather_traces=gather_traces, rhat_fn=rhat_fn)
+                              bytes_per_leapfrog=488, gather_traces=gather_traces, rhat_fn=rhat_fn,
+                              ess_bulk=_rank_inputs.bulk, ess_bulk_s=0.03125)
 
 
 def _worker(rank, world, port, gather_traces, break_route, out_dir):
@@ -112,6 +117,10 @@ def test_line_does_not_depend_on_the_number_of_ranks(tmp_path, gather_traces):
         assert line["value"] * slowest == pytest.approx(line["mean_leapfrogs_per_draw"] * 40 * 12, rel=1e-12)
         assert line["divergent_transitions"] == one["divergent_transitions"]
         assert line["ess_min_total"] == pytest.approx(one["ess_min_total"], rel=1e-13)
+        # the rank-normalised ESS rides on every leg since round 5: summed over the ranks like the Geyer ESS
+        assert line["ess_bulk_min_total"] == pytest.approx(one["ess_bulk_min_total"], rel=1e-13)
+        assert line["ess_bulk_per_s"] == pytest.approx(
+            line["ess_bulk_min_total"] / (0.25 + slowest + 0.03125 + line["ess_wall_s"]["gather"]), rel=1e-12)
         # both R-hat routes see ALL chains: equal to the one-rank values
         assert line["rhat_max_from_chain_stats"] == pytest.approx(one["rhat_max_from_chain_stats"], rel=1e-12)
         assert line["rhat_max"] == pytest.approx(one["rhat_max"], rel=1e-12)
