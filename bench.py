@@ -786,6 +786,7 @@ def run_model_independent(args, model, spec, comp, opts, lanes, bytes_per_leapfr
             "note": "value and roofline count the leapfrogs of both phases; ess_wall_s.adaptation is 0 because the "
                     "adaptation is inside the timed launch"}
         out["reference_published"] = reference_published(model)
+        out["roofline"]["kernel"] = "indep_kernel"
         if world == 1:
             out["mean_leapfrogs_per_draw"] = lf.value / float(S * Ctot)   # the draws' own trees
     comp.close()

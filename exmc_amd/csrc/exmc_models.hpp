@@ -1086,6 +1086,7 @@ struct RadonConsts {
   const double* fl;     // dev [N]
   const double* y;      // dev [N]
   const double* cty;    // dev [N] the county of every observation
+  const double* pobs;   // dev [3][kObsCap + 64] y, floor and county again, zero-padded (the 64-lane layout's copies)
   double log2pi32, tiny32;
   double c_mu10;        // log2pi32 + 2*log(10)
   double c_n5;          // log2pi32 + 2*log(5)
@@ -1102,6 +1103,7 @@ struct Radon : ModelDefaults {
   static constexpr bool kSpread = (G == 64);           // observations over the lanes (see above)
   static constexpr int kObsCap = 1024;                 // observations the spread layout holds
   static constexpr int kSlots = kSpread ? kObsCap / 64 : 1;
+  static constexpr int kObsPad = kObsCap + 64;         // entries of each padded copy (Consts::pobs)
   static constexpr int kAlphaOff = kObsCap;            // strip: [a_i (kObsCap)] [alpha_j (J, padded)]
   static constexpr int kZeroCell = kObsCap + 95;       // the last pad cell of the strip holds 0.0
   static constexpr int kExtraLdsDoubles = kSpread ? kObsCap + 96 : 0;
@@ -1163,17 +1165,36 @@ struct Radon : ModelDefaults {
     // addresses depend on nothing computed here, and a wave that has its SIMD to itself sits out every
     // L2 round trip it starts late -- this one now runs beside the five transcendentals below
     // (round 5; same values, same bits)
+    // The slots every lane fills (nobs / 64 of them) and the one partly filled slot behind them are
+    // fetched apart, the latter from its own (run-time) index: the unrolled walk below then tests a
+    // full slot with ONE scalar compare, where a slot that could be either cost ten scalar
+    // instructions of lane-mask bookkeeping -- and a wave alone on its SIMD pays an issue slot for
+    // every instruction, whatever unit executes it.
     [[maybe_unused]] double oy[kSlots], ofl[kSlots], oc[kSlots];
+    [[maybe_unused]] double oy_t = 0.0, ofl_t = 0.0, oc_t = 0.0;
+    [[maybe_unused]] int nfull = 0;
     if constexpr (kSpread) {
-      const int last = ln.nobs - 1;
+      // (the padded copies: slot s of lane l is entry 64 s + l whatever the observation count. Buffer
+      // loads -- one descriptor, the lane's byte offset in ONE register, slot and array as an immediate
+      // plus a scalar offset -- where flat addresses were 51 register pairs, parked in accumulator
+      // registers and read back at every evaluation)
+      nfull = __builtin_amdgcn_readfirstlane(ln.nobs >> 6);
+      const __amdgpu_buffer_rsrc_t rs =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(c.pobs), 0, 3 * kObsPad * 8, 0x00020000);
+      const int l8 = l * 8;
+      auto fetch = [&](int arr, int voff, int soff) -> double {
+        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, arr * kObsPad * 8 + soff, 0));
+      };
 #pragma unroll
       for (int sl = 0; sl < kSlots; sl++) {
-        const int i = sl * 64 + l;
-        const int ic = i < last ? i : last;     // a valid address for an empty slot
-        oy[sl] = c.y[ic];
-        ofl[sl] = c.fl[ic];
-        oc[sl] = c.cty[ic];
+        const int vo = l8 + (sl & 7) * 512, so = (sl >> 3) * 4096;
+        oy[sl] = fetch(0, vo, so);
+        ofl[sl] = fetch(1, vo, so);
+        oc[sl] = fetch(2, vo, so);
       }
+      oy_t = fetch(0, l8, nfull * 512);           // entry 64 nfull + l <= kObsCap + 63
+      ofl_t = fetch(1, l8, nfull * 512);
+      oc_t = fetch(2, l8, nfull * 512);
       __builtin_amdgcn_sched_barrier(0);   // the scheduler would sink the loads back towards their uses
     }
     const double mu = group_bcast_c<G, J % G>(q[J / G]);
@@ -1247,16 +1268,15 @@ struct Radon : ModelDefaults {
       double av[kSlots];
 #pragma unroll
       for (int sl = 0; sl < kSlots; sl++) av[sl] = al[(int)oc[sl]];
+      const double av_t = al[(int)oc_t];
       double lik = 0.0, f = 0.0, z2s = 0.0;
-      const int nfull = __builtin_amdgcn_readfirstlane(ln.nobs >> 6);   // slots every lane fills
 #pragma unroll
-      for (int sl = 0; sl < kSlots; sl++) {
-        const int i = sl * 64 + l;
-        if (sl < nfull) {                     // wave-uniform: no lane mask on the full slots,
-          cell[i] = obs(av[sl], ofl[sl], oy[sl], lik, f, z2s);
-        } else if (sl == nfull) {             // one partly filled slot, and the empty ones cost nothing
-          if (i < ln.nobs) cell[i] = obs(av[sl], ofl[sl], oy[sl], lik, f, z2s);
-        }
+      for (int sl = 0; sl < kSlots; sl++)
+        if (__builtin_expect(sl < nfull, 1))                                         // wave-uniform test
+          cell[sl * 64 + l] = obs(av[sl], ofl[sl], oy[sl], lik, f, z2s);
+      {
+        const int i = nfull * 64 + l;         // the partly filled slot: the last terms of every lane's sums
+        if (i < ln.nobs) cell[i] = obs(av_t, ofl_t, oy_t, lik, f, z2s);
       }
       s[0] = lik;
       s[4] = f;

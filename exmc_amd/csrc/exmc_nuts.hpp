@@ -2402,8 +2402,12 @@ struct IndepParams {
   FlatOrder flat;
 };
 
+// Launch bounds as nuts_kernel's: where the model asks for two waves per SIMD (sv at 64 lanes, logistic at
+// 16) the 2048 waves of the bench protocol are one resident round, not two -- sv 2048 x (1000 + 1000)
+// 4.98 s -> 4.48 s on one box, same bits (profiles/r5_svi); the spills this buys (272 B per lane for sv)
+// sit in the window updates, outside the tree.
 template <class M, int G, int LDSL>
-__global__ void __launch_bounds__(kNutsBlock) indep_kernel(IndepParams P, typename M::Consts mc) {
+__global__ void __launch_bounds__(kNutsBlock, M::kNutsWavesPerSimd) indep_kernel(IndepParams P, typename M::Consts mc) {
   constexpr int D = M::D, DPL = M::DPL;
   constexpr int NSLOT = nuts_nslot<M>();
   static_assert(!M::kCoop, "wave-cooperative models evaluate every group at the same point of the same chain");
