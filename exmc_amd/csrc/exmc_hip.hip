@@ -1358,7 +1358,8 @@ int exmc_hip_model_create(int kind, int d, const double* data, int n_data, int d
       for (int i = 0; i < N; i++) {
         blob[off_pad + i] = data[2 * J + 1 + N + i];
         blob[off_pad + kRadonPad + i] = data[2 * J + 1 + i];
-        blob[off_pad + 2 * kRadonPad + i] = blob[off_cty + i];
+        const uint64_t off8 = 8ull * (uint64_t)blob[off_cty + i];   // the county's byte offset in the alpha strip
+        std::memcpy(&blob[off_pad + 2 * kRadonPad + i], &off8, 8);
       }
     }
     rc = m->data.ensure(blob.size() * 8);

@@ -1104,9 +1104,9 @@ struct Radon : ModelDefaults {
   static constexpr int kObsCap = 1024;                 // observations the spread layout holds
   static constexpr int kSlots = kSpread ? kObsCap / 64 : 1;
   static constexpr int kObsPad = kObsCap + 64;         // entries of each padded copy (Consts::pobs)
-  static constexpr int kAlphaOff = kObsCap;            // strip: [a_i (kObsCap)] [alpha_j (J, padded)]
-  static constexpr int kZeroCell = kObsCap + 95;       // the last pad cell of the strip holds 0.0
-  static constexpr int kExtraLdsDoubles = kSpread ? kObsCap + 96 : 0;
+  static constexpr int kAlphaOff = kObsCap;            // strip: [a_i (kObsCap)] [alpha_j (DPL * 64 cells, 0.0 from J on)]
+  static constexpr int kZeroRun = kObsCap + 88;        // eight cells of 0.0 in a row (past the J = 85 intercepts)
+  static constexpr int kExtraLdsDoubles = kSpread ? kObsCap + 128 : 0;
   struct Lane {
     double u[DPL];
     int i0[DPL], i1[DPL];   // own counties: their observations [i0, i1)
@@ -1195,6 +1195,8 @@ struct Radon : ModelDefaults {
       oy_t = fetch(0, l8, nfull * 512);           // entry 64 nfull + l <= kObsCap + 63
       ofl_t = fetch(1, l8, nfull * 512);
       oc_t = fetch(2, l8, nfull * 512);
+      // (the third copy holds 8 * county as an integer in the low word of each entry: the byte offset of the
+      // county's intercept in the alpha strip, used as it comes)
       __builtin_amdgcn_sched_barrier(0);   // the scheduler would sink the loads back towards their uses
     }
     const double mu = group_bcast_c<G, J % G>(q[J / G]);
@@ -1259,16 +1261,20 @@ struct Radon : ModelDefaults {
     if constexpr (kSpread) {
       double* const cell = ln.sh;               // a_i of observation i
       double* const al = ln.sh + kAlphaOff;     // alpha_j of county j
+      // every lane writes every slot, 0.0 from county J on: no lane mask, and the cells from J on are the
+      // zeros a lane past the end of its county adds (below)
 #pragma unroll
-      for (int k = 0; k < DPL; k++)
-        if (l + k * G < J) al[l + k * G] = alpha_own[k];
-      if (l == 0) al[kZeroCell - kAlphaOff] = 0.0;   // what a lane past the end of its county adds (below)
+      for (int k = 0; k < DPL; k++) al[l + k * G] = (l + k * G < J) ? alpha_own[k] : 0.0;
       wave_lds_fence();
       // (this lane's observations were requested at the top) the counties' intercepts
+      auto alpha_at = [&](double packed) -> double {
+        const int off = (int)__builtin_bit_cast(unsigned long long, packed);   // 8 * county
+        return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(al) + off);
+      };
       double av[kSlots];
 #pragma unroll
-      for (int sl = 0; sl < kSlots; sl++) av[sl] = al[(int)oc[sl]];
-      const double av_t = al[(int)oc_t];
+      for (int sl = 0; sl < kSlots; sl++) av[sl] = alpha_at(oc[sl]);
+      const double av_t = alpha_at(oc_t);
       double lik = 0.0, f = 0.0, z2s = 0.0;
 #pragma unroll
       for (int sl = 0; sl < kSlots; sl++)
@@ -1296,15 +1302,44 @@ struct Radon : ModelDefaults {
 #define EXMC_RADON_AHEAD 8
 #endif
         constexpr int kAhead = EXMC_RADON_AHEAD;
-        // (a lane past the end of its own county reads the strip's zero cell: sj + 0.0 is sj -- the sum
+        // (a lane past the end of its own county reads the strip's zeros: sj + 0.0 is sj -- the sum
         // starts at +0.0 and a sum of doubles is never -0.0 unless every term is -- so the addition
         // needs no mask: two selects per cell less, same bits)
-        for (int b = 0; b < nb; b += kAhead) {
+        // Round 5: whole batches of eight cells first -- ONE select per lane and batch between this lane's run
+        // and the run of eight zeros, the cell's place in the batch as the read's immediate offset -- then the
+        // (up to seven) cells a county has beyond its last whole batch, selected cell by cell. A lane adds its
+        // own cells in index order with zeros in between, which leaves every sum as it was (was: index,
+        // compare, select and shift for every cell of every batch up to the largest county).
+        static_assert(kAhead == 8, "the zero run holds eight cells; batches of eight");
+        const double* const pz = ln.sh + kZeroRun;
+        const int n = i1 - i0;
+        const int nwhole = n >> 3;                       // this lane's whole batches
+        const int rest = n & 7;
+        const double* pa = cell + i0;
+        const double* const prest = pa + (n & ~7);
+        const int nbw = nb >> 3;                         // wave-uniform: whole batches of the largest county
+        for (int b = 0; b < nbw; b++) {
+          const double* const base = (b < nwhole) ? pa : pz;
           double v[kAhead];
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int j = 0; j < kAhead; j++) v[j] = cell[(i0 + b + j < i1) ? i0 + b + j : kZeroCell];
+          for (int j = 0; j < kAhead; j++) v[j] = base[j];
+          __builtin_amdgcn_sched_barrier(0);   // all the reads in flight before the first addition waits
 #pragma unroll
           for (int j = 0; j < kAhead; j++) sj = sj + v[j];
+          pa += kAhead;
+        }
+        {
+          const double* ad[kAhead - 1];
+          double v[kAhead - 1];
+#pragma unroll
+          for (int j = 0; j < kAhead - 1; j++) ad[j] = ((rest > j) ? prest : pz) + j;
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < kAhead - 1; j++) v[j] = *ad[j];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < kAhead - 1; j++) sj = sj + v[j];
         }
         sj_own[k] = sj;
       }
@@ -1337,9 +1372,38 @@ struct Radon : ModelDefaults {
     // additions, half its instructions) and six scalar broadcasts -- the same bits
     if constexpr (G == 64) rs64_allsum6(s);
     else group_allsum_n<G, 6>(s);
-    const double zmu = dv(mu - 0.0, ln.ten), zg = dv(gam - 0.0, ln.five), zb = dv(beta - 0.0, ln.five);
     const bool in_a = (zsa_raw > -200.0) && (zsa_raw < 200.0);
     const bool in_y = (zsy_raw > -200.0) && (zsy_raw < 200.0);
+    if constexpr (kSpread) {
+      // The five scalar parameters sit on five lanes of the last slot. Written as five lane-specific
+      // branches (below, the other layouts) the wavefront walks all five bodies one after another with one
+      // lane live in each; here the three Normal priors are ONE evaluation with per-lane operands and the
+      // two HalfCauchy derivatives another -- the same operations on the same values, lane by lane.
+      constexpr int ks = J / G;
+      const int j = l + ks * G;
+      const bool is_mu = j == J, is_g = j == J + 1, is_a = j == J + 2, is_y = j == J + 3, is_b = j == J + 4;
+      const double v = is_mu ? mu : (is_g ? gam : beta);
+      Recip rc;
+      rc.b = is_mu ? ln.ten.b : ln.five.b;
+      rc.r = is_mu ? ln.ten.r : ln.five.r;
+      const double cst = is_mu ? ln.kc[kMu10] : ln.kc[kN5];
+      const double sx = is_mu ? s[1] : (is_g ? s[2] : s[4]);
+      const double zn = dv(v - 0.0, rc);
+      const double Tn = -0.5 * (zn * zn + cst);
+      const double gn = (-dv(zn, rc)) + sx;
+      const double zc = is_a ? za : zy, zc2 = is_a ? za2 : zy2;
+      const double dc = -dv(dv(2.0 * zc, ln.c25), 1.0 + zc2);
+      const double ga = in_a ? ((dc + s[3]) * sa + 1.0) : 0.0;
+      const double gy = in_y ? ((dc * sy + s[5]) + 1.0) : 0.0;
+      const bool is_n = is_mu || is_g || is_b;
+      T[ks] = is_n ? Tn : (is_a ? t_sa : (is_y ? t_sy : T[ks]));
+      g[ks] = is_n ? gn : (is_a ? ga : (is_y ? gy : g[ks]));
+#pragma unroll
+      for (int k = 0; k < DPL; k++)
+        if (l + k * G >= D) g[k] = 0.0;
+      return group_sum_slots<G, DPL>(T, valid, l, s[0]);
+    }
+    const double zmu = dv(mu - 0.0, ln.ten), zg = dv(gam - 0.0, ln.five), zb = dv(beta - 0.0, ln.five);
 #pragma unroll
     for (int k = 0; k < DPL; k++) {
       const int j = l + k * G;
