@@ -510,6 +510,45 @@ struct ZigTables {
 
 // :rand.normal_s — 256-layer ziggurat on one 58-bit word (bit 6 sign, bits 7..57 the
 // 51-bit R whose low 8 bits select the layer).
+// (words: incremented by the number of generator words the draw consumed -- one when the first word is
+// accepted at once)
+template <bool kCount = false>
+__device__ inline double rng_normal_impl(Rng& r0, const ZigTables& zt, double nor_r, int& words) {
+  struct Counted {
+    Rng& r;
+    int& n;
+  } cr{r0, words};
+  auto next = [&]() -> uint64_t {
+    if constexpr (kCount) cr.n++;
+    return rng_next(cr.r);
+  };
+  auto uniform = [&]() -> double { return (double)(next() >> 5) * 0x1p-53; };
+  for (;;) {
+    const uint64_t w = next();
+    const int sign = (int)((w >> 6) & 1);
+    const uint64_t R = w >> 7;
+    const int idx = (int)(R & 255);
+    double x = (double)R * zt.wi[idx];
+    if (R < zt.ki[idx]) return sign ? -x : x;
+    if (sign) x = -x;
+    if (idx == 0) {
+      for (;;) {
+        const double u0 = uniform();
+        const double xt = (-(1.0 / nor_r)) * exmc_log(u0);
+        const double u1 = uniform();
+        const double y = -exmc_log(u1);
+        if (y + y > xt * xt) return sign ? (-nor_r - xt) : (nor_r + xt);
+      }
+    }
+    const double fi2 = zt.fi[idx];
+    const double u0 = uniform();
+    if ((zt.fi[idx - 1] - fi2) * u0 + fi2 < exmc_exp(-0.5 * x * x)) return x;
+  }
+}
+__device__ inline double rng_normal_counted(Rng& r, const ZigTables& zt, double nor_r, int& words) {
+  return rng_normal_impl<true>(r, zt, nor_r, words);
+}
+
 __device__ inline double rng_normal(Rng& r, const ZigTables& zt, double nor_r) {
   for (;;) {
     const uint64_t w = rng_next(r);

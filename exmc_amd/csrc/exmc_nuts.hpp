@@ -451,10 +451,141 @@ __device__ __forceinline__ int group_min_i32(int v) {
 // made the long way from the state in front of it (taken from the lane that owns that
 // dimension), and the pass repeats from j + 1. Expected passes: 1 + 0.015 d, against d sequential
 // draws.
+//
+// 64 lanes per chain (round 5): the generator state is the same on every lane, so the stream is advanced
+// on the SCALAR unit -- eight 64-bit instructions a step where the vector unit needed thirteen plus ten
+// for the lanes' selects -- and the tail word b_i of the state in front of word i is written into lane
+// i % 64 of a register pair (v_writelane): an orbit of D + 16 words, built once. State i is
+// (b_{i-1}, b_i) (the head word of a state is the tail word of the one before), so the orbit holds
+// every state. Draw r reads the word at r + shift, shift = the words earlier draws consumed beyond
+// their first; after a draw made the long way only that shift changes and the lanes fetch again
+// (ds_bpermute) -- no second advance unless the shift runs past the orbit's margin.
+template <int NORB>
+struct RngOrbit {
+  static_assert(NORB <= 128, "two register pairs of 64 lanes");
+  uint32_t lo[2], hi[2];   // lane i of pair w: b_{64 w + i}
+  uint64_t a0;             // head word of state 0
+  // (v_writelane reads its data from a scalar register, so the lane has to be an immediate -- one scalar
+  // operand per vector instruction: the steps are unrolled, ten instructions each)
+  template <int I>
+  __device__ __forceinline__ void step(uint64_t& a, uint64_t& b) {
+    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(lo[I >> 6]) : "s"((uint32_t)b), "n"(I & 63));
+    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(hi[I >> 6]) : "s"((uint32_t)(b >> 32)), "n"(I & 63));
+    Rng r{a, b};
+    rng_advance(r);
+    a = r.a;
+    b = r.b;
+  }
+  template <int... I>
+  __device__ __forceinline__ void steps(uint64_t& a, uint64_t& b, std::integer_sequence<int, I...>) {
+    (step<I>(a, b), ...);
+  }
+  __device__ __forceinline__ void build(const Rng& rng) {
+    uint64_t a = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(rng.a >> 32)) << 32) |
+                 (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)rng.a);
+    uint64_t b = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(rng.b >> 32)) << 32) |
+                 (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)rng.b);
+    a0 = a;
+    lo[0] = lo[1] = hi[0] = hi[1] = 0;
+    steps(a, b, std::make_integer_sequence<int, NORB>{});
+  }
+  // b_p for a per-lane position p in [0, NORB)
+  __device__ __forceinline__ uint64_t at(int p) const {
+    const int src = (p & 63) << 2;
+    const uint32_t l0 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)lo[0]);
+    const uint32_t h0 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)hi[0]);
+    const uint32_t l1 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)lo[1]);
+    const uint32_t h1 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)hi[1]);
+    const bool up = p >= 64;
+    return ((uint64_t)(up ? h1 : h0) << 32) | (uint64_t)(up ? l1 : l0);
+  }
+  // state p for a wave-uniform position p in [0, NORB)
+  __device__ __forceinline__ Rng state(int p) const {
+    auto word = [&](int q) -> uint64_t {
+      const int w = q >> 6, i = q & 63;
+      const uint32_t l = (w == 0) ? __builtin_amdgcn_readlane((int)lo[0], i) : __builtin_amdgcn_readlane((int)lo[1], i);
+      const uint32_t h = (w == 0) ? __builtin_amdgcn_readlane((int)hi[0], i) : __builtin_amdgcn_readlane((int)hi[1], i);
+      return ((uint64_t)h << 32) | (uint64_t)l;
+    };
+    Rng r;
+    r.b = word(p);
+    r.a = (p == 0) ? a0 : word(p > 0 ? p - 1 : 0);
+    return r;
+  }
+};
+
+#ifndef EXMC_RNG_ORBIT_MARGIN
+#define EXMC_RNG_ORBIT_MARGIN 16
+#endif
+
+template <class M, int G>
+__device__ __forceinline__ void draw_momentum_orbit(const NutsLane<M, G>& L, Rng& rng, double (&z)[M::DPL]) {
+  constexpr int D = M::D, DPL = M::DPL;
+  constexpr int NORB = D + EXMC_RNG_ORBIT_MARGIN;
+#pragma unroll
+  for (int k = 0; k < DPL; k++) z[k] = 0.0;
+  int pos = 0;   // draws [0, pos) are final and rng stands in front of draw pos
+  for (;;) {
+    RngOrbit<NORB> orb;
+    orb.build(rng);
+    const int org = pos;   // orbit position 0 = the state in front of draw org (with shift 0)
+    int shift = 0;
+    bool rebuild = false;
+    for (;;) {
+      bool fail[DPL];
+#pragma unroll
+      for (int k = 0; k < DPL; k++) {
+        const bool live = L.valid[k] && (L.rank[k] >= pos);
+        const int pp = live ? (L.rank[k] - org + shift) : 0;
+        double zz;
+        const bool acc = normal_fast(rng_scramble(orb.at(pp)), L.zt, zz);
+        fail[k] = live && !acc;
+        z[k] = (live && acc) ? zz : z[k];
+      }
+      int j = D;   // first draw that needs the long way, D if none
+      if (L.perm == nullptr) {
+#pragma unroll
+        for (int k = DPL - 1; k >= 0; k--) {
+          const unsigned long long m = __ballot(fail[k] ? 1 : 0);
+          j = (m != 0) ? (k * G + __ffsll((long long)m) - 1) : j;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < DPL; k++) j = fail[k] ? min(j, L.rank[k]) : j;
+        j = group_min_i32<G>(j);
+      }
+      j = __builtin_amdgcn_readfirstlane(j);
+      if (j >= D) {
+        rng = orb.state(D - org + shift);
+        return;
+      }
+      Rng rj = orb.state(j - org + shift);
+      int words = 0;
+      const double zz = rng_normal_counted(rj, L.zt, L.nor_r, words);
+#pragma unroll
+      for (int k = 0; k < DPL; k++) z[k] = (L.rank[k] == j) ? zz : z[k];
+      words = __builtin_amdgcn_readfirstlane(words);
+      pos = j + 1;
+      shift += words - 1;
+      if (D - org + shift > NORB - 1) {   // the remaining draws run past the orbit: build another from here
+        rng = rj;
+        rebuild = true;
+        break;
+      }
+    }
+    if (!rebuild) return;
+    if (pos >= D) return;   // (rng = rj already stands behind the last draw)
+  }
+}
+
 template <class M, int G>
 __device__ __forceinline__ void draw_momentum_variates(const NutsLane<M, G>& L, Rng& rng,
                                                        double (&z)[M::DPL]) {
   constexpr int D = M::D, DPL = M::DPL;
+  if constexpr (G == 64 && D + EXMC_RNG_ORBIT_MARGIN <= 128) {
+    draw_momentum_orbit<M, G>(L, rng, z);
+    return;
+  }
   const int base = (threadIdx.x & 63) & ~(G - 1);
 #pragma unroll
   for (int k = 0; k < DPL; k++) z[k] = 0.0;
