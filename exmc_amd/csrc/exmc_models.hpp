@@ -48,6 +48,10 @@ struct ModelDefaults {
   // in accumulator registers goes to scratch instead. Worth it when the configuration launches
   // more waves than SIMDs and the spilled values are per-transition state, not leaf-pass state.
   static constexpr int kNutsWavesPerSimd = 1;
+  // 64 lanes per chain: the momentum draw advances the generator on the scalar unit into an orbit held
+  // across the lanes (exmc_nuts.hpp draw_momentum_orbit) -- ten unrolled instructions per word of code, so
+  // only where the draw is a visible share of a transition (radon: 90 draws against ~15 leapfrogs)
+  static constexpr bool kRngOrbit = false;
   // one chain per wave, two waves per SIMD: a chain may move to a SIMD that has run empty while
   // its own SIMD still holds two chains (exmc_nuts.hpp "chain migration")
   static constexpr bool kMigrate = false;
@@ -1104,6 +1108,7 @@ struct Radon : ModelDefaults {
   static constexpr int kObsCap = 1024;                 // observations the spread layout holds
   static constexpr int kSlots = kSpread ? kObsCap / 64 : 1;
   static constexpr int kObsPad = kObsCap + 64;         // entries of each padded copy (Consts::pobs)
+  static constexpr bool kRngOrbit = kSpread;
   static constexpr int kAlphaOff = kObsCap;            // strip: [a_i (kObsCap)] [alpha_j (DPL * 64 cells, 0.0 from J on)]
   static constexpr int kZeroRun = kObsCap + 88;        // eight cells of 0.0 in a row (past the J = 85 intercepts)
   static constexpr int kExtraLdsDoubles = kSpread ? kObsCap + 128 : 0;

@@ -582,7 +582,7 @@ template <class M, int G>
 __device__ __forceinline__ void draw_momentum_variates(const NutsLane<M, G>& L, Rng& rng,
                                                        double (&z)[M::DPL]) {
   constexpr int D = M::D, DPL = M::DPL;
-  if constexpr (G == 64 && D + EXMC_RNG_ORBIT_MARGIN <= 128) {
+  if constexpr (G == 64 && M::kRngOrbit && D + EXMC_RNG_ORBIT_MARGIN <= 128) {
     draw_momentum_orbit<M, G>(L, rng, z);
     return;
   }
