@@ -895,9 +895,27 @@ struct Logistic : ModelDefaults {
 #pragma unroll
       for (int j = 0; j < K; j++) s[1 + j] = __builtin_fma(xr[j], r, s[1 + j]);
     }
-    // (64 lanes: the two cross-row stages of the 22 sums through the LDS crossbar -- with v_readlane each
-    // value passes through eight scalar registers, 176 in flight, which is where the scalar spills came from)
-    group_allsum_n<G, D + 1, (G == 64)>(s);
+    if constexpr (G == 64) {
+      // Round 5: the 22 sums of the one-chain warmup layout as a reduce-scatter -- over each 16-lane row
+      // first (row16_reduce_scatter: a lane ends with the row partials of quantities l % 16 and 16 + l % 16),
+      // then those two values through the two cross-row stages. The butterfly's own additions on the lanes
+      // that need them (same bits: the pairs, quads, eights ... of group_allsum_n<64, 22>), about 180
+      // instructions where the full butterfly took 400 and the per-lane pick of a total another 42 -- and
+      // lanes 0 .. 20 already hold the gradient entry of their own dimension.
+      static_assert(DPL == 1 && D + 1 <= 32, "two totals per lane");
+      double tot[2];
+      row16_reduce_scatter<D + 1>(s, tot);
+      tot[0] = sum_xor32(sum_xor16(tot[0]));
+      tot[1] = sum_xor32(sum_xor16(tot[1]));
+      const double gi = (l < 16) ? tot[0] : tot[1];
+      const double lik = readlane_f64(tot[1], D - 16);
+      const bool valid[1] = {l < D};
+      const double z = (q[0] - 0.0) / 10.0;
+      const double T[1] = {-0.5 * (z * z + c.c10)};
+      g[0] = valid[0] ? ((-(z / 10.0)) + gi) : 0.0;
+      return group_sum_slots<G, DPL>(T, valid, l, lik);
+    }
+    group_allsum_n<G, D + 1>(s);
     double T[DPL];
     bool valid[DPL];
 #pragma unroll
@@ -1109,6 +1127,10 @@ struct Radon : ModelDefaults {
   static constexpr int kSlots = kSpread ? kObsCap / 64 : 1;
   static constexpr int kObsPad = kObsCap + 64;         // entries of each padded copy (Consts::pobs)
   static constexpr bool kRngOrbit = kSpread;
+  // the tree's own exp / log (nuts_run) as the one-instruction-per-step asm cores: the coefficients sit in
+  // vector registers either way, the compiler's spelling spends a v_mov per Horner step on top (68.8 ->
+  // 68.4 ms, adaptation 75.4 -> 74.8 ms)
+  static constexpr bool kVregMath = true;
   static constexpr int kAlphaOff = kObsCap;            // strip: [a_i (kObsCap)] [alpha_j (DPL * 64 cells, 0.0 from J on)]
   static constexpr int kZeroRun = kObsCap + 88;        // eight cells of 0.0 in a row (past the J = 85 intercepts)
   static constexpr int kExtraLdsDoubles = kSpread ? kObsCap + 128 : 0;
