@@ -1342,25 +1342,24 @@ int exmc_hip_model_create(int kind, int d, const double* data, int n_data, int d
         blob[off_yp + n] = data[(size_t)N * K + n];
       }
     }
-    size_t off_cty = 0, off_pad = 0;
+    size_t off_pad = 0;
     constexpr int kRadonPad = Radon<64>::kObsPad;   // the capacity + one slot: every (slot, lane) index is an address
     if (kind == EXMC_MODEL_RADON) {
-      // the county of every observation, as a double (the 64-lane layout reads it next to y and floor)
-      const int J = 85, N = (n_data - (2 * J + 1)) / 2;
-      off_cty = blob.size();
-      blob.resize(blob.size() + (size_t)N, 0.0);
-      for (int j = 0; j < J; j++)
-        for (int i = (int)data[J + j]; i < (int)data[J + j + 1]; i++) blob[off_cty + i] = (double)j;
       // the 64-lane layout's copies of y, floor and county, zero-padded to 17 slots of 64 so that lane l
-      // fetches slot s at base + 8 (64 s + l) with no clamp, [y | floor | county] (RadonConsts::pobs)
+      // fetches slot s at base + 8 (64 s + l) with no clamp: [y | floor | 8 * county] (RadonConsts::pobs;
+      // the county as the byte offset of its intercept in the kernel's alpha strip, an integer)
+      const int J = 85, N = (n_data - (2 * J + 1)) / 2;
       off_pad = blob.size();
       blob.resize(blob.size() + (size_t)3 * kRadonPad, 0.0);
       for (int i = 0; i < N; i++) {
         blob[off_pad + i] = data[2 * J + 1 + N + i];
         blob[off_pad + kRadonPad + i] = data[2 * J + 1 + i];
-        const uint64_t off8 = 8ull * (uint64_t)blob[off_cty + i];   // the county's byte offset in the alpha strip
-        std::memcpy(&blob[off_pad + 2 * kRadonPad + i], &off8, 8);
       }
+      for (int j = 0; j < J; j++)
+        for (int i = (int)data[J + j]; i < (int)data[J + j + 1]; i++) {
+          const uint64_t off8 = 8ull * (uint64_t)j;
+          std::memcpy(&blob[off_pad + 2 * kRadonPad + i], &off8, 8);
+        }
     }
     rc = m->data.ensure(blob.size() * 8);
     if (rc) return bail(rc);
@@ -1379,7 +1378,6 @@ int exmc_hip_model_create(int kind, int d, const double* data, int n_data, int d
       m->rd.cs = base + J;
       m->rd.fl = base + 2 * J + 1;
       m->rd.y = base + 2 * J + 1 + N;
-      m->rd.cty = base + off_cty;
       m->rd.pobs = base + off_pad;
     }
   }

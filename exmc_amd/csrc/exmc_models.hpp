@@ -1094,8 +1094,9 @@ struct Logistic<4> : ModelDefaults {
 // (round 2 walked each county on its owner lane in chunks: 35 lock-step iterations, 43 % of them
 // carrying an observation; round 3's generated radon, which derives this spread from the node
 // list, ran 19 % faster than that kernel). Per leapfrog a lane fetches the y, floor and county of
-// its slots in one batch (held in registers across the kernel they cost more in accumulator-
-// register moves than the loads do), the owner lanes publish their counties' intercepts
+// its slots in one batch of buffer loads from zero-padded copies (held in registers across the
+// kernel they cost more in accumulator-register moves than the loads do; as flat loads from clamped
+// addresses they cost 51 parked address pairs), the owner lanes publish their counties' intercepts
 // alpha_j in an LDS strip, every observation reads its county's, and leaves a_i = z_i / sigma_y in
 // a second strip from which the owner lane of a county adds its observations in index order.
 // Sums: the likelihood / floor / z^2 totals = each lane's terms in slot order, then the lanes; a
@@ -1107,8 +1108,8 @@ struct RadonConsts {
   const double* cs;     // dev [J+1] county start offsets (as doubles)
   const double* fl;     // dev [N]
   const double* y;      // dev [N]
-  const double* cty;    // dev [N] the county of every observation
-  const double* pobs;   // dev [3][kObsCap + 64] y, floor and county again, zero-padded (the 64-lane layout's copies)
+  const double* pobs;   // dev [3][kObsCap + 64]: y | floor | 8 * county (an integer in the low word), each zero-padded:
+                        // the 64-lane layout's copies, slot s of lane l at entry 64 s + l whatever N
   double log2pi32, tiny32;
   double c_mu10;        // log2pi32 + 2*log(10)
   double c_n5;          // log2pi32 + 2*log(5)
