@@ -210,6 +210,35 @@ def test_hip_native_equals_the_python_mirror(hip, mods):
         hn.call("set_dense_mass", ref, np.zeros(5), np.zeros(5))
 
 
+def test_sample_independent_through_the_nif(hip, mods):
+    """HipNative.sample_independent/10 (sample_chains vectorized: false, sampler.ex:1139-1176) = the Python
+    mirror of the same C entry point: a shard [2, 7) of 9 chains, every chain its own adaptation."""
+    hn = mods["HipNative"]
+    spec = models.eight_schools()
+    ok, ref = hn.call("model_create", spec.kind, spec.data)
+    assert ok == H.Atom("ok")
+    assert hn.call("model_set_flat_order", ref, spec.flat_order()) == H.Atom("ok")
+    q0 = spec.to_unconstrained(spec.default_init)
+    tr, tune, lf, dv = hn.call("sample_independent", ref, q0, 9, 2, 7, 80, 25, 10, 0.8, 17)
+    comp = sampler.compile(spec)
+    try:
+        opts = dict(num_warmup=80, num_samples=25, seed=17, vectorized=False, init_values=spec.default_init)
+        _, stats = sampler.sample_chains_independent_compiled(comp, 9, opts, chain_lo=2, chain_hi=7)
+    finally:
+        comp.close()
+    raw = stats[0]["extra"]["raw"]
+    assert np.array_equal(H.f64(tr["draws"]).reshape(5, 25, spec.d), raw["draws"])
+    assert np.array_equal(H.i32(tr["n_steps"]).reshape(5, 25), raw["n_steps"])
+    assert np.array_equal(H.f64(tr["energy"]).reshape(5, 25), raw["energy"])
+    tune = H.f64(tune).reshape(5, 3 + spec.d)
+    assert np.array_equal(tune, stats[0]["extra"]["tuning"])      # step size, warmup divergences / leapfrogs, inv_mass
+    assert [float(t[0]) for t in tune] == [s_["step_size"] for s_ in stats]
+    assert len({float(t[0]) for t in tune}) == 5                  # every chain tuned its own step size
+    assert lf == int(raw["n_steps"].sum())
+    with pytest.raises(H.BadArg):
+        hn.call("sample_independent", ref, q0, 9, 7, 7, 80, 25, 10, 0.8, 17)   # an empty chain range
+
+
 def test_generated_model_through_the_nif(hip, mods):
     """HipNative.model_create_plugin/2: a model generated from Builder IR (eight schools as 26 nodes,
     and sv in the lane layout) reaches the BEAM side -- the plug-in library is dlopen'ed by the shim,
