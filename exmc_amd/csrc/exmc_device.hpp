@@ -183,8 +183,28 @@ __device__ __forceinline__ int xor4_b32(int x) {
 // through the LDS crossbar (ds_bpermute) -- two vector instructions per value instead of the
 // eleven of the v_readlane form, for kernels that are bound by vector issue and have a second
 // wave on the SIMD to cover the LDS round trips (a lone wave would sit them out).
+template <int N>
+__device__ __forceinline__ void rs64_allsum_generic(double (&v)[N]);   // below, behind row16_reduce_scatter
+
+template <int G, int N, bool kLds = false>
+__device__ __forceinline__ void group_allsum_butterfly_n(double (&v)[N]);
+
 template <int G, int N, bool kLds = false>
 __device__ __forceinline__ void group_allsum_n(double (&v)[N]) {
+#if EXMC_XROW_PERMLANE
+  if constexpr (G == 64 && N >= 3 && N <= 32) {
+    // a whole wavefront, several sums: the reduce-scatter computes the butterfly's own totals (same
+    // bits) in about half the instructions and hands them back as scalars (round 5; the generated
+    // 64-lane layouts' six to eight sums, the dense lane layouts)
+    rs64_allsum_generic<N>(v);
+    return;
+  }
+#endif
+  group_allsum_butterfly_n<G, N, kLds>(v);
+}
+
+template <int G, int N, bool kLds>
+__device__ __forceinline__ void group_allsum_butterfly_n(double (&v)[N]) {
   static_assert(G == 1 || G == 2 || G == 4 || G == 8 || G == 16 || G == 32 || G == 64, "G");
   if (G >= 2) {
 #pragma unroll
@@ -750,6 +770,21 @@ __device__ __forceinline__ void row16_reduce_scatter(const double (&v)[N], doubl
   }
 }
 
+// N (3 .. 32) sums over all 64 lanes, every lane ends with every total: the rows' reduce-scatter, the two
+// cross-row stages on the one or two values a lane keeps, and a scalar broadcast of total j from lane
+// j % 16 -- the additions of group_allsum_n<64, N> (pairs, quads, eights, rows, row pairs, halves), so
+// the same bits (tools/probe/allsum_rs_probe.hip).
+template <int N>
+__device__ __forceinline__ void rs64_allsum_generic(double (&v)[N]) {
+  constexpr int NT = (N + 15) / 16;
+  double tot[NT];
+  row16_reduce_scatter<N>(v, tot);
+#pragma unroll
+  for (int k = 0; k < NT; k++) tot[k] = sum_xor32(sum_xor16(tot[k]));
+#pragma unroll
+  for (int j = 0; j < N; j++) v[j] = readlane_f64(tot[j / 16], j % 16);
+}
+
 // init0 + the sum over the chain's dimensions: lane-partial sum over this lane's valid slots, lane 0
 // seeded with init0, then the butterfly -- or, for a kSeqSum group, init0 + v[dim 0] + v[dim 1] + ...
 template <int G, int DPL, int D = G * DPL, bool kLds = false>
@@ -811,7 +846,10 @@ __device__ __forceinline__ bool uturn(const double (&rho)[DPL], const double (&p
     row_seqsum<D>(s[0], s[1], v * pa[0], v * pb[0]);
   } else {
     uturn_partials<DPL>(rho, pa, pb, im, valid, s[0], s[1]);
-    if constexpr (G == 64 && kLds) {
+    if constexpr (G == 64 && (kLds || EXMC_XROW_PERMLANE)) {
+      // (since the cross-row stages are permlane swaps the reduce-scatter touches no LDS: also for the
+      // models whose waves are alone on their SIMDs -- radon's merges ran the full butterfly of six
+      // until round 5: 108 instructions against 45)
       // only the signs of the two totals are needed: they sit in lanes 0 and 1
       const unsigned long long neg = __ballot((rs64_reduce2(s) < 0.0) ? 1 : 0);
       return (neg & 0x3ULL) != 0;
@@ -846,7 +884,7 @@ __device__ __forceinline__ void uturn3(const double (&r1)[DPL], const double (&a
     uturn_partials<DPL>(r1, a1, b1, im, valid, s[0], s[1]);
     uturn_partials<DPL>(r2, a2, b2, im, valid, s[2], s[3]);
     uturn_partials<DPL>(r3, a3, b3, im, valid, s[4], s[5]);
-    if constexpr (G == 64 && kLds) {
+    if constexpr (G == 64 && (kLds || EXMC_XROW_PERMLANE)) {
       // signs only: totals 0, 3, 2, 5, 1, 4 sit in lanes 0 .. 5 (rs64_reduce6)
       const unsigned long long neg = __ballot((rs64_reduce6(s) < 0.0) ? 1 : 0);
       c1 = (neg & ((1ULL << 0) | (1ULL << 4))) != 0;

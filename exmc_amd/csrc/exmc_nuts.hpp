@@ -334,6 +334,10 @@ __device__ __forceinline__ bool mass_uturn(const NutsLane<M, G>& L, const double
       for (int k = 0; k < M::DPL; k++) x[0][k] = rho[k];
       lane_dense_times<G, M::DPL, M::D, 1, M::kDenseImage>(L.ld, L.l, L.rank, L.valid, x, v);
       uturn_partials_v<M::DPL>(v[0], pa, pb, L.valid, s[0], s[1]);
+      if constexpr (G == 64 && EXMC_XROW_PERMLANE) {   // signs only, as exmc_device.hpp uturn
+        const unsigned long long neg = __ballot((rs64_reduce2(s) < 0.0) ? 1 : 0);
+        return (neg & 0x3ULL) != 0;
+      }
       group_allsum_n<G, 2, M::kXRowLds>(s);
       return (s[0] < 0.0) || (s[1] < 0.0);
     }
@@ -376,6 +380,12 @@ __device__ __forceinline__ void mass_uturn3(const NutsLane<M, G>& L, const doubl
       uturn_partials_v<M::DPL>(v[0], a1, b1, L.valid, s[0], s[1]);
       uturn_partials_v<M::DPL>(v[1], a2, b2, L.valid, s[2], s[3]);
       uturn_partials_v<M::DPL>(v[2], a3, b3, L.valid, s[4], s[5]);
+      if constexpr (G == 64 && EXMC_XROW_PERMLANE) {   // signs only, as exmc_device.hpp uturn3
+        const unsigned long long neg = __ballot((rs64_reduce6(s) < 0.0) ? 1 : 0);
+        c1 = (neg & ((1ULL << 0) | (1ULL << 4))) != 0;
+        c23 = (neg & ((1ULL << 1) | (1ULL << 2) | (1ULL << 3) | (1ULL << 5))) != 0;
+        return;
+      }
       group_allsum_n<G, 6, M::kXRowLds>(s);
       c1 = (s[0] < 0.0) || (s[1] < 0.0);
       c23 = (s[2] < 0.0) || (s[3] < 0.0) || (s[4] < 0.0) || (s[5] < 0.0);

@@ -18,8 +18,8 @@ __global__ void k(const double* in, double* out) {   // one wave: in [6][64], ou
   for (int j = 0; j < 6; j++) v[j] = in[j * 64 + l];
   double a[6], b[6];
   for (int j = 0; j < 6; j++) a[j] = b[j] = v[j];
-  group_allsum_n<64, 6, false>(a);
-  group_allsum_n<64, 6, true>(b);
+  group_allsum_butterfly_n<64, 6, false>(a);
+  group_allsum_butterfly_n<64, 6, true>(b);
   for (int j = 0; j < 6; j++) { out[(0 * 6 + j) * 64 + l] = a[j]; out[(1 * 6 + j) * 64 + l] = b[j]; }
   out[(2 * 6 + 0) * 64 + l] = rs64_reduce6(v);
   const double v4[4] = {v[0], v[1], v[2], v[3]};
@@ -46,6 +46,21 @@ __global__ void k16(const double* in, double* out) {
   double c[6] = {v[0], v[1], v[2], v[3], v[4], v[5]};
   rs64_allsum6(c);
   for (int j = 0; j < 6; j++) out[(24 + j) * 64 + l] = c[j];
+}
+
+// the generic 64-lane form (group_allsum_n<64, N> since round 5) against the plain butterfly, N = 22 and 7:
+// in [22][64], out [2][22][64] (butterfly, reduce-scatter) then [2][7][64]
+__global__ void kgen(const double* in, double* out) {
+  const int l = threadIdx.x;
+  double a[22], b[22], a7[7], b7[7];
+  for (int j = 0; j < 22; j++) a[j] = b[j] = in[j * 64 + l];
+  for (int j = 0; j < 7; j++) a7[j] = b7[j] = in[(j + 3) * 64 + l];
+  group_allsum_butterfly_n<64, 22>(a);
+  group_allsum_n<64, 22>(b);
+  group_allsum_butterfly_n<64, 7>(a7);
+  group_allsum_n<64, 7>(b7);
+  for (int j = 0; j < 22; j++) { out[j * 64 + l] = a[j]; out[(22 + j) * 64 + l] = b[j]; }
+  for (int j = 0; j < 7; j++) { out[(44 + j) * 64 + l] = a7[j]; out[(51 + j) * 64 + l] = b7[j]; }
 }
 
 int main() {
@@ -103,6 +118,22 @@ int main() {
         for (int l = 0; l < 64; l += 5) bad += !same(out16[(24 + j) * 64 + l], ref6[j * 64 + 0]);
     }
   }
-  printf("allsum_rs_probe: 2000 trials of 6 sums over 64 lanes, 500 of 22 sums over 16-lane rows, %ld mismatches\n", bad);
+  {
+    static double ing[22 * 64], outg[58 * 64];
+    double *dgi, *dgo;
+    hipMalloc(&dgi, sizeof ing);
+    hipMalloc(&dgo, sizeof outg);
+    for (int trial = 0; trial < 500; trial++) {
+      for (int i = 0; i < 22 * 64; i++) ing[i] = ldexp((double)rand() / RAND_MAX - 0.5, rand() % 40 - 20);
+      hipMemcpy(dgi, ing, sizeof ing, hipMemcpyHostToDevice);
+      hipLaunchKernelGGL(kgen, dim3(1), dim3(64), 0, 0, dgi, dgo);
+      hipMemcpy(outg, dgo, sizeof outg, hipMemcpyDeviceToHost);
+      for (int j = 0; j < 22; j++)
+        for (int l = 0; l < 64; l++) bad += memcmp(&outg[j * 64 + l], &outg[(22 + j) * 64 + l], 8) != 0;
+      for (int j = 0; j < 7; j++)
+        for (int l = 0; l < 64; l++) bad += memcmp(&outg[(44 + j) * 64 + l], &outg[(51 + j) * 64 + l], 8) != 0;
+    }
+  }
+  printf("allsum_rs_probe: 2000 trials of 6 sums over 64 lanes, 500 of 22 sums over 16-lane rows, 500 of 22 and of 7 sums over 64 lanes (generic form), %ld mismatches\n", bad);
   return bad != 0;
 }
