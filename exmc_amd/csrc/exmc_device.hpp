@@ -1033,6 +1033,11 @@ __device__ __forceinline__ void lane_dense_stage(const LaneDense& ld, int l) {
   for (int e = l; e < 64; e += G) ld.covl[D * D + e] = 0.0;
 }
 
+// s_waitcnt lgkmcnt(0) alone (vector-memory and export counters untouched): behind a batch of LDS reads
+// whose values are consumed one after another it replaces the compiler's wait per consumer -- the same
+// stall in total, fewer instructions, which is what a wave alone on its SIMD is short of
+__device__ __forceinline__ void exmc_wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0xc07f); }
+
 __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();

@@ -1303,6 +1303,9 @@ struct Radon : ModelDefaults {
 #pragma unroll
       for (int sl = 0; sl < kSlots; sl++) av[sl] = alpha_at(oc[sl]);
       const double av_t = alpha_at(oc_t);
+      // ONE wait for the seventeen reads (the walk needs the last of them anyway): left to the compiler every
+      // observation carries its own s_waitcnt, and a wave alone on its SIMD pays a slot for each
+      exmc_wait_lgkm0();
       double lik = 0.0, f = 0.0, z2s = 0.0;
 #pragma unroll
       for (int sl = 0; sl < kSlots; sl++)
@@ -1353,6 +1356,7 @@ struct Radon : ModelDefaults {
 #pragma unroll
           for (int j = 0; j < kAhead; j++) v[j] = base[j];
           __builtin_amdgcn_sched_barrier(0);   // all the reads in flight before the first addition waits
+          exmc_wait_lgkm0();                   // (one wait per batch, not one per pair of cells)
 #pragma unroll
           for (int j = 0; j < kAhead; j++) sj = sj + v[j];
           pa += kAhead;
@@ -1366,6 +1370,7 @@ struct Radon : ModelDefaults {
 #pragma unroll
           for (int j = 0; j < kAhead - 1; j++) v[j] = *ad[j];
           __builtin_amdgcn_sched_barrier(0);
+          exmc_wait_lgkm0();
 #pragma unroll
           for (int j = 0; j < kAhead - 1; j++) sj = sj + v[j];
         }
