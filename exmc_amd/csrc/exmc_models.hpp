@@ -1327,12 +1327,9 @@ struct Radon : ModelDefaults {
         double sj = 0.0;
         const int i0 = ln.i0[k], i1 = ln.i1[k];
         const int nb = __builtin_amdgcn_readfirstlane(ln.maxc[k]);
-        // (kAhead reads in flight: a wave that has its SIMD to itself waits out every LDS round trip,
+        // (eight reads in flight: a wave that has its SIMD to itself waits out every LDS round trip,
         // and the additions behind them are one dependent chain in index order whatever the batch)
-#ifndef EXMC_RADON_AHEAD
-#define EXMC_RADON_AHEAD 8
-#endif
-        constexpr int kAhead = EXMC_RADON_AHEAD;
+        constexpr int kAhead = 8;
         // (a lane past the end of its own county reads the strip's zeros: sj + 0.0 is sj -- the sum
         // starts at +0.0 and a sum of doubles is never -0.0 unless every term is -- so the addition
         // needs no mask: two selects per cell less, same bits)
@@ -1341,7 +1338,6 @@ struct Radon : ModelDefaults {
         // (up to seven) cells a county has beyond its last whole batch, selected cell by cell. A lane adds its
         // own cells in index order with zeros in between, which leaves every sum as it was (was: index,
         // compare, select and shift for every cell of every batch up to the largest county).
-        static_assert(kAhead == 8, "the zero run holds eight cells; batches of eight");
         const double* const pz = ln.sh + kZeroRun;
         const int n = i1 - i0;
         const int nwhole = n >> 3;                       // this lane's whole batches

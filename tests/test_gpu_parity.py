@@ -130,6 +130,63 @@ def test_radon_chunked_counties_bit_exact(hip, sort_counties):
     assert np.array_equal(tuning["inv_mass"], np.array(st.inv_mass[:spec.d]))
 
 
+def _radon_shape(sizes, seed):
+    rng = np.random.default_rng(seed)
+    sizes = np.asarray(sizes, int)
+    J, N = len(sizes), int(sizes.sum())
+    assert J == 85
+    start = np.concatenate([[0], np.cumsum(sizes)])
+    u = rng.normal(0.0, 0.5, size=J)
+    county = np.repeat(np.arange(J), sizes)
+    floor = (rng.uniform(size=N) < 0.2).astype(float)
+    y = 1.4 + 0.7 * u[county] - 0.7 * floor + 0.7 * rng.normal(size=N)
+    return u, start, floor, y
+
+
+_RADON_SHAPES = {
+    # every slot of the 64-lane layout full to the brim: 16 x 64 observations, no partly filled slot
+    "n1024": [12] * 84 + [16],
+    # fewer observations than lanes: no full slot at all, only the partly filled one
+    "n40": [1] * 40 + [0] * 45,
+    # exactly one full slot, an empty partly filled one; empty counties between full ones
+    "n64": [0, 8, 0, 16, 0, 24, 0, 16] + [0] * 77,
+    # counties of exactly one, two and five whole batches of eight, and 8 k + 7
+    "batches": [40, 16, 8, 15, 23, 7, 1] + [3] * 78,
+    # one county holds nearly everything (its owner lane walks 100 whole batches of eight)
+    "one_big": [800] + [1] * 84,
+}
+
+
+@pytest.mark.parametrize("shape", sorted(_RADON_SHAPES))
+@pytest.mark.parametrize("sort_counties", [False, True])
+def test_radon_observation_and_county_shapes_bit_exact(hip, shape, sort_counties):
+    """The 64-lane radon layout's addressing at its edges (round 5: observations fetched by slot from
+    zero-padded copies, the slots every lane fills behind a scalar test, county sums in whole batches of
+    eight cells plus up to seven more): no full slot, only full slots, the capacity, empty counties,
+    counties of exactly k batches, one county with 800 observations. logp / gradient and a short run."""
+    sizes = _RADON_SHAPES[shape]
+    assert min(sizes) >= 0 and sum(sizes) <= 1024
+    spec = models.radon(_radon_shape(sizes, 11), sort_counties=sort_counties)
+    comp = sampler.compile(spec)
+    om = O.model_for(spec)
+    rng = np.random.default_rng(7)
+    C_ = 9
+    q = _rand_q(rng, C_, spec.d, 0.4)
+    lp = np.zeros(C_)
+    g = np.zeros((C_, spec.d))
+    _lib.check(hip.exmc_hip_logp_grad_host(comp.h, _dp(q), C_, 64, _dp(lp), _dp(g)))
+    cfg = O.Cfg(1, 64)
+    for c in range(C_):
+        olp, og = om.logp_grad(q[c], cfg)
+        assert olp == lp[c], (shape, c, olp, lp[c])
+        assert np.array_equal(og, g[c]), (shape, c)
+    opts = dict(num_warmup=30, num_samples=12, seed=3, lanes_per_chain=64)
+    tuning = sampler.warmup(comp, spec.default_init, opts)
+    st = O.warmup(om, spec.to_unconstrained(spec.default_init), num_warmup=30, seed=3, cfg=cfg)
+    assert tuning["epsilon"] == st.step_size
+    assert np.array_equal(tuning["inv_mass"], np.array(st.inv_mass[:spec.d]))
+
+
 @pytest.mark.parametrize("lanes", [1, 8, 16])
 @pytest.mark.parametrize("eps", [0.3, -0.3])
 def test_multi_step_bit_exact(es, hip, lanes, eps):
