@@ -95,6 +95,27 @@ DEFAULT_CHAINS_PER_GPU = {"eight_schools": 4096, "logistic": 8192, "sv": 2048, "
                           "gen_eight_schools": 4096, "gen_sv": 2048, "gen_radon": 1024, "gen_logistic": 8192}
 
 
+def kernel_source_sha16():
+    """sha256[:16] over the kernel sources (exmc_amd/csrc/*, include/*.h): the counter entries of
+    profiles/pmc_traffic.json are stamped with it when they are collected (tools/pmc_table_update.py), so
+    that a line can say whether the counters it quotes were taken on the kernels it timed."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "exmc_amd", "csrc", "*")) + glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        if os.path.isfile(f):
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def counters_current(entry):
+    """True: the entry was collected on this tree's kernel sources; False: on other sources (the same
+    instruction stream is then an assumption, the equal leapfrog count its only check); None: unstamped."""
+    sha = (entry or {}).get("csrc_sha16")
+    return None if sha is None else (sha == kernel_source_sha16())
+
+
 def measured_traffic(model, chains, steps, lanes):
     """HBM bytes of one timed launch from the PMC passes committed under profiles/ (rocprofv3
     --pmc FETCH_SIZE / WRITE_SIZE on this same command, see profiles/README.md); None when no
@@ -104,6 +125,14 @@ def measured_traffic(model, chains, steps, lanes):
     except (OSError, ValueError):
         return None
     return table.get("%s:%d:%d:%d" % (model, chains, steps, lanes), {}).get("hbm_bytes")
+
+
+def traffic_entry(model, chains, steps, lanes):
+    try:
+        table = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    except (OSError, ValueError):
+        return {}
+    return table.get("%s:%d:%d:%d" % (model, chains, steps, lanes), {})
 
 
 SIMDS = 1024               # 256 CUs x 4 SIMDs
@@ -134,7 +163,7 @@ def issue_roofline(model, chains, steps, lanes, kernel_ms, leapfrogs):
            "frac": valu / t / 1e9 / peak, "kernel": "nuts_kernel",
            "valu_per_leapfrog": valu / leapfrogs, "f64_arith_share_of_valu": f64 / valu,
            "instructions_per_leapfrog": every / leapfrogs,
-           "source": e.get("source")}
+           "source": e.get("source"), "counters_on_these_sources": counters_current(e)}
     if chains * lanes <= SIMDS * 64:
         # the bound of a LONE wave per SIMD; a launch with two waves per SIMD (sv, logistic) issues
         # past it by design, so the figure is only emitted where it applies
@@ -178,7 +207,9 @@ def multi_step_roofline(comp, spec, dev, n_chains=262144, n_steps=32, lanes=1, r
         table = {}
     traffic = table.get("multi_step:%s:%d:%d:%d" % (spec.name, n_chains, n_steps, lanes), {}).get("hbm_bytes")
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "multi_step_kernel",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "traffic_on_these_sources": counters_current(table.get("multi_step:%s:%d:%d:%d" % (spec.name, n_chains, n_steps, lanes))),
+            "kernel": "multi_step_kernel",
             "kernel_ms": best, "chains": n_chains, "steps": n_steps, "lanes_per_chain": lanes,
             "leapfrog_steps_per_s": n_chains * n_steps / (best * 1e-3),
             "bytes_per_launch": nbytes}
@@ -663,6 +694,7 @@ def run_model(args, model, rank, local_rank, world, dev, dist, barrier, primary)
                            force=bool(getattr(args, "force_dist", False)) and world == 1,
                            ess_bulk=essb, ess_bulk_s=ess_bulk_s)
     if rank == 0:
+        out["roofline"]["traffic_on_these_sources"] = counters_current(traffic_entry(model, Cper, S, lanes))
         value, local_lf = out["value"], float(leap_local)
         if model == "eight_schools":
             # the HBM fraction of this kernel has a ceiling that is not HBM
