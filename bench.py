@@ -513,6 +513,10 @@ def main():
                          "every collective of the multi-GPU path anyway (all_reduce, all_gather_into_tensor, "
                          "all_gather, barrier); the line must equal the ordinary one")
     args = ap.parse_args()
+    # before the first torch.cuda call: the HIP / HSA runtime reads its environment when it is
+    # initialised (the host driver supports dmabuf IPC only; RCCL needs this for more than one rank,
+    # and --force-dist is to run under the same runtime configuration as the ranks it stands for)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -539,7 +543,6 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     elif args.force_dist:
         import torch.distributed as dist
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         store = dist.TCPStore("127.0.0.1", 0, 1, is_master=True, wait_for_workers=False)
         dist.init_process_group("nccl", store=store, rank=0, world_size=1, device_id=dev)
 

@@ -83,12 +83,15 @@ static ERL_NIF_TERM raise_api(ErlNifEnv* env, const exmc_api* A, int rc) {
  * the thread leaves its tid in g_reap and whoever calls into this library next (or unloads it)
  * joins it. tid / has_tid are written and read under g_tid_lock, and the creator holds that lock
  * across enif_thread_create, so the new thread cannot observe a half-published pair. */
-typedef struct { exmc_hip_model* m; const exmc_api* api; ErlNifTid tid; int has_tid; } model_res;
+typedef struct reap_node { ErlNifTid tid; struct reap_node* next; } reap_node;
+/* spare: the list node the sender would park itself in, allocated by stream_run TOGETHER with the
+ * thread (has_tid != 0 implies spare != NULL), so that the path on which a thread drops its own last
+ * reference never allocates and a tid can never be lost to a failed allocation. */
+typedef struct { exmc_hip_model* m; const exmc_api* api; ErlNifTid tid; int has_tid; reap_node* spare; } model_res;
 
 static ErlNifMutex* g_tid_lock;
 /* senders that ended on their own last reference, waiting to be joined: a list under g_tid_lock
  * (no bound: every such thread is joined, as ERTS requires) */
-typedef struct reap_node { ErlNifTid tid; struct reap_node* next; } reap_node;
 static reap_node* g_reap;
 
 /* Join the parked senders. A parked sender may still be inside its handle's destructor (model
@@ -115,14 +118,15 @@ static void reap_senders(void) {
 }
 
 static void join_sender(model_res* r) {
-  /* (the node is allocated before the lock is taken: nothing allocates under g_tid_lock) */
-  reap_node* n = (reap_node*)enif_alloc(sizeof(reap_node));
+  /* (nothing allocates here: the node came with the thread) */
   enif_mutex_lock(g_tid_lock);
   const int has = r->has_tid;
   const ErlNifTid t = r->tid;
+  reap_node* n = r->spare;
   r->has_tid = 0;
+  r->spare = NULL;
   const int self = has && enif_equal_tids(enif_thread_self(), t);
-  if (self && n) {               /* joined by the next caller / at unload */
+  if (self) {                    /* joined by the next caller / at unload; n != NULL since has */
     n->tid = t;
     n->next = g_reap;
     g_reap = n;
@@ -178,6 +182,7 @@ static ERL_NIF_TERM make_handle(ErlNifEnv* env, const exmc_api* A, int kind, con
   r->m = m;
   r->api = A;
   r->has_tid = 0;
+  r->spare = NULL;
   ERL_NIF_TERM ref = enif_make_resource(env, r);
   enif_release_resource(r);
   return tuple2(env, enif_make_atom(env, "ok"), ref);
@@ -624,7 +629,12 @@ static ERL_NIF_TERM stream_run(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv
   if (!m || !enif_get_int(env, argv[1], &n) || n < 1 || !enif_get_local_pid(env, argv[2], &pid))
     return enif_make_badarg(env);
   stream_job* j = (stream_job*)enif_alloc(sizeof(stream_job));
-  if (!j) return enif_make_badarg(env);
+  reap_node* spare = (reap_node*)enif_alloc(sizeof(reap_node));   /* see model_res.spare */
+  if (!j || !spare) {
+    if (j) enif_free(j);
+    if (spare) enif_free(spare);
+    return enif_raise_exception(env, enif_make_atom(env, "enomem"));
+  }
   j->res = R;
   j->pid = pid;
   j->n = n;
@@ -632,6 +642,7 @@ static ERL_NIF_TERM stream_run(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv
   int rc = A->stream_start(m, n, &j->view, &j->progress);
   if (rc != EXMC_OK) {          /* includes: the previous run's sender has not finished yet */
     enif_free(j);
+    enif_free(spare);
     return raise_api(env, A, rc);
   }
   join_sender(j->res);          /* the previous sender has called stream_finish: it is ending */
@@ -643,10 +654,12 @@ static ERL_NIF_TERM stream_run(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv
   if (!failed) {
     j->res->tid = tid;
     j->res->has_tid = 1;
+    j->res->spare = spare;
   }
   enif_mutex_unlock(g_tid_lock);
   if (failed) {
     int32_t dv;
+    enif_free(spare);
     (void)A->stream_finish(m, &dv);
     enif_release_resource(j->res);
     enif_free(j);

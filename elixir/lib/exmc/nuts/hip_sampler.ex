@@ -71,6 +71,9 @@ defmodule Exmc.NUTS.HipSampler do
       HipNative.sample_chains(ref, tuning.epsilon, tuning.inv_mass, init_q, num_chains, 0, num_chains,
         opts[:num_samples], opts[:max_tree_depth], opts[:seed])
 
+    # tuning.inv_mass stays in KERNEL order (it goes back into HipNative.sample_chains above);
+    # stats.inv_mass_diag is reported in the flat order of the trace, as the reference's is
+    tuning = Map.put(tuning, :inv_mass_diag, flat_inv_mass(compiled, tuning.inv_mass))
     {tuning, chains(compiled, trace, num_chains, opts[:num_samples]), trace}
   end
 
@@ -94,7 +97,7 @@ defmodule Exmc.NUTS.HipSampler do
         <<eps::float-64-native, wdiv::float-64-native, _wlf::float-64-native, im::binary-size(d * 8)>> =
           binary_part(tuning_bin, c * row, row)
 
-        %{epsilon: eps, warmup_divergences: trunc(wdiv), inv_mass: im}
+        %{epsilon: eps, warmup_divergences: trunc(wdiv), inv_mass: im, inv_mass_diag: flat_inv_mass(compiled, im)}
       end
 
     {tunings, chains(compiled, trace, num_chains, opts[:num_samples]), trace}
@@ -118,6 +121,15 @@ defmodule Exmc.NUTS.HipSampler do
     for c <- 0..(num_chains - 1) do
       flat_draws(binary_part(draws, c * chain_bytes, chain_bytes), num_samples, d, perm)
     end
+  end
+
+  @doc """
+  A kernel-order inverse mass diagonal (f64 binary, as the NIF returns it) as the `{d}` tensor
+  `stats.inv_mass_diag` carries: flat (PointMap) order, the order of the trace. For the built kinds
+  `perm` is not the identity (e.g. radon's counties by size, sv's string sort).
+  """
+  def flat_inv_mass(%{perm: perm}, inv_mass_bin) do
+    Nx.from_binary(inv_mass_bin, :f64) |> Nx.take(Nx.tensor(perm, type: :s64))
   end
 
   @doc false

@@ -326,13 +326,23 @@ def sample_chains_independent_compiled(compiled, num_chains, opts=None, chain_lo
     if num_chains < 1:
         raise ValueError("num_chains must be >= 1")
     o = _merge_opts(opts)
-    if o.get("dense_mass") or o.get("warm_start"):
-        raise ValueError("vectorized: false runs the diagonal cold-start adaptation per chain "
-                         "(dense_mass / warm_start: use sample/3 per chain)")
-    spec = compiled.spec
-    L = compiled.L
     chain_hi = num_chains if chain_hi is None else chain_hi
     nc = chain_hi - chain_lo
+    if o.get("dense_mass") or o.get("warm_start"):
+        # The one-launch kernel adapts a diagonal mass from a cold start. The reference forwards
+        # every sample/3 option to each chain (sampler.ex:1146-1153), so these two run as what they
+        # are there: sample_from_compiled per chain, seed + 7919 i, one after the other.
+        drop = ("init_values", "parallel", "max_concurrency", "vectorized", "devices")
+        base = {k: v for k, v in o.items() if k not in drop}
+        init_values = o.get("init_values") or {}
+        traces, stats = [], []
+        for i in range(chain_lo, chain_hi):
+            tr, st = sample_compiled(compiled, init_values, dict(base, seed=int(o["seed"]) + 7919 * i))
+            traces.append(tr)
+            stats.append(st)
+        return traces, stats
+    spec = compiled.spec
+    L = compiled.L
     iq = _init_q(spec, o.get("init_values") or {})
     lf, dv = C.c_int64(), C.c_int32()
     tune = np.zeros((nc, 3 + spec.d))
@@ -367,9 +377,10 @@ def sample_chains(ir, num_chains, opts=None):
     devices = opts.get("devices")
     vectorized = opts.get("vectorized", num_chains > 1)
     if not (vectorized and num_chains > 1):
-        if devices is not None and len(devices) > 1:
+        if devices is not None and len(devices) > 1 and num_chains > 1:
             raise ValueError("vectorized: false is a single-device mode here (shard the chain range yourself: "
                              "sample_chains_independent_compiled(..., chain_lo, chain_hi))")
+        # (one chain has nothing to shard: it runs on the first device named)
         o1 = dict(opts, device=devices[0]) if devices else opts
         compiled = ir if isinstance(ir, Compiled) else Compiled(ir, device=o1.get("device", 0))
         return sample_chains_independent_compiled(compiled, num_chains, o1)

@@ -21,9 +21,17 @@ CASES = {
     "es_g16_div": ("eight_schools", 16, 1.70, 3, 40, 10, 11),
     "simple_g1": ("simple", 1, 0.30, 2, 40, 10, 0),
     "sv_g64": ("sv", 64, 0.05, 2, 10, 6, 42),
-    "logistic_g16": ("logistic", 16, 0.30, 2, 12, 6, 5),
-    "radon_g64": ("radon", 64, 0.20, 2, 12, 6, 6),
-    "logistic_g4_mfma": ("logistic", 4, 0.30, 3, 12, 6, 5),
+    # round 6: step sizes at which these three models build real trees and MOVE. At the
+    # round-1 values (logistic 0.30, radon 0.20, with inv_mass_for's 0.5..2) every transition was
+    # rejected or diverged on its first leapfrog: the draws never left the start, so the traces could
+    # not see a change of the per-observation arithmetic. The old cases stay as *_stuck / *_div0.
+    "sv_g64_fine": ("sv", 64, 0.02, 2, 10, 6, 42),
+    "logistic_g16": ("logistic", 16, 0.06, 2, 12, 6, 5),
+    "logistic_g16_stuck": ("logistic", 16, 0.30, 2, 12, 6, 5),
+    "radon_g64": ("radon", 64, 0.02, 2, 12, 6, 6),
+    "radon_g64_div": ("radon", 64, 0.04, 2, 12, 6, 6),
+    "radon_g64_div0": ("radon", 64, 0.20, 2, 12, 6, 6),
+    "logistic_g4_mfma": ("logistic", 4, 0.06, 3, 12, 6, 5),
 }
 
 

@@ -33,6 +33,29 @@ def test_golden_traces_cover_edge_cases():
     assert np.array_equal(GOLD["sv_returns"], G.sv_returns())
 
 
+@pytest.mark.parametrize("name", ["radon_g64", "logistic_g16", "logistic_g4_mfma", "sv_g64_fine", "es_g16"])
+def test_golden_traces_pin_real_trees(name):
+    """a case whose transitions all die on the first leapfrog pins nothing of the
+    per-observation arithmetic. These cases must build real trees, accept, and move."""
+    n_steps, div = GOLD[name + "/n_steps"], GOLD[name + "/divergent"]
+    draws, logp = GOLD[name + "/draws"], GOLD[name + "/logp"]
+    assert n_steps.max() > 1 and n_steps.mean() > 3
+    assert div.sum() < div.size // 4
+    moved = (np.diff(draws, axis=1) != 0).any(axis=2)
+    assert moved.mean() > 0.7                      # most transitions leave their start
+    assert np.unique(logp).size > logp.size // 2   # and the log-density is not a constant
+    assert GOLD[name + "/accept_prob"].mean() > 0.3
+
+
+def test_golden_traces_keep_the_degenerate_cases_too():
+    """every transition divergent after real steps (radon_g64_div), on the first leapfrog
+    (radon_g64_div0), or rejected outright (logistic_g16_stuck): the revert paths of tree.ex:1042-1048."""
+    assert GOLD["radon_g64_div/divergent"].all() and GOLD["radon_g64_div/n_steps"].min() >= 3
+    assert GOLD["radon_g64_div0/divergent"].all() and GOLD["radon_g64_div0/n_steps"].max() == 1
+    assert not GOLD["logistic_g16_stuck/divergent"].any()
+    assert (GOLD["logistic_g16_stuck/draws"] == 0.0).all()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", sorted(G.CASES))
 def test_hip_reproduces_committed_traces(name, hip):

@@ -86,8 +86,17 @@ def test_api_route_and_one_chain_equals_sample():
     for name in one_t[0]:
         assert np.array_equal(one_t[0][name], t1[name]), name
     assert np.array_equal(one_t[0]["mu"], tr[0]["mu"])   # chain 0 of three is that same chain
-    with pytest.raises(ValueError):
-        sampler.sample_chains(spec, 3, dict(opts, vectorized=False, dense_mass=True))
+    # dense_mass / warm_start are forwarded to each chain as the reference does (sampler.ex:1146-1153):
+    # chain i = sample/3 with seed + 7919 i, not a refusal
+    dn_t, dn_s = sampler.sample_chains(spec, 2, dict(opts, vectorized=False, dense_mass=True))
+    for i in range(2):
+        ti, si = sampler.sample(spec, None, dict(opts, dense_mass=True, seed=5 + 7919 * i))
+        assert dn_s[i]["step_size"] == si["step_size"] and np.array_equal(dn_s[i]["chol_cov"], si["chol_cov"])
+        assert np.array_equal(dn_t[i]["tau"], ti["tau"])
+    ws = dict(inv_mass_diag=s1["inv_mass_diag"], step_size=s1["step_size"])
+    ws_t, ws_s = sampler.sample_chains(spec, 1, dict(opts, warm_start=ws, devices=[0]))
+    tw, sw = sampler.sample(spec, None, dict(opts, warm_start=ws))
+    assert ws_s[0]["step_size"] == sw["step_size"] and np.array_equal(ws_t[0]["mu"], tw["mu"])
 
 
 def test_logistic_and_radon_chains_adapt_independently():

@@ -80,6 +80,64 @@ def test_modes_and_lane_layouts_agree_to_rounding(name, m):
             assert np.allclose(g, g0, rtol=1e-11, atol=1e-12)
 
 
+def _radon_logp_numpy(spec, q):
+    """The radon model of notebooks/09_radon_bhm.livemd written once more, with numpy and the
+    distributions' own formulas (dist/normal.ex:15-24, dist/half_cauchy.ex:17-25 incl. the :log
+    Jacobian) -- no code shared with oracle/exmc_oracle.c."""
+    J = spec.d - 5
+    blob = np.asarray(spec.data)
+    u, cs = blob[:J], blob[J:2 * J + 1].astype(int)
+    N = cs[J]
+    fl, y = blob[2 * J + 1:2 * J + 1 + N], blob[2 * J + 1 + N:2 * J + 1 + 2 * N]
+    ar, mu, gam, zsa, zsy, beta = q[:J], q[J], q[J + 1], q[J + 2], q[J + 3], q[J + 4]
+    sa, sy = np.exp(zsa), np.exp(zsy)
+    county = np.repeat(np.arange(J), np.diff(cs))
+
+    # the reference's literals are f32 tensors promoted to f64 (SURVEY 8a, row a3)
+    log_2pi = float(np.float32(np.log(float(np.float32(2 * np.pi)))))
+    log_2_over_pi = float(np.float32(np.log(2 / np.pi)))
+
+    def normal(x, m, s):
+        return -0.5 * (((x - m) / s) ** 2 + log_2pi + 2 * np.log(s))
+
+    def half_cauchy_log(z, x, scale):       # log density of x = exp(z) + log |dx/dz|
+        return log_2_over_pi - np.log(scale) - np.log1p((x / scale) ** 2) + z
+    alpha = mu + gam * u + sa * ar
+    return (normal(ar, 0.0, 1.0).sum() + normal(mu, 0.0, 10.0) + normal(gam, 0.0, 5.0) + normal(beta, 0.0, 5.0)
+            + half_cauchy_log(zsa, sa, 2.5) + half_cauchy_log(zsy, sy, 2.5)
+            + normal(y, alpha[county] + beta * fl, sy).sum())
+
+
+@pytest.mark.parametrize("log_sigma_y", [-0.8, -0.3567, 0.45, 1.3])
+def test_radon_modes_agree_away_from_unit_noise_scale(log_sigma_y):
+    """the kernels' unit arithmetic of radon (round 5: fused multiply-adds, z = resid * (1 /
+    sigma_y)) is restated in the checker's deterministic mode; at sigma_y = 1 the reciprocal is exact
+    and a wrong restatement would not show. Here sigma_y != 1: deterministic mode (1, 64 lanes), the
+    reference's arithmetic (libm, left to right, quotients) and an independent numpy statement of the
+    model must agree to rounding, value and gradient."""
+    from exmc_amd import models
+    spec = models.radon()
+    m = O.model_for(spec)
+    rng = np.random.default_rng(int(1000 * abs(log_sigma_y)))
+    for _ in range(3):
+        q = rng.normal(size=m.d) * 0.6
+        q[m.d - 2] = log_sigma_y
+        lp0, g0 = m.logp_grad(q, O.Cfg(0, 1))
+        assert abs(lp0 - _radon_logp_numpy(spec, q)) <= 2e-12 * abs(lp0)
+        for cfg in (O.Cfg(1, 1), O.Cfg(1, 32), O.Cfg(1, 64)):
+            lp, g = m.logp_grad(q, cfg)
+            assert abs(lp - lp0) <= 1e-12 * abs(lp0)
+            assert np.allclose(g, g0, rtol=1e-11, atol=1e-11)
+        # gradient of the independent statement by central differences
+        h = 1e-6
+        for i in (0, 40, m.d - 5, m.d - 4, m.d - 3, m.d - 2, m.d - 1):
+            a, b = q.copy(), q.copy()
+            a[i] += h
+            b[i] -= h
+            fd = (_radon_logp_numpy(spec, a) - _radon_logp_numpy(spec, b)) / (2 * h)
+            assert abs(fd - g0[i]) <= 2e-5 * max(1.0, abs(g0[i]))
+
+
 def test_single_transition_tolerance_between_modes():
     """One NUTS transition from the same state and rng: integer outputs identical, floats within
     1e-9 relative, for libm vs deterministic math and G = 1 vs 16."""
