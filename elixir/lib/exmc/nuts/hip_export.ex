@@ -42,6 +42,10 @@ defmodule Exmc.NUTS.HipExport do
     %{
       "ncp" => ncp,
       "data" => data && Nx.to_list(data),
+      # Map.keys/1 in THIS VM's iteration order = the order compiler.ex:176-180 (Map.values/1) builds
+      # its terms in and sum_logps adds them: sorted for up to 32 keys, the map's internal hash order
+      # above. A JSON object does not keep it, so it travels as a list and the generator follows it.
+      "term_order" => Map.keys(nodes),
       "nodes" => Map.new(nodes, fn {id, %Exmc.Node{op: op}} -> {id, node(op)} end)
     }
     |> Jason.encode!()

@@ -35,7 +35,9 @@ Numeric contract of the generated code:
     (Nx.tensor(<float>) is f32), sums left to right from the first element as Nx.sum on the
     BinaryBackend, exp/log/log1p from include/exmc_detmath.h;
   * terms in Map.values order of the node map = ids sorted as strings (exact for <= 32 nodes,
-    where Erlang maps are sorted; larger maps iterate in hash order, which is not restated);
+    where Erlang maps are sorted; a larger map iterates in its hash order: the exporter on the
+    BEAM writes that order into the document ("term_order", IR.order) and the terms follow it --
+    without one, sorted ids);
   * gradient: reverse-mode accumulation over the same graph with the local rules listed at
     `_Grad` below. Nx's own AD rewrites are not restated ("parity unpinned"), so the
     checker for a generated model is the same generated C compiled for the host
@@ -100,6 +102,18 @@ class IR:
     def __init__(self):
         self.nodes = {}
         self.data_tensor = None
+        self.term_order = None   # the ids in the BEAM's own Map.values order, when an exporter sent it
+
+    def order(self, ids):
+        """Map.keys(ir.nodes) as the VM that exported the IR iterates it (elixir/.../hip_export.ex:
+        "term_order"). compiler.ex:176-180 builds the terms in Map.values order and sum_logps adds
+        them in that order; up to 32 keys an Erlang map is sorted, a larger one iterates in the order
+        of its internal hash, which only the VM knows -- so the exporter writes it down."""
+        ids = list(ids)
+        if sorted(ids) != sorted(self.nodes) or len(set(ids)) != len(ids):
+            raise CodegenError("term_order must name every node id exactly once")
+        self.term_order = ids
+        return self
 
     def data(self, tensor):
         """Builder.data (builder.ex:19-21): the model's observation tensor (rank 0, 1 or 2). A
@@ -901,8 +915,10 @@ def generate(ir, ncp=True, vectorize=True, rewrite_passes=False, lanes=None, wav
 
     Term order: Map.values of the node map (compiler.ex:176-180) = ids sorted as strings for up to
     MAX_NODES_SORTED nodes. A larger Erlang map iterates in the order of its internal hash, which
-    is not restated: terms are taken in sorted-id order there too, a reordering of the final sum
-    (a few ulp of the log-density; the gradient's entries are sums over the same terms)."""
+    is not restated here: an IR exported from a BEAM carries that order (`ir.term_order`, written by
+    HipExport.to_json) and the terms follow it; an IR built in Python has no VM to ask and takes
+    sorted-id order there too -- a reordering of the final sum (a few ulp of the log-density; the
+    gradient's entries are sums over the same terms)."""
     if rewrite_passes:
         ir = rewrite(ir)
     nodes, ncp_info = _apply_ncp(ir, ncp)
@@ -1052,7 +1068,13 @@ def generate(ir, ncp=True, vectorize=True, rewrite_passes=False, lanes=None, wav
         raise CodegenError("obs %r: a vector-valued term needs a reduce" % id_)
 
     terms = []
-    for id_ in sorted(nodes):                     # Map.values order, compiler.ex:176-180
+    term_order = getattr(ir, "term_order", None)
+    if term_order is not None and (sorted(term_order) != sorted(nodes) or len(term_order) != len(nodes)):
+        raise CodegenError("term_order does not match the node map")   # (a rewrite pass changed the key set)
+    if term_order is not None and len(nodes) <= MAX_NODES_SORTED and list(term_order) != sorted(nodes):
+        raise CodegenError("term_order of a map of <= %d keys must be the sorted ids (Erlang flatmaps "
+                           "are sorted)" % MAX_NODES_SORTED)
+    for id_ in (term_order if term_order is not None else sorted(nodes)):   # Map.values order, compiler.ex:176-180
         n = nodes[id_]
         if n["op"] == "det":                      # compiler.ex:268-269
             continue
@@ -1688,6 +1710,8 @@ def ir_from_json(doc):
             ir.meas_obs(id_, n["target"], n["value"], tuple(n["info"]))
         else:
             raise CodegenError("node %r: op %r is not covered" % (id_, n.get("op")))
+    if doc.get("term_order") is not None:
+        ir.order(doc["term_order"])
     return ir
 
 
