@@ -27,6 +27,7 @@ DEPS = [
     os.path.join(HERE, "csrc", "exmc_plugin_layouts.inc"),
     os.path.join(ROOT, "include", "exmc_hip.h"),
     os.path.join(ROOT, "include", "exmc_detmath.h"),
+    os.path.join(ROOT, "include", "exmc_logtab.h"),
     os.path.join(ROOT, "include", "exmc_zig_tables.h"),
 ]
 

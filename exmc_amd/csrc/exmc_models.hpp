@@ -25,6 +25,7 @@ struct ModelDefaults {
   static constexpr bool kCoop = false;
   static constexpr int kExtraLdsDoubles = 0;
   static constexpr int kStageDoubles = 0;
+  static constexpr int kStageRowOffset = 0;   // where Lane::xs points inside the image (doubles)
   // kLdsDataDoubles: observations every NUTS workgroup keeps in LDS for the whole kernel
   // (stage_data fills the image, Lane::xoff = its offset in the dynamic LDS array or -1)
   static constexpr int kLdsDataDoubles = 0;
@@ -85,6 +86,16 @@ extern __shared__ double exmc_dyn_lds[];
 typedef double exmc_v2d __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) exmc_v2d lds_v2d;
 typedef __attribute__((address_space(3))) double lds_f64_m;
+// the table of exmc_log_tab (include/exmc_logtab.h) in global memory: the copy a kernel stages into LDS,
+// and what the layouts without an LDS image read (128 x 16 bytes: resident in the vector L1)
+static __device__ const double exmc_logtab_dev[2 * EXMC_LOGTAB_ENTRIES] = {EXMC_LOGTAB_VALUES};
+// exmc_log_tab from the global copy (a normal positive argument)
+__device__ static __forceinline__ double exmc_log_tab_global(double x) {
+  double m;
+  int e;
+  const int i = exmc_logtab_split(x, &m, &e);
+  return exmc_logtab_finish(m, e, exmc_logtab_dev[2 * i], exmc_logtab_dev[2 * i + 1]);
+}
 
 // ------------------------------------------------------------------------------------------
 // eight_schools, non-centered (benchmark/posteriordb/validate_posteriordb.exs:246-324).
@@ -595,6 +606,12 @@ struct LogisticConsts {
 #ifndef EXMC_LG_ROW_AHEAD
 #define EXMC_LG_ROW_AHEAD 0
 #endif
+// 1: the sampling kernel reads the (c, l) pair of exmc_log_tab from the LDS image; 0: from the global copy
+// (vector L1). Measured (profiles/r6_lg_logtab): 2.578 ns per leapfrog before the table, 2.547 with the
+// global copy, 2.456 with the LDS copy.
+#ifndef EXMC_LG_LOGTAB_LDS
+#define EXMC_LG_LOGTAB_LDS 1
+#endif
 template <int G>
 struct Logistic : ModelDefaults {
   static constexpr bool kPipeWarmup = false;
@@ -613,7 +630,12 @@ struct Logistic : ModelDefaults {
   // and for the sampling kernel in its workgroup form (kWgWaves, exmc_nuts.hpp nuts_kernel_wg).
   static constexpr int kObsCap = 512;
   static constexpr int kRowStride = K + 2;
-  static constexpr int kStageDoubles = kObsCap * kRowStride;
+  // ... behind the 128 (c, l) pairs of the table-driven logarithm (exmc_detmath.h exmc_log_tab): the
+  // table comes FIRST so that in the workgroup form of the sampling kernel it lies below 64 KB and the
+  // pair's ds_read_b128 takes its base as the instruction's 16-bit offset. Lane::xs points at the rows.
+  static constexpr int kRowDoubles = kObsCap * kRowStride;
+  static constexpr int kStageRowOffset = 2 * EXMC_LOGTAB_ENTRIES;
+  static constexpr int kStageDoubles = kStageRowOffset + kRowDoubles;
   // G = 16: the sampling kernel as workgroups of eight wavefronts (two per SIMD, one workgroup per
   // compute unit) that share ONE image: 8192 chains x 16 lanes are exactly 256 such workgroups.
   // 88 KB of image + 6 KB of ziggurat tables leave one tree-stack level per wavefront in LDS
@@ -626,16 +648,30 @@ struct Logistic : ModelDefaults {
     const double* xs;   // LDS image, or null (rows stream from L2)
   };
   __device__ static __forceinline__ void wg_stage(const Consts& c, double* image) { stage(c, image); }
-  __device__ static __forceinline__ void wg_attach(Lane& ln, double* image, int) { ln.xs = image; }
+  __device__ static __forceinline__ void wg_attach(Lane& ln, double* image, int) { ln.xs = image + kStageRowOffset; }
   __device__ static __forceinline__ void load(const Consts&, int, Lane& ln) { ln.xs = nullptr; }
   // cooperative (whole workgroup); the caller synchronises afterwards and guarantees N <= kObsCap
-  __device__ static __forceinline__ void stage(const Consts& c, double* dst) {
-    for (int i = threadIdx.x; i < kStageDoubles; i += blockDim.x) {
+  __device__ static __forceinline__ void stage(const Consts& c, double* image) {
+    for (int i = threadIdx.x; i < 2 * EXMC_LOGTAB_ENTRIES; i += blockDim.x) image[i] = exmc_logtab_dev[i];
+    double* const dst = image + kStageRowOffset;
+    for (int i = threadIdx.x; i < kRowDoubles; i += blockDim.x) {
       const int n = i / kRowStride, j = i % kRowStride;
       double v = 0.0;
       if (n < c.N) v = (j < K) ? c.X[(size_t)n * K + j] : ((j == K) ? c.y[n] : 0.0);
       dst[i] = v;
     }
+  }
+  // log of a clipped probability (normal, positive): exmc_log_tab with the pair fetched from the LDS
+  // image (img != null) or from the global copy
+  template <bool kStaged>
+  __device__ static __forceinline__ double log_tab(const lds_v2d* img, double x) {
+    double m;
+    int e;
+    const int i = exmc_logtab_split(x, &m, &e);
+    exmc_v2d cl;
+    if constexpr (kStaged && EXMC_LG_LOGTAB_LDS != 0) cl = img[i - EXMC_LOGTAB_ENTRIES];   // the table sits in front of the rows
+    else cl = ((const exmc_v2d*)exmc_logtab_dev)[i];
+    return exmc_logtab_finish_s(m, e, cl[0], cl[1]);
   }
 
   // every lane needs the whole coefficient vector: dim i lives in slot i / G of lane i % G
@@ -739,8 +775,8 @@ struct Logistic : ModelDefaults {
   // one step: observations it * 16 + l of the row's sixteen lanes, from the row already in registers.
   // kTail: the last, partly filled step (N mod 16 lanes carry an observation): `live` masks the two
   // contributions; the full steps carry no mask at all.
-  template <bool kTail>
-  __device__ static __forceinline__ void step_row16(const Row& row, bool live, double q0, double q1,
+  template <bool kTail, bool kStaged>
+  __device__ static __forceinline__ void step_row16(const Row& row, const lds_v2d* img, bool live, double q0, double q1,
                                                     double (&s)[D + 1]) {
     constexpr double kLo = (double)1.0e-7f, kHi = 1.0 - (double)1.0e-7f;   // = Consts::lo, hi
     const double yn = row.y;
@@ -754,11 +790,11 @@ struct Logistic : ModelDefaults {
       // y = 1: pc, y = 0: 1 - pc, as ONE fma(pc, 2y - 1, 1 - y): pc * 1 + 0 and pc * (-1) + 1 are the
       // two values exactly (a compare and two selects less); [1e-7, 1 - 1e-7]: normal, positive
       const double sgn = __builtin_fma(yn, 2.0, -1.0), off = 1.0 - yn;
-      ll = exmc_log_normal_s(__builtin_fma(pc, sgn, off));
+      ll = log_tab<kStaged>(img, __builtin_fma(pc, sgn, off));
     } else {
       p = 1.0 / (1.0 + exmc_exp(-eta));
       const double pc = fmin(fmax(p, kLo), kHi);
-      ll = exmc_log((yn == 1.0) ? pc : (1.0 - pc));
+      ll = log_tab<kStaged>(img, (yn == 1.0) ? pc : (1.0 - pc));
     }
     const bool in = p > kLo && p < kHi;
     const double r = (kTail ? (live && in) : in) ? (yn - p) : 0.0;
@@ -783,11 +819,11 @@ struct Logistic : ModelDefaults {
         const bool two = it + 1 < steps;                 // wave-uniform
         const int nb = two ? n + 16 : n;
         load_row<kStaged>(c, img, nb, nb < c.N, b);
-        step_row16<true>(a, n < c.N, q0, q1, s);
+        step_row16<true, kStaged>(a, img, n < c.N, q0, q1, s);
         if (two) {
           const int na = (it + 2 < steps) ? n + 32 : n;
           load_row<kStaged>(c, img, na, na < c.N, a);
-          step_row16<true>(b, nb < c.N, q0, q1, s);
+          step_row16<true, kStaged>(b, img, nb < c.N, q0, q1, s);
         }
       }
     } else {
@@ -796,12 +832,12 @@ struct Logistic : ModelDefaults {
       for (int it = 0; it < full; it++, n += 16) {
         Row cur;
         load_row<kStaged>(c, img, n, true, cur);
-        step_row16<false>(cur, true, q0, q1, s);
+        step_row16<false, kStaged>(cur, img, true, q0, q1, s);
       }
       if (full < steps) {                                  // wave-uniform
         Row cur;
         load_row<kStaged>(c, img, n, n < c.N, cur);
-        step_row16<true>(cur, n < c.N, q0, q1, s);
+        step_row16<true, kStaged>(cur, img, n < c.N, q0, q1, s);
       }
     }
   }
@@ -841,6 +877,23 @@ struct Logistic : ModelDefaults {
       g[k] = valid[k] ? ((-(z / 10.0)) + tot[k]) : 0.0;
     }
     return group_sum_slots<G, DPL>(T, valid, l, lik);
+  }
+
+  // (the layouts below decide at run time whether an image is there: `staged` is wave-uniform)
+  __device__ static __forceinline__ double log_tab_any(bool staged, int xoff, double x) {
+    double m;
+    int e;
+    const int i = exmc_logtab_split(x, &m, &e);
+    double c, lv;
+    if (staged) {
+      const double* t = exmc_dyn_lds + xoff - kStageRowOffset + 2 * i;   // in front of the rows
+      c = t[0];
+      lv = t[1];
+    } else {
+      c = exmc_logtab_dev[2 * i];
+      lv = exmc_logtab_dev[2 * i + 1];
+    }
+    return exmc_logtab_finish(m, e, c, lv);
   }
 
   // The three per-observation specials in their short forms while every linear predictor of the
@@ -883,11 +936,11 @@ struct Logistic : ModelDefaults {
         // the 1000-iteration warmup -- this kernel already spills scalar registers, 163 -> 328)
         p = dv(1.0, 1.0 + exmc_exp_pm200(-eta));
         const double pc = fmin(fmax(p, c.lo), c.hi);
-        ll = exmc_log_unit((yn == 1.0) ? pc : (1.0 - pc));
+        ll = log_tab_any(staged, xoff, (yn == 1.0) ? pc : (1.0 - pc));
       } else {
         p = 1.0 / (1.0 + exmc_exp(-eta));
         const double pc = fmin(fmax(p, c.lo), c.hi);
-        ll = exmc_log((yn == 1.0) ? pc : (1.0 - pc));
+        ll = log_tab_any(staged, xoff, (yn == 1.0) ? pc : (1.0 - pc));
       }
       const double r = (p > c.lo && p < c.hi) ? (yn - p) : 0.0;
       s[D] = s[D] + ll;
@@ -1046,7 +1099,7 @@ struct Logistic<4> : ModelDefaults {
         const double yn = yv[r];
         const double p = 1.0 / (1.0 + exmc_exp(-eta[r]));
         const double pc = fmin(fmax(p, c.lo), c.hi);
-        const double ll = exmc_log((yn == 1.0) ? pc : (1.0 - pc));
+        const double ll = exmc_log_tab_global((yn == 1.0) ? pc : (1.0 - pc));   // (the contract of logp_logistic)
         const double rv = (p > c.lo && p < c.hi) ? (yn - p) : 0.0;
         const bool live = n < c.N;
         likp = live ? (likp + ll) : likp;

@@ -2223,7 +2223,7 @@ __global__ void __launch_bounds__(kPipe ? 2 * kNutsBlock : kNutsBlock)
 
   NutsLane<M, G> L;
   lane_setup<M, G, LDSL>(L, mc, lds, P.stack, P.inv_mass0, P.sqrt_inv_mass0, zt, P.nor_r, P.flat);
-  if constexpr (M::kStageDoubles > 0) L.ln.xs = stage_ptr;
+  if constexpr (M::kStageDoubles > 0) L.ln.xs = stage_ptr ? stage_ptr + M::kStageRowOffset : nullptr;
   if constexpr (M::kLdsDataDoubles > 0) L.ln.xoff = xoff;
   using Pipe = std::conditional_t<kPipe, PipeBox<DPL>, NoPipe>;
   Pipe pipe;

@@ -408,4 +408,87 @@ static __device__ __forceinline__ double exmc_log_normal_s(double x) {
 #undef EXMC_RHD
 #endif
 
+/* ---- table-driven log (round 6) ----
+ * log(x) for a NORMAL positive x (the caller proves it: e.g. a probability clipped into
+ * [1e-7, 1 - 1e-7]) in 21 operations where the atanh-series form above takes 38 -- it has no
+ * quotient. x = 2^e m by the high-word normalisation of fdlibm with the base moved from sqrt(2)/2 to
+ * 0x3fe6b000 (m in [0.7090, 1.4180)) so that 1.0 is the MIDDLE of its segment; the top seven bits of
+ * m's normalised mantissa pick (c, l) = (~1/m, -log c) from include/exmc_logtab.h;
+ * r = fma(m, c, -1) (|r| <= 2^-7, abs. error 2^-61); log m = l + log1p(r), log1p by its Taylor
+ * series to r^8 (truncation below 2^-66); log x = (e ln2_hi + l) + (e ln2_lo + log1p r). The segment
+ * around 1.0, [1 - 2^-9, 1 + 2^-8), has c = 1, l = 0: log keeps its relative accuracy as x -> 1.
+ * Accuracy (tests/test_detmath_logtab.py, against the long double logarithm): <= 1.6 ulp where
+ * |log x| >= 0.02, <= 2.5 ulp in the segments next to the one around 1.
+ * A DIFFERENT rounding contract from exmc_log (the two differ in the last bit for about a fifth of
+ * the arguments): a model uses one of them throughout, in the kernels and in the checker
+ * (logp_logistic: this one). The split / finish halves are separate so that a kernel can fetch
+ * (c, l) from wherever it keeps the table (LDS, or global memory). */
+#include "exmc_logtab.h"
+EXMC_HD int exmc_logtab_split(double x, double* m_out, int* e_out) {
+  const uint64_t ix = exmc_to_bits(x);
+  uint32_t hx = (uint32_t)(ix >> 32);
+  hx += 0x3FF00000u - EXMC_LOGTAB_BASE;
+  *e_out = (int)(hx >> 20) - 0x3FF;
+  const int i = (int)((hx >> 13) & 0x7Fu);
+  hx = (hx & 0x000FFFFFu) + EXMC_LOGTAB_BASE;
+  *m_out = exmc_from_bits(((uint64_t)hx << 32) | (ix & 0xFFFFFFFFull));
+  return i;
+}
+EXMC_HD double exmc_logtab_finish(double m, int e, double c, double l) {
+  const double r = __builtin_fma(m, c, -1.0);
+  double q = __builtin_fma(r, -0.125, 0x1.2492492492492p-3);   /* -1/8, 1/7 */
+  q = __builtin_fma(q, r, -0x1.5555555555555p-3);              /* -1/6 */
+  q = __builtin_fma(q, r, 0x1.999999999999ap-3);               /* 1/5 */
+  q = __builtin_fma(q, r, -0.25);
+  q = __builtin_fma(q, r, 0x1.5555555555555p-2);               /* 1/3 */
+  q = __builtin_fma(q, r, -0.5);
+  const double r2 = r * r;
+  const double lp = __builtin_fma(q, r2, r);                   /* log1p(r) */
+  const double dk = (double)e;
+  const double hi = __builtin_fma(dk, 6.93147180369123816490e-01, l);   /* e ln2_hi is exact */
+  const double lo = __builtin_fma(dk, 1.90821492927058770002e-10, lp);
+  return hi + lo;
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+/* exmc_logtab_finish with the series as one asm block, its coefficients in scalar registers (the _s
+ * spelling of the cores above: left to the compiler every Horner step with a non-inline constant is a
+ * v_mov_b64 + v_fmac_f64 pair). Same operations in the same order: same bits. */
+static __device__ __forceinline__ double exmc_logtab_finish_s(double m, int e, double c, double l) {
+  const double r = __builtin_fma(m, c, -1.0);
+  double q, r2, lp;
+  __asm__("v_fma_f64 %0, %3, %4, %5\n\t"
+          "v_fma_f64 %0, %0, %3, %6\n\t"
+          "v_fma_f64 %0, %0, %3, %7\n\t"
+          "v_fma_f64 %0, %0, %3, %8\n\t"
+          "v_fma_f64 %0, %0, %3, %9\n\t"
+          "v_fma_f64 %0, %0, %3, -0.5\n\t"
+          "v_mul_f64 %1, %3, %3\n\t"
+          "v_fma_f64 %2, %0, %1, %3"
+          : "=&v"(q), "=&v"(r2), "=&v"(lp)
+          : "v"(r), "s"(-0.125), "v"(0x1.2492492492492p-3), "s"(-0x1.5555555555555p-3), "s"(0x1.999999999999ap-3),
+            "s"(-0.25), "s"(0x1.5555555555555p-2));
+  const double dk = (double)e;
+  const double hi = __builtin_fma(dk, 6.93147180369123816490e-01, l);
+  const double lo = __builtin_fma(dk, 1.90821492927058770002e-10, lp);
+  return hi + lo;
+}
+#elif defined(__HIPCC__)
+static __device__ __forceinline__ double exmc_logtab_finish_s(double m, int e, double c, double l) {
+  return exmc_logtab_finish(m, e, c, l);
+}
+#endif
+/* the host's function (a hipcc device pass parses host code too, so it is declared there as well) */
+static const double EXMC_LOGTAB_HOST[2 * EXMC_LOGTAB_ENTRIES] = {EXMC_LOGTAB_VALUES};
+#if defined(__HIPCC__)
+static __host__ __forceinline__
+#else
+static inline
+#endif
+double exmc_log_tab(double x) {
+  double m;
+  int e;
+  const int i = exmc_logtab_split(x, &m, &e);
+  return exmc_logtab_finish(m, e, EXMC_LOGTAB_HOST[2 * i], EXMC_LOGTAB_HOST[2 * i + 1]);
+}
+
 #endif /* EXMC_DETMATH_H */

@@ -514,7 +514,11 @@ static double logp_logistic(const exo_model* m, const double* q, double* g, exo_
       for (int j = 0; j < K; j++) eta = mac(x[j], q[1 + j], eta, mm);
       double p = 1.0 / (1.0 + exo_exp(-eta, mm));
       double pc = fmin(fmax(p, lo), hi);
-      double ll = (y[n] == 1.0) ? exo_log(pc, mm) : exo_log(1.0 - pc, mm);
+      /* deterministic mode: the table-driven logarithm of include/exmc_detmath.h (exmc_log_tab; round 6 --
+       * the argument is a probability clipped into [1e-7, 1 - 1e-7]: normal and positive), which is what
+       * every layout of the kernels evaluates here; libm mode: the reference's own log */
+      double la = (y[n] == 1.0) ? pc : (1.0 - pc);
+      double ll = mm ? exmc_log_tab(la) : log(la);
       double r = (p > lo && p < hi) ? (y[n] - p) : 0.0;
       lik = lik + ll;
       rbuf[n] = r;

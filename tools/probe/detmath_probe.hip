@@ -12,6 +12,15 @@
 
 #include "exmc_detmath.h"
 
+// exmc_log_tab on the device: the pair from a global copy of the table (the kernels also keep one in LDS)
+static __device__ const double logtab_dev[2 * EXMC_LOGTAB_ENTRIES] = {EXMC_LOGTAB_VALUES};
+static __device__ double log_tab_dev(double x) {
+  double m;
+  int e;
+  const int i = exmc_logtab_split(x, &m, &e);
+  return exmc_logtab_finish(m, e, logtab_dev[2 * i], logtab_dev[2 * i + 1]);
+}
+
 __global__ void k(const double* x, int n, int which, double* out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -29,7 +38,8 @@ __global__ void k(const double* x, int n, int which, double* out) {
     case 8: r = exmc_log_ge1(v); break;
     case 9: r = exmc_log_ge1_v(v); break;
     case 10: r = exmc_log_unit(v); break;
-    default: r = exmc_log_unit_v(v); break;
+    case 11: r = exmc_log_unit_v(v); break;
+    default: r = log_tab_dev(v); break;
   }
   out[i] = r;
 }
@@ -39,7 +49,7 @@ static double rnd() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (dou
 
 int main() {
   const int N = 1 << 20;
-  std::vector<double> any(N), pm200(N), le0(N), ge1(N), unit(N), pos(N);
+  std::vector<double> any(N), pm200(N), le0(N), ge1(N), unit(N), pos(N), normal(N);
   for (int i = 0; i < N; i++) {
     any[i] = (rnd() * 2 - 1) * ((i & 3) == 0 ? 760.0 : 30.0);
     pm200[i] = (rnd() * 2 - 1) * 200.0;
@@ -47,7 +57,11 @@ int main() {
     ge1[i] = (i & 1) ? 1.0 + rnd() : std::exp(rnd() * 709.0);
     unit[i] = std::floor(rnd() * 9007199254740992.0) / 9007199254740992.0;
     pos[i] = std::exp((rnd() * 2 - 1) * 700.0);
+    // normal positive arguments: clipped probabilities, the neighbourhood of 1, every binade
+    normal[i] = (i & 3) == 0 ? 1e-7 + rnd() * (1.0 - 2e-7) : ((i & 3) == 1 ? 1.0 + (rnd() - 0.5) * 0.05 : std::exp((rnd() * 2 - 1) * 700.0));
   }
+  normal[0] = 1.0; normal[1] = 2.2250738585072014e-308; normal[2] = 1.7976931348623157e308; normal[3] = 1.0 - 0x1p-53;
+  normal[4] = 1.0 + 0x1p-52; normal[5] = 0.70710678118654752; normal[6] = 1.4142135623730951;
   const double sp_exp[] = {0.0, -0.0, -INFINITY, INFINITY, NAN, 709.782712893384, 709.79, -745.1332191019412, -745.14, -746.0, -1e300, 1e300};
   const double sp_log[] = {0.0, -0.0, -1.0, INFINITY, NAN, 1.0, 5e-324, 2.2250738585072014e-308, 1e-310, 1.7976931348623157e308};
   for (unsigned i = 0; i < sizeof sp_exp / 8; i++) any[i] = sp_exp[i];
@@ -66,7 +80,8 @@ int main() {
       {"exmc_exp_pm200", 4, &pm200, exmc_exp}, {"exmc_exp_pm200_v", 5, &pm200, exmc_exp},
       {"exmc_exp_le0", 6, &le0, exmc_exp}, {"exmc_exp_le0_v", 7, &le0, exmc_exp},
       {"exmc_log_ge1", 8, &ge1, exmc_log}, {"exmc_log_ge1_v", 9, &ge1, exmc_log},
-      {"exmc_log_unit", 10, &unit, exmc_log}, {"exmc_log_unit_v", 11, &unit, exmc_log}};
+      {"exmc_log_unit", 10, &unit, exmc_log}, {"exmc_log_unit_v", 11, &unit, exmc_log},
+      {"exmc_log_tab", 12, &normal, exmc_log_tab}};
   double *dx, *dout;
   (void)hipMalloc(&dx, N * 8); (void)hipMalloc(&dout, N * 8);
   std::vector<double> out(N);
