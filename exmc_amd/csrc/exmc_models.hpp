@@ -612,6 +612,11 @@ struct LogisticConsts {
 #ifndef EXMC_LG_LOGTAB_LDS
 #define EXMC_LG_LOGTAB_LDS 1
 #endif
+// 1: the 16-lane layout with an LDS image checks the short forms' domain per PASS (a sticky lane mask, one
+// branch at the end of the pass); 0: per step of sixteen observations (a compare and two branches each).
+#ifndef EXMC_LG_PASS_GUARD
+#define EXMC_LG_PASS_GUARD 1
+#endif
 template <int G>
 struct Logistic : ModelDefaults {
   static constexpr bool kPipeWarmup = false;
@@ -775,15 +780,22 @@ struct Logistic : ModelDefaults {
   // one step: observations it * 16 + l of the row's sixteen lanes, from the row already in registers.
   // kTail: the last, partly filled step (N mod 16 lanes carry an observation): `live` masks the two
   // contributions; the full steps carry no mask at all.
-  template <bool kTail, bool kStaged>
+  // kMode 0: short forms or general forms decided in this step (one compare and two branches per step);
+  // 1: short forms whatever the predictors are, the lanes outside [-200, 200] reported in `out` (the caller
+  // evaluates the pass again in mode 2 if any was: same bits, decided once per pass); 2: general forms.
+  template <bool kTail, bool kStaged, int kMode = 0>
   __device__ static __forceinline__ void step_row16(const Row& row, const lds_v2d* img, bool live, double q0, double q1,
-                                                    double (&s)[D + 1]) {
+                                                    double (&s)[D + 1], unsigned long long* out = nullptr) {
     constexpr double kLo = (double)1.0e-7f, kHi = 1.0 - (double)1.0e-7f;   // = Consts::lo, hi
     const double yn = row.y;
     const double eta = eta_row16(q0, q1, row.x);
     double p, ll;
     const bool inr = fabs(eta) <= 200.0;   // false for a NaN
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!inr) == 0, 1)) {
+    bool fast;
+    if constexpr (kMode == 0) fast = __builtin_expect(__builtin_amdgcn_ballot_w64(!inr) == 0, 1);
+    else fast = kMode == 1;
+    if constexpr (kMode == 1) *out |= __builtin_amdgcn_ballot_w64(!inr);
+    if (fast) {
       const double u = 1.0 + exmc_exp_pm200_s(-eta);   // [1, e^200 + 1): inside the division window
       p = exmc_div_core(1.0, u, exmc_rcp_refined(u));
       const double pc = fmin(fmax(p, kLo), kHi);
@@ -806,25 +818,31 @@ struct Logistic : ModelDefaults {
   // all steps of a pass; kAhead: the next step's row is requested before this step's arithmetic (the
   // LDS image: a ds_read_b128 burst whose latency the specials cover; from L2 the second row buffer
   // costs more in registers than the wait it hides)
-  template <bool kStaged, bool kAhead>
+  template <bool kStaged, bool kAhead, int kMode = 0>
   __device__ static __forceinline__ void steps_row16(const Consts& c, const lds_v2d* img, int l, double q0,
-                                                     double q1, double (&s)[D + 1]) {
+                                                     double q1, double (&s)[D + 1], unsigned long long* out = nullptr) {
     const int steps = (c.N + 15) >> 4;
     if constexpr (kAhead) {
-      // two row buffers taking turns (a rotating copy would be 21 register moves per step)
+      // two row buffers taking turns (a rotating copy would be 21 register moves per step): the row of
+      // step it + 1 is requested before the arithmetic of step it
+      const int full = c.N >> 4;
       Row a, b;
       load_row<kStaged>(c, img, l, l < c.N, a);
-      for (int it = 0; it < steps; it += 2) {
+      int it = 0;
+      for (; it + 2 <= full; it += 2) {                      // steps it and it + 1 are full
         const int n = l + (it << 4);
-        const bool two = it + 1 < steps;                 // wave-uniform
-        const int nb = two ? n + 16 : n;
-        load_row<kStaged>(c, img, nb, nb < c.N, b);
-        step_row16<true, kStaged>(a, img, n < c.N, q0, q1, s);
-        if (two) {
-          const int na = (it + 2 < steps) ? n + 32 : n;
-          load_row<kStaged>(c, img, na, na < c.N, a);
-          step_row16<true, kStaged>(b, img, nb < c.N, q0, q1, s);
-        }
+        load_row<kStaged>(c, img, n + 16, true, b);
+        step_row16<false, kStaged, kMode>(a, img, true, q0, q1, s, out);
+        if (it + 2 < steps) load_row<kStaged>(c, img, n + 32, n + 32 < c.N, a);   // wave-uniform
+        step_row16<false, kStaged, kMode>(b, img, true, q0, q1, s, out);
+      }
+      const int n = l + (it << 4);
+      if (it < full) {                                       // one full step left, then perhaps the tail
+        if (it + 1 < steps) load_row<kStaged>(c, img, n + 16, n + 16 < c.N, b);
+        step_row16<false, kStaged, kMode>(a, img, true, q0, q1, s, out);
+        if (it + 1 < steps) step_row16<true, kStaged, kMode>(b, img, n + 16 < c.N, q0, q1, s, out);
+      } else if (it < steps) {                               // the tail step's row is in a
+        step_row16<true, kStaged, kMode>(a, img, n < c.N, q0, q1, s, out);
       }
     } else {
       const int full = c.N >> 4;                           // steps in which every lane has an observation
@@ -832,12 +850,12 @@ struct Logistic : ModelDefaults {
       for (int it = 0; it < full; it++, n += 16) {
         Row cur;
         load_row<kStaged>(c, img, n, true, cur);
-        step_row16<false, kStaged>(cur, img, true, q0, q1, s);
+        step_row16<false, kStaged, kMode>(cur, img, true, q0, q1, s, out);
       }
       if (full < steps) {                                  // wave-uniform
         Row cur;
         load_row<kStaged>(c, img, n, n < c.N, cur);
-        step_row16<true, kStaged>(cur, img, n < c.N, q0, q1, s);
+        step_row16<true, kStaged, kMode>(cur, img, n < c.N, q0, q1, s, out);
       }
     }
   }
@@ -855,7 +873,19 @@ struct Logistic : ModelDefaults {
     for (int j = 0; j <= D; j++) s[j] = 0.0;
     const double q0 = q[0], q1 = q[DPL > 1 ? 1 : 0];
     if (kImage || ln.xs != nullptr) {   // wave-uniform
-      steps_row16<true, EXMC_LG_ROW_AHEAD != 0>(c, (const lds_v2d*)ln.xs, l, q0, q1, s);
+      if constexpr (EXMC_LG_PASS_GUARD == 0) {
+        steps_row16<true, EXMC_LG_ROW_AHEAD != 0>(c, (const lds_v2d*)ln.xs, l, q0, q1, s);
+      } else {
+        // the short forms for the whole pass, the domain checked lane by lane on the way and decided ONCE:
+        // a pass that saw a predictor outside [-200, 200] (or a NaN) is evaluated again in the general forms
+        unsigned long long out = 0;
+        steps_row16<true, EXMC_LG_ROW_AHEAD != 0, 1>(c, (const lds_v2d*)ln.xs, l, q0, q1, s, &out);
+        if (__builtin_expect(out != 0, 0)) {
+#pragma unroll
+          for (int j = 0; j <= D; j++) s[j] = 0.0;
+          steps_row16<true, false, 2>(c, (const lds_v2d*)ln.xs, l, q0, q1, s);   // (rare: no row buffers ahead)
+        }
+      }
     } else {
       steps_row16<false, false>(c, nullptr, l, q0, q1, s);
     }
