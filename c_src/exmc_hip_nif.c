@@ -12,6 +12,7 @@
  *   warmup/6                run_warmup of the shared chain (sampler.ex:537-762, 1068-1080)
  *   sample_chains/10        sample_chains_vectorized_compiled's sampling loop (sampler.ex:1082-1130)
  *   sample/7                sample/3 for one chain (sampler.ex:126-257)
+ *   sample_warm/9, sample_dense/8   the same with opts[:warm_start] / dense_mass: true (sampler.ex:156, 167-197)
  *   stream_begin/6, stream_next/2   sample_stream/4 (sampler.ex:1186-1277), pulled in chunks
  *   stream_run/3            sample_stream/4's sender: one launch, a message per finished draw
  *
@@ -49,6 +50,10 @@ static int g_device = 0;
   X(int, sample_chains_host, (exmc_hip_model*, const exmc_hip_tuning*, const double*, int, int, int,           \
                               exmc_hip_opts, exmc_hip_trace, int64_t*, int32_t*))                              \
   X(int, sample_host, (exmc_hip_model*, const double*, exmc_hip_opts, exmc_hip_trace, exmc_hip_tuning*, int32_t*)) \
+  X(int, sample_warm_host, (exmc_hip_model*, const double*, exmc_hip_opts, const exmc_hip_tuning*, exmc_hip_trace, \
+                            exmc_hip_tuning*, int32_t*))                                                        \
+  X(int, sample_dense_host, (exmc_hip_model*, const double*, exmc_hip_opts, exmc_hip_trace, exmc_hip_tuning*,   \
+                             double*, double*, int32_t*))                                                       \
   X(int, sample_independent_host, (exmc_hip_model*, const double*, int, int, int, exmc_hip_opts, exmc_hip_trace, \
                                    double*, int64_t*, int32_t*))                                               \
   X(int, stream_begin, (exmc_hip_model*, const double*, exmc_hip_opts, exmc_hip_tuning*))                      \
@@ -530,6 +535,75 @@ static ERL_NIF_TERM sample(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) 
   return tuple3(env, trace_map(env, &b), tuning_map(env, &tun, d), enif_make_int(env, dv));
 }
 
+/* argv[0..4] = num_warmup, num_samples, max_tree_depth, target_accept, seed (the options of sample/3) */
+static int get_sample_opts(ErlNifEnv* env, const ERL_NIF_TERM argv[], exmc_hip_opts* o) {
+  ErlNifUInt64 seed;
+  memset(o, 0, sizeof *o);
+  if (!enif_get_int(env, argv[0], &o->num_warmup) || !enif_get_int(env, argv[1], &o->num_samples) ||
+      !enif_get_int(env, argv[2], &o->max_tree_depth) || !get_f64(env, argv[3], &o->target_accept) ||
+      !enif_get_uint64(env, argv[4], &seed) || o->num_samples < 1)
+    return 0;
+  o->seed = seed;
+  return 1;
+}
+
+/* sample_warm(ref, init_q | nil, num_warmup, num_samples, max_tree_depth, target_accept, seed,
+ *             prev_epsilon, prev_inv_mass_bin) -> {trace_map, tuning_map, divergences}
+ * Sampler.sample/3 with opts[:warm_start] (sampler.ex:167-197): the previous run's step size and inverse
+ * mass (kernel order, as every inv_mass binary of this module), min(num_warmup, 50) warmup iterations on
+ * top of them, then the draws of the SAME chain from where that warmup ended. */
+static ERL_NIF_TERM sample_warm(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  HANDLE(argv[0]);
+  const double *iq, *im;
+  size_t nim;
+  exmc_hip_opts o;
+  exmc_hip_tuning prev, tun;
+  (void)argc;
+  memset(&prev, 0, sizeof prev);
+  if (!m) return enif_make_badarg(env);
+  const int d = A->model_dim(m);
+  if (!get_init_q(env, argv[1], d, &iq) || !get_sample_opts(env, argv + 2, &o) ||
+      !get_f64(env, argv[7], &prev.epsilon) || !get_f64_bin(env, argv[8], &im, &nim) || nim != (size_t)d)
+    return enif_make_badarg(env);
+  memcpy(prev.inv_mass, im, (size_t)d * 8);
+  trace_bins b;
+  new_trace(env, (size_t)o.num_samples, (size_t)d, &b);
+  int32_t dv = 0;
+  int rc = A->sample_warm_host(m, iq, o, &prev, b.tr, &tun, &dv);
+  if (rc != EXMC_OK) return raise_api(env, A, rc);
+  return tuple3(env, trace_map(env, &b), tuning_map(env, &tun, d), enif_make_int(env, dv));
+}
+
+/* sample_dense(ref, init_q | nil, num_warmup, num_samples, max_tree_depth, target_accept, seed,
+ *              lanes_per_chain) -> {trace_map, tuning_map + cov + chol_cov, divergences}
+ * Sampler.sample/3 with dense_mass: true (sampler.ex:156, 412-431): the dense adaptation windows, then the
+ * draws of the same chain under the dense mass; cov / chol_cov are d x d row-major binaries in FLAT order
+ * (the covariance of the flat vector, sampler.ex:682-705). lanes_per_chain 0 = the kind's dense layout. */
+static ERL_NIF_TERM sample_dense(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  HANDLE(argv[0]);
+  const double* iq;
+  exmc_hip_opts o;
+  exmc_hip_tuning tun;
+  (void)argc;
+  if (!m) return enif_make_badarg(env);
+  const int d = A->model_dim(m);
+  if (!get_init_q(env, argv[1], d, &iq) || !get_sample_opts(env, argv + 2, &o) ||
+      !enif_get_int(env, argv[7], &o.lanes_per_chain) || o.lanes_per_chain < 0)
+    return enif_make_badarg(env);
+  trace_bins b;
+  new_trace(env, (size_t)o.num_samples, (size_t)d, &b);
+  ERL_NIF_TERM tc, tl;
+  double* cov = new_f64_bin(env, (size_t)d * d, &tc);
+  double* chol = new_f64_bin(env, (size_t)d * d, &tl);
+  int32_t dv = 0;
+  int rc = A->sample_dense_host(m, iq, o, b.tr, &tun, cov, chol, &dv);
+  if (rc != EXMC_OK) return raise_api(env, A, rc);
+  ERL_NIF_TERM map = tuning_map(env, &tun, d);
+  map = map_put(env, map, "cov", tc);
+  map = map_put(env, map, "chol_cov", tl);
+  return tuple3(env, trace_map(env, &b), map, enif_make_int(env, dv));
+}
+
 /* stream_begin(ref, init_q | nil, num_warmup, max_tree_depth, target_accept, seed) -> tuning_map */
 static ERL_NIF_TERM stream_begin(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
   HANDLE(argv[0]);
@@ -681,6 +755,8 @@ static ErlNifFunc nif_funcs[] = {
     {"clear_dense_mass", 1, clear_dense_mass, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"sample_chains", 10, sample_chains, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"sample", 7, sample, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"sample_warm", 9, sample_warm, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"sample_dense", 8, sample_dense, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"sample_independent", 10, sample_independent, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"stream_begin", 6, stream_begin, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"stream_next", 2, stream_next, ERL_NIF_DIRTY_JOB_IO_BOUND},

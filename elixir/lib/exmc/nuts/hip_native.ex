@@ -83,6 +83,21 @@ defmodule Exmc.NUTS.HipNative do
   def sample(_ref, _init_q, _num_warmup, _num_samples, _max_tree_depth, _target_accept, _seed),
     do: :erlang.nif_error(:nif_not_loaded)
 
+  @doc """
+  Sampler.sample/3 with opts[:warm_start] (sampler.ex:167-197): the previous run's step size and inverse
+  mass (kernel order), min(num_warmup, 50) warmup iterations, then the chain's draws
+  -> {trace_map, tuning_map, divergences}
+  """
+  def sample_warm(_ref, _init_q, _num_warmup, _num_samples, _max_tree_depth, _target_accept, _seed, _prev_epsilon, _prev_inv_mass),
+    do: :erlang.nif_error(:nif_not_loaded)
+
+  @doc """
+  Sampler.sample/3 with dense_mass: true (sampler.ex:156, 412-431) -> {trace_map, tuning_map, divergences};
+  the tuning map also carries :cov and :chol_cov (d x d row-major f64 binaries, flat order). lanes 0 = the kind's layout.
+  """
+  def sample_dense(_ref, _init_q, _num_warmup, _num_samples, _max_tree_depth, _target_accept, _seed, _lanes_per_chain),
+    do: :erlang.nif_error(:nif_not_loaded)
+
   @doc "sample_stream/4, pull style: warmup, the chain stays resident -> tuning_map"
   def stream_begin(_ref, _init_q, _num_warmup, _max_tree_depth, _target_accept, _seed),
     do: :erlang.nif_error(:nif_not_loaded)

@@ -56,6 +56,36 @@ defmodule Exmc.NUTS.HipSampler do
   end
 
   @doc """
+  sample_from_compiled/3 (sampler.ex:126-257), one chain: adaptation and draws as ONE NIF call. opts[:dense_mass]
+  (sampler.ex:156) and opts[:warm_start] (sampler.ex:167-197; the `stats` of a previous run: `inv_mass_diag` in
+  flat order as every stats map reports it, `step_size`) pick the call. Returns `{tuning, flat draws, trace_map}`;
+  `tuning.inv_mass_diag` is the flat-order tensor for the stats map, `tuning.warmup_divergences` the warmup's share
+  of `stats.divergences` (sampler.ex:245 counts both phases); a dense tuning also carries `:cov` / `:chol_cov`.
+  """
+  def sample(%{ref: ref} = compiled, opts) do
+    opts = Keyword.merge(@default_opts, opts)
+    init_q = init_q(compiled, Keyword.get(opts, :init_q))
+    common = [opts[:num_warmup], opts[:num_samples], opts[:max_tree_depth], opts[:target_accept], opts[:seed]]
+
+    {trace, tuning, _divergences} =
+      cond do
+        Keyword.get(opts, :dense_mass, false) ->
+          apply(HipNative, :sample_dense, [ref, init_q] ++ common ++ [0])
+
+        ws = Keyword.get(opts, :warm_start) ->
+          prev_im = kernel_inv_mass(compiled, ws.inv_mass_diag)
+          apply(HipNative, :sample_warm, [ref, init_q] ++ common ++ [ws.step_size * 1.0, prev_im])
+
+        true ->
+          apply(HipNative, :sample, [ref, init_q] ++ common)
+      end
+
+    tuning = Map.put(tuning, :inv_mass_diag, flat_inv_mass(compiled, tuning.inv_mass))
+    [draws] = chains(compiled, trace, 1, opts[:num_samples])
+    {tuning, draws, trace}
+  end
+
+  @doc """
   sample_chains_vectorized_compiled/3 (sampler.ex:1020-1136): the shared warmup on chain 0, then
   every chain with its tuning, as two NIF calls. Returns `{tuning, [flat draws per chain], trace_map}`;
   the caller builds traces and stats with its own build_trace/3.
@@ -130,6 +160,19 @@ defmodule Exmc.NUTS.HipSampler do
   """
   def flat_inv_mass(%{perm: perm}, inv_mass_bin) do
     Nx.from_binary(inv_mass_bin, :f64) |> Nx.take(Nx.tensor(perm, type: :s64))
+  end
+
+  @doc """
+  The inverse of `flat_inv_mass/2`: a flat-order `{d}` tensor (what `stats.inv_mass_diag` holds, e.g. inside
+  opts[:warm_start]) as the kernel-order f64 binary the NIFs take. Kernel dimension perm[r] takes flat entry r.
+  """
+  def kernel_inv_mass(%{perm: perm}, %Nx.Tensor{} = flat) do
+    vals = flat |> Nx.as_type(:f64) |> Nx.to_flat_list()
+
+    perm
+    |> Enum.zip(vals)
+    |> Enum.sort()
+    |> Enum.reduce(<<>>, fn {_k, x}, acc -> <<acc::binary, x::float-64-native>> end)
   end
 
   @doc false

@@ -67,6 +67,10 @@ int exmc_hip_warmup_dense(exmc_hip_model* m, const double* q, exmc_hip_opts o, e
 int exmc_hip_sample_chains_host(exmc_hip_model* m, const exmc_hip_tuning* t, const double* q, int n, int lo, int hi,
                                 exmc_hip_opts o, exmc_hip_trace tr, int64_t* lf, int32_t* dv) NO_DEVICE()
 int exmc_hip_sample_host(exmc_hip_model* m, const double* q, exmc_hip_opts o, exmc_hip_trace tr, exmc_hip_tuning* t, int32_t* dv) NO_DEVICE()
+int exmc_hip_sample_warm_host(exmc_hip_model* m, const double* q, exmc_hip_opts o, const exmc_hip_tuning* w, exmc_hip_trace tr,
+                              exmc_hip_tuning* t, int32_t* dv) NO_DEVICE()
+int exmc_hip_sample_dense_host(exmc_hip_model* m, const double* q, exmc_hip_opts o, exmc_hip_trace tr, exmc_hip_tuning* t,
+                               double* cov, double* chol, int32_t* dv) NO_DEVICE()
 int exmc_hip_sample_independent_host(exmc_hip_model* m, const double* q, int n, int lo, int hi, exmc_hip_opts o,
                                      exmc_hip_trace tr, double* tu, int64_t* lf, int32_t* dv) NO_DEVICE()
 int exmc_hip_stream_next_host(exmc_hip_model* m, int n, exmc_hip_trace tr, int32_t* dv) NO_DEVICE()

@@ -17,6 +17,7 @@ pytestmark = pytest.mark.gpu
 GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden",
                                    "reference_known_answers.json")))["native_tree"]
 A = np.array
+GOLD_SV = np.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_traces.npz"))["sv_returns"]
 
 
 @pytest.fixture(scope="module")
@@ -208,6 +209,42 @@ def test_hip_native_equals_the_python_mirror(hip, mods):
     assert hn.call("clear_dense_mass", ref) == H.Atom("ok")
     with pytest.raises(H.BadArg):
         hn.call("set_dense_mass", ref, np.zeros(5), np.zeros(5))
+
+
+def test_sample_with_warm_start_and_dense_mass_through_the_nif(hip, mods):
+    """HipNative.sample_warm/9 and sample_dense/8 (round 6: sample/3 with opts[:warm_start], sampler.ex:167-197, and
+    dense_mass: true, sampler.ex:156) = the Python mirror of the same C entry points (which the checker pins),
+    draws included; on sv, whose kernel order is not the flat order."""
+    hn = mods["HipNative"]
+    for spec, lanes in ((models.eight_schools(), 16), (models.sv(GOLD_SV), 64)):
+        ok, ref = hn.call("model_create", spec.kind, spec.data)
+        assert ok == H.Atom("ok")
+        assert hn.call("model_set_flat_order", ref, spec.flat_order()) == H.Atom("ok")
+        q0 = spec.to_unconstrained(spec.default_init)
+        nw, ns = (150, 20) if spec.d < 50 else (60, 6)
+        tr0, tun0, dv0 = hn.call("sample", ref, q0, nw, ns, 10, 0.8, 5)
+        t0, s0 = sampler.sample(spec, spec.default_init, dict(num_warmup=nw, num_samples=ns, seed=5))
+        assert tun0["epsilon"] == s0["step_size"]
+        assert np.array_equal(H.f64(tr0["draws"]).reshape(ns, spec.d), s0["raw"]["draws"][0])
+        # warm start from that run's tuning: min(num_warmup, 50) iterations, then the same chain's draws
+        trw, tunw, dvw = hn.call("sample_warm", ref, q0, nw, ns, 10, 0.8, 9, tun0["epsilon"], H.f64(tun0["inv_mass"]))
+        tw, sw = sampler.sample(spec, spec.default_init, dict(num_warmup=nw, num_samples=ns, seed=9,
+                                                              warm_start=dict(step_size=s0["step_size"],
+                                                                              inv_mass_diag=s0["inv_mass_diag"])))
+        assert tunw["epsilon"] == sw["step_size"] and np.array_equal(H.f64(tunw["inv_mass"]), sw["inv_mass_diag"])
+        assert np.array_equal(H.f64(trw["draws"]).reshape(ns, spec.d), sw["raw"]["draws"][0])
+        assert np.array_equal(H.i32(trw["n_steps"]), sw["raw"]["n_steps"][0]) and dvw == sw["divergences"]
+        with pytest.raises(H.BadArg):
+            hn.call("sample_warm", ref, q0, nw, ns, 10, 0.8, 9, tun0["epsilon"], np.zeros(3))
+        if spec.d > 50:
+            continue      # (the dense windows of sv at this size are a test of their own, test_dense_mass_*)
+        trd, tund, dvd = hn.call("sample_dense", ref, q0, 300, ns, 10, 0.8, 13, 0)
+        td, sd = sampler.sample(spec, spec.default_init, dict(num_warmup=300, num_samples=ns, seed=13, dense_mass=True))
+        assert tund["epsilon"] == sd["step_size"]
+        assert np.array_equal(H.f64(tund["chol_cov"]).reshape(spec.d, spec.d), sd["chol_cov"])
+        assert np.array_equal(H.f64(tund["cov"]).reshape(spec.d, spec.d), sd["cov"])
+        assert np.array_equal(H.f64(trd["draws"]).reshape(ns, spec.d), sd["raw"]["draws"][0])
+        assert dvd == sd["divergences"]
 
 
 def test_sample_independent_through_the_nif(hip, mods):
