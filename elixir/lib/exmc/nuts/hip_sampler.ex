@@ -65,24 +65,57 @@ defmodule Exmc.NUTS.HipSampler do
   def sample(%{ref: ref} = compiled, opts) do
     opts = Keyword.merge(@default_opts, opts)
     init_q = init_q(compiled, Keyword.get(opts, :init_q))
-    common = [opts[:num_warmup], opts[:num_samples], opts[:max_tree_depth], opts[:target_accept], opts[:seed]]
+    {nw, ns, depth, accept, seed} =
+      {opts[:num_warmup], opts[:num_samples], opts[:max_tree_depth], opts[:target_accept], opts[:seed]}
 
     {trace, tuning, _divergences} =
       cond do
         Keyword.get(opts, :dense_mass, false) ->
-          apply(HipNative, :sample_dense, [ref, init_q] ++ common ++ [0])
+          HipNative.sample_dense(ref, init_q, nw, ns, depth, accept, seed, 0)
 
         ws = Keyword.get(opts, :warm_start) ->
           prev_im = kernel_inv_mass(compiled, ws.inv_mass_diag)
-          apply(HipNative, :sample_warm, [ref, init_q] ++ common ++ [ws.step_size * 1.0, prev_im])
+          HipNative.sample_warm(ref, init_q, nw, ns, depth, accept, seed, ws.step_size * 1.0, prev_im)
 
         true ->
-          apply(HipNative, :sample, [ref, init_q] ++ common)
+          HipNative.sample(ref, init_q, nw, ns, depth, accept, seed)
       end
 
     tuning = Map.put(tuning, :inv_mass_diag, flat_inv_mass(compiled, tuning.inv_mass))
     [draws] = chains(compiled, trace, 1, opts[:num_samples])
     {tuning, draws, trace}
+  end
+
+  @doc """
+  sample_from_compiled_tuned/4 (sampler.ex:259-335; `sample_compiled_tuned/4`, and what
+  `Distributed.run_chain_remote` calls): no warmup, the draws of one chain under the tuning map
+  `%{epsilon, inv_mass, chol_cov}` of the reference -- `inv_mass` a flat-order `{d}` tensor, or the `{d, d}`
+  covariance together with its Cholesky factor `chol_cov` for a dense mass (sampler.ex:274, 292).
+  Returns `{flat draws, trace_map}`.
+  """
+  def sample_tuned(%{ref: ref, pm: pm} = compiled, tuning, opts) do
+    opts = Keyword.merge(@default_opts, opts)
+    init_q = init_q(compiled, Keyword.get(opts, :init_q))
+    d = pm.size
+
+    diag =
+      case Map.get(tuning, :chol_cov) do
+        nil ->
+          :ok = HipNative.clear_dense_mass(ref)
+          tuning.inv_mass
+
+        chol ->
+          f64 = fn t -> t |> Nx.as_type(:f64) |> Nx.reshape({d * d}) |> Nx.to_binary() end
+          :ok = HipNative.set_dense_mass(ref, f64.(tuning.inv_mass), f64.(chol))
+          Nx.take_diagonal(tuning.inv_mass)
+      end
+
+    {trace, _leapfrogs, _divergences} =
+      HipNative.sample_chains(ref, tuning.epsilon * 1.0, kernel_inv_mass(compiled, diag), init_q, 1, 0, 1,
+        opts[:num_samples], opts[:max_tree_depth], opts[:seed])
+
+    [draws] = chains(compiled, trace, 1, opts[:num_samples])
+    {draws, trace}
   end
 
   @doc """

@@ -135,3 +135,17 @@ def test_patches_are_well_formed_unified_diffs(name, target):
     assert "Exmc.NUTS.HipSampler." in added
     # context / removed lines quoted from the reference stay a handful (the patch is an anchor, not a copy)
     assert sum(1 for ln in body_lines if ln[0] in "- ") <= 8
+    # the line counts of every hunk header are exact and the new-file positions add up (round 6: `patch`
+    # refuses a hunk whose counts are off; the patches were dry-run against the reference's two files)
+    lines = src.split("\n")
+    at = [i for i, ln in enumerate(lines) if ln.startswith("@@ ")]
+    offset = 0
+    last = 0
+    for n, i in enumerate(at):
+        end = at[n + 1] if n + 1 < len(at) else len(lines)
+        body = [ln for ln in lines[i + 1:end] if ln]
+        o0, oc, n0, nc = map(int, re.match(r"^@@ -(\d+),(\d+) \+(\d+),(\d+) @@$", lines[i]).groups())
+        assert oc == sum(1 for ln in body if ln[0] in " -") and nc == sum(1 for ln in body if ln[0] in " +"), lines[i]
+        assert n0 == o0 + offset and o0 > last, lines[i]
+        offset += nc - oc
+        last = o0
