@@ -241,3 +241,68 @@ def test_vectorized_chains_share_the_warmup(hip):
         assert sum(s["divergences"] for s in stats) < 50
     finally:
         comp.close()
+
+
+# ---- test/nuts_test.exs, the "Sampler" block (tests 14-19, 22) ----
+def _std_normal(name="x"):
+    return cg.IR().rv(name, "normal", dict(mu=0.0, sigma=1.0))
+
+
+def test_nuts_standard_normal_moments(hip):
+    """nuts_test.exs:306-321 (500 + 500, seed 42: |mean| < 0.3, |var - 1| < 1, divergences <= 15) and :554-569 (the
+    same model at 300 + 300 -- "speculative pre-computation" is the identity the device path has no need for)."""
+    spec = _spec(_std_normal("mu"), "rn_std")
+    for nw, ns in ((500, 500), (300, 300)):
+        trace, stats = sampler.sample(spec, {}, dict(num_warmup=nw, num_samples=ns, seed=42))
+        assert abs(trace["mu"].mean()) < 0.3 and abs(trace["mu"].var() - 1.0) < 1.0 and stats["divergences"] <= 15
+
+
+def test_nuts_two_parameter_prior_means(hip):
+    """nuts_test.exs:323-357: mu1 ~ N(2, 0.5), mu2 ~ N(-1, 0.5): means within 0.2, variances 0.25 +- 0.2."""
+    ir = cg.IR().rv("mu1", "normal", dict(mu=2.0, sigma=0.5))
+    ir.rv("mu2", "normal", dict(mu=-1.0, sigma=0.5))
+    trace, stats = sampler.sample(_spec(ir, "rn_two"), {}, dict(num_warmup=300, num_samples=300, seed=123))
+    assert abs(trace["mu1"].mean() - 2.0) < 0.2 and abs(trace["mu2"].mean() + 1.0) < 0.2
+    assert abs(trace["mu1"].var() - 0.25) < 0.2 and abs(trace["mu2"].var() - 0.25) < 0.2
+    assert stats["divergences"] <= 15
+
+
+def test_nuts_support_divergences_reproducibility_and_stats(hip):
+    """nuts_test.exs:359-371 (Exponential(1): every draw positive), :373-382 (standard Normal: < 20 divergences),
+    :384-393 (the same seed gives the same trace -- here to the bit) and :396-412 (the stats map)."""
+    trace, _ = sampler.sample(_spec(cg.IR().rv("rate", "exponential", {"lambda": 1.0}), "rn_exp"), {},
+                              dict(num_warmup=200, num_samples=200, seed=77))
+    assert trace["rate"].min() > 0.0
+    spec = _spec(_std_normal(), "rn_x")
+    _, stats = sampler.sample(spec, {}, dict(num_warmup=200, num_samples=200, seed=11))
+    assert stats["divergences"] < 20
+    t1, _ = sampler.sample(spec, {}, dict(num_warmup=200, num_samples=100, seed=999))
+    t2, _ = sampler.sample(spec, {}, dict(num_warmup=200, num_samples=100, seed=999))
+    assert np.array_equal(t1["x"], t2["x"])
+    _, st = sampler.sample(spec, {}, dict(num_warmup=50, num_samples=50, seed=0))
+    assert isinstance(st["step_size"], float) and st["inv_mass_diag"].shape == (1,)
+    assert isinstance(st["divergences"], int) and st["num_warmup"] == 50 and st["num_samples"] == 50
+
+
+def test_momentum_variance_matches_the_mass_matrix(hip):
+    """nuts_test.exs:92-115: p = z / sqrt(inv_mass) has variance 1 / inv_mass (0.15): the kinetic energy the kernels
+    report for the momentum they draw. energy = -joint_logp_0 = KE - logp(q) at the START of a transition
+    (sampler.ex:905); with a tuning given (inv_mass [0.25, 4.0]) and the chain's previous position known, KE follows,
+    and E[KE] = d / 2 whatever the mass -- the check that p was scaled by 1 / sqrt(inv_mass)."""
+    ir = cg.IR().rv("a", "normal", dict(mu=0.0, sigma=2.0))
+    ir.rv("b", "normal", dict(mu=0.0, sigma=0.5))
+    spec = _spec(ir, "rn_mass")
+    comp = sampler.compile(spec)
+    try:
+        tuning = dict(epsilon=0.3, inv_mass=np.array([4.0, 0.25]))      # = the variances of a and b
+        _, _, extra = sampler.sample_compiled_tuned(comp, tuning, {"a": 0.0, "b": 0.0}, dict(num_samples=2500, seed=123),
+                                                    num_chains=2)
+        raw = extra["raw"]
+        logp = raw["logp"]                                             # log-density AFTER each transition
+        prev = np.concatenate([np.full((2, 1), np.nan), logp[:, :-1]], axis=1)
+        ke = raw["energy"] + prev                                      # KE_0 = energy + logp(q_0)
+        ke = ke[:, 1:].ravel()
+        assert np.all(ke >= 0.0)
+        assert abs(ke.mean() - 1.0) <= 0.15                            # d / 2 with d = 2
+    finally:
+        comp.close()
