@@ -178,9 +178,9 @@ class IR:
             meta["weight"] = w
         if opts.get("mask") is not None:
             mk = np.asarray(opts["mask"]).astype(bool)
-            if mk.shape != shape or len(shape) != 1:
-                raise CodegenError("mask must be a vector matching the value")
-            meta["mask"] = mk
+            if mk.shape != shape or len(shape) > 1:
+                raise CodegenError("mask must match the value (a scalar for a scalar, a vector for a vector)")
+            meta["mask"] = mk                    # (a scalar mask on a scalar obs: test/exmc_test.exs:188-209)
         return self._add(id_, dict(op="obs", target=rv_id, value=v, meta=meta))
 
     def det(self, id_, fun, args):
@@ -198,7 +198,13 @@ class IR:
             raise CodegenError("meas_obs values are scalars or vectors")
         kind = op_info[0]
         if kind == "affine" and len(op_info) == 3:
-            info = ("affine", float(op_info[1]), float(op_info[2]))
+            # a, b scalars, or vectors that broadcast against the value (compiler.ex:363-369 divides and
+            # subtracts tensors; test/exmc_test.exs:348-372)
+            a_, b_ = np.asarray(op_info[1], dtype=np.float64), np.asarray(op_info[2], dtype=np.float64)
+            for c in (a_, b_):
+                if c.ndim > 1 or (c.ndim == 1 and (v.ndim != 1 or c.shape != v.shape)):
+                    raise CodegenError("affine meas_obs: a and b are scalars or vectors matching the value")
+            info = ("affine", float(a_) if a_.ndim == 0 else a_, float(b_) if b_.ndim == 0 else b_)
         elif kind == "matmul" and len(op_info) == 2:
             a = np.asarray(op_info[1], dtype=np.float64)
             if a.ndim != 2 or a.shape[0] != a.shape[1] or v.ndim != 1 or a.shape[0] != v.shape[0]:
@@ -1053,9 +1059,15 @@ def generate(ir, ncp=True, vectorize=True, rewrite_passes=False, lanes=None, wav
                 elems = g.mul(elems, g.datum(float(w)))
         mk = meta.get("mask")
         if mk is not None:
-            if not is_vec or len(mk) != len(elems):
-                raise CodegenError("obs %r: mask does not match the term" % id_)
-            elems = [e if bool(mk[i]) else g.lit(0.0) for i, e in enumerate(elems)]
+            mk = np.asarray(mk)
+            if not is_vec:                        # Nx.select(mask, logp, 0.0) with a scalar mask
+                if mk.ndim != 0:
+                    raise CodegenError("obs %r: a vector mask on a scalar term" % id_)
+                elems = elems if bool(mk) else g.lit(0.0)
+            else:
+                if mk.ndim != 1 or len(mk) != len(elems):
+                    raise CodegenError("obs %r: mask does not match the term" % id_)
+                elems = [e if bool(mk[i]) else g.lit(0.0) for i, e in enumerate(elems)]
         red = meta.get("reduce")
         if not is_vec:
             return elems
@@ -1114,10 +1126,14 @@ def generate(ir, ncp=True, vectorize=True, rewrite_passes=False, lanes=None, wav
             params = resolve_params(tgt["dist"], tgt["params"])
             val, info, tr = n["value"], n["info"], tgt["transform"]
             if info[0] == "affine":
-                a, b = g.datum(info[1]), g.datum(info[2])
-                conv = lambda v: g.div(g.sub(g.datum(float(v)), b), a)   # noqa: E731
-                x = conv(val) if val.ndim == 0 else [conv(v) for v in val]
-                jac = g.neg(g.log(g.abs(a)))
+                av, bv = np.asarray(info[1], dtype=np.float64), np.asarray(info[2], dtype=np.float64)
+                at = lambda c, i: g.datum(float(c if c.ndim == 0 else c[i]))   # noqa: E731
+                conv = lambda v, i: g.div(g.sub(g.datum(float(v)), at(bv, i)), at(av, i))   # noqa: E731
+                x = conv(val, 0) if val.ndim == 0 else [conv(v, i) for i, v in enumerate(val)]
+                if av.ndim == 0:
+                    jac = g.neg(g.log(g.abs(g.datum(float(av)))))
+                else:                             # -log|a| element by element: added to the vector term below
+                    jac = [g.neg(g.log(g.abs(g.datum(float(c))))) for c in av]
             else:
                 sol = np.linalg.solve(info[1], val)                  # jit_solve: third-party LinAlg
                 x = [g.datum(float(v)) for v in sol]
@@ -1133,7 +1149,7 @@ def generate(ir, ncp=True, vectorize=True, rewrite_passes=False, lanes=None, wav
                 # reduce (or, without one, sum_logps' Nx.sum, compiler.ex:396-397) folds it
                 if tjac is not None:
                     t = [g.add(e, tjac[i if len(tjac) > 1 else 0]) for i, e in enumerate(t)]
-                t = [g.add(e, jac) for e in t]
+                t = [g.add(e, jac[i] if isinstance(jac, list) else jac) for i, e in enumerate(t)]
             else:
                 if tjac is not None:
                     t = g.add(t, tjac[0])
