@@ -128,3 +128,77 @@ def test_softplus_and_logit_default_transforms():
     assert gen.transforms == {"z": "logit"}
     s = 1.0 / (1.0 + math.exp(-0.3))
     assert abs(lp - (math.log(s) + math.log1p(-s))) <= TOL
+
+
+# ---- test/compiler_test.exs: PointMap layout and gradients; test/hierarchical_test.exs ----
+def _fd(gen, q, h=1e-5):
+    q = np.asarray(q, dtype=np.float64)
+    out = np.zeros_like(q)
+    for i in range(q.size):
+        e = np.zeros_like(q)
+        e[i] = h
+        out[i] = (GC.logp_grad(gen, q + e)[0] - GC.logp_grad(gen, q - e)[0]) / (2 * h)
+    return out
+
+
+def test_point_map_free_versus_observed_and_order():
+    """compiler_test.exs:46-60 (an observed rv has no entry), :62-74 (all free: ids in order), :89-104 (mixed: the
+    entries are the free ones, alphabetically), :106-123 (the rewrite records :log for Exponential, nothing for Normal);
+    :76-87 (no free rv: size 0 -- the generator refuses such a model: there is nothing to sample)."""
+    ir = _std()
+    _std(ir, "y")
+    ir.obs("y_obs", "y", 0.5)
+    gen = cg.generate(ir, rewrite_passes=True)
+    assert gen.var_names == ["x"] and gen.d == 1
+    ir = _std(None, "a")
+    _std(ir, "b")
+    assert cg.generate(ir, rewrite_passes=True).var_names == ["a", "b"]
+    ir = cg.IR().rv("alpha", "exponential", {"lambda": 1.0})
+    _std(ir, "beta")
+    _std(ir, "gamma")
+    ir.obs("gamma_obs", "gamma", 0.3)
+    gen = cg.generate(ir, rewrite_passes=True)
+    assert gen.var_names == ["alpha", "beta"] and gen.transforms == {"alpha": "log"}
+    ir = _std()
+    ir.obs("x_obs", "x", 0.5)
+    with pytest.raises(cg.CodegenError):
+        cg.generate(ir, rewrite_passes=True)
+
+
+def test_compiled_gradients():
+    """compiler_test.exs:257-274 (N(0, 1): d/dx logp = -x at 0.3), :276-293 (Exponential(1.5) under its default :log:
+    gradient against finite differences, 1e-4), :295-311 (two free rvs, 1e-3)."""
+    gen = cg.generate(_std(), rewrite_passes=True)
+    lp, g = GC.logp_grad(gen, np.array([0.3]))
+    assert abs(lp - base(0.3)) <= TOL and abs(g[0] + 0.3) <= TOL
+    gen = cg.generate(cg.IR().rv("z", "exponential", {"lambda": 1.5}), rewrite_passes=True)
+    _, g = GC.logp_grad(gen, np.array([0.1]))
+    assert np.allclose(g, _fd(gen, [0.1]), atol=1e-4)
+    ir = _std(None, "a")
+    ir.rv("b", "normal", dict(mu=1.0, sigma=2.0))
+    gen = cg.generate(ir, rewrite_passes=True)
+    _, g = GC.logp_grad(gen, np.array([0.5, -0.3]))
+    assert np.allclose(g, _fd(gen, [0.5, -0.3]), atol=1e-3)
+
+
+def test_hierarchical_param_refs():
+    """hierarchical_test.exs:8-25 / :29-45 (mu ~ N(0, 10), x ~ N(mu, 1) at mu = 2, x = 3: the two Normal terms, 1e-6),
+    :47-84 (its gradient against finite differences, 0.01), :86-109 (sigma ~ Exp(1) [:log], mu ~ N(0, sigma) observed at
+    5: one entry, `sigma`, a finite log-density at log 2), :111-129 (the observation pulls: logp(5) > logp(0))."""
+    ir = cg.IR().rv("mu", "normal", dict(mu=0.0, sigma=10.0))
+    ir.rv("x", "normal", dict(mu="mu", sigma=1.0))
+    gen = cg.generate(ir, ncp=False, rewrite_passes=True)
+    lp, g = GC.logp_grad(gen, np.array([2.0, 3.0]))
+    expected = (-0.5 * (LOG_2PI + 2 * math.log(10.0) + (2.0 / 10.0) ** 2)) + (-0.5 * (LOG_2PI + (3.0 - 2.0) ** 2))
+    assert abs(lp - expected) <= 1e-6
+    assert np.allclose(g, _fd(gen, [2.0, 3.0]), atol=0.01)
+    ir = cg.IR().rv("sigma", "exponential", {"lambda": 1.0}, transform="log")
+    ir.rv("mu", "normal", dict(mu=0.0, sigma="sigma"))
+    ir.obs("mu_obs", "mu", 5.0)
+    gen = cg.generate(ir, rewrite_passes=True)
+    assert gen.var_names == ["sigma"] and math.isfinite(GC.logp_grad(gen, np.array([math.log(2.0)]))[0])
+    ir = cg.IR().rv("mu", "normal", dict(mu=0.0, sigma=10.0))
+    ir.rv("x", "normal", dict(mu="mu", sigma=1.0))
+    ir.obs("x_obs", "x", 5.0)
+    gen = cg.generate(ir, rewrite_passes=True)
+    assert gen.d == 1 and GC.logp_grad(gen, np.array([5.0]))[0] > GC.logp_grad(gen, np.array([0.0]))[0]
