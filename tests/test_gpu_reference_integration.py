@@ -306,3 +306,14 @@ def test_momentum_variance_matches_the_mass_matrix(hip):
         assert abs(ke.mean() - 1.0) <= 0.15                            # d / 2 with d = 2
     finally:
         comp.close()
+
+
+def test_custom_distribution_with_the_sampler(hip):
+    """custom_dist_test.exs:190-212: x ~ the closure -(0.5 z^2 + log sigma) with mu 0, sigma 1: 300 draws after 200 warmup
+    iterations, seed 42: mean 0.0 +- 0.5, a positive step size."""
+    def normal(o, x, p):
+        z = o.div(o.sub(x, p["mu"]), p["sigma"])
+        return o.neg(o.add(o.mul(o.f32(0.5), o.mul(z, z)), o.log(p["sigma"])))
+    ir = cg.IR().rv("x", "custom", dict(logpdf=normal, mu=0.0, sigma=1.0))
+    trace, stats = sampler.sample(cg.compile_ir(ir, ncp=False, name="rc_custom"), {}, dict(num_samples=300, seed=42, num_warmup=200))
+    assert trace["x"].shape == (300,) and abs(trace["x"].mean()) <= 0.5 and stats["step_size"] > 0.0

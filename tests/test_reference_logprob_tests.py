@@ -202,3 +202,31 @@ def test_hierarchical_param_refs():
     ir.obs("x_obs", "x", 5.0)
     gen = cg.generate(ir, rewrite_passes=True)
     assert gen.d == 1 and GC.logp_grad(gen, np.array([5.0]))[0] > GC.logp_grad(gen, np.array([0.0]))[0]
+
+
+# ---- test/custom_dist_test.exs: Custom distributions (closures over the declarative op set) ----
+def _custom_normal(o, x, p):
+    """normal_logpdf of custom_dist_test.exs:10-19: -(0.5 z^2 + log sigma), no normalising constant."""
+    z = o.div(o.sub(x, p["mu"]), p["sigma"])
+    return o.neg(o.add(o.mul(o.f32(0.5), o.mul(z, z)), o.log(p["sigma"])))
+
+
+def test_custom_distribution_logpdf_and_transform():
+    """custom_dist_test.exs:59-76 (x = 1, mu 0, sigma 1 -> -0.5; x = mu = 3 -> 0.0), :129-163 (compiled: one entry,
+    finite value and gradient at 0.5), :165-186 (a :positive support gets :log: the exponential-like closure at z = 0 is
+    log(1) - 1 * exp(0) + 0)."""
+    ir = cg.IR().rv("x", "custom", dict(logpdf=_custom_normal, mu=0.0, sigma=1.0))
+    gen = cg.generate(ir, ncp=False)
+    assert gen.d == 1
+    assert abs(GC.logp_grad(gen, np.array([1.0]))[0] + 0.5) <= TOL
+    lp, g = GC.logp_grad(gen, np.array([0.5]))
+    assert math.isfinite(lp) and abs(g[0] + 0.5) <= TOL
+    gen = cg.generate(cg.IR().rv("x", "custom", dict(logpdf=_custom_normal, mu=3.0, sigma=1.0)), ncp=False)
+    assert abs(GC.logp_grad(gen, np.array([3.0]))[0]) <= TOL
+
+    def expo(o, x, p):
+        return o.sub(o.log(p["rate"]), o.mul(p["rate"], x))
+    ir = cg.IR().rv("x", "custom", dict(logpdf=expo, rate=1.0), transform="log")    # Custom.new(f, support: :positive)
+    gen = cg.generate(ir, ncp=False)
+    assert gen.transforms == {"x": "log"}
+    assert abs(GC.logp_grad(gen, np.array([0.0]))[0] - (-1.0)) <= TOL
