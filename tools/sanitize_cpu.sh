@@ -30,7 +30,7 @@ tests="tests/test_nif_shim.py tests/test_elixir_sources.py tests/test_ess_series
 LD_PRELOAD="$asan $ubsan" ASAN_OPTIONS=detect_leaks=0:abort_on_error=0:halt_on_error=1 \
 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 EXMC_SANITIZE=address,undefined \
 EXMC_ORACLE_LIB="$work/libexmc_oracle_asan.so" \
-  python3 -m pytest $tests -x -q -p no:cacheprovider > "$out/asan_ubsan_pytest.log" 2>&1 || fail=1
+  python3 -m pytest $tests -x -q -m "not gpu" -p no:cacheprovider > "$out/asan_ubsan_pytest.log" 2>&1 || fail=1
 tail -3 "$out/asan_ubsan_pytest.log"
 if grep -q "ERROR: AddressSanitizer\|runtime error:" "$out/asan_ubsan_pytest.log"; then fail=1; fi
 
