@@ -138,6 +138,60 @@ def test_radon_modes_agree_away_from_unit_noise_scale(log_sigma_y):
             assert abs(fd - g0[i]) <= 2e-5 * max(1.0, abs(g0[i]))
 
 
+def test_logistic_and_sv_against_independent_numpy_statements():
+    """The same third-implementation check as radon's for the other two data models (round 6: logistic's
+    deterministic mode evaluates its per-observation logarithm by the table-driven exmc_log_tab): numpy / scipy,
+    the distributions' formulas with Nx's f32 literals, no code shared with oracle/exmc_oracle.c. logistic
+    (STANDARD_BENCHMARKS.md:41-49, bernoulli.ex:17-27 with its 1e-7 clip), sv (STANDARD_BENCHMARKS.md:51-61,
+    student_t.ex:15-29 with the reference's f32-coefficient Lanczos lgamma, math.ex:9-52)."""
+    from scipy.special import gammaln
+    from exmc_amd import models
+    f32 = lambda x: float(np.float32(x))   # noqa: E731
+    log_2pi = f32(np.log(float(np.float32(2 * np.pi))))
+    rng = np.random.default_rng(12)
+    # logistic
+    spec = models.logistic()
+    m = O.model_for(spec)
+    blob = np.asarray(spec.data)
+    X, y = blob[:500 * 20].reshape(500, 20), blob[500 * 20:]
+    lo, hi = f32(1e-7), 1.0 - f32(1e-7)
+    for _ in range(4):
+        q = rng.normal(size=21) * 0.4
+        eta = q[0] + X @ q[1:]
+        pc = np.clip(1.0 / (1.0 + np.exp(-eta)), lo, hi)
+        ref = np.sum(-0.5 * ((q / 10.0) ** 2 + log_2pi + 2 * np.log(10.0))) + np.sum(np.where(y == 1.0, np.log(pc), np.log(1.0 - pc)))
+        for cfg in (O.Cfg(0, 1), O.Cfg(1, 1), O.Cfg(1, 16), O.Cfg(1, 64)):
+            lp, _ = m.logp_grad(q, cfg)
+            assert abs(lp - ref) <= 2e-12 * abs(ref), cfg.lanes
+    # sv (the reference's lgamma is Lanczos g = 7 with f32-rounded coefficients, math.ex:9-52 -- about 5e-8 from the
+    # true function, so it is restated here, from the published constants, rather than replaced by scipy's)
+    LANCZOS = [0.99999999999980993, 676.5203681218851, -1259.1392167224028, 771.32342877765313, -176.61502916214059,
+               12.507343278686905, -0.13857109526572012, 9.9843695780195716e-6, 1.5056327351493116e-7]
+
+    def lgamma_ref(x):
+        ag = f32(LANCZOS[0]) + sum(f32(c) / (x + i) for i, c in enumerate(LANCZOS[1:]))
+        t = x + 6.5
+        return f32(0.5 * np.log(2 * np.pi)) + (x - 0.5) * np.log(t) - t + np.log(ag)
+    assert abs(lgamma_ref(5.0) - gammaln(5.0)) < 1e-6
+    r = sv_returns()
+    m = O.Model(O.SV, 102, r)
+    for _ in range(4):
+        q = rng.normal(size=102) * 0.3
+        q[100], q[101] = np.log(0.15) + 0.2 * rng.normal(), np.log(10.0) + 0.2 * rng.normal()
+        s_, zs, zn = q[:100], q[100], q[101]
+        sigma, nu = np.exp(zs), np.exp(zn)
+        prior = (f32(np.log(50.0)) - 50.0 * sigma + zs) + (f32(np.log(f32(0.1))) - f32(0.1) * nu + zn)
+        e = np.diff(np.concatenate([[0.0], s_])) / sigma
+        walk = np.sum(-0.5 * (e * e + log_2pi + 2 * np.log(sigma)))
+        z = r * np.exp(-s_)
+        lik = np.sum(lgamma_ref((nu + 1) / 2) - lgamma_ref(nu / 2) - 0.5 * np.log(nu * f32(np.pi)) - s_
+                     - (nu + 1) / 2 * np.log1p(z * z / nu))
+        ref = prior + walk + lik
+        for cfg in (O.Cfg(0, 1), O.Cfg(1, 64)):
+            lp, _ = m.logp_grad(q, cfg)
+            assert abs(lp - ref) <= 5e-12 * abs(ref), (cfg.lanes, lp, ref)
+
+
 def test_single_transition_tolerance_between_modes():
     """One NUTS transition from the same state and rng: integer outputs identical, floats within
     1e-9 relative, for libm vs deterministic math and G = 1 vs 16."""
