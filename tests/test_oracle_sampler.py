@@ -192,6 +192,44 @@ def test_logistic_and_sv_against_independent_numpy_statements():
             assert abs(lp - ref) <= 5e-12 * abs(ref), (cfg.lanes, lp, ref)
 
 
+def test_eight_schools_and_simple_against_independent_numpy_statements():
+    """The two remaining BASELINE models, written once more with numpy (f32 literals as Nx has them).
+    eight_schools non-centred (validate_posteriordb.exs:246-324): mu ~ N(0, 5), tau ~ HalfCauchy(5) [:log],
+    theta_trans_j ~ N(0, 1), and the script's Custom likelihood sum_j [-0.5 z_j^2 - log sigma_j] with
+    z_j = (y_j - (mu + tau theta_trans_j)) / sigma_j (it drops the 0.5 log 2 pi). simple (build-defined):
+    mu ~ N(0, 5), sigma ~ Exponential(1) [:log], ten observations N(mu, sigma)."""
+    f32 = lambda x: float(np.float32(x))   # noqa: E731
+    log_2pi = f32(np.log(float(np.float32(2 * np.pi))))
+    log_2_over_pi = f32(np.log(2 / np.pi))
+    rng = np.random.default_rng(21)
+    y = np.array([28.0, 8.0, -3.0, 7.0, -1.0, 1.0, 18.0, 12.0])
+    sg = np.array([15.0, 10.0, 16.0, 11.0, 9.0, 11.0, 10.0, 18.0])
+    m = O.eight_schools()
+
+    def normal(x, mu, s):
+        return -0.5 * (((x - mu) / s) ** 2 + log_2pi + 2 * np.log(s))
+    for _ in range(5):
+        q = rng.normal(size=10) * 0.8
+        mu, zt, th = q[0], q[1], q[2:]
+        tau = np.exp(zt)
+        z = (y - (mu + tau * th)) / sg
+        ref = (np.sum(-0.5 * z * z - np.log(sg)) + normal(mu, 0.0, 5.0)
+               + (log_2_over_pi - np.log(5.0) - np.log1p((tau / 5.0) ** 2) + zt) + np.sum(normal(th, 0.0, 1.0)))
+        for cfg in (O.Cfg(0, 1), O.Cfg(1, 1), O.Cfg(1, 16)):
+            lp, _ = m.logp_grad(q, cfg)
+            assert abs(lp - ref) <= 2e-12 * abs(ref), cfg.lanes
+    from exmc_amd import models
+    obs = np.asarray(models.simple().data)
+    m = O.simple()
+    for _ in range(5):
+        q = rng.normal(size=2) * 0.7
+        sigma = np.exp(q[1])
+        ref = normal(q[0], 0.0, 5.0) + ((0.0 - sigma) + q[1]) + np.sum(normal(obs, q[0], sigma))
+        for cfg in (O.Cfg(0, 1), O.Cfg(1, 1)):
+            lp, _ = m.logp_grad(q, cfg)
+            assert abs(lp - ref) <= 2e-12 * abs(ref)
+
+
 def test_single_transition_tolerance_between_modes():
     """One NUTS transition from the same state and rng: integer outputs identical, floats within
     1e-9 relative, for libm vs deterministic math and G = 1 vs 16."""
