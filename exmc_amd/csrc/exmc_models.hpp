@@ -1658,6 +1658,9 @@ namespace exmc {
 constexpr bool kGenLdsTable = EXMC_GEN_TABLE_IN_LDS != 0;
 }
 #endif
+#ifndef EXMC_GEN_FAST_WINDOW
+#define EXMC_GEN_FAST_WINDOW 1
+#endif
 #ifdef EXMC_GEN_LANES
 // the lane function twice: its tables in global memory, and in an LDS image the NUTS and warmup
 // workgroups stage once per kernel (a lone wave per SIMD would otherwise sit out an L2 round trip
@@ -1679,6 +1682,83 @@ constexpr bool kGenLdsTable = EXMC_GEN_TABLE_IN_LDS != 0;
 #define EXMC_GEN_LT(i) exmc::exmc_dyn_lds[ltoff + (i)]
 #define EXMC_GEN_IT(i) ((const int*)(exmc::exmc_dyn_lds + ltoff + EXMC_GEN_IOFF))[i]
 #include EXMC_CUSTOM_HEADER
+#if EXMC_GEN_FAST_WINDOW
+// Round 6 -- the fast window of the hand-written kinds, generically: the SAME generated text compiled once more
+// with exp / log / log1p as the main paths of the same algorithms (no special-case branches, v_ldexp_f64
+// scaling; the bits of the general functions on their domain, exmc_detmath.h) and every argument WATCHED:
+// a lane whose argument leaves the domain (an exp argument beyond +-700, a log argument that is not a
+// positive normal number, NaN) clears exmc_gen_ok, and a wavefront that saw one evaluates the exact form
+// again (Custom::logp_grad below; the function only stores to its strips, so a second evaluation simply
+// overwrites the first). A general exp / log is three to four compare-and-branch guards per call and a
+// two-product scaling; a generated body holds one to a dozen calls per unit.
+#undef EXMC_GENL_EXP
+#undef EXMC_GENL_LOG
+#undef EXMC_GENL_LOG1P
+#undef EXMC_GEN_BATCH_LOG
+#undef EXMC_GEN_BATCH_EXP
+#undef EXMC_GEN_BATCH_LOG1P
+#define EXMC_GENL_EXP(x) exmc::genf_exp((x), exmc_gen_ok)
+#define EXMC_GENL_LOG(x) exmc::genf_log((x), exmc_gen_ok)
+#define EXMC_GENL_LOG1P(x) exmc::genf_log1p((x), exmc_gen_ok)
+#define EXMC_GEN_BATCH_LOG(n, b) exmc::lane_batch<EXMC_GEN_LANES, n>(b, l, [&](double a_) { return EXMC_GENL_LOG(a_); })
+#define EXMC_GEN_BATCH_EXP(n, b) exmc::lane_batch<EXMC_GEN_LANES, n>(b, l, [&](double a_) { return EXMC_GENL_EXP(a_); })
+#define EXMC_GEN_BATCH_LOG1P(n, b) exmc::lane_batch<EXMC_GEN_LANES, n>(b, l, [&](double a_) { return EXMC_GENL_LOG1P(a_); })
+namespace exmc {
+__device__ __forceinline__ double genf_exp(double x, bool& ok) {
+  ok = ok && (fabs(x) <= 700.0);                       // false for a NaN
+  return exmc_exp_pm200_v(x);                          // the main path: valid while the result is a normal number
+}
+__device__ __forceinline__ double genf_log(double x, bool& ok) {
+  ok = ok && __builtin_amdgcn_class(x, 0x100);         // a positive normal number
+  return exmc_log_normal_v(x);
+}
+__device__ __forceinline__ double genf_log1p(double x, bool& ok) {
+  const double u = 1.0 + x;                            // exmc_log1p: log(u) + (x - (u - 1)) / u, x itself when u == 1
+  ok = ok && __builtin_amdgcn_class(u, 0x100);
+  const double r = exmc_log_normal_v(u) + (x - (u - 1.0)) / u;
+  return (u == 1.0) ? x : r;
+}
+}  // namespace exmc
+#undef EXMC_GEN_LANES_NAME
+#undef EXMC_GEN_LT
+#undef EXMC_GEN_IT
+#undef EXMC_GEN_CTX_DECL
+#define EXMC_GEN_CTX_DECL , int shoff, bool& exmc_gen_ok
+#define EXMC_GEN_LANES_NAME exmc_gen_lanes_global_fast
+#define EXMC_GEN_LT(i) lt[i]
+#define EXMC_GEN_IT(i) ((const int*)(lt + EXMC_GEN_IOFF))[i]
+#include EXMC_CUSTOM_HEADER
+#undef EXMC_GEN_LANES_NAME
+#undef EXMC_GEN_LT
+#undef EXMC_GEN_IT
+#undef EXMC_GEN_CTX_DECL
+#define EXMC_GEN_CTX_DECL , int shoff, int ltoff, bool& exmc_gen_ok
+#define EXMC_GEN_LANES_NAME exmc_gen_lanes_lds_fast
+#define EXMC_GEN_LT(i) exmc::exmc_dyn_lds[ltoff + (i)]
+#define EXMC_GEN_IT(i) ((const int*)(exmc::exmc_dyn_lds + ltoff + EXMC_GEN_IOFF))[i]
+#include EXMC_CUSTOM_HEADER
+// (back to the exact forms for whatever is included below)
+#undef EXMC_GENL_EXP
+#undef EXMC_GENL_LOG
+#undef EXMC_GENL_LOG1P
+#undef EXMC_GEN_BATCH_LOG
+#undef EXMC_GEN_BATCH_EXP
+#undef EXMC_GEN_BATCH_LOG1P
+#undef EXMC_GEN_CTX_DECL
+#define EXMC_GEN_CTX_DECL , int shoff, int ltoff
+#ifdef EXMC_GENL_CALLED_MATH
+#define EXMC_GENL_EXP exmc_gen_exp_call
+#define EXMC_GENL_LOG exmc_gen_log_call
+#define EXMC_GENL_LOG1P exmc_gen_log1p_call
+#else
+#define EXMC_GENL_EXP exmc::Math<true>::exp
+#define EXMC_GENL_LOG exmc::Math<true>::log
+#define EXMC_GENL_LOG1P exmc_log1p
+#endif
+#define EXMC_GEN_BATCH_LOG(n, b) exmc::lane_batch<EXMC_GEN_LANES, n>(b, l, [](double a_) { return EXMC_GENL_LOG(a_); })
+#define EXMC_GEN_BATCH_EXP(n, b) exmc::lane_batch<EXMC_GEN_LANES, n>(b, l, [](double a_) { return EXMC_GENL_EXP(a_); })
+#define EXMC_GEN_BATCH_LOG1P(n, b) exmc::lane_batch<EXMC_GEN_LANES, n>(b, l, [](double a_) { return EXMC_GENL_LOG1P(a_); })
+#endif
 #if EXMC_GEN_LANES < 64
 // a third time for the one-chain warmup of a layout with fewer than 64 lanes per chain: the units of
 // a family over ALL 64 / G lane groups of the wavefront (group g takes the slots g, g + NG, ...), the
@@ -1787,6 +1867,15 @@ struct Custom<EXMC_GEN_LANES> : ModelDefaults {
       if (l + k * G < D) exmc_dyn_lds[shoff + l + k * G] = q[k];
     wave_lds_fence();
     const int* el = kEllRegs ? ln.ell : ((const int*)c.lt + EXMC_GEN_ELL_OFF + l * EXMC_GEN_NELL);
+#if EXMC_GEN_FAST_WINDOW
+    // the fast window first; the exact forms again if any lane of the wavefront left it (see above)
+    bool ok = true;
+    double r;
+    if (kLdsTable && ln.xoff >= 0) r = exmc_gen_lanes_lds_fast(c.lt, el, l, g, shoff, ln.xoff, ok);   // wave-uniform
+    else r = exmc_gen_lanes_global_fast(c.lt, el, l, g, shoff, ok);
+    if (__builtin_expect(__any(ok ? 0 : 1) == 0, 1)) return r;
+    wave_lds_fence();
+#endif
     if constexpr (kLdsTable) {
       if (ln.xoff >= 0) return exmc_gen_lanes_lds(c.lt, el, l, g, shoff, ln.xoff);   // wave-uniform
     }

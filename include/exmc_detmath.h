@@ -405,6 +405,10 @@ static __device__ __forceinline__ double exmc_log_normal_s(double x) {
   EXMC_LOG_MAIN(exmc_log_core_s, x, res)
   return res;
 }
+static __device__ __forceinline__ double exmc_log_normal_v(double x) {   /* ... with the vector-register cores */
+  EXMC_LOG_MAIN(exmc_log_core_v, x, res)
+  return res;
+}
 #undef EXMC_RHD
 #endif
 
