@@ -1257,7 +1257,8 @@ def generate(ir, ncp=True, vectorize=True, rewrite_passes=False, lanes=None, wav
     if lanes is None and len(nodes) <= MAX_NODES_SORTED:
         out.vec = codegen_vec.generate(ir, ncp=ncp) if (vectorize and plain) else None
     if out.vec is not None:
-        out.header += "\n" + out.vec["text"]
+        # (the plate layout's lane function is a section its users may include again, codegen_vec._emit)
+        out.header = "#ifndef EXMC_GEN_VEC_SECTION\n" + out.header + "\n" + out.vec["text"]
         out.data = np.concatenate([out.data, out.vec["vdata"]])
         out.lanes = codegen_vec.G
     if lanes is not None:

@@ -430,8 +430,17 @@ def _emit(g, D, s_out, gown, sg, scal_lp, nlr):
     L.append("/* one lane: s[0] = partial log-density of the vectorised terms, s[1..] = partial adjoints of"
              "\n * the shared variables, *gown = adjoint of the lane's own variable, sg[] / *slp = the"
              " scalar part */")
-    L.append("EXMC_GEN_FN void exmc_gen_lane(const double* vc, const double* lc, const double* qs, "
-             "double qown,\n                               double* s, double* gown, double* sg, double* slp) {")
+    # everything above is included once; the lane function is a section of its own, so that a device
+    # build can compile the same text a second time under another name with watched main-path
+    # exp / log (exmc_models.hpp "fast window": EXMC_GEN_VEC_SECTION, EXMC_GENV_NAME, EXMC_GENV_CTX_DECL)
+    L.append("#endif   /* !EXMC_GEN_VEC_SECTION */")
+    L.append("#ifndef EXMC_GENV_NAME")
+    L.append("#define EXMC_GENV_NAME exmc_gen_lane")
+    L.append("#define EXMC_GENV_CTX_DECL")
+    L.append("#endif")
+    L.append("EXMC_GEN_FN void EXMC_GENV_NAME(const double* vc, const double* lc, const double* qs, "
+             "double qown,\n                               double* s, double* gown, double* sg, double* slp"
+             " EXMC_GENV_CTX_DECL) {")
     for i in sorted(live):
         if not g.const[i] and g.ops[i][0] not in ("q", "qown"):
             L.append(stmt(i, "dyn"))

@@ -1661,6 +1661,44 @@ constexpr bool kGenLdsTable = EXMC_GEN_TABLE_IN_LDS != 0;
 #ifndef EXMC_GEN_FAST_WINDOW
 #define EXMC_GEN_FAST_WINDOW 1
 #endif
+#if EXMC_GEN_FAST_WINDOW
+// the watched main paths of the fast window (the lane layouts and the plate layout below)
+namespace exmc {
+__device__ __forceinline__ double genf_exp(double x, bool& ok) {
+  ok = ok && (fabs(x) <= 700.0);                       // false for a NaN
+  return exmc_exp_pm200_v(x);                          // the main path: valid while the result is a normal number
+}
+__device__ __forceinline__ double genf_log(double x, bool& ok) {
+  ok = ok && __builtin_amdgcn_class(x, 0x100);         // a positive normal number
+  return exmc_log_normal_v(x);
+}
+__device__ __forceinline__ double genf_log1p(double x, bool& ok) {
+  const double u = 1.0 + x;                            // exmc_log1p: log(u) + (x - (u - 1)) / u, x itself when u == 1
+  ok = ok && __builtin_amdgcn_class(u, 0x100);
+  const double r = exmc_log_normal_v(u) + (x - (u - 1.0)) / u;
+  return (u == 1.0) ? x : r;
+}
+}  // namespace exmc
+#if defined(EXMC_GEN_VEC) && !defined(EXMC_GENV_CALLED_MATH)
+#define EXMC_GENV_FAST 1
+// the plate layout's lane function once more, as the lane layouts' below: the same text with watched
+// main-path exp / log / log1p (Custom<16>::logp_grad evaluates the exact one again when a lane's
+// argument left the domain)
+#define EXMC_GEN_VEC_SECTION
+#undef EXMC_GENV_NAME
+#undef EXMC_GENV_CTX_DECL
+#undef EXMC_GENV_EXP
+#undef EXMC_GENV_LOG
+#undef EXMC_GENV_LOG1P
+#define EXMC_GENV_NAME exmc_gen_lane_fast
+#define EXMC_GENV_CTX_DECL , bool& exmc_gen_ok
+#define EXMC_GENV_EXP(x) exmc::genf_exp((x), exmc_gen_ok)
+#define EXMC_GENV_LOG(x) exmc::genf_log((x), exmc_gen_ok)
+#define EXMC_GENV_LOG1P(x) exmc::genf_log1p((x), exmc_gen_ok)
+#include EXMC_CUSTOM_HEADER
+#undef EXMC_GEN_VEC_SECTION
+#endif
+#endif
 #ifdef EXMC_GEN_LANES
 // the lane function twice: its tables in global memory, and in an LDS image the NUTS and warmup
 // workgroups stage once per kernel (a lone wave per SIMD would otherwise sit out an L2 round trip
@@ -1703,22 +1741,6 @@ constexpr bool kGenLdsTable = EXMC_GEN_TABLE_IN_LDS != 0;
 #define EXMC_GEN_BATCH_LOG(n, b) exmc::lane_batch<EXMC_GEN_LANES, n>(b, l, [&](double a_) { return EXMC_GENL_LOG(a_); })
 #define EXMC_GEN_BATCH_EXP(n, b) exmc::lane_batch<EXMC_GEN_LANES, n>(b, l, [&](double a_) { return EXMC_GENL_EXP(a_); })
 #define EXMC_GEN_BATCH_LOG1P(n, b) exmc::lane_batch<EXMC_GEN_LANES, n>(b, l, [&](double a_) { return EXMC_GENL_LOG1P(a_); })
-namespace exmc {
-__device__ __forceinline__ double genf_exp(double x, bool& ok) {
-  ok = ok && (fabs(x) <= 700.0);                       // false for a NaN
-  return exmc_exp_pm200_v(x);                          // the main path: valid while the result is a normal number
-}
-__device__ __forceinline__ double genf_log(double x, bool& ok) {
-  ok = ok && __builtin_amdgcn_class(x, 0x100);         // a positive normal number
-  return exmc_log_normal_v(x);
-}
-__device__ __forceinline__ double genf_log1p(double x, bool& ok) {
-  const double u = 1.0 + x;                            // exmc_log1p: log(u) + (x - (u - 1)) / u, x itself when u == 1
-  ok = ok && __builtin_amdgcn_class(u, 0x100);
-  const double r = exmc_log_normal_v(u) + (x - (u - 1.0)) / u;
-  return (u == 1.0) ? x : r;
-}
-}  // namespace exmc
 #undef EXMC_GEN_LANES_NAME
 #undef EXMC_GEN_LT
 #undef EXMC_GEN_IT
@@ -1946,7 +1968,12 @@ struct Custom<16> : ModelDefaults {
                                                      const double (&q)[DPL], double (&g)[DPL]) {
     double qs[D], s[EXMC_GEN_NS], sg[D], gown, slp;
     bcast_all(q[0], qs, std::make_integer_sequence<int, D>{});
-    exmc_gen_lane(c.vc, ln.lc, qs, q[0], s, &gown, sg, &slp);
+#ifdef EXMC_GENV_FAST
+    bool ok = true;
+    exmc_gen_lane_fast(c.vc, ln.lc, qs, q[0], s, &gown, sg, &slp, ok);
+    if (__builtin_expect(__any(!ok), 0))   // wave-uniform: some lane's exp / log argument left the main path's domain
+#endif
+      exmc_gen_lane(c.vc, ln.lc, qs, q[0], s, &gown, sg, &slp);
     group_allsum_n<G, EXMC_GEN_NS>(s);
     constexpr int smap[D] = EXMC_GEN_SMAP;
     double gi = 0.0;
