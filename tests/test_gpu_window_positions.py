@@ -59,3 +59,41 @@ def test_positions_that_leave_the_window_bit_exact(hip, name, factory, lane_list
             assert np.array_equal(og, g[c], equal_nan=True), (name, lanes, c, q[c], og, g[c])
             n_nonfinite += not (np.isfinite(olp) and np.all(np.isfinite(og)))
         assert 0 < n_nonfinite < n, (name, lanes, n_nonfinite)
+
+
+@pytest.mark.parametrize("name,factory,lane_list", _kinds(), ids=lambda x: x if isinstance(x, str) else "")
+def test_multi_step_through_exploding_trajectories_bit_exact(hip, name, factory, lane_list):
+    """multi_step_fn (the batched leapfrog, B2) along trajectories that blow up: a step size far too large
+    and momenta from 1 to 1e150, so that within a dozen steps the positions pass through every magnitude up to
+    infinity and NaN -- every step of every chain against the checker."""
+    spec = factory()
+    comp = sampler.compile(spec)
+    om = O.model_for(spec)
+    rng = np.random.default_rng(31)
+    C_, n, d = 48, 12, spec.d
+    q0 = spec.to_unconstrained(spec.default_init)
+    q = np.ascontiguousarray(q0[None, :] + rng.normal(size=(C_, d)) * 0.3)
+    scale = 10.0 ** rng.choice([0, 0, 1, 2, 3, 5, 8, 20, 80, 150], size=(C_, 1))
+    scale[::4] = 1.0                                     # every fourth chain stays tame
+    p = np.ascontiguousarray(rng.normal(size=(C_, d)) * scale)
+    im = np.ascontiguousarray(rng.uniform(0.5, 2.0, size=d))
+    for lanes in lane_list:
+        cfg = O.Cfg(1, lanes)
+        g = np.array([om.logp_grad(q[c], cfg)[1] for c in range(C_)])
+        for eps in (0.05, 1.5):
+            aq = np.zeros((C_, n, d)); ap = np.zeros((C_, n, d)); ag = np.zeros((C_, n, d))
+            alp = np.zeros((C_, n))
+            _lib.check(hip.exmc_hip_multi_step_host(comp.h, _dp(q), _dp(p), _dp(g), eps, _dp(im), n, C_,
+                                                    lanes, _dp(aq), _dp(ap), _dp(alp), _dp(ag)))
+            bad = 0
+            for c in range(C_):
+                oq, op, olp, og = om.multi_step(q[c], p[c], g[c], eps, im, n, cfg)
+                assert np.array_equal(oq, aq[c], equal_nan=True), (name, lanes, eps, c)
+                assert np.array_equal(op, ap[c], equal_nan=True), (name, lanes, eps, c)
+                assert np.array_equal(olp, alp[c], equal_nan=True), (name, lanes, eps, c)
+                assert np.array_equal(og, ag[c], equal_nan=True), (name, lanes, eps, c)
+                with np.errstate(invalid="ignore"):
+                    bad += (not np.all(np.isfinite(olp))) or bool(np.nanmax(np.abs(oq)) > 1e50)
+            if eps < 1.0:
+                assert bad < C_                           # at the small step size not every chain blew up
+        assert bad > 0                                    # (at the large one some did)
