@@ -97,3 +97,36 @@ def test_multi_step_through_exploding_trajectories_bit_exact(hip, name, factory,
             if eps < 1.0:
                 assert bad < C_                           # at the small step size not every chain blew up
         assert bad > 0                                    # (at the large one some did)
+
+
+def _sample_kinds():
+    import test_golden_traces as TG
+    return [("simple", models.simple, 1), ("eight_schools", models.eight_schools, 16),
+            ("sv", lambda: models.sv(TG.GOLD["sv_returns"]), 64), ("logistic", models.logistic, 16),
+            ("radon", models.radon, 64)]
+
+
+@pytest.mark.parametrize("spread", [6.0, 40.0])
+@pytest.mark.parametrize("name,factory,lanes", _sample_kinds(), ids=lambda x: x if isinstance(x, str) else "")
+def test_sample_from_a_hostile_start_bit_exact(hip, name, factory, lanes, spread):
+    """Sampler.sample/3 (step-size search, warmup, draws) started far from the mode -- every coordinate a few
+    (6) or many (40) units away on the unconstrained scale, scales from e^-100 to e^+100: the first trees
+    diverge at their first leaf or run into the clamps, the step-size search halves dozens of times, and the
+    adaptation has to walk back. The whole run against the checker, bit for bit."""
+    spec = factory()
+    comp = sampler.compile(spec)
+    om = O.model_for(spec)
+    rng = np.random.default_rng(37)
+    q_far = spec.to_unconstrained(spec.default_init) + rng.normal(size=spec.d) * spread
+    init = {n: float(np.exp(q_far[i])) if spec.transforms.get(n) == "log" else float(q_far[i])
+            for i, n in enumerate(spec.var_names)}
+    q0 = spec.to_unconstrained(init)
+    assert np.all(np.isfinite(q0))
+    nw, ns = (40, 12) if name == "sv" else (60, 25)
+    opts = dict(num_warmup=nw, num_samples=ns, seed=5, lanes_per_chain=lanes, max_tree_depth=8)
+    _, stats = sampler.sample_compiled(comp, init, opts)
+    t, st = O.sample(om, init_q=q0, num_warmup=nw, num_samples=ns, seed=5, cfg=O.Cfg(1, lanes), max_tree_depth=8)
+    assert stats["step_size"] == st.step_size or (np.isnan(stats["step_size"]) and np.isnan(st.step_size))
+    raw = stats["raw"]
+    for k in ("tree_depth", "n_steps", "divergent", "draws", "energy"):
+        assert np.array_equal(raw[k][0], t[k], equal_nan=True), (name, spread, k)
