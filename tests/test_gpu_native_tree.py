@@ -309,3 +309,62 @@ def test_merge_invariants_on_the_gpu_subtree_records(hip):
     assert np.array_equal(full["q_left_bin"], a["q_left_bin"]) and np.array_equal(full["p_left_bin"], a["p_left_bin"])
     assert np.array_equal(full["q_right_bin"], b["q_right_bin"]) and np.array_equal(full["p_right_bin"], b["p_right_bin"])
     assert np.array_equal(full["q_left_bin"], aq[:, 0]) and np.array_equal(full["q_right_bin"], aq[:, 7])
+
+
+@pytest.mark.parametrize("budget,max_depth,eps", [(31, 5, 0.35), (15, 10, 0.5)])
+def test_full_tree_on_poisoned_trajectories_bit_exact(hip, budget, max_depth, eps):
+    """build_full_tree_bin consumes PRE-COMPUTED trajectories (tree.ex:155-263), so what it does with a NaN
+    log-density, an infinite momentum or a 1e300 position is the tree code's own business (the divergence
+    test, log-sum-exp, the U-turn products, the multinomial pick): the same 48 chains as above with a few
+    entries of the forward / backward arrays replaced by such values -- every output against the checker's
+    restatement of tree.rs."""
+    L = O.lib()
+    om = O.eight_schools()
+    rng = np.random.default_rng(1000 + budget)
+    Cn, d = 48, 10
+    cfg = O.Cfg(1, 1)
+    im = np.ascontiguousarray(rng.uniform(0.5, 2.0, size=d))
+    q0 = rng.normal(size=(Cn, d)) * 0.5
+    p0 = rng.normal(size=(Cn, d)) / np.sqrt(im)
+    g0 = np.zeros((Cn, d)); logp0 = np.zeros(Cn); jlp0 = np.zeros(Cn)
+    fwd = [np.zeros((Cn, budget, d)) for _ in range(3)] + [np.zeros((Cn, budget))]
+    bwd = [np.zeros((Cn, budget, d)) for _ in range(3)] + [np.zeros((Cn, budget))]
+    for c in range(Cn):
+        logp0[c], g0[c] = om.logp_grad(q0[c], cfg)
+        jlp0[c] = logp0[c] - L.exo_kinetic_energy(O.dptr(np.ascontiguousarray(p0[c])), O.dptr(im), d, cfg)
+        aq, ap, alp, ag = om.multi_step(q0[c], p0[c], g0[c], eps, im, budget, cfg)
+        fwd[0][c], fwd[1][c], fwd[2][c], fwd[3][c] = aq, ap, ag, alp
+        aq, ap, alp, ag = om.multi_step(q0[c], p0[c], g0[c], -eps, im, budget, cfg)
+        bwd[0][c], bwd[1][c], bwd[2][c], bwd[3][c] = aq, ap, ag, alp
+    poison = [np.nan, np.inf, -np.inf, 1e300, -1e300, 1e200, -1e200, 0.0, -0.0, 5e-324]
+    n_poisoned = 0
+    for c in range(Cn):
+        if c % 4 == 0:
+            continue                                     # every fourth chain stays clean
+        for _ in range(int(rng.integers(1, 4))):
+            side = fwd if rng.integers(2) else bwd
+            which = int(rng.integers(4))
+            step = int(rng.integers(min(budget, 8)))     # early steps: the tree reaches them
+            v = poison[int(rng.integers(len(poison)))]
+            if which == 3:
+                side[3][c, step] = v
+            else:
+                side[which][c, step, int(rng.integers(d))] = v
+            n_poisoned += 1
+    assert n_poisoned > Cn // 2
+    seeds = rng.integers(0, 10 ** 12, size=Cn).astype(np.uint64)
+    res = native_tree.build_full_tree_bin(q0, p0, g0, logp0, fwd[0], fwd[1], fwd[3], fwd[2],
+                                          bwd[0], bwd[1], bwd[3], bwd[2], im, jlp0, max_depth, d, seeds)
+    n_div = 0
+    for c in range(Cn):
+        qo, go, r = _oracle_full_tree(q0[c], p0[c], g0[c], logp0[c], fwd[0][c], fwd[1][c], fwd[3][c],
+                                      fwd[2][c], bwd[0][c], bwd[1][c], bwd[3][c], bwd[2][c], im,
+                                      jlp0[c], max_depth, seeds[c])
+        assert (res["n_steps"][c], res["depth"][c], bool(res["divergent"][c])) == \
+            (r.n_steps, r.depth, bool(r.divergent)), c
+        assert np.array_equal(np.array([res["accept_sum"][c], res["logp"][c]]),
+                              np.array([r.accept_sum, r.logp]), equal_nan=True), c
+        assert np.array_equal(res["q_bin"][c], qo, equal_nan=True), c
+        assert np.array_equal(res["grad_bin"][c], go, equal_nan=True), c
+        n_div += bool(r.divergent)
+    assert 0 < n_div < Cn
