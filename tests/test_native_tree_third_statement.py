@@ -89,3 +89,51 @@ def test_subtree_record_agrees_with_the_third_statement(depth, right):
             assert np.array_equal(got[row], np.array(s[key])), (k, key)
         assert (sc[0], sc[1], sc[2]) == (s["lpp"], s["lsw"], s["acc"]), k
         assert list(ints) == [s["n"], int(s["div"]), int(s["turn"]), s["depth"]], k
+
+
+
+POISON = [float("nan"), float("inf"), float("-inf"), 1e300, -1e300, 1e200, -1e200, 0.0, -0.0, 5e-324]
+
+
+@pytest.mark.parametrize("eps,max_depth,budget", [(0.3, 5, 32), (0.05, 4, 16), (1.6, 6, 64)])
+def test_full_tree_on_poisoned_trajectories(eps, max_depth, budget):
+    """The same comparison on trajectories with NaN / infinite / 1e300 entries in a few early states: what
+    tree.rs does with them (f64 comparisons that are false for NaN, exp / ln on infinities, the U-turn dot
+    products, the multinomial pick) is restated twice -- in C and in Python -- and both must agree in every
+    output bit, NaN for NaN."""
+    L = O.lib()
+    L.exo_nt_set_math_mode(0)
+    m = O.eight_schools()
+    rng = np.random.default_rng(7000 + budget)
+    n_div = n_cases = 0
+    for k in range(40):
+        q = rng.normal(size=10) * 0.7
+        im = 0.5 + rng.uniform(size=10)
+        p = rng.normal(size=10) / np.sqrt(im)
+        lp, g = m.logp_grad(q)
+        jlp0 = lp - sum(0.5 * a * b * a for a, b in zip(p, im))
+        ch = _chains(m, q, p, g, eps, im, budget)
+        for _ in range(int(rng.integers(1, 4))):
+            side = ch["fwd" if rng.integers(2) else "bwd"]
+            key = ("q", "p", "logp", "g")[int(rng.integers(4))]
+            step = int(rng.integers(min(budget, 8)))       # early states: the tree reaches them
+            v = POISON[int(rng.integers(len(POISON)))]
+            if key == "logp":
+                side[key][step] = v
+            else:
+                side[key][step, int(rng.integers(10))] = v
+        seed = 3000 + k
+        qo, go, r = np.zeros(10), np.zeros(10), O.TreeResult()
+        f, b = ch["fwd"], ch["bwd"]
+        L.exo_nt_build_full_tree(O.dptr(q), O.dptr(p), O.dptr(g), lp, O.dptr(f["q"]), O.dptr(f["p"]), O.dptr(f["logp"]),
+                                 O.dptr(f["g"]), budget, O.dptr(b["q"]), O.dptr(b["p"]), O.dptr(b["logp"]), O.dptr(b["g"]),
+                                 budget, O.dptr(np.ascontiguousarray(im)), jlp0, max_depth, 10, seed, O.dptr(qo), O.dptr(go),
+                                 C.byref(r))
+        py = PN.build_full_tree(q, p, g, lp, f, b, list(im), jlp0, max_depth, seed)
+        assert (r.depth, r.n_steps, bool(r.divergent)) == (py["depth"], py["n_steps"], py["divergent"]), k
+        assert np.array_equal(np.array([r.accept_sum, r.logp]), np.array([py["accept_sum"], py["logp"]]), equal_nan=True), k
+        assert np.array_equal(qo, np.array(py["q"]), equal_nan=True), k
+        assert np.array_equal(go, np.array(py["grad"]), equal_nan=True), k
+        n_div += bool(r.divergent)
+        n_cases += 1
+    assert 0 < n_div < n_cases
