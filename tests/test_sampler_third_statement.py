@@ -53,3 +53,20 @@ def test_window_schedule_literals():
     assert PS.windows(75, 950) == [(75, 100), (100, 150), (150, 250), (250, 450), (450, 950)]
     assert PS.windows(50, 100) == [(50, 75), (75, 100)]
     assert PS.windows(10, 10) == []
+
+
+@pytest.mark.parametrize("name,spread,seed", [("eight_schools", 6.0, 1), ("eight_schools", 40.0, 2), ("simple", 40.0, 3),
+                                              ("std_normal", 300.0, 4)])
+def test_whole_chains_from_hostile_starts_agree_with_the_third_statement(name, spread, seed):
+    """The same comparison started far from the mode (the step-size search halves dozens of times, first trees diverge
+    at their first leaf or run into the transforms' clamps, Welford windows see a drifting chain): where NaN or an
+    infinite energy enters the control flow, both statements must take the same branch."""
+    m = {"eight_schools": O.eight_schools, "simple": O.simple, "std_normal": lambda: O.std_normal(4)}[name]()
+    q0 = np.random.default_rng(seed).normal(size=m.d) * spread
+    t, st = O.sample(m, q0, num_warmup=60, num_samples=20, max_tree_depth=8, seed=seed)
+    p, ps = PS.sample(m, q0, num_warmup=60, num_samples=20, max_tree_depth=8, seed=seed)
+    assert st.step_size == ps["step_size"]
+    assert np.array_equal(np.array(st.inv_mass[:m.d]), ps["inv_mass"], equal_nan=True)
+    assert st.divergences == ps["divergences"]
+    for k in ("draws", "logp", "tree_depth", "n_steps", "divergent", "accept_prob", "energy"):
+        assert np.array_equal(t[k], p[k], equal_nan=True), (name, k)
