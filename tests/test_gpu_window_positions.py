@@ -130,3 +130,31 @@ def test_sample_from_a_hostile_start_bit_exact(hip, name, factory, lanes, spread
     raw = stats["raw"]
     for k in ("tree_depth", "n_steps", "divergent", "draws", "energy"):
         assert np.array_equal(raw[k][0], t[k], equal_nan=True), (name, spread, k)
+
+
+@pytest.mark.parametrize("spread", [6.0, 40.0])
+@pytest.mark.parametrize("name,lanes", [("eight_schools", 16), ("eight_schools", 1), ("simple", 1)])
+def test_dense_mass_warmup_from_a_hostile_start_bit_exact(hip, name, lanes, spread):
+    """opts[:dense_mass] from a start far from the mode: the dense Welford windows collect a chain that is still
+    walking in (near-singular covariances before the shrinkage), the Cholesky factor and the step size must be
+    the checker's bits all the same, and so must draws under that mass."""
+    spec = models.eight_schools() if name == "eight_schools" else models.simple()
+    om = O.eight_schools() if name == "eight_schools" else O.simple()
+    comp = sampler.compile(spec)
+    rng = np.random.default_rng(47)
+    q_far = spec.to_unconstrained(spec.default_init) + rng.normal(size=spec.d) * spread
+    init = {n: float(np.exp(q_far[i])) if spec.transforms.get(n) == "log" else float(q_far[i])
+            for i, n in enumerate(spec.var_names)}
+    q0 = spec.to_unconstrained(init)
+    opts = dict(num_warmup=320, num_samples=20, seed=19, lanes_per_chain=lanes, dense_mass=True)
+    tuning = sampler.warmup(comp, init, opts)
+    st, cov, chol = O.warmup_dense(om, q0, num_warmup=320, seed=19, cfg=O.Cfg(1, lanes))
+    assert st.step_size == tuning["epsilon"] or (np.isnan(st.step_size) and np.isnan(tuning["epsilon"]))
+    assert np.array_equal(cov, tuning["cov"], equal_nan=True)
+    assert np.array_equal(chol, tuning["chol_cov"], equal_nan=True)
+    _, _, extra = sampler.sample_compiled_tuned(comp, tuning, init, opts, num_chains=3)
+    for c in range(3):
+        t, _ = O.sample_tuned_dense(om, st.step_size, cov, chol, q0, num_samples=20, seed=19 + 7919 * c,
+                                    cfg=O.Cfg(1, lanes))
+        for k in ("draws", "tree_depth", "n_steps", "divergent", "energy", "accept_prob"):
+            assert np.array_equal(t[k], extra["raw"][k][c], equal_nan=True), (name, lanes, spread, c, k)
