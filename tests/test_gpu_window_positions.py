@@ -158,3 +158,30 @@ def test_dense_mass_warmup_from_a_hostile_start_bit_exact(hip, name, lanes, spre
                                     cfg=O.Cfg(1, lanes))
         for k in ("draws", "tree_depth", "n_steps", "divergent", "energy", "accept_prob"):
             assert np.array_equal(t[k], extra["raw"][k][c], equal_nan=True), (name, lanes, spread, c, k)
+
+
+@pytest.mark.parametrize("name,factory,lanes", _sample_kinds(), ids=lambda x: x if isinstance(x, str) else "")
+def test_chain_batches_from_a_hostile_start_bit_exact(hip, name, factory, lanes):
+    """sample_chains (vectorized: the shared warmup of chain 0, then the batch seeded seed + 7919 i) from a start 6
+    units from the mode on the unconstrained scale, with a SHORT warmup -- the batch starts its draws with a step size
+    and a mass that are not yet right for where the chains are, so the chains of a wavefront diverge, turn and run
+    to the depth cap side by side. Tuning and every per-draw output against the checker."""
+    spec = factory()
+    comp = sampler.compile(spec)
+    om = O.model_for(spec)
+    rng = np.random.default_rng(53)
+    q_far = spec.to_unconstrained(spec.default_init) + rng.normal(size=spec.d) * 6.0
+    init = {n: float(np.exp(q_far[i])) if spec.transforms.get(n) == "log" else float(q_far[i])
+            for i, n in enumerate(spec.var_names)}
+    q0 = spec.to_unconstrained(init)
+    nc, nw, ns = (6, 25, 8) if name == "sv" else (21, 30, 15)
+    opts = dict(num_warmup=nw, num_samples=ns, seed=61, lanes_per_chain=lanes, warmup_lanes=lanes, max_tree_depth=7)
+    tuning = sampler.warmup(comp, init, opts)
+    t, st = O.sample_chains(om, nc, init_q=q0, num_warmup=nw, num_samples=ns, seed=61, cfg=O.Cfg(1, lanes),
+                            max_tree_depth=7, n_threads=8)
+    assert st.step_size == tuning["epsilon"]
+    assert np.array_equal(np.array(st.inv_mass[:spec.d]), tuning["inv_mass"])
+    _, _, extra = sampler.sample_compiled_tuned(comp, tuning, init, opts, num_chains=nc)
+    raw = extra["raw"]
+    for k in ("tree_depth", "n_steps", "divergent", "draws", "logp", "accept_prob", "energy"):
+        assert np.array_equal(t[k], raw[k], equal_nan=True), (name, k)
