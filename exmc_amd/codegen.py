@@ -1476,6 +1476,8 @@ def build_plugin(gen, force=False, verbose=False):
             parts = [(k, lay) for k in (3, 4, 7, 1, 2, 5) for lay in layouts]
             if 3 in layouts and gen.lanes < 64:     # the one-chain warmup form of the lane layout (CustomSplit)
                 parts.append((6, 3))
+            if 3 in layouts and "#define EXMC_GEN_WG 1" in gen.header:   # the workgroup form of the sampling kernel
+                parts.append((8, 3))
             part_flags = ([f for f in flags if f != "-fPIC"] + ["--cuda-device-only"]) if modules else host_flags
             ext = "hsaco" if modules else "o"
             jobs += [([hipcc] + part_flags + defs + ["-DEXMC_PLUGIN_PART=%d" % k, "-DEXMC_PLUGIN_LAYOUT=%d" % lay, "-c", "-o",

@@ -68,6 +68,7 @@ from . import codegen as cg
 MIN_FAMILY = 4          # fewer units than this are evaluated by every lane (the uniform part)
 # doubles of table rows / gathered variables fetched ahead per lane (emit_family), by resident waves
 # per SIMD: a lone wave has 512 registers and nobody to hide its latency, a pair 256 each
+PAIR_MIN_COLS = 8      # families of at least this many per-unit columns store them in interleaved pairs (generate)
 PREFETCH_DOUBLES = {1: int(__import__("os").environ.get("EXMC_GEN_PREFETCH", "64")), 2: 24}
 
 
@@ -854,11 +855,28 @@ def generate(g, term_roots, custom_roots, D, G, waves_per_simd=1):
                 ell.append(contrib[i][j] if (i < D and j < len(contrib[i])) else zero_cell)
 
     # ---- table layout: [uc][double columns][int32 columns (gather indices, owner lists)] ----
+    # Per-unit columns in PAIRS since round 6: columns 2p and 2p + 1 of a family are interleaved over its units
+    # (unit u's two entries at doff + 2 p npad + 2 u, + 1; an odd last column alone, one double per unit), the first
+    # pair on a 128-byte boundary of the table. A unit's pair is one 16-byte load, and the G lanes of a chain --
+    # and the 64 / G chains of a wavefront, which read the same units -- read 16 G CONSECUTIVE bytes per load:
+    # whole cache lines from L2, and no bank conflict when the table sits in an LDS image. Row-major (unit u's
+    # columns consecutive: a stride of 8 ncol bytes between lanes) cost the generated 500 x 20 regression 21
+    # bank-conflict cycles per LDS read in the workgroup form (profiles/r6_gen_wg).
     NUC = max(1, len(uc_vals))
+    NUC += (-NUC) % 16
     doff = NUC
     for f in families + ufams:
-        f.doff = doff                     # row-major: unit u's constants are len(cols) consecutive doubles
-        doff += len(f.cols) * f.npad
+        f.doff = doff
+        nc_ = len(f.cols)
+        # (offset, stride in doubles) of column c. Short rows stay row-major (unit u's columns consecutive): one or
+        # two loads per unit either way, and the lone-wave kernels of radon / sv measured 3-7 % slower in pairs
+        f.paired = nc_ >= PAIR_MIN_COLS
+        if f.paired:
+            f.cpos = [(doff + (c // 2) * 2 * f.npad + (c & 1), 2) if c < nc_ - (nc_ & 1)
+                      else (doff + (nc_ - 1) * f.npad, 1) for c in range(nc_)]
+        else:
+            f.cpos = [(doff + c, nc_) for c in range(nc_)]
+        doff += nc_ * f.npad
     ints = []
     for f in families:
         f.ioff = len(ints)
@@ -874,7 +892,14 @@ def generate(g, term_roots, custom_roots, D, G, waves_per_simd=1):
         if f.cols:
             rows = np.stack(f.cols, axis=1)                       # [n][ncol]
             rows = np.concatenate([rows, np.repeat(rows[:1], f.npad - f.n, axis=0)])
-            dtab.append(rows.ravel())
+            nc_ = rows.shape[1]
+            if not f.paired:
+                dtab.append(rows.ravel())                                               # [npad][ncol]
+                continue
+            for p_ in range(nc_ // 2):
+                dtab.append(np.ascontiguousarray(rows[:, 2 * p_:2 * p_ + 2]).ravel())   # [npad][2]
+            if nc_ & 1:
+                dtab.append(np.ascontiguousarray(rows[:, nc_ - 1]))                     # [npad]
     data = np.concatenate(dtab + [np.asarray(ints, dtype=np.int32).view(np.float64)]) \
         if ints else np.concatenate(dtab)
     ioff_doubles = doff
@@ -1024,6 +1049,13 @@ def generate(g, term_roots, custom_roots, D, G, waves_per_simd=1):
     L.append("#define EXMC_GEN_ELL_OFF %d   /* ... of lane l at ((const int*)lt)[EXMC_GEN_ELL_OFF + l * EXMC_GEN_NELL] */"
              % (2 * ioff_doubles + ell_base))
     L.append("#define EXMC_GEN_WAVES_PER_SIMD %d" % waves_per_simd)
+    # the sampling kernel as workgroups of eight wavefronts around ONE LDS image of the tables (exmc_nuts.hpp
+    # nuts_kernel_wg): for a layout of several chains per wavefront with two waves per SIMD whose tables are too
+    # large to sit beside a one-wave workgroup (exmc_models.hpp EXMC_GEN_TABLE_IN_LDS) and fit beside eight tree
+    # stacks, the ziggurat tables and eight sets of strips in a compute unit's 160 KB
+    wg_lds = 8 * ((5 * DPL + 3) * 64 * 8 + (64 // G) * lsh * 8) + 768 * 8 + 8 + int(data.size) * 8
+    wg = int(G < 64 and waves_per_simd == 2 and data.size > 2048 and wg_lds <= 160 * 1024)
+    L.append("#define EXMC_GEN_WG %d   /* 1: the plug-in carries the workgroup form of the sampling kernel too */" % wg)
     L.append("")
     L.append("#define EXMC_GEN_IOFF %d   /* the int32 tables start at double EXMC_GEN_IOFF of lt */" % ioff_doubles)
     L.append("")
@@ -1095,7 +1127,11 @@ def generate(g, term_roots, custom_roots, D, G, waves_per_simd=1):
             L.append("      un_[j] = (sl < %d && un < %d) ? un : -1;" % (f.S, f.n))
             L.append("      const int uc = un_[j] < 0 ? 0 : un;")
             for c in range(nc):
-                L.append("      c_[j][%d] = EXMC_GEN_LT(%d + uc * %d + %d);" % (c, f.doff, nc, c))
+                if f.paired and c + 1 < nc and not (c & 1):   # a pair: ONE 16-byte load (EXMC_GEN_LT2: aligned)
+                    L.append("      { const exmc_gen_d2 cc_ = EXMC_GEN_LT2(%d + uc * 2); c_[j][%d] = cc_.x; c_[j][%d] = cc_.y; }"
+                             % (f.cpos[c][0], c, c + 1))
+                elif not (f.paired and (c & 1)):
+                    L.append("      c_[j][%d] = EXMC_GEN_LT(%d + uc * %d);" % (c, f.cpos[c][0], f.cpos[c][1]))
             for p in range(ngat):
                 L.append("      ix_[j][%d] = EXMC_GEN_IT(%d + uc);" % (p, f.ioff + p * f.npad))
             L.append("    }")
@@ -1118,10 +1154,13 @@ def generate(g, term_roots, custom_roots, D, G, waves_per_simd=1):
                 L.append("    if (un < %d) {" % f.n)
             for p in range(ngat):
                 L.append("    const double v%d = EXMC_GEN_SH(EXMC_GEN_IT(%d + un));" % (p, f.ioff + p * f.npad))
-            if nc:
-                L.append("    const int row = %d + un * %d;" % (f.doff, nc))
             for c in range(nc):
-                L.append("    const double c%d = EXMC_GEN_LT(row + %d);" % (c, c))
+                if f.paired and c + 1 < nc and not (c & 1):   # a pair: ONE 16-byte load (EXMC_GEN_LT2: aligned)
+                    L.append("    const exmc_gen_d2 cc%d = EXMC_GEN_LT2(%d + un * 2);" % (c, f.cpos[c][0]))
+                    L.append("    const double c%d = cc%d.x;" % (c, c))
+                    L.append("    const double c%d = cc%d.y;" % (c + 1, c))
+                elif not (f.paired and (c & 1)):
+                    L.append("    const double c%d = EXMC_GEN_LT(%d + un * %d);" % (c, f.cpos[c][0], f.cpos[c][1]))
         n_use = {}
         for x in [f.troot] + list(f.ext_adj.values()):
             n_use[x] = n_use.get(x, 0) + 1
@@ -1198,4 +1237,4 @@ def generate(g, term_roots, custom_roots, D, G, waves_per_simd=1):
     return dict(text=text, data=data, lanes=G, dpl=DPL, lsh=lsh, n_families=len(families),
                 family_sizes=[f.n for f in families], n_scalar_units=len(scalar_units),
                 spread_sizes=[f.n for f in ufams], n_spread_sums=NW, n_batches=n_batches[0],
-                n_reduced=NS, n_boundary=len(boundary), gather_width=width)
+                n_reduced=NS, n_boundary=len(boundary), gather_width=width, wg=wg)

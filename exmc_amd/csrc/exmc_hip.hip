@@ -1400,6 +1400,9 @@ int exmc_hip_model_create(int kind, int d, const double* data, int n_data, int d
 #ifdef EXMC_GEN_ONE_LANE
     exmc_gen_fold(data, folded.data());
 #endif
+#ifdef EXMC_GEN_LANES
+    while (folded.size() % 16) folded.push_back(0.0);   // the lane layout's table on a 128-byte boundary (codegen_lanes.py)
+#endif
     const size_t n_folded = folded.size();
 #ifdef EXMC_GEN_LANES
     // the lane layout's tables were folded when the model was generated: they travel as they are

@@ -1624,6 +1624,21 @@ static __host__ __device__ __noinline__ double exmc_gen_erf_call(double x) { ret
 #define EXMC_GEN_BATCH_LOG1P(n, b) exmc::lane_batch<EXMC_GEN_LANES, n>(b, l, [](double a_) { return EXMC_GENL_LOG1P(a_); })
 #define EXMC_GEN_BATCH_RCP(n, b) exmc::lane_batch<EXMC_GEN_LANES, n>(b, l, [](double a_) { return 1.0 / a_; })
 #define EXMC_GEN_FENCE() exmc::wave_lds_fence()
+// a pair of per-unit columns (codegen_lanes.py: interleaved over the units, 16-byte aligned in every placement of the
+// table): one global_load_dwordx4 / ds_read_b128 -- the alignment is what lets the compiler choose ds_read_b128 over
+// ds_read2_b64, a quarter of its LDS cycles
+struct alignas(16) exmc_gen_d2 { double x, y; };
+namespace exmc {
+// (the LDS placements say so in the pointer's type: the compiler then reads the pair with ds_read_b128; behind a generic
+// pointer it chose ds_read2_b64, four times the LDS cycles)
+__device__ __forceinline__ exmc_gen_d2 gen_lt2_lds(int k) {
+  // (k is even and the image 16-byte aligned: said out loud, because the compiler sees exmc_dyn_lds, an array of doubles)
+  const exmc_v2d v = *(const lds_v2d*)__builtin_assume_aligned(exmc_dyn_lds + k, 16);
+  return exmc_gen_d2{v.x, v.y};
+}
+}  // namespace exmc
+#define EXMC_GEN_LT2_GLOBAL(i) (*(const exmc_gen_d2*)&lt[i])
+#define EXMC_GEN_LT2_LDS(i) exmc::gen_lt2_lds(ltoff + (i))
 #define EXMC_GEN_FMA(a, b, c) __builtin_fma(a, b, c)
 #include EXMC_CUSTOM_HEADER
 #ifdef EXMC_GEN_LANES
@@ -1660,6 +1675,9 @@ constexpr bool kGenLdsTable = EXMC_GEN_TABLE_IN_LDS != 0;
 #endif
 #ifndef EXMC_GEN_FAST_WINDOW
 #define EXMC_GEN_FAST_WINDOW 1
+#endif
+#ifndef EXMC_GEN_WG     // (headers generated before round 6, and the layouts that do not ask for the workgroup form)
+#define EXMC_GEN_WG 0
 #endif
 #if EXMC_GEN_FAST_WINDOW
 // the watched main paths of the fast window (the lane layouts and the plate layout below)
@@ -1709,15 +1727,18 @@ __device__ __forceinline__ double genf_log1p(double x, bool& ok) {
 #define EXMC_GEN_XGROUP(s)
 #define EXMC_GEN_LANES_NAME exmc_gen_lanes_global
 #define EXMC_GEN_LT(i) lt[i]
+#define EXMC_GEN_LT2(i) EXMC_GEN_LT2_GLOBAL(i)
 #define EXMC_GEN_IT(i) ((const int*)(lt + EXMC_GEN_IOFF))[i]
 #include EXMC_CUSTOM_HEADER
 #undef EXMC_GEN_LANES_NAME
 #undef EXMC_GEN_LT
+#undef EXMC_GEN_LT2
 #undef EXMC_GEN_IT
 #undef EXMC_GEN_CTX_DECL
 #define EXMC_GEN_CTX_DECL , int shoff, int ltoff
 #define EXMC_GEN_LANES_NAME exmc_gen_lanes_lds
 #define EXMC_GEN_LT(i) exmc::exmc_dyn_lds[ltoff + (i)]
+#define EXMC_GEN_LT2(i) EXMC_GEN_LT2_LDS(i)
 #define EXMC_GEN_IT(i) ((const int*)(exmc::exmc_dyn_lds + ltoff + EXMC_GEN_IOFF))[i]
 #include EXMC_CUSTOM_HEADER
 #if EXMC_GEN_FAST_WINDOW
@@ -1743,20 +1764,24 @@ __device__ __forceinline__ double genf_log1p(double x, bool& ok) {
 #define EXMC_GEN_BATCH_LOG1P(n, b) exmc::lane_batch<EXMC_GEN_LANES, n>(b, l, [&](double a_) { return EXMC_GENL_LOG1P(a_); })
 #undef EXMC_GEN_LANES_NAME
 #undef EXMC_GEN_LT
+#undef EXMC_GEN_LT2
 #undef EXMC_GEN_IT
 #undef EXMC_GEN_CTX_DECL
 #define EXMC_GEN_CTX_DECL , int shoff, bool& exmc_gen_ok
 #define EXMC_GEN_LANES_NAME exmc_gen_lanes_global_fast
 #define EXMC_GEN_LT(i) lt[i]
+#define EXMC_GEN_LT2(i) EXMC_GEN_LT2_GLOBAL(i)
 #define EXMC_GEN_IT(i) ((const int*)(lt + EXMC_GEN_IOFF))[i]
 #include EXMC_CUSTOM_HEADER
 #undef EXMC_GEN_LANES_NAME
 #undef EXMC_GEN_LT
+#undef EXMC_GEN_LT2
 #undef EXMC_GEN_IT
 #undef EXMC_GEN_CTX_DECL
 #define EXMC_GEN_CTX_DECL , int shoff, int ltoff, bool& exmc_gen_ok
 #define EXMC_GEN_LANES_NAME exmc_gen_lanes_lds_fast
 #define EXMC_GEN_LT(i) exmc::exmc_dyn_lds[ltoff + (i)]
+#define EXMC_GEN_LT2(i) EXMC_GEN_LT2_LDS(i)
 #define EXMC_GEN_IT(i) ((const int*)(exmc::exmc_dyn_lds + ltoff + EXMC_GEN_IOFF))[i]
 #include EXMC_CUSTOM_HEADER
 // (back to the exact forms for whatever is included below)
@@ -1793,14 +1818,16 @@ __device__ __forceinline__ double genf_log1p(double x, bool& ok) {
 #define EXMC_GEN_G0 ((int)(threadIdx.x & 63) / EXMC_GEN_LANES)
 #define EXMC_GEN_NG (64 / EXMC_GEN_LANES)
 #define EXMC_GEN_XGROUP(s) exmc::xgroup_sum_n<EXMC_GEN_LANES>(s)
-#if EXMC_GEN_TABLE_IN_LDS
+#if EXMC_GEN_TABLE_IN_LDS || EXMC_GEN_WG
 #define EXMC_GEN_LANES_NAME exmc_gen_lanes_split_lds
 #include EXMC_CUSTOM_HEADER
 #undef EXMC_GEN_LANES_NAME
 #endif
 #undef EXMC_GEN_LT
+#undef EXMC_GEN_LT2
 #undef EXMC_GEN_IT
 #define EXMC_GEN_LT(i) lt[i]
+#define EXMC_GEN_LT2(i) EXMC_GEN_LT2_GLOBAL(i)
 #define EXMC_GEN_IT(i) ((const int*)(lt + EXMC_GEN_IOFF))[i]
 #define EXMC_GEN_LANES_NAME exmc_gen_lanes_split_global
 #include EXMC_CUSTOM_HEADER
@@ -1865,6 +1892,7 @@ struct Custom<EXMC_GEN_LANES> : ModelDefaults {
   struct Lane {
     double* sh;   // the wavefront's scratch (attach_scratch / lane_setup)
     int xoff;     // the LDS image of the tables (offset in doubles), or -1: read from global memory
+    const double* xs;   // the one-chain warmup's image of tables too large for xoff's budget (CustomSplit::stage), or null
     int ell[kEllRegs ? EXMC_GEN_NELL : 1];
   };
   // cooperative (whole workgroup); the caller synchronises afterwards
@@ -1872,9 +1900,22 @@ struct Custom<EXMC_GEN_LANES> : ModelDefaults {
     for (int i = threadIdx.x; i < EXMC_GEN_NLT; i += blockDim.x) dst[i] = c.lt[i];
     return true;
   }
+  // Round 6: the workgroup form of the sampling kernel (exmc_nuts.hpp nuts_kernel_wg) for a layout whose tables do
+  // not fit beside a one-wave workgroup -- eight wavefronts around ONE image of the tables (EXMC_GEN_WG, decided by
+  // the generator from the same sizes). The generated 500 x 20 regression read ten 16-byte rows per unit and lane
+  // from L2 at every leapfrog, the same sixteen rows for the four chains of a wavefront.
+  static constexpr int kWgWaves = EXMC_GEN_WG ? 8 : 0;
+  static constexpr int kWgLdsLevels = 1;
+  static constexpr int kWgImageDoubles = EXMC_GEN_WG ? EXMC_GEN_NLT : 0;
+  __host__ __device__ static bool wg_ok(const Consts&) { return EXMC_GEN_WG != 0; }
+  __device__ static __forceinline__ void wg_stage(const Consts& c, double* image) {
+    for (int i = threadIdx.x; i < EXMC_GEN_NLT; i += blockDim.x) image[i] = c.lt[i];
+  }
+  __device__ static __forceinline__ void wg_attach(Lane& ln, double*, int image_offset) { ln.xoff = image_offset; }
   __device__ static __forceinline__ void load(const Consts& c, int l, Lane& ln) {
     ln.sh = nullptr;
     ln.xoff = -1;
+    ln.xs = nullptr;
     if constexpr (kEllRegs) {
       const int* e = (const int*)c.lt + EXMC_GEN_ELL_OFF + l * EXMC_GEN_NELL;
 #pragma unroll
@@ -1903,6 +1944,23 @@ struct Custom<EXMC_GEN_LANES> : ModelDefaults {
     }
     return exmc_gen_lanes_global(c.lt, el, l, g, shoff);
   }
+  // the workgroup form: always from the image wg_attach pointed the lane at
+  __device__ static __forceinline__ double logp_grad_staged(const Consts& c, const Lane& ln, int l,
+                                                            const double (&q)[DPL], double (&g)[DPL]) {
+    const int shoff = (int)(ln.sh - exmc_dyn_lds) + (int)((threadIdx.x & 63) / G) * EXMC_GEN_LSH;
+#pragma unroll
+    for (int k = 0; k < DPL; k++)
+      if (l + k * G < D) exmc_dyn_lds[shoff + l + k * G] = q[k];
+    wave_lds_fence();
+    const int* el = kEllRegs ? ln.ell : ((const int*)c.lt + EXMC_GEN_ELL_OFF + l * EXMC_GEN_NELL);
+#if EXMC_GEN_FAST_WINDOW
+    bool ok = true;
+    const double r = exmc_gen_lanes_lds_fast(c.lt, el, l, g, shoff, ln.xoff, ok);
+    if (__builtin_expect(__any(ok ? 0 : 1) == 0, 1)) return r;
+    wave_lds_fence();
+#endif
+    return exmc_gen_lanes_lds(c.lt, el, l, g, shoff, ln.xoff);
+  }
 };
 
 #if EXMC_GEN_LANES < 64
@@ -1918,6 +1976,14 @@ struct Custom<EXMC_GEN_LANES> : ModelDefaults {
 struct CustomSplit : Custom<EXMC_GEN_LANES> {
   using Base = Custom<EXMC_GEN_LANES>;
   static constexpr bool kCoop = true;
+  static constexpr int kWgWaves = 0;          // (a warmup form: no sampling kernel of its own)
+  static constexpr int kWgImageDoubles = 0;
+  // tables too large for the sampling layout's LDS budget (EXMC_GEN_WG): the one-workgroup warmup has a compute
+  // unit's whole LDS to itself and keeps an image of them (warmup_kernel: P.stage_model, Lane::xs)
+  static constexpr int kStageDoubles = EXMC_GEN_WG ? EXMC_GEN_NLT : 0;
+  __device__ static __forceinline__ void stage(const Consts& c, double* dst) {
+    for (int i = threadIdx.x; i < EXMC_GEN_NLT; i += blockDim.x) dst[i] = c.lt[i];
+  }
   // one wave: where this form pays the pass is nearly all model (like the hand-written logistic
   // kind, ModelDefaults::kPipeWarmup), and a plug-in build is spared its heaviest kernel
   static constexpr bool kPipeWarmup = false;
@@ -1930,8 +1996,9 @@ struct CustomSplit : Custom<EXMC_GEN_LANES> {
       if (l + k * G < D) exmc_dyn_lds[shoff + l + k * G] = q[k];   // the same value from every group
     wave_lds_fence();
     const int* el = kEllRegs ? ln.ell : ((const int*)c.lt + EXMC_GEN_ELL_OFF + l * EXMC_GEN_NELL);
-#if EXMC_GEN_TABLE_IN_LDS
-    if (ln.xoff >= 0) return exmc_gen_lanes_split_lds(c.lt, el, l, g, shoff, ln.xoff);   // wave-uniform
+#if EXMC_GEN_TABLE_IN_LDS || EXMC_GEN_WG
+    const int xo = (EXMC_GEN_WG && ln.xs) ? (int)(ln.xs - exmc_dyn_lds) : ln.xoff;
+    if (xo >= 0) return exmc_gen_lanes_split_lds(c.lt, el, l, g, shoff, xo);   // wave-uniform
 #endif
     return exmc_gen_lanes_split_global(c.lt, el, l, g, shoff, -1);
   }

@@ -4,7 +4,8 @@
 // kernel instead of the sum). EXMC_PLUGIN_PART: 1 nuts_kernel, 2 nuts_kernel (stream form),
 // 3 warmup_kernel (two-wave pipeline), 4 warmup_kernel (one wave), 5 the auxiliary kernels (vag_fn
 // batches, chain init, step-size search), 6 the one-chain warmup form of a short lane layout, 7 indep_kernel
-// (warmup + sampling per chain in one launch: sample_chains vectorized: false). exmc_hip.hip, compiled with
+// (warmup + sampling per chain in one launch: sample_chains vectorized: false), 8 nuts_kernel_wg of a lane layout
+// that asks for it (EXMC_GEN_WG). exmc_hip.hip, compiled with
 // -DEXMC_PLUGIN_SPLIT, declares the same instantiations `extern template` and keeps everything else.
 #include <hip/hip_runtime.h>
 

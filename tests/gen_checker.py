@@ -39,6 +39,7 @@ WRAPPER = """
 /* the lane layout (exmc_amd/codegen_lanes.py) on virtual lanes: every lane runs the function up to
  * the butterfly (pass 0: its partial sums are collected), the sums are added in the order of the
  * device's xor butterfly, every lane runs it again to the end (pass 1) */
+typedef struct { double x, y; } exmc_gen_d2;
 typedef struct { double* sh; int pass; double* S; const double* R; double* SW; const double* RW; int g0, ng; } exmc_gen_ctx;
 /* the one-chain warmup spreads the units of a family over the 64 / G lane groups of the wavefront
  * (Custom...Split of exmc_models.hpp): group g0 takes the slots g0, g0 + ng, ...; the groups' sums are
@@ -68,6 +69,7 @@ typedef struct { double* sh; int pass; double* S; const double* R; double* SW; c
 #define EXMC_GEN_LANES_SECTION
 #define EXMC_GEN_LANES_NAME exmc_gen_lanes
 #define EXMC_GEN_LT(i) lt[i]
+#define EXMC_GEN_LT2(i) (*(const exmc_gen_d2*)&EXMC_GEN_LT(i))   /* a pair of columns, one load on the device */
 #define EXMC_GEN_IT(i) ((const int*)(lt + EXMC_GEN_IOFF))[i]
 #include "%(header)s"
 #endif
