@@ -250,10 +250,16 @@ def sample_chains_sharded(spec, num_chains, opts=None, devices=None, engine="exm
     one GPU) and handed to the parent as shared-memory tensors: no file is written, nothing is
     pickled. The returned ({name: draws}[], stats[]) equal the single-device sample_chains whatever
     the number of devices. `engine` names the module that provides compile / warmup /
-    sample_compiled_tuned (the tests substitute the CPU checker). A rank that fails takes the call
-    down with it (the reference retries a failed chain on the coordinator, distributed.ex:172-180; a
-    GPU fault is not something to retry blindly), and so does a rank that neither finishes nor fails
-    within opts["shard_timeout_s"] (default six hours): its process is terminated and the call raises."""
+    sample_compiled_tuned (the tests substitute the CPU checker). A rank OTHER than the coordinator's
+    (rank 0, devices[0]) that fails ends the fan-out -- the gather is a collective, so its peers cannot
+    finish without it -- and the chains are run again on the coordinator's device alone, as the
+    reference retries a failed chain on the coordinator (distributed.ex:158-180: `catch kind, reason ->
+    ... run_chain_local`); chain i keeps its seed, so the answer is the one the ranks would have
+    given, and stats[*]["extra"]["retried_on_coordinator"] names the rank that failed and why.
+    opts["retry_on_coordinator"] = False turns that off (the failure raises). A failure of rank 0
+    itself raises (there is no other coordinator to fall back to), and so does a rank that neither
+    finishes nor fails within opts["shard_timeout_s"] (default six hours): which rank hangs is not
+    known, its device may be the coordinator's, so the processes are terminated and the call raises."""
     import importlib
     import pickle
     import time
@@ -327,16 +333,34 @@ def sample_chains_sharded(spec, num_chains, opts=None, devices=None, engine="exm
                 received.set()
             while not procs.join(timeout=0.05):
                 expired()
-        except BaseException:
+        except BaseException as e:
             stop_ranks()     # a failed rank (join raised) must not leave its peers holding their GPUs
-            raise
+            # the reference's fallback (distributed.ex:172-180): a failed peer's chains run on the coordinator.
+            # torch's spawn says which rank raised or died (error_index); rank 0 IS the coordinator.
+            failed_rank = getattr(e, "error_index", None)
+            if not (isinstance(e, Exception) and not isinstance(e, TimeoutError) and failed_rank not in (None, 0)
+                    and o.get("retry_on_coordinator", True)):
+                raise
+            retried = dict(rank=int(failed_rank), device=devices[failed_rank],
+                           error=("%s: %s" % (type(e).__name__, e))[:2000])
+            import logging
+            logging.getLogger("exmc_amd.distributed").warning(
+                "rank %d (device %r) failed (%s); retrying all %d chains on the coordinator's device %r",
+                retried["rank"], retried["device"], type(e).__name__, num_chains, devices[0])
+            first = None
         finally:
             del store        # the rendezvous store goes with the call, whichever way it ends
-        if not first["same_tuning"]:
-            raise RuntimeError("ranks disagree on the shared tuning: the warmup is not deterministic")
-        shards = [shard_range(num_chains, r, world) for r in range(world)]
-        raw = first["raw"]
-        total_lf = first["leapfrogs"]
+        if first is None:    # the retry: one shard, the coordinator's device, this process
+            res = run_shard(eng, spec, num_chains, opts, devices[0], 0, 1)
+            raw, total_lf, first = res["raw"], res["leapfrogs"], res
+            shards = [(res["lo"], res["hi"])]
+        else:
+            retried = None
+            if not first["same_tuning"]:
+                raise RuntimeError("ranks disagree on the shared tuning: the warmup is not deterministic")
+            shards = [shard_range(num_chains, r, world) for r in range(world)]
+            raw = first["raw"]
+            total_lf = first["leapfrogs"]
     traces, stats = [], []
     for c in range(num_chains):
         traces.append(eng._build_trace(spec, raw["draws"][c]))
@@ -348,6 +372,8 @@ def sample_chains_sharded(spec, num_chains, opts=None, devices=None, engine="exm
         stats.append(st)
     extra = dict(total_leapfrogs=int(total_lf), raw=raw, shards=[(int(a), int(b)) for a, b in shards],
                  devices=devices)
+    if world > 1 and retried is not None:
+        extra["retried_on_coordinator"] = retried
     for s_ in stats:
         s_["extra"] = extra
     return traces, stats

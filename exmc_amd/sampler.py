@@ -370,9 +370,10 @@ def sample_chains(ir, num_chains, opts=None):
     sample_chains_parallel (False: every chain adapts on its own, sample_chains_independent_compiled).
     With opts["devices"] = [0, 1, ...] the chains are sharded over those GPUs, one process each
     (exmc_amd.distributed.sample_chains_sharded, the analogue of Exmc.NUTS.Distributed.sample_chains/2);
-    the result does not depend on the number of devices. A rank process that fails or hangs takes a
-    sharded call down with it (distributed.sample_chains_sharded; the reference retries a failed chain
-    on the coordinator, distributed.ex:172-180 -- a GPU fault is not retried blindly)."""
+    the result does not depend on the number of devices. A peer rank that fails has its call's chains run
+    again on the coordinator's device (devices[0]), as the reference retries a failed chain on the
+    coordinator (distributed.ex:158-180; opts["retry_on_coordinator"] = False: raise instead); a failing
+    rank 0 and ranks that hang past opts["shard_timeout_s"] take the call down."""
     opts = opts or {}
     devices = opts.get("devices")
     vectorized = opts.get("vectorized", num_chains > 1)

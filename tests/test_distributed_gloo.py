@@ -149,3 +149,31 @@ def test_sharded_api_gives_up_on_ranks_that_hang():
         xd.sample_chains_sharded(models.eight_schools(), 4, dict(num_warmup=10, num_samples=5, shard_timeout_s=4.0),
                                  devices=[0, 1], engine="hang_engine")
     assert time.monotonic() - t0 < 60.0
+
+
+def test_sharded_api_retries_a_failed_peer_on_the_coordinator(monkeypatch):
+    """A rank other than the coordinator's fails (an engine that raises in the shard that does not start at chain 0):
+    the call runs the chains again on the coordinator's device alone and returns what the ranks would have -- chain i
+    keeps its seed -- as the reference retries a failed chain locally (distributed.ex:158-180). With
+    retry_on_coordinator off, or when the coordinator's own rank is the one that fails, the failure raises."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle as O
+    from exmc_amd import distributed as xd
+    from exmc_amd import models
+    monkeypatch.delenv("EXMC_TEST_FAIL_RANK0", raising=False)
+    spec = models.eight_schools()
+    opts = dict(num_warmup=40, num_samples=12, seed=4, init_values=spec.default_init)
+    traces, stats = xd.sample_chains_sharded(spec, 5, opts, devices=[0, 1, 2], engine="flaky_engine")
+    t, st = O.sample_chains(O.model_for(spec), 5, init_q=spec.to_unconstrained(spec.default_init),
+                            num_warmup=40, num_samples=12, seed=4, cfg=O.Cfg(1, 1))
+    extra = stats[0]["extra"]
+    assert np.array_equal(extra["raw"]["draws"], t["draws"]) and np.array_equal(extra["raw"]["n_steps"], t["n_steps"])
+    assert stats[0]["step_size"] == st.step_size and extra["total_leapfrogs"] == st.total_leapfrogs
+    assert extra["retried_on_coordinator"]["rank"] in (1, 2) and "injected failure" in extra["retried_on_coordinator"]["error"]
+    assert extra["shards"] == [(0, 5)] and len(traces) == 5
+    with pytest.raises(Exception, match="injected failure"):
+        xd.sample_chains_sharded(spec, 5, dict(opts, retry_on_coordinator=False), devices=[0, 1, 2], engine="flaky_engine")
+    monkeypatch.setenv("EXMC_TEST_FAIL_RANK0", "1")        # (inherited by the spawned ranks)
+    with pytest.raises(Exception, match="injected failure"):
+        xd.sample_chains_sharded(spec, 5, opts, devices=[0, 1], engine="flaky_engine")
