@@ -9,6 +9,7 @@
  *   model_set_flat_order/2  PointMap.build's sorted-id layout (point_map.ex:30-60)
  *   logp_grad/3             vag_fn, batched (compiler.ex:131-141)
  *   multi_step/8            multi_step_fn, batched (batched_leapfrog.ex:21-48)
+ *   leapfrog_chain_normal/7 the fused-chain hook of the speculative path (tree.ex:613-653)
  *   warmup/6                run_warmup of the shared chain (sampler.ex:537-762, 1068-1080)
  *   sample_chains/10        sample_chains_vectorized_compiled's sampling loop (sampler.ex:1082-1130)
  *   sample/7                sample/3 for one chain (sampler.ex:126-257)
@@ -59,7 +60,9 @@ static int g_device = 0;
   X(int, stream_begin, (exmc_hip_model*, const double*, exmc_hip_opts, exmc_hip_tuning*))                      \
   X(int, stream_next_host, (exmc_hip_model*, int, exmc_hip_trace, int32_t*))                                   \
   X(int, stream_start, (exmc_hip_model*, int, exmc_hip_trace*, const volatile int32_t**))                      \
-  X(int, stream_finish, (exmc_hip_model*, int32_t*))
+  X(int, stream_finish, (exmc_hip_model*, int32_t*))                                                          \
+  X(int, leapfrog_chain_normal_host, (int, int, int, const double*, const double*, const double*, int, double,  \
+                                      double, double, double*, double*, double*, double*))
 
 typedef struct {
   void* dl;   /* dlopen handle of a plug-in; NULL: the library this shim is linked against */
@@ -312,6 +315,35 @@ static ERL_NIF_TERM multi_step(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv
   double* ag = new_f64_bin(env, (size_t)c * n * d, &t[3]);
   int rc = A->multi_step_host(m, q, p, g, eps, im, n, c, 0, aq, ap, al, ag);
   return rc == EXMC_OK ? enif_make_tuple_from_array(env, t, 4) : raise_api(env, A, rc);
+}
+
+/* leapfrog_chain_normal(q, p, inv_mass :: binary [d], k, signed_eps, mu, sigma)
+ *   -> {:ok, {q_chain, p_chain, grad_chain, logp_chain}} binaries [k][d] / [k]
+ * The fused-chain hook of the speculative path (tree.ex:613-653): name, argument order and result shape of
+ * Nx.Vulkan.leapfrog_chain_normal/7 as do_dispatch calls it (tree.ex:641-647), with f64 binaries where the
+ * Vulkan device takes uploaded f32 buffers. No model handle: mu and sigma ARE the model. Always the library
+ * this shim is linked against (g_base). */
+static ERL_NIF_TERM leapfrog_chain_normal(ErlNifEnv* env, int argc, const ERL_NIF_TERM argv[]) {
+  const double *q, *p, *im;
+  size_t nq, np, nim;
+  int k;
+  double eps, mu, sigma;
+  (void)argc;
+  reap_senders();
+  if (!get_f64_bin(env, argv[0], &q, &nq) || !get_f64_bin(env, argv[1], &p, &np) ||
+      !get_f64_bin(env, argv[2], &im, &nim) || !enif_get_int(env, argv[3], &k) || !get_f64(env, argv[4], &eps) ||
+      !get_f64(env, argv[5], &mu) || !get_f64(env, argv[6], &sigma) || nq < 1 || nq > 256 || np != nq ||
+      nim != nq || k < 0)
+    return enif_make_badarg(env);   /* d > 256: the reference's function head does not match either (tree.ex:636) */
+  const size_t d = nq;
+  ERL_NIF_TERM t[4];
+  double* aq = new_f64_bin(env, (size_t)k * d, &t[0]);
+  double* ap = new_f64_bin(env, (size_t)k * d, &t[1]);
+  double* ag = new_f64_bin(env, (size_t)k * d, &t[2]);
+  double* al = new_f64_bin(env, (size_t)k, &t[3]);
+  int rc = g_base.leapfrog_chain_normal_host(g_device, 1, (int)d, q, p, im, k, eps, mu, sigma, aq, ap, ag, al);
+  if (rc != EXMC_OK) return raise_api(env, &g_base, rc);
+  return tuple2(env, enif_make_atom(env, "ok"), enif_make_tuple_from_array(env, t, 4));
 }
 
 static ERL_NIF_TERM tuning_map(ErlNifEnv* env, const exmc_hip_tuning* tun, int d) {
@@ -748,6 +780,7 @@ static ErlNifFunc nif_funcs[] = {
     {"model_set_flat_order", 2, model_set_flat_order, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"logp_grad", 3, logp_grad, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"multi_step", 8, multi_step, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"leapfrog_chain_normal", 7, leapfrog_chain_normal, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"warmup", 6, warmup, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"warmup_from", 8, warmup_from, ERL_NIF_DIRTY_JOB_IO_BOUND},
     {"warmup_dense", 7, warmup_dense, ERL_NIF_DIRTY_JOB_IO_BOUND},

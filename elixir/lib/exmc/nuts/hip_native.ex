@@ -45,6 +45,15 @@ defmodule Exmc.NUTS.HipNative do
   def multi_step(_ref, _q, _p, _grad, _eps, _inv_mass, _n_steps, _n_chains),
     do: :erlang.nif_error(:nif_not_loaded)
 
+  @doc """
+  The fused-chain hook of the speculative path (`tree.ex:613-653`): K leapfrog steps of a chain of d <= 256
+  independent Normal(mu, sigma) coordinates in one launch. Name, argument order and result of
+  `Nx.Vulkan.leapfrog_chain_normal/7`, on f64 binaries `[d]` -> `{:ok, {q_chain, p_chain, grad_chain, logp_chain}}`
+  (`[k][d]`, `[k]`); `elixir/patches/tree.ex.diff` adds the `do_dispatch` clause that calls it.
+  """
+  def leapfrog_chain_normal(_q, _p, _inv_mass, _k, _signed_eps, _mu, _sigma),
+    do: :erlang.nif_error(:nif_not_loaded)
+
   @doc "Shared warmup on chain 0 (sampler.ex:1053-1080) -> %{epsilon, inv_mass, warmup_divergences}"
   def warmup(_ref, _init_q, _num_warmup, _max_tree_depth, _target_accept, _seed),
     do: :erlang.nif_error(:nif_not_loaded)

@@ -26,6 +26,7 @@ EXPORTS = [
     "exmc_hip_warmup_dense", "exmc_hip_model_set_dense_mass", "exmc_hip_model_clear_dense_mass",
     "exmc_hip_sample_dense_host",
     "exmc_hip_sample_independent", "exmc_hip_sample_independent_host",
+    "exmc_hip_leapfrog_chain_normal_host",
 ]
 
 
@@ -124,6 +125,8 @@ def bind(path):
     L.exmc_hip_build_subtree_host.argtypes = [
         C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, C.c_int, dp, dp, ip, ip, up,
         dp, dp, dp, dp, dp, dp, dp, dp, dp, dp, ip, ip, dp, ip, ip, dp]
+    L.exmc_hip_leapfrog_chain_normal_host.argtypes = [C.c_int, C.c_int, C.c_int, dp, dp, dp, C.c_int, C.c_double,
+                                                      C.c_double, C.c_double, dp, dp, dp, dp]
     L.exmc_hip_sample_independent.argtypes = [vp, dp, C.c_int, C.c_int, C.c_int, Opts, Trace, dp,
                                               C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
     L.exmc_hip_sample_independent_host.argtypes = L.exmc_hip_sample_independent.argtypes

@@ -2448,4 +2448,49 @@ int exmc_hip_build_subtree_host(int device, int C, int d, const double* all_q, c
   return rc;
 }
 
+// B2' (tree.ex:613-653): see leapfrog_chain_normal_kernel. Blocking, on the null stream, like the other
+// handle-less seams: the reference's hook uploads, dispatches and downloads per call as well.
+int exmc_hip_leapfrog_chain_normal_host(int device, int C, int d, const double* q, const double* p,
+                                        const double* inv_mass, int k, double signed_eps, double mu,
+                                        double sigma, double* q_chain, double* p_chain,
+                                        double* grad_chain, double* logp_chain) {
+  if (C < 1 || d < 1 || d > kChainNormalMaxD || k < 0 || !q || !p || !inv_mass)
+    return fail(EXMC_ERR_BADARG, "leapfrog_chain_normal: need n_chains >= 1, 1 <= d <= 256, k >= 0 and q, p, inv_mass");
+  int rc = select_device(device);
+  if (rc) return rc;
+  if (k == 0) return EXMC_OK;
+  const size_t vec = (size_t)C * d, rows = (size_t)C * k * d, lps = (size_t)C * k;
+  DevBuf buf;
+  rc = buf.ensure((2 * vec + (size_t)d + 3 * rows + lps) * 8);
+  if (rc) return rc;
+  double* dq = (double*)buf.p;
+  double* dp = dq + vec;
+  double* dim = dp + vec;
+  ChainNormalParams P{};
+  P.q = dq; P.p = dp; P.inv_mass = dim;
+  P.d = d; P.k = k; P.n_chains = C;
+  P.eps = signed_eps; P.mu = mu; P.sigma = sigma;
+  P.tiny32 = f32r(1.0e-30);
+  P.log2pi32 = f32r(std::log(f32r(2.0 * M_PI)));
+  P.q_chain = dim + d;
+  P.p_chain = P.q_chain + rows;
+  P.g_chain = P.p_chain + rows;
+  P.logp_chain = P.g_chain + rows;
+  hipError_t e = hipMemcpy(dq, q, vec * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dp, p, vec * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dim, inv_mass, (size_t)d * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(leapfrog_chain_normal_kernel, dim3((unsigned)C), dim3(64), 0, 0, P);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) rc = fail(EXMC_ERR_HIP, std::string("leapfrog_chain_normal: ") + hipGetErrorString(e));
+  if (!rc) rc = down(q_chain, P.q_chain, rows * 8);
+  if (!rc) rc = down(p_chain, P.p_chain, rows * 8);
+  if (!rc) rc = down(grad_chain, P.g_chain, rows * 8);
+  if (!rc) rc = down(logp_chain, P.logp_chain, lps * 8);
+  buf.release();
+  return rc;
+}
+
 }  // extern "C"

@@ -500,4 +500,91 @@ rhat_kernel(const double* draws, int S, int D, int C, double* stats, double* rha
 
 #endif  // EXMC_PLUGIN_PART
 
+// ------------------------------------------------------------------------------------------
+// B2': the fused-chain hook of the speculative path (tree.ex:613-653, do_dispatch) --
+// leapfrog_chain_normal(q, p, inv_mass, k, signed_eps, mu, sigma): K leapfrog steps of a chain of d
+// independent Normal(mu, sigma) coordinates in ONE launch, the rows of multi_step_fn out
+// (batched_leapfrog.ex:50-101; raw logp, :87). The caller hands over no gradient (tree.ex:637): the
+// first half-kick takes it at q. One wavefront per chain; lane l owns dimensions l, l + 64, l + 128,
+// l + 192 (d <= 256, the hook's own bound, tree.ex:636); the density's sum over the dimensions is the
+// 64-lane group sum of every other kernel here (lane partials in ascending dimension, then the
+// butterfly) = the checker's lane_sum(.., 64, ..). Rows per chain [k][d] row-major as the hook
+// returns them: a wavefront writes a row in runs of 512 contiguous bytes.
+// ------------------------------------------------------------------------------------------
+struct ChainNormalParams {
+  const double* q;         // [C][d]
+  const double* p;         // [C][d]
+  const double* inv_mass;  // [d]
+  int d, k, n_chains;
+  double eps;              // signed
+  double mu, sigma;
+  double tiny32, log2pi32; // Nx.tensor(1.0e-30), log(Nx.tensor(2 pi)): f32 literals (normal.ex:18-19)
+  double* q_chain;         // [C][k][d]
+  double* p_chain;
+  double* g_chain;
+  double* logp_chain;      // [C][k]
+};
+
+constexpr int kChainNormalMaxD = 256;
+
+__global__ void __launch_bounds__(64) leapfrog_chain_normal_kernel(ChainNormalParams P)
+#ifdef EXMC_COMMON_DECL_ONLY
+;   // defined in the prebuilt exmc_common object (exmc_common.hip)
+#else
+{
+  constexpr int G = 64, DPL = kChainNormalMaxD / G;
+  const int chain = blockIdx.x;
+  const int l = threadIdx.x;
+  const int d = P.d;
+  double q[DPL], p[DPL], g[DPL], im[DPL], t[DPL];
+  bool valid[DPL];
+#pragma unroll
+  for (int j = 0; j < DPL; j++) {
+    const int i = l + j * G;
+    valid[j] = i < d;
+    const size_t o = (size_t)chain * d + i;
+    q[j] = valid[j] ? P.q[o] : 0.0;
+    p[j] = valid[j] ? P.p[o] : 0.0;
+    im[j] = valid[j] ? P.inv_mass[i] : 1.0;
+  }
+  // normal.ex:18-22: safe_sigma, log(2 pi) + 2 log(safe_sigma)
+  const double mu = P.mu;
+  const double ss = fmax(P.sigma, P.tiny32);
+  const double log_term = P.log2pi32 + 2.0 * exmc_log(ss);
+  const double eps = P.eps;
+  const double h = eps / 2.0;
+  // density and gradient at the lane's coordinates (normal.ex:20-23 and its reverse mode)
+  auto density = [&]() {
+#pragma unroll
+    for (int j = 0; j < DPL; j++) {
+      const double z = (q[j] - mu) / ss;
+      t[j] = -0.5 * (z * z + log_term);
+      g[j] = (-z) / ss;
+    }
+  };
+  density();
+  for (int s = 0; s < P.k; s++) {
+#pragma unroll
+    for (int j = 0; j < DPL; j++) {
+      p[j] = p[j] + h * g[j];
+      q[j] = q[j] + eps * (im[j] * p[j]);
+    }
+    density();
+    const double logp = group_sum_slots<G, DPL>(t, valid, l, 0.0);
+    const size_t row = ((size_t)chain * P.k + s) * d;
+#pragma unroll
+    for (int j = 0; j < DPL; j++) {
+      p[j] = p[j] + h * g[j];
+      if (valid[j]) {
+        const size_t o = row + l + j * G;
+        P.q_chain[o] = q[j];
+        P.p_chain[o] = p[j];
+        P.g_chain[o] = g[j];
+      }
+    }
+    if (l == 0) P.logp_chain[(size_t)chain * P.k + s] = logp;
+  }
+}
+#endif
+
 }  // namespace exmc

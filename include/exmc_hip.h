@@ -350,6 +350,21 @@ int exmc_hip_build_subtree_host(int device, int n_chains, int d, const double* a
                                 double* accept_sum, int32_t* turning, int32_t* subtree_depth,
                                 double* rho);
 
+/* B2' -- the fused-chain hook of the speculative path (lib/exmc/nuts/tree.ex:613-653: dispatch_multi_step /
+ * do_dispatch call `Nx.Vulkan.leapfrog_chain_normal(q_ref, p_ref, inv_mass_ref, k, signed_eps, mu, sigma)` when
+ * the application sets :fused_leapfrog_normal_meta = {mu, sigma} and d <= 256; "Output contract is identical in
+ * both branches: {all_q, all_p, all_logp, all_grad}", tree.ex:620-621). K leapfrog steps of a chain whose d
+ * coordinates are independent Normal(mu, sigma) terms (lib/exmc/dist/normal.ex:15-24) in one launch, the rows of
+ * multi_step_fn out (batched_leapfrog.ex:50-101; raw logp). The hook passes no gradient: the first half-kick
+ * uses the gradient at q. signed_eps = dir_sign * epsilon (tree.ex:639). Batched over n_chains independent
+ * chains (the reference calls it for one). Host buffers, native-endian f64 where the Vulkan hook moves f32:
+ *   q, p [C][d]; inv_mass [d]; q_chain, p_chain, grad_chain out [C][k][d]; logp_chain out [C][k]
+ * (any output may be NULL). 1 <= d <= 256 (the hook's own guard, tree.ex:636), k >= 0. */
+int exmc_hip_leapfrog_chain_normal_host(int device, int n_chains, int d, const double* q,
+                                        const double* p, const double* inv_mass, int k,
+                                        double signed_eps, double mu, double sigma, double* q_chain,
+                                        double* p_chain, double* grad_chain, double* logp_chain);
+
 /* wall-clock of the last timed kernel region on the handle's stream, HIP events (ms) */
 double exmc_hip_last_kernel_ms(const exmc_hip_model* m);
 

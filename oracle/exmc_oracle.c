@@ -779,6 +779,52 @@ void exo_multi_step(const exo_model* m, const double* q0, const double* p0, cons
   }
 }
 
+/* B2' -- the fused-chain hook of the speculative path (tree.ex:613-653, dispatch_multi_step / do_dispatch):
+ * `leapfrog_chain_normal(q, p, inv_mass, k, signed_eps, mu, sigma)` = K leapfrog steps of ONE chain whose d
+ * coordinates are independent Normal(mu, sigma) terms, in one dispatch. The function itself lives in
+ * nx_vulkan@718d80a (mix.lock; absent from the reference tree), so what is restated is what its call site
+ * fixes: "Output contract is identical in both branches: {all_q, all_p, all_logp, all_grad}" (tree.ex:620-621)
+ * = multi_step's rows (batched_leapfrog.ex:50-101: the step of leapfrog.ex:14-31 iterated, RAW logp stored,
+ * :87), with the density of dist/normal.ex:15-24 per coordinate. The call passes no gradient (tree.ex:637 binds
+ * `_grad`): the chain's first half-kick uses the gradient of the density at q. signed_eps = dir_sign * epsilon
+ * (tree.ex:639). Rows [k][d] row-major, logp [k]. */
+static double chain_normal_logp_grad(const double* q, int d, double mu, double ss, double log_term,
+                                     double* g, exo_cfg c) {
+  double T[EXO_MAX_D];
+  for (int i = 0; i < d; i++) {
+    double z = (q[i] - mu) / ss;
+    T[i] = -0.5 * (z * z + log_term);
+    g[i] = (-z) / ss;   /* reverse mode of -0.5 * (z * z + c): (-0.5 z) + (-0.5 z), then / sigma */
+  }
+  return lane_sum(T, d, c.lanes, 0.0);
+}
+
+int exo_leapfrog_chain_normal(const double* q0, const double* p0, const double* im, int d, int k,
+                              double signed_eps, double mu, double sigma, double* q_chain,
+                              double* p_chain, double* grad_chain, double* logp_chain, exo_cfg c) {
+  if (d < 1 || d > EXO_MAX_D || k < 0) return -1;
+  double q[EXO_MAX_D], p[EXO_MAX_D], g[EXO_MAX_D];
+  const double ss = fmax(sigma, TINY_F32());                               /* normal.ex:18 */
+  const double log_term = LOG_2PI_F32() + 2.0 * exo_log(ss, c.math_mode);  /* normal.ex:19,22 */
+  const double h = signed_eps / 2.0;                                       /* batched_leapfrog.ex:64 */
+  memcpy(q, q0, sizeof(double) * d);
+  memcpy(p, p0, sizeof(double) * d);
+  chain_normal_logp_grad(q, d, mu, ss, log_term, g, c);
+  for (int s = 0; s < k; s++) {
+    for (int i = 0; i < d; i++) {
+      p[i] = p[i] + h * g[i];
+      q[i] = q[i] + signed_eps * (im[i] * p[i]);
+    }
+    double lp = chain_normal_logp_grad(q, d, mu, ss, log_term, g, c);
+    for (int i = 0; i < d; i++) p[i] = p[i] + h * g[i];
+    memcpy(q_chain + (size_t)s * d, q, sizeof(double) * d);
+    memcpy(p_chain + (size_t)s * d, p, sizeof(double) * d);
+    memcpy(grad_chain + (size_t)s * d, g, sizeof(double) * d);
+    logp_chain[s] = lp;
+  }
+  return 0;
+}
+
 /* ======================================================================================
  * Tree (tree.ex). Recursive, as the reference; nodes live on a bump arena.
  * ==================================================================================== */

@@ -107,6 +107,12 @@ void exo_multi_step(const exo_model* m, const double* q, const double* p, const 
                     double eps, const double* inv_mass, int n_steps, double* all_q,
                     double* all_p, double* all_logp, double* all_g, exo_cfg cfg);
 
+/* B2' fused-chain hook (tree.ex:613-653): k leapfrog steps of one chain of d independent Normal(mu, sigma)
+ * coordinates from (q, p), the first gradient taken at q; rows [k][d], raw logp [k]. 0, or -1 on bad sizes. */
+int exo_leapfrog_chain_normal(const double* q, const double* p, const double* inv_mass, int d, int k,
+                              double signed_eps, double mu, double sigma, double* q_chain,
+                              double* p_chain, double* grad_chain, double* logp_chain, exo_cfg cfg);
+
 /* ---- one NUTS tree (tree.ex:266-500) from state (q,p,logp,g); rng is COPIED */
 typedef struct {
   double logp;

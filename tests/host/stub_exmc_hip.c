@@ -61,6 +61,8 @@ int exmc_hip_model_clear_dense_mass(exmc_hip_model* m) { (void)m; return EXMC_OK
 int exmc_hip_logp_grad_host(exmc_hip_model* m, const double* q, int c, int l, double* lp, double* g) NO_DEVICE()
 int exmc_hip_multi_step_host(exmc_hip_model* m, const double* q, const double* p, const double* g, double e,
                              const double* im, int n, int c, int l, double* a, double* b, double* cc, double* dd) NO_DEVICE()
+int exmc_hip_leapfrog_chain_normal_host(int dev, int c, int d, const double* q, const double* p, const double* im, int k,
+                                        double e, double mu, double sg, double* a, double* b, double* cc, double* dd) NO_DEVICE()
 int exmc_hip_warmup(exmc_hip_model* m, const double* q, exmc_hip_opts o, exmc_hip_tuning* t) NO_DEVICE()
 int exmc_hip_warmup_from(exmc_hip_model* m, const double* q, exmc_hip_opts o, const exmc_hip_tuning* s, exmc_hip_tuning* t) NO_DEVICE()
 int exmc_hip_warmup_dense(exmc_hip_model* m, const double* q, exmc_hip_opts o, exmc_hip_tuning* t, double* a, double* b) NO_DEVICE()

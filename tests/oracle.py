@@ -128,6 +128,9 @@ def lib():
     L.exo_leapfrog.restype = C.c_double
     L.exo_multi_step.argtypes = [C.c_void_p, dp, dp, dp, C.c_double, dp, C.c_int, dp, dp, dp, dp,
                                  Cfg]
+    L.exo_leapfrog_chain_normal.argtypes = [dp, dp, dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
+                                            dp, dp, dp, dp, Cfg]
+    L.exo_leapfrog_chain_normal.restype = C.c_int
     L.exo_tree_build.argtypes = [C.c_void_p, dp, dp, C.c_double, dp, C.c_double, dp, C.c_int, Rng,
                                  C.c_double, dp, dp, C.POINTER(TreeResult), Cfg]
     L.exo_check_uturn.argtypes = [dp, dp, dp, dp, C.c_int, Cfg]
@@ -384,6 +387,20 @@ def eight_schools():
 
 def simple():
     return Model(SIMPLE, 2, SIMPLE_Y)
+
+
+def leapfrog_chain_normal(q, p, inv_mass, k, signed_eps, mu, sigma, cfg=None):
+    """B2' (tree.ex:613-653): the checker's statement of the fused-chain hook -> (q_chain [k][d], p_chain,
+    logp_chain [k], grad_chain) -- the order of do_dispatch's result tuple {all_q, all_p, all_logp, all_grad}."""
+    cfg = cfg or Cfg(0, 1)
+    q, p, im = arr(q), arr(p), arr(inv_mass)
+    d = q.shape[0]
+    aq = np.zeros((k, d)); ap = np.zeros((k, d)); ag = np.zeros((k, d)); alp = np.zeros(k)
+    rc = lib().exo_leapfrog_chain_normal(dptr(q), dptr(p), dptr(im), d, k, signed_eps, mu, sigma, dptr(aq), dptr(ap),
+                                         dptr(ag), dptr(alp), cfg)
+    if rc:
+        raise ValueError("exo_leapfrog_chain_normal: bad sizes")
+    return aq, ap, alp, ag
 
 
 def std_normal(d):

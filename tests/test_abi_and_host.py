@@ -143,7 +143,7 @@ def test_plugin_carries_its_kernels_as_code_objects_not_host_stubs():
     syms = subprocess.run(["nm", "--defined-only", so], capture_output=True, text=True, check=True).stdout
     assert " exmc_blob_table" in syms
     stubs = [ln for ln in syms.splitlines() if "__device_stub__" in ln]
-    assert stubs and all(any(k in ln for k in ("ess_", "rhat_kernel", "rank_scores", "full_tree", "subtree", "traj_build"))
+    assert stubs and all(any(k in ln for k in ("ess_", "rhat_kernel", "rank_scores", "full_tree", "subtree", "traj_build", "chain_normal"))
                          for ln in stubs), stubs
     for k in ("nuts_kernel", "warmup_kernel", "multi_step_kernel", "logp_grad_kernel", "init_chains_kernel", "find_eps_kernel"):
         assert not any(k in ln for ln in stubs), k

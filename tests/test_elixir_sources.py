@@ -149,3 +149,27 @@ def test_patches_are_well_formed_unified_diffs(name, target):
         assert n0 == o0 + offset and o0 > last, lines[i]
         offset += nc - oc
         last = o0
+
+
+def test_tree_patch_adds_the_fused_chain_clause():
+    """elixir/patches/tree.ex.diff: one hunk, between the Nx.Vulkan clause of do_dispatch/10 and the fall-through
+    (tree.ex:653-656); it calls the stub with its arity and returns the tuple both existing clauses return."""
+    src = _read(EX, "patches", "tree.ex.diff")
+    assert "--- a/lib/exmc/nuts/tree.ex" in src and "+++ b/lib/exmc/nuts/tree.ex" in src
+    hunks = list(re.finditer(r"^@@ -(\d+),(\d+) \+(\d+),(\d+) @@$", src, re.M))
+    assert len(hunks) == 1
+    o0, oc, n0, nc = map(int, hunks[0].groups())
+    body = [ln for ln in src[hunks[0].end():].split("\n") if ln]
+    assert all(ln[0] in "+ " for ln in body)
+    assert oc == sum(1 for ln in body if ln[0] == " ") == 4 and nc == len(body) and o0 == n0 == 653
+    added = _strip("\n".join(ln[1:] for ln in body if ln[0] == "+"))
+    m = re.search(r"HipNative\.leapfrog_chain_normal\(", added)
+    i, depth = m.end(), 1
+    while depth:
+        depth += {"(": 1, ")": -1}.get(added[i], 0)
+        i += 1
+    assert len(_split_args(added[m.end():i - 1])) == _stubs()["leapfrog_chain_normal"] == 7
+    assert "Exmc.NUTS.HipSampler.available?()" in added and "d <= 256" in added
+    assert "ten.(q_chain, {k, d}), ten.(p_chain, {k, d}), ten.(logp_chain, {k}), ten.(grad_chain, {k, d})" in added
+    opens = len(re.findall(r"\bdo\b(?!:)", added)) + len(re.findall(r"\bfn\b", added))
+    assert opens == len(re.findall(r"\bend\b", added))

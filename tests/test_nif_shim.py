@@ -62,6 +62,7 @@ def test_hip_native_entry(mods):
     assert m.name == "Elixir.Exmc.NUTS.HipNative"
     assert {(n, a) for n, a, _ in m.table()} == {
         ("model_create", 2), ("model_create_plugin", 2), ("model_set_flat_order", 2), ("logp_grad", 3), ("multi_step", 8),
+        ("leapfrog_chain_normal", 7),
         ("warmup", 6), ("warmup_from", 8), ("warmup_dense", 7), ("set_dense_mass", 3), ("clear_dense_mass", 1),
         ("sample_chains", 10), ("sample_independent", 10), ("sample", 7), ("sample_warm", 9), ("sample_dense", 8),
         ("stream_begin", 6), ("stream_next", 2), ("stream_run", 3)}
