@@ -26,7 +26,7 @@ FMA=$(grep -q -m1 ' fma ' /proc/cpuinfo 2>/dev/null && echo -mfma)
 gcc -O1 -g -std=gnu11 -fPIC -ffp-contract=off -fno-fast-math $FMA -fsanitize=address,undefined -fno-omit-frame-pointer \
     -shared -o "$work/libexmc_oracle_asan.so" oracle/exmc_oracle.c -lm -lpthread || exit 1
 tests="tests/test_nif_shim.py tests/test_elixir_sources.py tests/test_ess_series_host.py tests/test_detmath_ranges.py"
-[ "$quick" = quick ] || tests="$tests tests/test_golden_reference.py tests/test_oracle_sampler.py tests/test_detmath_rng.py tests/test_dense_mass_oracle.py tests/test_flat_order.py tests/test_radon_chunks.py tests/test_reference_diagnostics.py tests/test_golden_traces.py tests/test_tree_third_statement.py tests/test_sampler_third_statement.py tests/test_native_tree_third_statement.py tests/test_diagnostics_third_statement.py"
+[ "$quick" = quick ] || tests="$tests tests/test_golden_reference.py tests/test_oracle_sampler.py tests/test_detmath_rng.py tests/test_dense_mass_oracle.py tests/test_flat_order.py tests/test_radon_chunks.py tests/test_reference_diagnostics.py tests/test_golden_traces.py tests/test_tree_third_statement.py tests/test_sampler_third_statement.py tests/test_native_tree_third_statement.py tests/test_diagnostics_third_statement.py tests/test_fused_chain.py"
 LD_PRELOAD="$asan $ubsan" ASAN_OPTIONS=detect_leaks=0:abort_on_error=0:halt_on_error=1 \
 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 EXMC_SANITIZE=address,undefined \
 EXMC_ORACLE_LIB="$work/libexmc_oracle_asan.so" \
