@@ -2295,6 +2295,16 @@ struct SubtreeUpload {
   }
 };
 
+// scratch of exmc_hip_leapfrog_chain_normal_host (see there), one per device, never freed
+struct ChainScratch {
+  std::mutex mu;
+  void* dev = nullptr;
+  void* host = nullptr;
+};
+constexpr size_t kChainScratchBytes = (size_t)8 << 20;
+constexpr int kChainScratchDevices = 16;
+ChainScratch g_chain_scratch[kChainScratchDevices];
+
 int down(void* dst, const void* src, size_t bytes) {
   if (!dst) return EXMC_OK;
   HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
@@ -2449,7 +2459,11 @@ int exmc_hip_build_subtree_host(int device, int C, int d, const double* all_q, c
 }
 
 // B2' (tree.ex:613-653): see leapfrog_chain_normal_kernel. Blocking, on the null stream, like the other
-// handle-less seams: the reference's hook uploads, dispatches and downloads per call as well.
+// handle-less seams: the reference's hook uploads, dispatches and downloads per call as well. The hook exists
+// to cut the cost of a DISPATCH (tree.ex:613-619), so a call of ordinary size pays for no allocation: a scratch
+// per device (device buffer + page-locked staging, kChainScratchBytes each, made on first use and kept), ONE
+// packed upload (q, p, inv_mass) and ONE packed download (the three row sets and logp). Calls on a device are
+// serialised by its scratch's lock (they share the null stream anyway). Larger batches allocate and free.
 int exmc_hip_leapfrog_chain_normal_host(int device, int C, int d, const double* q, const double* p,
                                         const double* inv_mass, int k, double signed_eps, double mu,
                                         double sigma, double* q_chain, double* p_chain,
@@ -2460,28 +2474,59 @@ int exmc_hip_leapfrog_chain_normal_host(int device, int C, int d, const double* 
   if (rc) return rc;
   if (k == 0) return EXMC_OK;
   const size_t vec = (size_t)C * d, rows = (size_t)C * k * d, lps = (size_t)C * k;
+  const size_t n_in = 2 * vec + (size_t)d, n_out = 3 * rows + lps;
+  const bool cached = (n_in + n_out) * 8 <= kChainScratchBytes && device < kChainScratchDevices;
+  ChainScratch* sc = cached ? &g_chain_scratch[device] : nullptr;
+  std::unique_lock<std::mutex> lock;
   DevBuf buf;
-  rc = buf.ensure((2 * vec + (size_t)d + 3 * rows + lps) * 8);
-  if (rc) return rc;
-  double* dq = (double*)buf.p;
-  double* dp = dq + vec;
-  double* dim = dp + vec;
+  double* dbase = nullptr;
+  double* hbase = nullptr;
+  if (sc) {
+    lock = std::unique_lock<std::mutex>(sc->mu);
+    if (!sc->dev) HIP_TRY(hipMalloc(&sc->dev, kChainScratchBytes));
+    if (!sc->host) HIP_TRY(hipHostMalloc(&sc->host, kChainScratchBytes, hipHostMallocDefault));
+    dbase = (double*)sc->dev;
+    hbase = (double*)sc->host;
+  } else {
+    rc = buf.ensure((n_in + n_out) * 8);
+    if (rc) return rc;
+    dbase = (double*)buf.p;
+  }
   ChainNormalParams P{};
-  P.q = dq; P.p = dp; P.inv_mass = dim;
+  P.q = dbase; P.p = dbase + vec; P.inv_mass = dbase + 2 * vec;
   P.d = d; P.k = k; P.n_chains = C;
   P.eps = signed_eps; P.mu = mu; P.sigma = sigma;
   P.tiny32 = f32r(1.0e-30);
   P.log2pi32 = f32r(std::log(f32r(2.0 * M_PI)));
-  P.q_chain = dim + d;
+  P.q_chain = dbase + n_in;
   P.p_chain = P.q_chain + rows;
   P.g_chain = P.p_chain + rows;
   P.logp_chain = P.g_chain + rows;
-  hipError_t e = hipMemcpy(dq, q, vec * 8, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(dp, p, vec * 8, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(dim, inv_mass, (size_t)d * 8, hipMemcpyHostToDevice);
+  hipError_t e;
+  if (hbase) {
+    std::memcpy(hbase, q, vec * 8);
+    std::memcpy(hbase + vec, p, vec * 8);
+    std::memcpy(hbase + 2 * vec, inv_mass, (size_t)d * 8);
+    e = hipMemcpy(dbase, hbase, n_in * 8, hipMemcpyHostToDevice);
+  } else {
+    e = hipMemcpy(dbase, q, vec * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dbase + vec, p, vec * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dbase + 2 * vec, inv_mass, (size_t)d * 8, hipMemcpyHostToDevice);
+  }
   if (e == hipSuccess) {
     hipLaunchKernelGGL(leapfrog_chain_normal_kernel, dim3((unsigned)C), dim3(64), 0, 0, P);
     e = hipGetLastError();
+  }
+  if (hbase) {
+    // the blocking copy waits for the kernel (same stream)
+    if (e == hipSuccess) e = hipMemcpy(hbase + n_in, P.q_chain, n_out * 8, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return fail(EXMC_ERR_HIP, std::string("leapfrog_chain_normal: ") + hipGetErrorString(e));
+    const double* o = hbase + n_in;
+    if (q_chain) std::memcpy(q_chain, o, rows * 8);
+    if (p_chain) std::memcpy(p_chain, o + rows, rows * 8);
+    if (grad_chain) std::memcpy(grad_chain, o + 2 * rows, rows * 8);
+    if (logp_chain) std::memcpy(logp_chain, o + 3 * rows, lps * 8);
+    return EXMC_OK;
   }
   if (e == hipSuccess) e = hipDeviceSynchronize();
   if (e != hipSuccess) rc = fail(EXMC_ERR_HIP, std::string("leapfrog_chain_normal: ") + hipGetErrorString(e));

@@ -42,7 +42,7 @@ def test_one_chain_bit_exact(hip, d):
         _check_against_checker(q, p, im, k, eps, mu, sigma)
 
 
-@pytest.mark.parametrize("n_chains,d", [(2, 5), (7, 64), (300, 10), (64, 256), (1025, 3)])
+@pytest.mark.parametrize("n_chains,d", [(2, 5), (7, 64), (300, 10), (64, 256), (1025, 3), (2000, 64)])
 def test_batches_of_independent_chains_bit_exact(hip, n_chains, d):
     """the batched form: every chain of a launch equals the one-chain call of the checker."""
     rng = np.random.default_rng(1000 + n_chains)
