@@ -2303,6 +2303,7 @@ struct ChainScratch {
 };
 constexpr size_t kChainScratchBytes = (size_t)8 << 20;
 constexpr int kChainScratchDevices = 16;
+constexpr size_t kChainZeroCopyBytes = (size_t)1 << 20;   // rows the kernel writes straight into the staging buffer
 ChainScratch g_chain_scratch[kChainScratchDevices];
 
 int down(void* dst, const void* src, size_t bytes) {
@@ -2462,7 +2463,8 @@ int exmc_hip_build_subtree_host(int device, int C, int d, const double* all_q, c
 // handle-less seams: the reference's hook uploads, dispatches and downloads per call as well. The hook exists
 // to cut the cost of a DISPATCH (tree.ex:613-619), so a call of ordinary size pays for no allocation: a scratch
 // per device (device buffer + page-locked staging, kChainScratchBytes each, made on first use and kept), ONE
-// packed upload (q, p, inv_mass) and ONE packed download (the three row sets and logp). Calls on a device are
+// packed upload (q, p, inv_mass) and ONE packed download (the three row sets and logp) -- and up to 1 MB of rows no
+// copy at all (the kernel works on the staging buffer itself). Calls on a device are
 // serialised by its scratch's lock (they share the null stream anyway). Larger batches allocate and free.
 int exmc_hip_leapfrog_chain_normal_host(int device, int C, int d, const double* q, const double* p,
                                         const double* inv_mass, int k, double signed_eps, double mu,
@@ -2503,6 +2505,30 @@ int exmc_hip_leapfrog_chain_normal_host(int device, int C, int d, const double* 
   P.g_chain = P.p_chain + rows;
   P.logp_chain = P.g_chain + rows;
   hipError_t e;
+  // a call of ordinary size (the reference's: one chain, K = 32) moves so little that the two copies cost more
+  // than the kernel: it reads its inputs from, and writes its rows to, the page-locked staging directly (the
+  // buffer is device-accessible; the kernel's end makes the rows visible to the host) -- no copy kernels at all
+  const bool zero_copy = hbase && n_out * 8 <= kChainZeroCopyBytes;
+  if (zero_copy) {
+    std::memcpy(hbase, q, vec * 8);
+    std::memcpy(hbase + vec, p, vec * 8);
+    std::memcpy(hbase + 2 * vec, inv_mass, (size_t)d * 8);
+    P.q = hbase; P.p = hbase + vec; P.inv_mass = hbase + 2 * vec;
+    P.q_chain = hbase + n_in;
+    P.p_chain = P.q_chain + rows;
+    P.g_chain = P.p_chain + rows;
+    P.logp_chain = P.g_chain + rows;
+    hipLaunchKernelGGL(leapfrog_chain_normal_kernel, dim3((unsigned)C), dim3(64), 0, 0, P);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(0);
+    if (e != hipSuccess) return fail(EXMC_ERR_HIP, std::string("leapfrog_chain_normal: ") + hipGetErrorString(e));
+    const double* o = hbase + n_in;
+    if (q_chain) std::memcpy(q_chain, o, rows * 8);
+    if (p_chain) std::memcpy(p_chain, o + rows, rows * 8);
+    if (grad_chain) std::memcpy(grad_chain, o + 2 * rows, rows * 8);
+    if (logp_chain) std::memcpy(logp_chain, o + 3 * rows, lps * 8);
+    return EXMC_OK;
+  }
   if (hbase) {
     std::memcpy(hbase, q, vec * 8);
     std::memcpy(hbase + vec, p, vec * 8);
